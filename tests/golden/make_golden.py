@@ -1,0 +1,322 @@
+"""Generate golden vectors by running the REFERENCE on CPU (this container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [--full]
+
+Writes tests/golden/*.npz: inputs + expected outputs (data only, no reference source).
+`--full` also produces the full-size (256^2 / 1024^2) strided-sample fixtures (minutes of CPU).
+Every fixture records which reference entry point produced it (file:line in `_src`).
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [HERE, os.path.dirname(os.path.dirname(HERE))]
+from _ref_import import import_reference  # noqa: E402
+
+ref = import_reference()
+from exp.cips3d import nerf_utils as ref_nerf  # noqa: E402
+from exp.cips3d import volume_renderer as ref_vr  # noqa: E402
+import op as ref_op  # noqa: E402
+
+from cips_3dplusplus_amd import configs, weights  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def npy(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def save(name, **d):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **npy(d))
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KB")
+
+
+# ---------------------------------------------------------------- 1. cameras
+def g_camera():
+    out = {"_src": "cips3d/nerf_utils.py:344-436,466-564"}
+    locs = torch.tensor([[0.0, 0.0], [0.4, -0.1], [-0.77, 0.0], [3.0, 0.1]])
+    for tag, cam in (("ffhq", configs.FFHQ_CAM_CFG), ("cars", configs.COMPCARS_CAM_CFG)):
+        e, f, n, fa, vp = ref_nerf.Camera.generate_camera_params(
+            img_size=64, device="cpu", locations=locs, fov_ang=cam["fov_ang"], dist_radius=cam["dist_radius"])
+        out.update({f"{tag}_extr": e, f"{tag}_focal": f, f"{tag}_near": n, f"{tag}_far": fa, f"{tag}_vp": vp})
+    out["locs"] = locs
+    fov_t = torch.tensor([[6.0], [6.5], [7.0], [8.0]])
+    e, f, n, fa, _ = ref_nerf.Camera.generate_camera_params(
+        img_size=64, device="cpu", locations=locs, fov_ang=fov_t, dist_radius=0.12)
+    out.update(fovt=fov_t, fovt_extr=e, fovt_focal=f)
+    # in-plane roll trajectory of the translate_rotate demo (render_video_web_v10.py:1625-1641)
+    t = torch.linspace(0, 1, 8)
+    alpha = t * 2 * torch.pi + 0.5 * torch.pi
+    ups = torch.stack([torch.cos(alpha), torch.sin(alpha), torch.zeros(8)], dim=1)
+    e, f, n, fa, _ = ref_nerf.Camera.generate_camera_params_v1(
+        img_size=64, device="cpu", locations=torch.zeros(8, 2), up=ups, fov_ang=6, dist_radius=0.12)
+    out.update(roll_ups=ups, roll_extr=e, roll_focal=f)
+    # straight-up camera: exercises the degenerate-x replacement branch
+    locs_deg = torch.tensor([[0.0, 1.5707963], [0.3, 0.0]])
+    e, f, n, fa, _ = ref_nerf.Camera.generate_camera_params(
+        img_size=64, device="cpu", locations=locs_deg, fov_ang=6, dist_radius=0.12)
+    out.update(deg_locs=locs_deg, deg_extr=e)
+    save("camera", **out)
+
+
+# ---------------------------------------------------------------- 2. rays / z
+def g_rays():
+    out = {"_src": "cips3d/nerf_utils.py:18-121,136-170"}
+    locs = torch.tensor([[0.25, -0.1], [-0.5, 0.12]])
+    e, f, n, fa, _ = ref_nerf.Camera.generate_camera_params(
+        img_size=8, device="cpu", locations=locs, fov_ang=6, dist_radius=0.12)
+    out.update(extr=e, focal=f, near=n, far=fa)
+    for static in (False, True):
+        o, d, v = ref_nerf.Render.get_rays_in_world(f, 8, e, static_viewdirs=static)
+        out.update({f"rays_o_{int(static)}": o.contiguous(), f"rays_d_{int(static)}": d, f"viewdirs_{int(static)}": v})
+    _, d, _ = ref_nerf.Render.get_rays_in_world(f, 8, e)
+    for N in (4, 24):
+        out[f"z_{N}"] = ref_nerf.Render.get_z_vals(n, fa, d, N, perturb=False)
+        torch.manual_seed(100 + N)
+        out[f"zp_{N}"] = ref_nerf.Render.get_z_vals(n, fa, d, N, perturb=True)
+        torch.manual_seed(100 + N)
+        out[f"u_{N}"] = torch.rand(2, 8, 8, 1)
+    pts, rd, vd, zz = ref_nerf.Render.prepare_nerf_inputs(f, 8, e, n, fa, N_samples=6, perturb=False)
+    out.update(pts_6=pts, pts_n_6=ref_nerf.Render.normalize_points(pts, n, fa))
+    save("rays", **out)
+
+
+# ---------------------------------------------------------------- 3. FiLM-SIREN + compositing
+def g_siren():
+    out = {"_src": "cips3d/volume_renderer.py:15-160; cips3d/nerf_utils.py:230-338"}
+    torch.manual_seed(3)
+    W = 32
+    net = ref_vr.SirenGenerator(D=2, W=W, style_dim=W, input_ch=3, input_ch_views=3)
+    sd = {"network." + k: v for k, v in net.state_dict().items()}
+    out.update({"sd." + k: v for k, v in sd.items()})
+    B, R, N = 2, 16, 8
+    x = torch.rand(B, R, N, 6) * 2 - 1
+    styles = torch.randn(B, 3, W)
+    rgb, sdf, feat = net(x, styles)
+    out.update(x=x, styles=styles, rgb=rgb, sdf=sdf, feat=feat)
+    for i, (cin, name) in enumerate(((3, "first"), (W, "hid"), (W + 3, "view"))):
+        layer = [net.pts_linears[0], net.pts_linears[1], net.views_linears][i]
+        xin = torch.rand(B, R, N, cin) * 2 - 1
+        out[f"film_{name}_in"] = xin
+        out[f"film_{name}_out"] = layer(xin, styles[:, i])
+    # compositing, including a ray that saturates early and one that is background only
+    z = torch.sort(torch.rand(B, R, N) * 0.24 + 0.88, dim=-1)[0]
+    rays_d = torch.randn(B, R, 3)
+    pts = torch.randn(B, R, N, 3)
+    sdf2 = torch.randn(B, R, N, 1) * 0.05
+    sdf2[0, 0] = -3.0      # alpha -> 1 at the first sample
+    sdf2[0, 1] = +3.0      # empty space: everything lands on the last (1e10) interval
+    sdf2[1, 2, :4] = 0.5
+    sdf2[1, 2, 4:] = -0.5
+    beta = torch.tensor([0.1])
+    rgb_map, fmap, xyz, mask, _ = ref_nerf.Render.volume_integration(
+        rgb=rgb, sdf=sdf2, features=feat, z_vals=z, rays_d=rays_d, pts=pts, sigmoid_beta=beta)
+    out.update(vi_z=z, vi_rays_d=rays_d, vi_pts=pts, vi_sdf=sdf2, vi_beta=beta,
+               vi_rgb_map=rgb_map, vi_feature_map=fmap, vi_xyz=xyz, vi_mask=mask)
+    save("siren", **out)
+
+
+# ---------------------------------------------------------------- 4/5. ops
+def g_ops():
+    out = {"_src": "op/upfirdn2d.py:146-201; op/fused_act.py:87-119"}
+    torch.manual_seed(4)
+    k4 = ref.make_kernel([1, 3, 3, 1])
+    k3 = ref.make_kernel([1, 2, 1])
+    k2 = ref.make_kernel([1, 1])
+    cases = [
+        ("blur_up1", (1, 2, 7, 7), k4 * 4, 1, 1, (2, 2)),
+        ("up2", (1, 3, 8, 8), k4 * 4, 2, 1, (2, 1)),
+        ("down2", (1, 1, 9, 9), k4, 1, 2, (1, 1)),
+        ("k3", (2, 2, 6, 5), k3, 1, 1, (1, 1)),
+        ("k2_up2", (1, 2, 5, 6), k2 * 4, 2, 1, (1, 0)),
+        ("crop", (1, 1, 10, 10), k4, 1, 1, (-1, 2)),
+        ("big_up2", (2, 3, 33, 35), k4 * 4, 2, 1, (2, 1)),
+        ("big_blur", (1, 5, 63, 63), k4 * 4, 1, 1, (2, 2)),
+        ("down2_odd", (1, 2, 17, 16), k4, 1, 2, (2, 1)),
+    ]
+    names = []
+    for name, shp, k, up, down, pad in cases:
+        x = torch.randn(*shp)
+        out[f"ufd_{name}_x"] = x
+        out[f"ufd_{name}_k"] = k
+        out[f"ufd_{name}_cfg"] = np.array([up, down, pad[0], pad[1]])
+        out[f"ufd_{name}_y"] = ref_op.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        names.append(name)
+    out["ufd_names"] = np.array(names)
+    for name, shp, scale, use_b in (("2d_g1", (4, 32), 1.0, True), ("2d_gs", (4, 32), 2 ** 0.5, True),
+                                    ("4d", (2, 8, 5, 5), 2 ** 0.5, True), ("4d_nob", (2, 8, 5, 5), 2 ** 0.5, False),
+                                    ("3d", (2, 6, 7), 1.0, True)):
+        x = torch.randn(*shp)
+        b = torch.randn(shp[1]) if use_b else None
+        out[f"flr_{name}_x"] = x
+        if use_b:
+            out[f"flr_{name}_b"] = b
+        out[f"flr_{name}_scale"] = np.float32(scale)
+        out[f"flr_{name}_y"] = ref_op.fused_leaky_relu(x, b, scale=scale)
+    save("ops", **out)
+
+
+# ---------------------------------------------------------------- 6/7. decoder blocks
+def g_modconv():
+    out = {"_src": "models/model_v3.py:218-314,418-482"}
+    torch.manual_seed(6)
+    B, Cin, Cout, H, S = 2, 8, 12, 6, 16
+    names = []
+    for k in (1, 3):
+        for up in (False, True):
+            for demod in (True, False):
+                tag = f"k{k}_up{int(up)}_d{int(demod)}"
+                m = ref.ModulatedConv2d(Cin, Cout, k, S, demodulate=demod, upsample=up)
+                m.modulation.bias.data += torch.randn(Cin) * 0.2
+                x = torch.randn(B, Cin, H, H)
+                st = torch.randn(B, S)
+                out.update({f"mc_{tag}.sd.{n}": v for n, v in m.state_dict().items()})
+                out.update({f"mc_{tag}.x": x, f"mc_{tag}.style": st, f"mc_{tag}.y": m(x, st)})
+                names.append(tag)
+    out["mc_names"] = np.array(names)
+    for up in (False, True):
+        tag = f"up{int(up)}"
+        sc = ref.StyledConv(Cin, Cout, 1, S, upsample=up)
+        sc.noise.weight.data.fill_(0.3)
+        sc.activate.bias.data = torch.randn(Cout) * 0.2
+        x = torch.randn(B, Cin, H, H)
+        st = torch.randn(B, S)
+        Ho = H * 2 if up else H
+        nz = torch.randn(1, 1, Ho, Ho)
+        out.update({f"sc_{tag}.sd.{n}": v for n, v in sc.state_dict().items()})
+        out.update({f"sc_{tag}.x": x, f"sc_{tag}.style": st, f"sc_{tag}.noise": nz, f"sc_{tag}.y": sc(x, st, noise=nz)})
+        tr = ref.ToRGB(Cout, S, upsample=up)
+        tr.bias.data = torch.randn(1, 3, 1, 1) * 0.1
+        xin = torch.randn(B, Cout, Ho, Ho)
+        skip = torch.randn(B, 3, H, H)
+        out.update({f"rgb_{tag}.sd.{n}": v for n, v in tr.state_dict().items()})
+        out.update({f"rgb_{tag}.x": xin, f"rgb_{tag}.style": st, f"rgb_{tag}.skip": skip,
+                    f"rgb_{tag}.y": tr(xin, st, skip=skip), f"rgb_{tag}.y_noskip": tr(xin, st)})
+    save("modconv", **out)
+
+
+# ---------------------------------------------------------------- 8. tiny generator end-to-end
+def _run_ref(G, zs, cam, img_size, nerf_cfg, noise_bufs, truncation=1.0, means=None, **kw):
+    if means is not None:
+        G.style_render_mean, G.style_decoder_mean = means
+    r = G(zs=zs, cam_poses=cam[0], focals=cam[1], img_size=img_size, near=cam[2], far=cam[3],
+          noise_bufs=noise_bufs, truncation=truncation, nerf_cfg=nerf_cfg,
+          return_xyz=True, return_sdf=True, **kw)
+    return {k: v for k, v in r.items() if v is not None}
+
+
+def g_tiny_generator():
+    out = {"_src": "models/model_v3.py:875-1042 (tiny G_cfg, SURVEY Appendix D)"}
+    for tag, hidden, D, ks in (("h32_d2", 32, 2, 1), ("h32_d3", 32, 3, 1), ("h32_d2_k3", 32, 2, 3)):
+        cfg = configs.tiny_G_cfg(hidden=hidden, N_layers_renderer=D, kernel_size=ks)
+        G = ref.Generator(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        sd = weights.synth_state_dict(shapes, seed=7)
+        G.load_state_dict(sd, strict=True)
+        out[f"{tag}.keys"] = np.array(list(shapes.keys()))
+        out.update({f"{tag}.sd.{k}": v for k, v in sd.items()})
+        g = torch.Generator().manual_seed(11)
+        zs = [torch.randn(2, hidden, generator=g), torch.randn(2, hidden, generator=g)]
+        locs = torch.tensor([[0.2, -0.05], [-0.6, 0.1]])
+        cam = ref_nerf.Camera.generate_camera_params(img_size=8, device="cpu", locations=locs,
+                                                     fov_ang=6, dist_radius=0.12)
+        nb = [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(8, "cpu")]
+        means = (torch.randn(1, hidden, generator=g) * 0.3, torch.randn(1, 32, generator=g) * 0.3)
+        out.update({f"{tag}.z0": zs[0], f"{tag}.z1": zs[1], f"{tag}.locs": locs,
+                    f"{tag}.mean_r": means[0], f"{tag}.mean_d": means[1]})
+        out.update({f"{tag}.noise{i}": b for i, b in enumerate(nb)})
+        for vtag, ncfg, trunc in (("a", dict(N_samples=6, perturb=False, static_viewdirs=False), 1.0),
+                                  ("b", dict(N_samples=5, perturb=False, static_viewdirs=True), 0.5)):
+            r = _run_ref(G, zs, cam, 8, ncfg, nb, truncation=trunc, means=means)
+            out.update({f"{tag}.{vtag}.{k}": v for k, v in r.items()})
+        # perturbed run with the uniform captured
+        torch.manual_seed(5)
+        r = _run_ref(G, zs, cam, 8, dict(N_samples=6, perturb=True, static_viewdirs=False), nb)
+        torch.manual_seed(5)
+        out[f"{tag}.c.u"] = torch.rand(2, 8, 8, 1)
+        out.update({f"{tag}.c.{k}": v for k, v in r.items()})
+        # mean latents with the z's captured (get_mean_latent, model_v3.py:1285-1297)
+        torch.manual_seed(9)
+        mr, md = G.get_mean_latent(64, "cpu")
+        torch.manual_seed(9)
+        out[f"{tag}.ml_zr"] = torch.randn(64, hidden)
+        out[f"{tag}.ml_zd"] = torch.randn(64, hidden)
+        out.update({f"{tag}.ml_r": mr, f"{tag}.ml_d": md})
+    save("tiny_generator", **out)
+
+
+# ---------------------------------------------------------------- 9. full size, strided samples
+FULL_CASES = [
+    # tag, resolution, D, N, static_viewdirs, truncation
+    ("r256_d2_n24", 256, 2, 24, False, 1.0),
+    ("r256_d8_n24", 256, 8, 24, False, 1.0),
+    ("r1024_d2_n24", 1024, 2, 24, False, 1.0),
+    ("r256_d6_n64_static_trunc", 256, 6, 64, True, 0.5),
+]
+STRIDE = 37
+
+
+def full_inputs(cfg, seed=12345):
+    """Inputs shared by make_golden and the GPU parity test (reproducible from seeds)."""
+    g = torch.Generator().manual_seed(seed)
+    zs = [torch.randn(1, 256, generator=g), torch.randn(1, 256, generator=g)]
+    locs = torch.tensor([[0.31, -0.08]])
+    from oracle import path as _o
+    nb = _o.create_noise_bufs(cfg, 64, generator=g)
+    means = (torch.randn(1, 256, generator=g) * 0.2, torch.randn(1, 512, generator=g) * 0.2)
+    return zs, locs, nb, means
+
+
+def g_full():
+    out = {"_src": "models/model_v3.py:875-1042 at release shapes; strided samples (every 37th)",
+           "stride": np.int64(STRIDE)}
+    for tag, res, D, N, static, trunc in FULL_CASES:
+        cfg = configs.ffhq_G_cfg(resolution=res, N_layers_renderer=D)
+        G = ref.Generator(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        sd = weights.synth_state_dict(shapes, seed=1)
+        G.load_state_dict(sd, strict=True)
+        zs, locs, nb, means = full_inputs(cfg)
+        cam = ref_nerf.Camera.generate_camera_params(img_size=64, device="cpu", locations=locs,
+                                                     fov_ang=6, dist_radius=0.12)
+        ncfg = dict(N_samples=N, perturb=False, static_viewdirs=static)
+        r = _run_ref(G, zs, cam, 64, ncfg, nb, truncation=trunc, means=means)
+        out[f"{tag}.sd_checksum"] = np.float64(weights.state_dict_checksum(sd))
+        out[f"{tag}.nkeys"] = np.int64(len(shapes))
+        out[f"{tag}.rgb_s"] = r["rgb"].flatten()[::STRIDE]
+        out[f"{tag}.rgb_absmax"] = r["rgb"].abs().max()
+        out[f"{tag}.thumb_rgb"] = r["thumb_rgb"]
+        out[f"{tag}.mask"] = r["mask"]
+        out[f"{tag}.depth"] = r["depth"]
+        out[f"{tag}.xyz"] = r["xyz"]
+        out[f"{tag}.sdf_s"] = r["sdf"].flatten()[::STRIDE]
+        # fp64 rerun: the reference's own fp32 noise floor for this case
+        G64 = G.double()
+        r64 = _run_ref(G64, [z.double() for z in zs], [c.double() for c in cam[:4]], 64, ncfg,
+                       [b.double() for b in nb], truncation=trunc, means=tuple(m.double() for m in means))
+        out[f"{tag}.noise_floor_rgb"] = (r64["rgb"].float() - r["rgb"]).abs().max()
+        out[f"{tag}.noise_floor_thumb"] = (r64["thumb_rgb"].float() - r["thumb_rgb"]).abs().max()
+        print(tag, "rgb absmax", float(out[f"{tag}.rgb_absmax"]), "fp32 noise floor rgb",
+              float(out[f"{tag}.noise_floor_rgb"]), "thumb", float(out[f"{tag}.noise_floor_thumb"]))
+    save("full_size", **out)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    jobs = dict(camera=g_camera, rays=g_rays, siren=g_siren, ops=g_ops, modconv=g_modconv,
+                tiny_generator=g_tiny_generator)
+    if a.full:
+        jobs["full_size"] = g_full
+    for name, fn in jobs.items():
+        if a.only is None or a.only == name:
+            fn()

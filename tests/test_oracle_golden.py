@@ -1,0 +1,152 @@
+"""Pins the CPU oracle (oracle/path.py) to golden vectors produced by the reference
+(tests/golden/make_golden.py).  CPU only; runs everywhere."""
+import numpy as np
+import pytest
+import torch
+
+from cips_3dplusplus_amd import configs
+from conftest import maxdiff
+from oracle import path as O
+
+TOL = 2e-6
+
+
+def test_camera(golden):
+    fx = golden("camera")
+    for tag, cam in (("ffhq", configs.FFHQ_CAM_CFG), ("cars", configs.COMPCARS_CAM_CFG)):
+        e, f, n, fa, vp = O.camera_params(fx["locs"], 64, cam["fov_ang"], cam["dist_radius"])
+        assert maxdiff(e, fx[f"{tag}_extr"]) < TOL
+        assert maxdiff(f, fx[f"{tag}_focal"]) < 1e-3 * 1e-2   # focal ~ 304: relative 3e-8
+        assert maxdiff(n, fx[f"{tag}_near"]) == 0 and maxdiff(fa, fx[f"{tag}_far"]) == 0
+        assert maxdiff(vp, fx[f"{tag}_vp"]) == 0
+    e, f, *_ = O.camera_params(fx["locs"], 64, fx["fovt"], 0.12)
+    assert maxdiff(e, fx["fovt_extr"]) < TOL and maxdiff(f, fx["fovt_focal"]) < 1e-4
+    e, f, *_ = O.camera_params(torch.zeros(8, 2), 64, 6, 0.12, up=fx["roll_ups"])
+    assert maxdiff(e, fx["roll_extr"]) < TOL
+    e, *_ = O.camera_params(fx["deg_locs"], 64, 6, 0.12)
+    assert maxdiff(e, fx["deg_extr"]) < TOL
+
+
+def test_frontal_camera_constants():
+    # locations = 0 -> focal 304.4597, near .88, far 1.12 (FFHQ cam_cfg)
+    e, f, n, fa, _ = O.camera_params(torch.zeros(1, 2), 64, 6, 0.12)
+    assert abs(float(f) - 304.4597) < 1e-3 and abs(float(n) - 0.88) < 1e-7 and abs(float(fa) - 1.12) < 1e-7
+    assert maxdiff(e[0], torch.tensor([[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1]])) < 1e-7
+
+
+def test_rays_and_samples(golden):
+    fx = golden("rays")
+    for static in (0, 1):
+        o, d, v = O.rays_in_world(fx["focal"], 8, fx["extr"], bool(static))
+        assert maxdiff(o, fx[f"rays_o_{static}"]) == 0
+        assert maxdiff(d, fx[f"rays_d_{static}"]) < TOL
+        assert maxdiff(v, fx[f"viewdirs_{static}"]) < TOL
+    for N in (4, 24):
+        assert maxdiff(O.z_vals(fx["near"], fx["far"], 2, 8, 8, N), fx[f"z_{N}"]) < TOL
+        assert maxdiff(O.z_vals(fx["near"], fx["far"], 2, 8, 8, N, fx[f"u_{N}"]), fx[f"zp_{N}"]) < TOL
+    o, d, _ = O.rays_in_world(fx["focal"], 8, fx["extr"])
+    pts = O.ray_points(o, d, O.z_vals(fx["near"], fx["far"], 2, 8, 8, 6))
+    assert maxdiff(pts, fx["pts_6"]) < TOL
+    assert maxdiff(O.normalize_points(pts, fx["near"], fx["far"]), fx["pts_n_6"]) < 2e-5
+
+
+def test_film_siren_and_compositing(golden):
+    fx = golden("siren")
+    sd = fx.sub("sd.")
+    styles = fx["styles"]
+    for i, (name, prefix) in enumerate((("first", "network.pts_linears.0"), ("hid", "network.pts_linears.1"),
+                                        ("view", "network.views_linears"))):
+        y = O.film_siren(sd, prefix, fx[f"film_{name}_in"], styles[:, i])
+        assert maxdiff(y, fx[f"film_{name}_out"]) < 5e-6
+    x = fx["x"]
+    # the reference net takes per-point view dirs; the oracle takes per-ray dirs, so evaluate
+    # sample-by-sample (one direction per ray per call)
+    outs = [O.siren_points(sd, "network", x[:, :, n:n + 1, :3], x[:, :, n, 3:], styles, 2) for n in range(x.shape[2])]
+    rgb = torch.cat([o[0] for o in outs], dim=2)
+    sdf = torch.cat([o[1] for o in outs], dim=2)
+    feat = torch.cat([o[2] for o in outs], dim=2)
+    assert maxdiff(rgb, fx["rgb"]) < 5e-6 and maxdiff(sdf, fx["sdf"]) < 5e-6 and maxdiff(feat, fx["feat"]) < 5e-6
+    rm, fm, xyz, mask = O.volume_integration(fx["rgb"], fx["vi_sdf"], fx["feat"], fx["vi_z"], fx["vi_rays_d"],
+                                             fx["vi_pts"], fx["vi_beta"])
+    assert maxdiff(rm, fx["vi_rgb_map"]) < TOL and maxdiff(fm, fx["vi_feature_map"]) < TOL
+    assert maxdiff(xyz, fx["vi_xyz"]) < TOL and maxdiff(mask, fx["vi_mask"]) < TOL
+
+
+def test_ops(golden):
+    fx = golden("ops")
+    for name in fx["ufd_names"]:
+        up, down, p0, p1 = [int(v) for v in fx[f"ufd_{name}_cfg"]]
+        y = O.upfirdn2d(fx[f"ufd_{name}_x"], fx[f"ufd_{name}_k"], up, down, (p0, p1))
+        assert y.shape == fx[f"ufd_{name}_y"].shape, name
+        assert maxdiff(y, fx[f"ufd_{name}_y"]) < TOL, name
+    for name in ("2d_g1", "2d_gs", "4d", "4d_nob", "3d"):
+        b = fx[f"flr_{name}_b"] if f"flr_{name}_b" in fx else None
+        y = O.fused_leaky_relu(fx[f"flr_{name}_x"], b, scale=float(fx[f"flr_{name}_scale"]))
+        assert maxdiff(y, fx[f"flr_{name}_y"]) < TOL, name
+
+
+def test_modulated_conv_blocks(golden):
+    fx = golden("modconv")
+    for tag in fx["mc_names"]:
+        sd = {"m." + k: v for k, v in fx.sub(f"mc_{tag}.sd.").items()}
+        y = O.modulated_conv2d(sd, "m", fx[f"mc_{tag}.x"], fx[f"mc_{tag}.style"],
+                               demodulate="_d1" in str(tag), upsample="_up1" in str(tag))
+        assert maxdiff(y, fx[f"mc_{tag}.y"]) < 2e-5, tag
+    for tag in ("up0", "up1"):
+        sd = {"m." + k: v for k, v in fx.sub(f"sc_{tag}.sd.").items()}
+        y = O.styled_conv(sd, "m", fx[f"sc_{tag}.x"], fx[f"sc_{tag}.style"], fx[f"sc_{tag}.noise"], upsample=tag == "up1")
+        assert maxdiff(y, fx[f"sc_{tag}.y"]) < 2e-5
+        sd = {"m." + k: v for k, v in fx.sub(f"rgb_{tag}.sd.").items()}
+        y = O.to_rgb(sd, "m", fx[f"rgb_{tag}.x"], fx[f"rgb_{tag}.style"], fx[f"rgb_{tag}.skip"], upsample=tag == "up1")
+        assert maxdiff(y, fx[f"rgb_{tag}.y"]) < 2e-5
+        y = O.to_rgb(sd, "m", fx[f"rgb_{tag}.x"], fx[f"rgb_{tag}.style"])
+        assert maxdiff(y, fx[f"rgb_{tag}.y_noskip"]) < 2e-5
+
+
+def test_k1_upsample_identity(golden):
+    """k=1 up-sampling conv == per-sample GEMM then upfirdn2d(up=2, pad=(2,1), kernel*4).
+    The HIP decoder is built on this identity, so pin it against the reference's output."""
+    fx = golden("modconv")
+    tag = "k1_up1_d1"
+    sd = {"m." + k: v for k, v in fx.sub(f"mc_{tag}.sd.").items()}
+    lo = O.modulated_conv2d(sd, "m", fx[f"mc_{tag}.x"], fx[f"mc_{tag}.style"], demodulate=True, upsample=False)
+    y = O.upfirdn2d(lo, sd["m.blur.kernel"], up=2, pad=(2, 1))
+    assert maxdiff(y, fx[f"mc_{tag}.y"]) < 2e-5
+
+
+def _tiny_cfg(tag):
+    hidden = 32
+    D = 3 if "d3" in tag else 2
+    return configs.tiny_G_cfg(hidden=hidden, N_layers_renderer=D, kernel_size=3 if "k3" in tag else 1)
+
+
+@pytest.mark.parametrize("tag", ["h32_d2", "h32_d3", "h32_d2_k3"])
+def test_tiny_generator_end_to_end(golden, tag):
+    fx = golden("tiny_generator")
+    cfg = _tiny_cfg(tag)
+    sd = fx.sub(f"{tag}.sd.")
+    assert list(fx[f"{tag}.keys"]) == list(sd.keys())
+    zs = [fx[f"{tag}.z0"], fx[f"{tag}.z1"]]
+    cam = O.camera_params(fx[f"{tag}.locs"], 8, 6, 0.12)
+    nb = [fx[f"{tag}.noise{i}"] for i in range(O.decoder_layout(cfg)["num_layers"])]
+    means = (fx[f"{tag}.mean_r"], fx[f"{tag}.mean_d"])
+    runs = (("a", dict(N_samples=6, perturb=False, static_viewdirs=False), 1.0, None),
+            ("b", dict(N_samples=5, perturb=False, static_viewdirs=True), 0.5, None),
+            ("c", dict(N_samples=6, perturb=True, static_viewdirs=False), 1.0, fx[f"{tag}.c.u"]))
+    for vtag, ncfg, trunc, u in runs:
+        r = O.generator_forward(sd, cfg, zs, cam[0], cam[1], 8, cam[2], cam[3], ncfg, nb, truncation=trunc,
+                                style_render_mean=means[0], style_decoder_mean=means[1], perturb_u=u,
+                                return_sdf=True, return_xyz=True)
+        for k in ("rgb", "thumb_rgb", "sdf", "xyz", "mask", "depth"):
+            assert r[k].shape == fx[f"{tag}.{vtag}.{k}"].shape
+            assert maxdiff(r[k], fx[f"{tag}.{vtag}.{k}"]) < 5e-5, (tag, vtag, k)
+    mr, md = O.mean_latents(sd, cfg, fx[f"{tag}.ml_zr"], fx[f"{tag}.ml_zd"])
+    assert maxdiff(mr, fx[f"{tag}.ml_r"]) < 1e-5 and maxdiff(md, fx[f"{tag}.ml_d"]) < 1e-5
+
+
+def test_noise_buf_shapes():
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    sizes = [b.shape[-1] for b in O.create_noise_bufs(cfg, 64)]
+    assert sizes == [64] * 9 + [128] * 2 + [256] * 2 + [512] * 2 + [1024] * 2
+    lay = O.decoder_layout(cfg)
+    assert lay["n_latent"] == 18 and lay["num_layers"] == 17
