@@ -1,0 +1,117 @@
+"""ctypes binding of libcips3d_hip.so (the C ABI declared in include/cips3d_hip.h).
+
+There is no CPU fallback: if the shared library is absent and cannot be built, importing the
+symbols raises; every wrapper refuses non-HIP tensors the way the reference's bindings refuse
+non-CUDA tensors (`TORCH_CHECK(x.is_cuda())`, exp/op/fused_bias_act.cpp:7-16).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcips3d_hip.so")
+
+c_f32p = C.c_void_p
+c_i64 = C.c_int64
+c_int = C.c_int
+c_f32 = C.c_float
+
+
+class LinearDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("x", C.c_void_p), ("out", C.c_void_p),
+                ("x_stride", C.c_int64), ("out_stride", C.c_int64), ("in_dim", C.c_int32),
+                ("out_dim", C.c_int32), ("w_scale", C.c_float), ("b_scale", C.c_float),
+                ("out_scale", C.c_float), ("out_shift", C.c_float), ("row_begin", C.c_int32),
+                ("pad_", C.c_int32)]
+
+
+class NerfParams(C.Structure):
+    _fields_ = [("cam_poses", C.c_void_p), ("focals", C.c_void_p), ("near_", C.c_void_p), ("far_", C.c_void_p),
+                ("perturb_u", C.c_void_p),
+                ("w_first", C.c_void_p), ("packed", C.c_void_p), ("w_view", C.c_void_p), ("film", C.c_void_p),
+                ("layer_bias", C.c_void_p), ("w_sigma", C.c_void_p), ("w_rgb", C.c_void_p),
+                ("b_sigma", C.c_void_p), ("b_rgb", C.c_void_p), ("sigmoid_beta", C.c_void_p),
+                ("B", C.c_int32), ("img_size", C.c_int32), ("n_samples", C.c_int32), ("hidden", C.c_int32),
+                ("depth", C.c_int32), ("static_viewdirs", C.c_int32), ("n_chunks", C.c_int32), ("pad_", C.c_int32),
+                ("part", C.c_void_p), ("sdf", C.c_void_p)]
+
+
+_SIGS = {
+    "cips3d_abi_version": (c_int, []),
+    "cips3d_strerror": (C.c_char_p, [c_int]),
+    "cips3d_fused_bias_act": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_f32, c_f32,
+                                      C.c_void_p]),
+    "cips3d_upfirdn2d": (c_int, [c_f32p, c_f32p, c_f32p, c_i64] + [c_int] * 13 + [C.c_void_p]),
+    "cips3d_linear": (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int,
+                              c_int, c_f32, c_f32, c_f32, c_f32p, c_f32, C.c_void_p]),
+    "cips3d_linear_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_camera_params": (c_int, [c_f32p, c_f32p, c_f32, c_f32p, c_f32, c_int, c_int, c_f32p, c_f32p, c_f32p,
+                                     c_f32p, C.c_void_p]),
+    "cips3d_nerf_pack_weights": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    "cips3d_nerf_suggest_chunks": (c_int, [c_int, c_int, c_int]),
+    "cips3d_nerf_part_floats": (c_i64, [c_int, c_int, c_int, c_int]),
+    "cips3d_nerf_render": (c_int, [C.POINTER(NerfParams), C.c_void_p]),
+    "cips3d_nerf_finish": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_modulate_weights": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int, c_f32, c_int,
+                                        C.c_void_p]),
+    "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
+    "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32,
+                                  c_f32p, C.c_void_p]),
+    "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32, c_f32p,
+                                   C.c_void_p]),
+    "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
+                             C.c_void_p]),
+    "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                   C.c_void_p]),
+}
+
+EXPORTED = tuple(_SIGS)
+_lib = None
+
+
+def load(build_if_missing=True):
+    """dlopen the HIP library (building it in-tree with hipcc first if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m cips_3dplusplus_amd.build`")
+        from . import build
+        build.build_library()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)   # AttributeError here = ABI mismatch between header and library
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cips3d_abi_version() != 1:
+        raise RuntimeError("libcips3d_hip.so ABI version mismatch; rebuild with cips_3dplusplus_amd.build")
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().cips3d_strerror(code).decode()
+        raise RuntimeError(f"{what} failed ({code}): {msg}")
+
+
+def dev_ptr(t, name="tensor", allow_none=False):
+    """Device pointer of a contiguous fp32 HIP tensor; loud failure for anything else."""
+    if t is None:
+        if allow_none:
+            return None
+        raise RuntimeError(f"{name} is required")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (the cips3d HIP path has no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,54 @@
+// Shared device/host helpers for the gfx950 kernels of libcips3d_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cips3d_hip.h"
+
+#define CIPS3D_WAVE 64
+
+static inline int cips3d_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T>
+__host__ __device__ static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+// floor division for possibly negative numerators (b > 0)
+__host__ __device__ static inline int floor_div_i(int a, int b) {
+  int q = a / b;
+  return (q * b > a) ? q - 1 : q;
+}
+
+__device__ static inline float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ static inline float lrelu02(float v) { return v > 0.f ? v : v * 0.2f; }
+
+// sin(x) for the FiLM-SIREN activations.  Arguments reach tens of radians (gamma ~ 30), so the
+// reduction must be exact: two-constant Cody-Waite with FMA (k*PI_HI is absorbed by the fused
+// multiply-add, PI_LO restores the bits PI_HI lacks), then an odd degree-11 polynomial on
+// [-pi/2, pi/2].  Max error ~1 ulp of the result for |x| < ~1e5; about 17 VALU ops.
+__device__ static inline float sin_accurate(float x) {
+  const float INV_PI = 0.318309886183790672f;
+  const float PI_HI = 3.14159274101257324f;        // float(pi)
+  const float PI_LO = -8.74227765734758577e-8f;    // pi - PI_HI
+  float k = rintf(x * INV_PI);
+  float r = fmaf(k, -PI_HI, x);
+  r = fmaf(k, -PI_LO, r);
+  float s = r * r;
+  float p = fmaf(s, -2.3889859e-08f, 2.7525562e-06f);
+  p = fmaf(p, s, -1.9840874e-04f);
+  p = fmaf(p, s, 8.3333310e-03f);
+  p = fmaf(p, s, -1.6666667e-01f);
+  float rs = r * s;
+  float y = fmaf(rs, p, r);
+  int ki = (int)k;
+  return __int_as_float(__float_as_int(y) ^ (ki << 31));
+}

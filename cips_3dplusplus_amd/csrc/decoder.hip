@@ -1,0 +1,442 @@
+// StyleGAN2-style decoder of CIPS-3D++ on gfx950 (reference models/model_v3.py:218-341,418-482,592-637).
+//
+//   cips3d_modulate_weights  per-sample weight modulation + demodulation (model_v3.py:267-278); optionally
+//                            emits the matrix in MFMA A-fragment order for the GEMM below
+//   cips3d_modconv1x1        the 1x1 ModulatedConv2d as a per-sample GEMM  out[o][n] = sum_i wm[o][i] x[i][n]
+//                            on v_mfma_f32_32x32x2_f32, NoiseInjection + FusedLeakyReLU fused in the epilogue
+//   cips3d_up2_fir_act       k=1 up-sampling conv = low-res GEMM followed by upfirdn2d(up=2, pad=(2,1)) of
+//                            its result (pinned by tests/test_oracle_golden.py), fused with
+//                            noise + bias + leaky-ReLU
+//   cips3d_torgb             ToRGB (C->3 modulated conv, bias, skip / FIR-upsampled skip add)
+//   cips3d_modconv_kxk       direct k x k modulated convolution / stride-2 transpose (generality path)
+//
+// Rooflines: 64^2 / 128^2 stages are MFMA-bound (2*Cin*Cout flop per pixel against (Cin+Cout)*4 B);
+// >= 256^2 stages, the FIR up-sampler and ToRGB are HBM-bound: every kernel reads its input once and
+// writes its output once with >= 128-byte row segments.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------------
+// weight modulation.  One wave per (b, o).
+//   plain : wm[b][o][i*ksq + t]
+//   packed (ksq == 1, Cout % 32 == 0, Cin % 8 == 0): MFMA A order
+//           wmp[b][ot][kq][lane][j] = wm[b][ot*32 + (lane&31)][8*kq + 2*j + (lane>>5)]
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) modulate_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                       int64_t s_stride, float* __restrict__ wm, int B, int Cout,
+                                                       int Cin, int ksq, float scale, int demod, int packed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Cout) return;
+  const int b = (int)(row / Cout), o = (int)(row % Cout);
+  const int len = Cin * ksq;
+  const float* w = W + (int64_t)o * len;
+  const float* sb = s + (int64_t)b * s_stride;
+  float ss = 0.f;
+  if (demod) {
+    for (int e = lane; e < len; e += 64) {
+      const float v = (scale * w[e]) * sb[e / ksq];
+      ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+  }
+  const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
+  for (int e = lane; e < len; e += 64) {
+    float v = (scale * w[e]) * sb[e / ksq];
+    if (demod) v *= d;
+    if (packed) {
+      const int i = e;  // ksq == 1
+      const int ot = o >> 5, kq = i >> 3, j = (i & 7) >> 1, hh = i & 1;
+      wm[(((int64_t)b * (Cout >> 5) + ot) * (Cin >> 3) + kq) * 256 + ((hh << 5) | (o & 31)) * 4 + j] = v;
+    } else {
+      wm[((int64_t)b * Cout + o) * len + e] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 modulated conv as GEMM.  Workgroup tile BM x BN, BK-deep stages through a 2-slot LDS ring filled
+// by LDS-DMA (A: packed fragments, linear copy; B: BK rows of BN pixels).  Wave tile = WM x WN MFMA tiles.
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  const float* x; const float* wmp; float* out;
+  int B, Cin, Cout; int64_t HW;
+  int epilogue; const float* noise; int64_t noise_bstride; float noise_w; const float* bias;
+};
+
+template <int WM, int WN, int WGM, int WGN, int BK>
+__global__ void __launch_bounds__(256) modconv1x1_kernel(GemmArgs a) {
+  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+  constexpr int A_STAGE = BM * BK;            // floats
+  constexpr int B_STAGE = BK * BN;
+  constexpr int STAGE = A_STAGE + B_STAGE;
+  constexpr int A_PIECES = A_STAGE / 256;     // 1-KiB pieces
+  constexpr int B_PIECES = B_STAGE / 256;
+  constexpr int PIECES = A_PIECES + B_PIECES;
+  constexpr int KQ = BK / 8;                  // A pieces per o-tile per stage
+  static_assert(WGM * WGN == 4, "four waves");
+  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm_i = wave / WGN, wn_i = wave % WGN;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * BM;
+  const int64_t n0 = (int64_t)blockIdx.x * BN;
+  const int64_t HW = a.HW;
+  const int K = a.Cin;
+  const int nstage = K / BK;
+  const float* xb = a.x + (int64_t)b * K * HW;
+  const float* ab = a.wmp + (int64_t)b * a.Cout * K;   // packed: [ot][kq][256]
+
+  auto stage_load = [&](int st, int slot) {
+    float* dstA = lds + slot * STAGE;
+    float* dstB = dstA + A_STAGE;
+    const int k0 = st * BK;
+#pragma unroll
+    for (int j = 0; j < (PIECES + 3) / 4; ++j) {
+      const int piece = j * 4 + wave;
+      if (PIECES % 4 != 0 && piece >= PIECES) break;
+      if (piece < A_PIECES) {
+        const int ot_l = piece / KQ, kq_l = piece % KQ;
+        const float* src = ab + ((int64_t)((m0 >> 5) + ot_l) * (K >> 3) + (k0 >> 3) + kq_l) * 256 + lane * 4;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
+      } else {
+        const int pb = piece - A_PIECES;
+        const int f = pb * 256 + lane * 4;
+        const int row = f / BN, col = f % BN;
+        int64_t n = n0 + col;
+        if (n > HW - 4) n = HW - 4;                       // clamp: those columns are never stored
+        const float* src = xb + (int64_t)(k0 + row) * HW + n;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  stage_load(0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  const int hh = lane >> 5, jn = lane & 31;
+  for (int st = 0; st < nstage; ++st) {
+    if (st + 1 < nstage) stage_load(st + 1, (st + 1) & 1);
+    const float* sA = lds + (st & 1) * STAGE;
+    const float* sB = sA + A_STAGE;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      f32x4 a4[WM];
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        a4[i] = *reinterpret_cast<const f32x4*>(sA + ((wm_i * WM + i) * KQ + kq) * 256 + lane * 4);
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const int krow = kq * 8 + j4 * 2 + hh;
+        float bf[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = sB[krow * BN + (wn_i * WN + j) * 32 + jn];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][j4], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D layout -> out[b][o][n]; lanes 0-31 / 32-63 write two 128-byte row segments
+  float* ob = a.out + (int64_t)b * a.Cout * HW;
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int64_t n = n0 + (wn_i * WN + j) * 32 + jn;
+    if (n >= HW) continue;
+    float nz = 0.f;
+    if (a.epilogue == 1 && a.noise) nz = a.noise_w * a.noise[(int64_t)b * a.noise_bstride + n];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int obase = m0 + (wm_i * WM + i) * 32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = obase + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float v = acc[i][j][r];
+        if (a.epilogue == 1) v = lrelu02((v + nz) + a.bias[o]) * 1.41421356237309515f;
+        ob[(int64_t)o * HW + n] = v;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int WGM, int WGN, int BK>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+  dim3 grid((unsigned)ceil_div<int64_t>(a.HW, BN), (unsigned)(a.Cout / BM), (unsigned)a.B);
+  hipLaunchKernelGGL((modconv1x1_kernel<WM, WN, WGM, WGN, BK>), grid, dim3(256), 0, st, a);
+  return cips3d_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x polyphase FIR up-sampler (upfirdn2d up=2, pad=(2,1), 4x4 taps) + noise + bias + leaky-ReLU.
+// Each thread produces 4 consecutive output pixels of one row (16-byte store).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, int W, int oy, int ox,
+                                         const float (&kf)[16]) {
+  // u[y][x] = in[(y-2)/2][(x-2)/2] on even (y-2),(x-2); out = sum_{ky,kx} u[oy+ky][ox+kx] * kf[ky][kx]
+  const int ky0 = oy & 1, kx0 = ox & 1;        // first tap with (oy+ky-2) even
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int ky = ky0 + 2 * a;
+    const int iy = (oy + ky - 2) >> 1;
+    if (iy < 0 || iy >= H) continue;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int kx = kx0 + 2 * c;
+      const int ix = (ox + kx - 2) >> 1;
+      if (ix < 0 || ix >= W) continue;
+      acc = fmaf(src[(int64_t)iy * W + ix], kf[ky * 4 + kx], acc);
+    }
+  }
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restrict__ y_lo, const float* __restrict__ fir,
+                                                          float* __restrict__ out, int B, int C, int H, int W,
+                                                          const float* __restrict__ noise, int64_t noise_bstride,
+                                                          float noise_w, const float* __restrict__ bias) {
+  float kf[16];   // flipped taps: kf[ky][kx] = fir[3-ky][3-kx]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
+  const int OW = 2 * W, OH = 2 * H;
+  const int qw = OW / 4;                                   // quads per output row (W >= 2)
+  const int64_t total = (int64_t)B * C * OH * qw;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int qx = (int)(t % qw); t /= qw;
+    const int oy = (int)(t % OH); t /= OH;
+    const int c = (int)(t % C);
+    const int b = (int)(t / C);
+    const float* src = y_lo + ((int64_t)b * C + c) * H * W;
+    const float bs = bias[c];
+    const int ox0 = qx * 4;
+    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (noise) nz = *reinterpret_cast<const float4*>(noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + ox0);
+    float4 o;
+    o.x = lrelu02((up2_tap(src, H, W, oy, ox0 + 0, kf) + noise_w * nz.x) + bs) * 1.41421356237309515f;
+    o.y = lrelu02((up2_tap(src, H, W, oy, ox0 + 1, kf) + noise_w * nz.y) + bs) * 1.41421356237309515f;
+    o.z = lrelu02((up2_tap(src, H, W, oy, ox0 + 2, kf) + noise_w * nz.z) + bs) * 1.41421356237309515f;
+    o.w = lrelu02((up2_tap(src, H, W, oy, ox0 + 3, kf) + noise_w * nz.w) + bs) * 1.41421356237309515f;
+    *reinterpret_cast<float4*>(out + (((int64_t)b * C + c) * OH + oy) * OW + ox0) = o;
+  }
+}
+
+// StyledConv epilogue on its own (generality path): out = lrelu(x + noise_w*noise + bias[c], 0.2)*sqrt(2)
+__global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                                                             int64_t noise_bstride, float noise_w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int B, int C, int64_t HW) {
+  const int64_t total = (int64_t)B * C * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i % HW;
+    const int c = (int)((i / HW) % C);
+    const int b = (int)(i / (HW * C));
+    const float nz = noise ? noise_w * noise[(int64_t)b * noise_bstride + n] : 0.f;
+    out[i] = lrelu02((x[i] + nz) + bias[c]) * 1.41421356237309515f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ToRGB: 3 x Cin GEMV per pixel on the VALU (HBM-bound: Cin*4 B read per pixel), + bias + skip.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) torgb_kernel(const float* __restrict__ x, const float* __restrict__ wm,
+                                                    const float* __restrict__ bias, const float* __restrict__ skip,
+                                                    int skip_up, const float* __restrict__ fir, float* __restrict__ out,
+                                                    int B, int Cin, int H, int W) {
+  extern __shared__ float s_w[];   // [3][Cin] of this sample
+  const int b = blockIdx.y;
+  for (int i = threadIdx.x; i < 3 * Cin; i += 256) s_w[i] = wm[(int64_t)b * 3 * Cin + i];
+  __syncthreads();
+  float kf[16];
+  if (skip && skip_up) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
+  }
+  const int64_t HW = (int64_t)H * W;
+  const int64_t quads = HW / 4;
+  const float* xb = x + (int64_t)b * Cin * HW;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < quads; q += (int64_t)gridDim.x * blockDim.x) {
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), g = r, bl = r;
+#pragma unroll 4
+    for (int i = 0; i < Cin; ++i) {
+      const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW + q * 4);
+      const float w0 = s_w[i], w1 = s_w[Cin + i], w2 = s_w[2 * Cin + i];
+      r.x = fmaf(w0, v.x, r.x); r.y = fmaf(w0, v.y, r.y); r.z = fmaf(w0, v.z, r.z); r.w = fmaf(w0, v.w, r.w);
+      g.x = fmaf(w1, v.x, g.x); g.y = fmaf(w1, v.y, g.y); g.z = fmaf(w1, v.z, g.z); g.w = fmaf(w1, v.w, g.w);
+      bl.x = fmaf(w2, v.x, bl.x); bl.y = fmaf(w2, v.y, bl.y); bl.z = fmaf(w2, v.z, bl.z); bl.w = fmaf(w2, v.w, bl.w);
+    }
+    float4 res[3] = {r, g, bl};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float4 o = res[c];
+      const float bs = bias[c];
+      o.x += bs; o.y += bs; o.z += bs; o.w += bs;
+      if (skip) {
+        if (skip_up) {
+          const int oy = (int)((q * 4) / W), ox0 = (int)((q * 4) % W);
+          const float* sp = skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2);
+          o.x += up2_tap(sp, H / 2, W / 2, oy, ox0 + 0, kf);
+          o.y += up2_tap(sp, H / 2, W / 2, oy, ox0 + 1, kf);
+          o.z += up2_tap(sp, H / 2, W / 2, oy, ox0 + 2, kf);
+          o.w += up2_tap(sp, H / 2, W / 2, oy, ox0 + 3, kf);
+        } else {
+          const float4 sv = *reinterpret_cast<const float4*>(skip + ((int64_t)b * 3 + c) * HW + q * 4);
+          o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
+        }
+      }
+      *reinterpret_cast<float4*>(out + ((int64_t)b * 3 + c) * HW + q * 4) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// direct k x k (generality path: k = 3 configs, channel counts the MFMA kernel does not tile)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) modconv_kxk_kernel(const float* __restrict__ x, const float* __restrict__ wm,
+                                                          float* __restrict__ out, int B, int Cin, int Cout, int H,
+                                                          int W, int k, int transpose2, int OH, int OW) {
+  const int64_t total = (int64_t)B * Cout * OH * OW;
+  const int pad = k / 2;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int ox = (int)(t % OW); t /= OW;
+    const int oy = (int)(t % OH); t /= OH;
+    const int o = (int)(t % Cout);
+    const int b = (int)(t / Cout);
+    const float* wrow = wm + ((int64_t)b * Cout + o) * Cin * k * k;
+    const float* xb = x + (int64_t)b * Cin * H * W;
+    float acc = 0.f;
+    for (int i = 0; i < Cin; ++i) {
+      const float* xi = xb + (int64_t)i * H * W;
+      const float* wi = wrow + i * k * k;
+      for (int ky = 0; ky < k; ++ky) {
+        int iy;
+        if (transpose2) { const int ty = oy - ky; if (ty < 0 || (ty & 1)) continue; iy = ty >> 1; }
+        else iy = oy + ky - pad;
+        if (iy < 0 || iy >= H) continue;
+        for (int kx = 0; kx < k; ++kx) {
+          int ix;
+          if (transpose2) { const int tx = ox - kx; if (tx < 0 || (tx & 1)) continue; ix = tx >> 1; }
+          else ix = ox + kx - pad;
+          if (ix < 0 || ix >= W) continue;
+          acc = fmaf(xi[(int64_t)iy * W + ix], wi[ky * k + kx], acc);
+        }
+      }
+    }
+    out[idx] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm, int B, int Cout,
+                                       int Cin, int ksq, float scale, int demodulate, void* stream) {
+  if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
+  const int packed = (demodulate & 2) ? 1 : 0;
+  if (packed && (ksq != 1 || Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
+  const int64_t rows = (int64_t)B * Cout;
+  hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)ceil_div<int64_t>(rows, 4)), dim3(256), 0, as_stream(stream), W,
+                     s, s_stride, wm, B, Cout, Cin, ksq, scale, demodulate & 1, packed);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
+  return (Cin % 32 == 0) && (Cout % 32 == 0) && (HW % 4 == 0) && HW >= 4;
+}
+
+extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
+                                 int epilogue, const float* noise, int64_t noise_bstride, float noise_w,
+                                 const float* bias, void* stream) {
+  if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (epilogue != 0 && epilogue != 1) return CIPS3D_E_BADARG;
+  if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;
+  if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias};
+  hipStream_t st = as_stream(stream);
+  if (Cout % 128 == 0 && Cout <= 128) return launch_gemm<2, 2, 2, 2, 32>(a, st);   // 128 x 128: x read once
+  if (Cout % 64 == 0 && Cout > 128) return launch_gemm<1, 2, 2, 2, 32>(a, st);     // 64 x 128
+  if (Cout == 64) return launch_gemm<2, 2, 1, 4, 16>(a, st);                        // 64 x 256
+  return launch_gemm<1, 2, 1, 4, 16>(a, st);                                        // 32 x 256 (any Cout % 32 == 0)
+}
+
+extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
+                                  const float* noise, int64_t noise_bstride, float noise_w, const float* bias,
+                                  void* stream) {
+  if (!y_lo || !fir || !out || !bias || B < 0 || C <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
+  if (W % 2 != 0) return CIPS3D_E_UNSUPP;     // 16-byte output quads
+  if (B == 0) return 0;
+  const int64_t total = (int64_t)B * C * (2 * H) * (2 * W / 4);
+  int64_t blocks = ceil_div<int64_t>(total, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(up2_fir_act_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), y_lo, fir, out, B,
+                     C, H, W, noise, noise_bstride, noise_w, bias);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, float noise_w,
+                                     const float* bias, float* out, int B, int C, int64_t HW, void* stream) {
+  if (!x || !bias || !out || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>((int64_t)B * C * HW, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(noise_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, noise,
+                     noise_bstride, noise_w, bias, out, B, C, HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,
+                            const float* fir, float* out, int B, int Cin, int H, int W, void* stream) {
+  if (!x || !wm || !bias || !out || B < 0 || Cin <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
+  if (skip && skip_up && (!fir || (H % 2) || (W % 2))) return CIPS3D_E_BADARG;
+  if (((int64_t)H * W) % 4 != 0 || W % 4 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  const int64_t quads = (int64_t)H * W / 4;
+  int64_t bx = ceil_div<int64_t>(quads, 256);
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(torgb_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), sizeof(float) * 3 * Cin,
+                     as_stream(stream), x, wm, bias, skip, skip_up, fir, out, B, Cin, H, W);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int H, int W,
+                                  int k, int transpose2, void* stream) {
+  if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || k <= 0 || (k % 2) == 0)
+    return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  const int OH = transpose2 ? 2 * H - 1 + k - 1 : H, OW = transpose2 ? 2 * W - 1 + k - 1 : W;
+  const int64_t total = (int64_t)B * Cout * OH * OW;
+  int64_t blocks = ceil_div<int64_t>(total, 256);
+  if (blocks > 65535) blocks = 65535;
+  hipLaunchKernelGGL(modconv_kxk_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, wm, out, B, Cin,
+                     Cout, H, W, k, transpose2, OH, OW);
+  return cips3d_launch_status();
+}

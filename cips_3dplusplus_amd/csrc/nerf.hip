@@ -1,0 +1,508 @@
+// NeRF-style volume renderer of CIPS-3D++ on gfx950:
+//   get_rays_in_world -> get_z_vals (offset sampling) -> get_points/normalize_points
+//   (reference cips3d/nerf_utils.py:18-170) -> FiLM-SIREN point MLP (cips3d/volume_renderer.py:39-160)
+//   -> volume_integration (cips3d/nerf_utils.py:230-338), fused in ONE kernel; point activations never
+//   leave the register file.
+//
+// Work decomposition.  A *task* = (view b, group of 16 rays, chunk c of the ray's samples); one
+// wavefront per task, eight tasks per 512-thread workgroup (two waves per SIMD).  Lane l works on ray
+// (l & 15); the four 16-lane quarters (qd = l >> 4) hold the four k-slices that
+// v_mfma_f32_16x16x4_f32 consumes.  The wave walks its chunk's samples one by one; per sample it
+// evaluates the whole MLP for its 16 points:
+//
+//   layer 0 (3 -> H)          VALU, written straight into MFMA "D layout"
+//   layers 1..D-1 (H -> H)    Y^T[o][p] = sum_k W[o][k] X^T[k][p] on fp32 MFMA: A = W tile (from LDS),
+//                             B = X^T, D = Y^T.  D has the point on the lane and 4 consecutive hidden
+//                             units in its 4 accumulator registers, which is exactly the B-operand
+//                             layout of the next layer -> no LDS round trip, no shuffles for activations.
+//   view layer (H+3 -> H)     3 view-direction terms pre-loaded into the accumulator, then MFMA; the
+//                             finished tile is folded straight into the feature accumulators
+//   sigma / rgb heads         per-lane dot over its registers + two cross-quarter adds
+//   compositing               per-lane running transmittance over the chunk (no scan needed because a
+//                             lane owns a ray), partial sums kept in registers
+//
+// Register budget per lane (H = 256): X 64 + Y 64 + feature accumulators 64 + scalars => < 256, so two
+// waves share a SIMD: one wave's sine epilogue (VALU) runs under the other's MFMAs, and the 40-cycle
+// dependent-accumulator latency of the 16x16x4 form is covered by the partner wave.
+//
+// Weights: every CU streams the same (D * H*H) packed floats from L2 through a 2-slot LDS ring, one
+// slab = TPS o-tiles (16*TPS rows x H) per step, fetched with global_load_lds (LDS-DMA) while the
+// previous slab is being multiplied.  The pack kernel stores W in the exact order the lanes read
+// their A fragments, so the LDS image is lane-linear and every ds_read_b128 is conflict-free.
+//
+// Chunk partials (T, sum w*feat, ...) are combined in sample order by nerf_finish (compositing is
+// associative: S = S_a + T_a * S_b, T = T_a * T_b), which also emits the NCHW feature map.
+//
+// Roofline: MFMA-bound. flops/point = 2*3*H + (D-1)*2*H^2 + 2*(H+3)*H + 2*H*4; HBM traffic is the
+// partials only (n_chunks * (H+8) * 4 B per ray).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RAYS = 16;    // rays per wave task
+constexpr int WAVES = 8;    // waves (tasks) per workgroup
+
+struct NerfArgs {
+  cips3d_nerf_params p;
+  int groups;          // ray groups of 16 per view
+  int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
+  int chunk;           // samples per chunk (uniform trip count)
+};
+
+// ------------------------------------------------------------------------------------------------
+// weight packing.  o-tile t = 16 output units; k-step s = 4 input units, one per lane quarter.
+//   packed[l][t][q4][lane][j] = W_l[t*16 + (lane&15)][ (s>>2)*16 + 4*(lane>>4) + (s&3) ],  s = 4*q4 + j
+// (s indexes the B-operand register of the previous layer's D layout: tile s>>2, register s&3.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict__ w_hidden,
+                                                        const float* __restrict__ w_view,
+                                                        float* __restrict__ packed, int H, int D) {
+  const int64_t per_layer = (int64_t)H * H;
+  const int64_t total = per_layer * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int l = (int)(i / per_layer);
+    int64_t rem = i - l * per_layer;
+    const int tile_floats = 16 * H;
+    const int t = (int)(rem / tile_floats);
+    rem -= (int64_t)t * tile_floats;
+    const int q4 = (int)(rem / 256);
+    const int lane = (int)((rem % 256) / 4);
+    const int j = (int)(rem % 4);
+    const int s = 4 * q4 + j;
+    const int o = t * 16 + (lane & 15);
+    const int k = (s >> 2) * 16 + 4 * (lane >> 4) + (s & 3);
+    float v;
+    if (l < D - 1) v = w_hidden[(int64_t)l * per_layer + (int64_t)o * H + k];
+    else           v = w_view[(int64_t)o * (H + 3) + k];
+    packed[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA of one weight slab (SLAB floats, linear copy, 1 KiB per wave-instruction)
+// ------------------------------------------------------------------------------------------------
+template <int SLAB>
+__device__ __forceinline__ void stage_slab(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
+  constexpr int PIECES = SLAB * 4 / 1024;
+  constexpr int PER_WAVE = (PIECES + WAVES - 1) / WAVES;
+#pragma unroll
+  for (int j = 0; j < PER_WAVE; ++j) {
+    const int piece = j * WAVES + wave;
+    if (PIECES % WAVES == 0 || piece < PIECES) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+          (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_acc(float v) { return 1.f / (1.f + expf(-v)); }
+
+// Per-wave streaming state of the weight ring.
+struct Ring {
+  const float* packed;   // global base of the packed stream (one sample's worth, repeated)
+  float* lds;            // 2 slots
+  int seq;               // slabs consumed so far
+  int seq_end;           // total slabs this workgroup will consume
+  int per_sample;        // slabs per sample
+};
+
+// One MFMA layer for the wave's 16 points.
+//   VIEW = false: Y = sin(gamma * (W X) + c)
+//   VIEW = true : f = sin(gamma * (W X + Wd v) + c);  FA += w * f;  rgb head partial sums += Wc f
+// The caller guarantees slab `seq` is resident in slot (seq & 1); every slab step prefetches seq+1
+// while multiplying and ends with wait + barrier.
+template <int NT, int TPS, bool VIEW>
+__device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[NT * 4], float (&FA)[NT * 4],
+                                           float wgt, float (&chead)[3], Ring& ring, const float* film_l,
+                                           const float* s_wd, const float* s_wc, float vx, float vy, float vz,
+                                           int wave, int lane, int q4o) {
+  constexpr int H = NT * 16;
+  constexpr int TILE = 16 * H;          // floats of one o-tile's A fragments
+  constexpr int SLAB = TILE * TPS;
+#pragma unroll
+  for (int sl = 0; sl < NT / TPS; ++sl) {
+    if (ring.seq + 1 < ring.seq_end) {
+      const int nxt = (ring.seq + 1) % ring.per_sample;
+      stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
+    }
+    const float* slab = ring.lds + (ring.seq & 1) * SLAB;
+#pragma unroll
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int t = sl * TPS + tt;
+      const int o4 = t * 16 + q4o;        // this lane's 4 consecutive output units
+      f32x4 acc;
+      if (VIEW) {
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(s_wd + o4);
+        const f32x4 wy = *reinterpret_cast<const f32x4*>(s_wd + H + o4);
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(s_wd + 2 * H + o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wz[i], vz, fmaf(wy[i], vy, wx[i] * vx));
+      } else {
+        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const float* tile = slab + tt * TILE;
+#pragma unroll
+      for (int q4 = 0; q4 < H / 16; ++q4) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tile + (q4 * 64 + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], X[4 * q4 + j], acc, 0, 0, 0);
+      }
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + o4);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(film_l + H + o4);
+      if (VIEW) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_wc + o4);
+        const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_wc + H + o4);
+        const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_wc + 2 * H + o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float f = sin_accurate(fmaf(g4[i], acc[i], c4[i]));
+          FA[t * 4 + i] = fmaf(wgt, f, FA[t * 4 + i]);
+          chead[0] = fmaf(w0[i], f, chead[0]);
+          chead[1] = fmaf(w1[i], f, chead[1]);
+          chead[2] = fmaf(w2[i], f, chead[2]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Y[t * 4 + i] = sin_accurate(fmaf(g4[i], acc[i], c4[i]));
+      }
+    }
+    // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
+    __syncthreads();
+    ++ring.seq;
+  }
+}
+
+template <int NT, int TPS>
+__global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
+  constexpr int H = NT * 16;
+  constexpr int SLAB = 16 * H * TPS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const cips3d_nerf_params& P = a.p;
+  const int D = P.depth;
+  const int L = D + 1;
+  float* ringmem = lds;                      // 2 * SLAB
+  float* s_film = ringmem + 2 * SLAB;        // L * 2 * H
+  float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed
+  float* s_wd = s_w0 + 3 * H;                // [3][H]  view-direction columns of the view layer
+  float* s_ws = s_wd + 3 * H;                // [H]     sigma head
+  float* s_wc = s_ws + H;                    // [3][H]  rgb head
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int qd = lane >> 4;
+  const int pl = lane & 15;
+
+  // ---- task decode (b is uniform over the workgroup: tasks_per_view is a multiple of WAVES)
+  const int64_t task0 = (int64_t)blockIdx.x * WAVES;
+  const int b = (int)(task0 / a.tasks_per_view);
+  const int tv = (int)(task0 % a.tasks_per_view) + wave;
+  const bool task_ok = tv < a.groups * P.n_chunks;
+  const int g = task_ok ? tv / P.n_chunks : 0;
+  const int c = task_ok ? tv % P.n_chunks : 0;
+  const int S = P.img_size;
+  const int R = S * S;
+  const int ray = g * RAYS + pl;
+  const bool ray_ok = task_ok && ray < R;
+  const int rayc = ray < R ? ray : R - 1;
+
+  // ---- stage the small per-view tables
+  {
+    // FiLM table: s_film[l][0][o] = gamma, s_film[l][1][o] = gamma * bias_l[o] + beta, so that
+    // sin(gamma * (W x + bias) + beta) = sin(gamma * (W x) + c) costs one FMA per unit.
+    const float* film_b = P.film + (int64_t)b * L * 2 * H;
+    for (int i = tid; i < L * H; i += 512) {
+      const int l = i / H, o = i - l * H;
+      const float gm = film_b[(l * 2) * H + o];
+      s_film[(l * 2) * H + o] = gm;
+      s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]);
+    }
+    for (int i = tid; i < 3 * H; i += 512) {
+      const int k = i / H, o = i - k * H;
+      s_w0[i] = P.w_first[o * 3 + k];
+      s_wd[i] = P.w_view[o * (H + 3) + H + k];
+      s_wc[i] = P.w_rgb[i];
+    }
+    for (int i = tid; i < H; i += 512) s_ws[i] = P.w_sigma[i];
+  }
+
+  const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
+  const float sig_beta = P.sigmoid_beta[0];
+
+  // ---- ray setup (nerf_utils.py:38-66)
+  const float focal = P.focals[b];
+  const float nearv = P.near_[b], farv = P.far_[b];
+  const float* cw = P.cam_poses + 12 * b;
+  const int pi = rayc / S, pj = rayc - pi * S;
+  const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+  const float dcx = (px - (float)S * 0.5f) / focal;
+  const float dcy = -(py - (float)S * 0.5f) / focal;
+  const float dcz = -1.f;
+  const float dx = (dcx * cw[0] + dcy * cw[1]) + dcz * cw[2];
+  const float dy = (dcx * cw[4] + dcy * cw[5]) + dcz * cw[6];
+  const float dz = (dcx * cw[8] + dcy * cw[9]) + dcz * cw[10];
+  const float ox = cw[3], oy = cw[7], oz = cw[11];
+  float vx = P.static_viewdirs ? dcx : dx, vy = P.static_viewdirs ? dcy : dy, vz = P.static_viewdirs ? dcz : dz;
+  {
+    const float n = fmaxf(sqrtf((vx * vx + vy * vy) + vz * vz), 1e-12f);
+    vx /= n; vy /= n; vz /= n;
+  }
+  const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
+  const float u = P.perturb_u ? P.perturb_u[(int64_t)b * R + rayc] : 0.f;
+  const float span = farv - nearv;
+  const int N = P.n_samples;
+  // torch.linspace(0, 1 - 1/N, N): symmetric evaluation around the midpoint
+  const float t_end = (float)(1.0 - 1.0 / (double)N);
+  const float t_step = N > 1 ? t_end / (float)(N - 1) : 0.f;
+  auto zbase = [&](int k) -> float {  // un-perturbed depth of sample k; k == N gives `far`
+    if (k >= N) return farv;
+    const float t = (k < N / 2) ? t_step * (float)k : t_end - t_step * (float)(N - 1 - k);
+    return nearv * (1.f - t) + farv * t;
+  };
+  auto zsample = [&](int k) -> float {
+    const float z0 = zbase(k);
+    return P.perturb_u ? z0 + (zbase(k + 1) - z0) * u : z0;
+  };
+
+  // ---- per-lane compositing state
+  float FA[NT * 4];
+#pragma unroll
+  for (int i = 0; i < NT * 4; ++i) FA[i] = 0.f;
+  float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, ax = 0.f, ay = 0.f, az = 0.f, wlast = 0.f;
+
+  Ring ring;
+  ring.packed = P.packed;
+  ring.lds = ringmem;
+  ring.seq = 0;
+  ring.per_sample = D * (NT / TPS);
+  ring.seq_end = a.chunk * ring.per_sample;
+  stage_slab<SLAB>(P.packed, ringmem, wave, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+
+  const int s_begin = c * a.chunk;
+  for (int si = 0; si < a.chunk; ++si) {
+    const int sg = s_begin + si;
+    const bool live = ray_ok && sg < N;
+    const int sk = sg < N ? sg : N - 1;
+    const float z = zsample(sk);
+    const float ptx = ox + dx * z, pty = oy + dy * z, ptz = oz + dz * z;
+    const float nx = ptx * 2.f / span, ny = pty * 2.f / span, nz = ptz * 2.f / span;
+    // Opaque zero folded into every table offset of this iteration: the tables are loop-invariant and
+    // LICM would otherwise hoist ~5*H/4 registers of them out of the sample loop (and spill them).
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const int q4o = 4 * qd + opq;
+
+    float X[NT * 4], Y[NT * 4];
+    // ---- layer 0: 3 -> H on the VALU, in D layout
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int o4 = t * 16 + q4o;
+      const f32x4 wx = *reinterpret_cast<const f32x4*>(s_w0 + o4);
+      const f32x4 wy = *reinterpret_cast<const f32x4*>(s_w0 + H + o4);
+      const f32x4 wz = *reinterpret_cast<const f32x4*>(s_w0 + 2 * H + o4);
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_film + o4);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(s_film + H + o4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
+        X[t * 4 + i] = sin_accurate(fmaf(g4[i], pre, c4[i]));
+      }
+    }
+    float chead[3] = {0.f, 0.f, 0.f};
+    // ---- hidden layers 1 .. D-1
+    for (int l = 1; l < D; ++l) {
+      mfma_layer<NT, TPS, false>(X, Y, FA, 0.f, chead, ring, s_film + l * 2 * H, s_wd, s_wc, vx, vy, vz, wave,
+                                 lane, q4o);
+#pragma unroll
+      for (int i = 0; i < NT * 4; ++i) X[i] = Y[i];
+    }
+    // ---- sigma head on h_D (volume_renderer.py:148)
+    float sdf = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_ws + t * 16 + q4o);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sdf = fmaf(w4[i], X[t * 4 + i], sdf);
+    }
+    sdf += __shfl_xor(sdf, 16, 64);
+    sdf += __shfl_xor(sdf, 32, 64);
+    sdf += b_sigma;
+
+    // ---- compositing weight of this sample (nerf_utils.py:264-307); known before the view layer
+    const float delta = (sk < N - 1 ? zsample(sk + 1) - z : 1e10f) * dnorm;
+    const float sigma = sigmoidf_acc(-sdf / sig_beta) / sig_beta;
+    const float alpha = 1.f - expf(-sigma * delta);
+    const float w = live ? alpha * T : 0.f;
+    if (live) T *= (1.f - alpha) + 1e-10f;
+
+    // ---- view layer -> features, folded into FA; rgb head partial sums
+    mfma_layer<NT, TPS, true>(X, Y, FA, w, chead, ring, s_film + D * 2 * H, s_wd, s_wc, vx, vy, vz, wave, lane,
+                              q4o);
+    float c0 = chead[0], c1 = chead[1], c2 = chead[2];
+    c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
+    c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+    c0 += b_rgb0; c1 += b_rgb1; c2 += b_rgb2;
+
+    cr = fmaf(w, sigmoidf_acc(c0), cr); cg = fmaf(w, sigmoidf_acc(c1), cg); cb = fmaf(w, sigmoidf_acc(c2), cb);
+    ax = fmaf(w, ptx, ax); ay = fmaf(w, pty, ay); az = fmaf(w, ptz, az);
+    if (sg == N - 1) wlast = w;
+    if (P.sdf && live && qd == 0) P.sdf[((int64_t)b * R + ray) * N + sg] = sdf;
+  }
+
+  // ---- write the chunk partial: part[c][b][ch][ray]
+  if (ray_ok) {
+    float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dst[(int64_t)(t * 16 + 4 * qd + r) * R] = FA[t * 4 + r];
+    if (qd == 0) {
+      dst[(int64_t)(H + 0) * R] = cr; dst[(int64_t)(H + 1) * R] = cg;
+    } else if (qd == 1) {
+      dst[(int64_t)(H + 2) * R] = cb; dst[(int64_t)(H + 3) * R] = ax;
+    } else if (qd == 2) {
+      dst[(int64_t)(H + 4) * R] = ay; dst[(int64_t)(H + 5) * R] = az;
+    } else {
+      dst[(int64_t)(H + 6) * R] = wlast; dst[(int64_t)(H + 7) * R] = T;
+    }
+  }
+}
+
+// features[b][ch][ray] = sum_c (prod_{c'<c} T_c') * part[c][b][ch][ray]; same for rgb/xyz/w_last.
+__global__ void __launch_bounds__(256) nerf_finish_kernel(const float* __restrict__ part, int C, int B, int R,
+                                                          int H, float* __restrict__ features,
+                                                          float* __restrict__ thumb, float* __restrict__ xyz,
+                                                          float* __restrict__ mask) {
+  const int CH = H + 8;
+  const int64_t total = (int64_t)B * (H + 7) * R;   // channel H+7 (T) is consumed, not emitted
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ray = (int)(i % R);
+  const int ch = (int)((i / R) % (H + 7));
+  const int b = (int)(i / ((int64_t)R * (H + 7)));
+  float Tp = 1.f, acc = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float* pc = part + ((int64_t)(c * B + b) * CH) * R + ray;
+    acc = fmaf(Tp, pc[(int64_t)ch * R], acc);
+    Tp *= pc[(int64_t)(H + 7) * R];
+  }
+  if (ch < H) {
+    features[((int64_t)b * H + ch) * R + ray] = acc;
+  } else if (ch < H + 3) {
+    thumb[((int64_t)b * 3 + (ch - H)) * R + ray] = -1.f + 2.f * acc;
+  } else if (ch < H + 6) {
+    xyz[((int64_t)b * 3 + (ch - H - 3)) * R + ray] = acc;
+  } else {
+    mask[((int64_t)b * 2 + 0) * R + ray] = acc;
+  }
+}
+
+// depth = -|xyz| (second mask channel); separate tiny pass because it needs all three xyz sums
+__global__ void __launch_bounds__(256) nerf_depth_kernel(const float* __restrict__ xyz, float* __restrict__ mask,
+                                                         int B, int R) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * R) return;
+  const int b = (int)(i / R), ray = (int)(i % R);
+  const float x = xyz[((int64_t)b * 3 + 0) * R + ray], y = xyz[((int64_t)b * 3 + 1) * R + ray],
+              z = xyz[((int64_t)b * 3 + 2) * R + ray];
+  mask[((int64_t)b * 2 + 1) * R + ray] = -sqrtf((x * x + y * y) + z * z);
+}
+
+template <int NT, int TPS>
+int launch_render(const NerfArgs& a, hipStream_t st) {
+  const cips3d_nerf_params& P = a.p;
+  constexpr int H = NT * 16;
+  const size_t lds_bytes = sizeof(float) * (2 * 16 * H * TPS + (size_t)(P.depth + 1) * 2 * H + 10 * H);
+  if (lds_bytes > 160 * 1024) return CIPS3D_E_UNSUPP;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS>), dim3((unsigned)wgs), dim3(512), lds_bytes, st, a);
+  return cips3d_launch_status();
+}
+
+}  // namespace
+
+extern "C" int cips3d_nerf_pack_weights(const float* w_hidden, const float* w_view, float* packed, int hidden,
+                                        int depth, void* stream) {
+  if (!w_view || !packed || hidden <= 0 || depth < 1 || (depth > 1 && !w_hidden)) return CIPS3D_E_BADARG;
+  if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return CIPS3D_E_UNSUPP;
+  const int64_t total = (int64_t)hidden * hidden * depth;
+  hipLaunchKernelGGL(nerf_pack_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0,
+                     as_stream(stream), w_hidden, w_view, packed, hidden, depth);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_nerf_suggest_chunks(int B, int img_size, int n_samples) {
+  if (B <= 0 || img_size <= 0 || n_samples <= 0) return 1;
+  const int64_t groups = ceil_div<int64_t>((int64_t)img_size * img_size, 16);
+  // want >= 2048 wave tasks (256 CUs x 4 SIMDs x 2 waves); more chunks = more partial traffic
+  int64_t want = ceil_div<int64_t>(2048, (int64_t)B * groups);
+  if (want < 1) want = 1;
+  if (want > n_samples) want = n_samples;
+  // round up to a divisor-friendly count: smallest C >= want whose chunk size ceil(N/C) wastes nothing
+  int best = (int)want;
+  for (int C = (int)want; C <= n_samples; ++C) {
+    if (n_samples % C == 0) { best = C; break; }
+  }
+  return best;
+}
+
+extern "C" int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int n_chunks) {
+  return (int64_t)n_chunks * B * (hidden + 8) * img_size * img_size;
+}
+
+extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
+  if (!p) return CIPS3D_E_BADARG;
+  const cips3d_nerf_params& P = *p;
+  if (!P.cam_poses || !P.focals || !P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
+      !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || !P.sigmoid_beta || !P.part)
+    return CIPS3D_E_BADARG;
+  if (P.B < 0 || P.img_size <= 0 || P.n_samples <= 0 || P.depth < 1 || P.n_chunks < 1 ||
+      P.n_chunks > P.n_samples)
+    return CIPS3D_E_BADARG;
+  if (P.B == 0) return 0;
+  NerfArgs a;
+  a.p = P;
+  a.groups = ceil_div(P.img_size * P.img_size, RAYS);
+  a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
+  a.chunk = ceil_div(P.n_samples, P.n_chunks);
+  hipStream_t st = as_stream(stream);
+  switch (P.hidden) {
+    case 32: return launch_render<2, 2>(a, st);
+    case 64: return launch_render<4, 2>(a, st);
+    case 128: return launch_render<8, 2>(a, st);
+    case 256: return launch_render<16, 2>(a, st);
+    default: return CIPS3D_E_UNSUPP;
+  }
+}
+
+extern "C" int cips3d_nerf_finish(const float* part, int n_chunks, int B, int img_size, int hidden,
+                                  float* features, float* thumb_rgb, float* xyz, float* mask, void* stream) {
+  if (!part || !features || !thumb_rgb || !xyz || !mask || n_chunks < 1 || B < 0 || img_size <= 0 || hidden <= 0)
+    return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  const int R = img_size * img_size;
+  const int64_t total = (int64_t)B * (hidden + 7) * R;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(nerf_finish_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, st, part,
+                     n_chunks, B, R, hidden, features, thumb_rgb, xyz, mask);
+  int rc = cips3d_launch_status();
+  if (rc) return rc;
+  hipLaunchKernelGGL(nerf_depth_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * R, 256)), dim3(256), 0, st,
+                     xyz, mask, B, R);
+  return cips3d_launch_status();
+}

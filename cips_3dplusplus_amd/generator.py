@@ -1,0 +1,180 @@
+"""Generator of CIPS-3D++ behind the reference call surface
+(/root/reference/exp/cips3d/models/model_v3.py:808-1490): same constructor dict arguments, same
+`forward(...)` keyword arguments, same `ret_maps` keys, same `state_dict` key names.
+
+forward = mapping networks (cips3d_linear chain) -> fused NeRF render (csrc/nerf.hip) -> decoder
+(csrc/decoder.hip).  Inference path only: no autograd graph is built (the reference's training-only
+switches raise, see `forward`).  RNG sites of the reference stay RNG sites here (per-ray jitter when
+`perturb`, fresh decoder noise when `noise_bufs` is None, 10 000 z's in `get_mean_latent`) and are
+injectable for parity runs (`perturb_u=`, `noise_bufs=`, preset `style_render_mean` /
+`style_decoder_mean` attributes).
+"""
+import torch
+from torch import nn
+
+from .decoder import Decoder, EqualLinear, MappingLinear, PixelNorm
+from .renderer import VolumeFeatureRenderer
+
+
+class Generator(nn.Module):
+    def __init__(self, enable_decoder, freeze_renderer, renderer_detach=True, predict_rgb_residual=False,
+                 scale_factor=None, renderer_cfg={}, mapping_renderer_cfg={}, decoder_cfg={},
+                 mapping_decoder_cfg={}, **kwargs):
+        super().__init__()
+        if not enable_decoder:
+            raise NotImplementedError("enable_decoder=False raises in the reference as well (model_v3.py:1025-1026)")
+        self.enable_decoder, self.freeze_renderer, self.renderer_detach = enable_decoder, freeze_renderer, renderer_detach
+        self.predict_rgb_residual, self.scale_factor = predict_rgb_residual, scale_factor
+        self.renderer_cfg, self.mapping_renderer_cfg = renderer_cfg, mapping_renderer_cfg
+        self.decoder_cfg, self.mapping_decoder_cfg = decoder_cfg, mapping_decoder_cfg
+        self.module_name_list = []
+
+        # construction order = reference order (renderer, style, decoder, style_decoder): seeded init parity
+        self.renderer = VolumeFeatureRenderer(style_dim=mapping_renderer_cfg["style_dim"], **renderer_cfg)
+        self.module_name_list.append("renderer")
+        self.N_layers_renderer = self.renderer.N_layers_renderer
+        self.create_mapping_nerf(**mapping_renderer_cfg)
+        self.z_dim = mapping_renderer_cfg["z_dim"]
+        self.decoder = Decoder(style_dim=mapping_decoder_cfg["style_dim"],
+                               **{**decoder_cfg, "in_channel": renderer_cfg["hidden_dim"]})
+        self.module_name_list.append("decoder")
+        self.create_mapping_decoder(z_dim=mapping_renderer_cfg["style_dim"], **mapping_decoder_cfg)
+
+    # ---------------------------------------------------------------- construction helpers
+    def create_mapping_nerf(self, z_dim, style_dim, N_layers):
+        self.style = nn.Sequential(*[MappingLinear(z_dim, style_dim, activation="fused_lrelu") for _ in range(N_layers)])
+        self.module_name_list += [f"style.{i}" for i in range(N_layers)] + ["style"]
+
+    def create_mapping_decoder(self, z_dim, style_dim, lr_mul_mapping, N_layers):
+        layers = [PixelNorm(), EqualLinear(z_dim, style_dim, lr_mul=lr_mul_mapping, activation="fused_lrelu")]
+        layers += [EqualLinear(style_dim, style_dim, lr_mul=lr_mul_mapping, activation="fused_lrelu")
+                   for _ in range(N_layers - 1)]
+        self.style_decoder = nn.Sequential(*layers)
+        self.module_name_list += [f"style_decoder.{i}" for i in range(N_layers + 1)] + ["style_decoder"]
+
+    # ---------------------------------------------------------------- mapping networks
+    def _run_style(self, z, trunc_mean=None, psi=1.0):
+        h = z.float().contiguous()
+        n = len(self.style)
+        for i, layer in enumerate(self.style):
+            last = i == n - 1
+            h = layer(h, trunc_mean=trunc_mean if last else None, trunc_psi=psi)
+        return h
+
+    def _run_style_decoder(self, z, trunc_mean=None, psi=1.0):
+        h = z.float().contiguous()
+        layers = list(self.style_decoder)[1:]
+        for i, layer in enumerate(layers):
+            last = i == len(layers) - 1
+            h = layer(h, pixelnorm=(i == 0), trunc_mean=trunc_mean if last else None, trunc_psi=psi)
+        return h
+
+    @torch.no_grad()
+    def get_mean_latent(self, N_noises, device):
+        """model_v3.py:1285-1297."""
+        zr = torch.randn(N_noises, self.z_dim, device=device)
+        mean_r = self._run_style(zr).mean(0, keepdim=True)
+        zd = torch.randn(N_noises, self.z_dim, device=device)
+        mean_d = self._run_style_decoder(zd).mean(0, keepdim=True)
+        return mean_r, mean_d
+
+    def mapping_renderer(self, zs, truncation, style_render_mean=None, **kwargs):
+        """model_v3.py:1402-1418."""
+        m = style_render_mean.reshape(-1).contiguous() if truncation < 1 else None
+        latents = [self._run_style(z, m, float(truncation)) for z in zs]
+        return latents[0].unsqueeze(1).repeat(1, self.N_layers_renderer + 1, 1), latents
+
+    def mapping_decoder(self, latents, truncation, style_decoder_mean, inject_index=None):
+        """model_v3.py:1350-1378."""
+        m = style_decoder_mean.reshape(-1).contiguous() if truncation < 1 else None
+        styles = [self._run_style_decoder(z, m, float(truncation)) for z in latents]
+        n_latent = self.decoder.n_latent
+        if len(styles) < 2:
+            return styles[0].unsqueeze(1).repeat(1, n_latent, 1)
+        if inject_index is None:
+            inject_index = n_latent
+        return torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                          styles[1].unsqueeze(1).repeat(1, n_latent - inject_index, 1)], 1)
+
+    def mapping_networks(self, zs, truncation, inject_index, path_reg=False, style_render=None, style_decoder=None,
+                         recompute_mean=False):
+        """model_v3.py:1299-1348."""
+        if style_render is not None and style_decoder is not None:
+            return style_render, style_decoder
+        if (style_render is None) != (style_decoder is None):
+            raise NotImplementedError
+        if truncation < 1:
+            if recompute_mean or not hasattr(self, "style_render_mean") or not hasattr(self, "style_decoder_mean"):
+                self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, zs[0].device)
+            mean_r, mean_d = self.style_render_mean, self.style_decoder_mean
+        else:
+            mean_r = mean_d = None
+        style_render, _ = self.mapping_renderer([zs[0]], truncation, mean_r)
+        style_decoder = self.mapping_decoder([zs[1]], truncation, mean_d, inject_index)
+        return style_render, style_decoder
+
+    def get_ws(self, zs, truncation, device):
+        """model_v3.py:1472-1490."""
+        mean_r, mean_d = self.get_mean_latent(10000, device)
+        w_r = self._run_style(zs[0], mean_r.reshape(-1).contiguous(), float(truncation))
+        w_d = self._run_style_decoder(zs[1], mean_d.reshape(-1).contiguous(), float(truncation))
+        return (w_r[:, None, :].repeat(1, self.N_layers_renderer + 1, 1),
+                w_d[:, None, :].repeat(1, self.decoder.n_latent, 1))
+
+    # ---------------------------------------------------------------- noise
+    def create_noise_bufs(self, start_size, device):
+        return self.decoder.create_noise_bufs(start_size=start_size, device=device)
+
+    def get_noise_bufs(self, noise_bufs, randomize_noise):
+        if noise_bufs is None:
+            if not randomize_noise:
+                raise NotImplementedError
+            noise_bufs = [None] * self.decoder.num_layers
+        return noise_bufs
+
+    # ---------------------------------------------------------------- forward
+    @torch.no_grad()
+    def forward(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
+                path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
+                eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
+                N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
+                renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, **kwargs):
+        assert len(zs) == 2
+        if eikonal_reg or path_reg:
+            raise NotImplementedError("eikonal_reg / path_reg are training-only (double backward); inference path here")
+        if N_rays_grad is not None or sample_idx_h is not None or sample_idx_w is not None:
+            raise NotImplementedError("ray sub-sampling is training-only (raises in the reference too, model_v3.py:954-956)")
+        if project_noise:
+            raise NotImplementedError("project_noise needs pytorch3d mesh rendering; unused by released configs")
+        # N_rays_forward / N_samples_forward only bound activation memory in the reference; the fused kernel
+        # never materialises per-point activations, so they are accepted and ignored.
+        style_render, style_decoder = self.mapping_networks(
+            zs=zs, truncation=truncation, inject_index=inject_index, style_render=style_render,
+            style_decoder=style_decoder, recompute_mean=recompute_mean)
+        noise_bufs = self.get_noise_bufs(noise_bufs, randomize_noise)
+
+        B = cam_poses.shape[0]
+        dev = cam_poses.device
+        N = int(nerf_cfg["N_samples"])
+        if nerf_cfg.get("perturb", False) and perturb_u is None:
+            perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)   # one jitter per ray (nerf_utils.py:110)
+        if not nerf_cfg.get("perturb", False):
+            perturb_u = None
+
+        def per_view(v):
+            return v if torch.is_tensor(v) else torch.full((B, 1, 1), float(v), device=dev)
+
+        thumb_rgb, features, sdf, mask, xyz = self.renderer.render(
+            cam_poses, per_view(focals), per_view(near), per_view(far), style_render, img_size, N,
+            perturb_u=perturb_u, static_viewdirs=nerf_cfg.get("static_viewdirs", False), return_sdf=return_sdf)
+        rgb = self.decoder(features=features, styles=style_decoder, rgbd_in=None, noise=noise_bufs)
+        return {
+            "rgb": rgb,
+            "thumb_rgb": thumb_rgb,
+            "style_decoder": None,
+            "eikonal_term": None,
+            "sdf": sdf if return_sdf else None,
+            "xyz": xyz if return_xyz else None,
+            "mask": mask[:, [0]],
+            "depth": mask[:, [1]],
+        }

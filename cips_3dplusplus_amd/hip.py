@@ -1,0 +1,210 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point of include/cips3d_hip.h).
+
+PyTorch is used for device memory and streams only: outputs are allocated with torch, pointers and
+the current stream are handed to the HIP library.  Nothing here computes on the host.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import dev_ptr, stream_ptr, check
+
+MOD_DEMODULATE = 1
+MOD_PACKED = 2
+
+
+def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False, lrelu=False, act_gain=1.0,
+           out_scale=1.0, out_shift=0.0, trunc_mean=None, trunc_psi=1.0):
+    """x [B,in] -> [B,out]; see cips3d_linear."""
+    lib = _lib.load()
+    B, in_dim = x.shape
+    out_dim = W.shape[0]
+    if out is None:
+        out = torch.empty(B, out_dim, device=x.device, dtype=torch.float32)
+    check(lib.cips3d_linear(dev_ptr(x, "x"), x.stride(0), dev_ptr(W, "W"), dev_ptr(bias, "bias", True), dev_ptr(out, "out"),
+                            out.stride(0), B, in_dim, out_dim, w_scale, b_scale, int(pixelnorm), int(lrelu), act_gain,
+                            out_scale, out_shift, dev_ptr(trunc_mean, "trunc_mean", True), trunc_psi, stream_ptr()),
+          "cips3d_linear")
+    return out
+
+
+class LinearTable:
+    """A device-resident table of independent dense heads evaluated by one launch."""
+
+    def __init__(self, device):
+        self.device = device
+        self._descs = []
+        self._rows = 0
+        self._dev = None
+        self._keep = []
+
+    def add(self, W, bias, x, x_stride, out, out_stride, w_scale=1.0, b_scale=1.0, out_scale=1.0, out_shift=0.0,
+            x_offset=0, out_offset=0):
+        out_dim, in_dim = W.shape
+        d = _lib.LinearDesc()
+        d.W = dev_ptr(W, "W")
+        d.bias = dev_ptr(bias, "bias", True)
+        d.x = dev_ptr(x, "x") + 4 * x_offset
+        d.out = dev_ptr(out, "out") + 4 * out_offset
+        d.x_stride, d.out_stride = x_stride, out_stride
+        d.in_dim, d.out_dim = in_dim, out_dim
+        d.w_scale, d.b_scale, d.out_scale, d.out_shift = w_scale, b_scale, out_scale, out_shift
+        d.row_begin = self._rows
+        self._rows += out_dim
+        self._descs.append(d)
+        self._keep += [W, bias, x, out]
+        self._dev = None
+
+    def _upload(self):
+        arr = (_lib.LinearDesc * len(self._descs))(*self._descs)
+        raw = bytes(memoryview(arr))
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self._dev = host.to(self.device)
+
+    def run(self, B):
+        if not self._descs:
+            return
+        if self._dev is None:
+            self._upload()
+        check(_lib.load().cips3d_linear_table(self._dev.data_ptr(), len(self._descs), self._rows, B, stream_ptr()),
+              "cips3d_linear_table")
+
+
+def camera_params(locations, img_size, fov_ang=6.0, dist_radius=0.12, up=None):
+    """locations [B,2] -> extrinsics [B,3,4], focal/near/far [B,1,1] (reference return shapes)."""
+    lib = _lib.load()
+    B = locations.shape[0]
+    dev = locations.device
+    loc = locations.detach().float().contiguous()
+    fov_t = None
+    fov_s = 0.0
+    if torch.is_tensor(fov_ang):
+        fov_t = fov_ang.detach().float().reshape(-1).contiguous()
+        if fov_t.numel() == 1 and B != 1:
+            fov_t = fov_t.expand(B).contiguous()
+    else:
+        fov_s = float(fov_ang)
+    up_t = up.detach().float().contiguous() if up is not None else None
+    extr = torch.empty(B, 3, 4, device=dev)
+    focal = torch.empty(B, 1, 1, device=dev)
+    near = torch.empty(B, 1, 1, device=dev)
+    far = torch.empty(B, 1, 1, device=dev)
+    check(lib.cips3d_camera_params(dev_ptr(loc, "locations"), dev_ptr(fov_t, "fov", True), fov_s, dev_ptr(up_t, "up", True),
+                                   float(dist_radius), int(img_size), B, dev_ptr(extr), dev_ptr(focal), dev_ptr(near),
+                                   dev_ptr(far), stream_ptr()), "cips3d_camera_params")
+    return extr, focal, near, far
+
+
+def nerf_pack_weights(w_hidden, w_view, hidden, depth):
+    lib = _lib.load()
+    packed = torch.empty(depth * hidden * hidden, device=w_view.device, dtype=torch.float32)
+    check(lib.cips3d_nerf_pack_weights(dev_ptr(w_hidden, "w_hidden", True), dev_ptr(w_view, "w_view"), dev_ptr(packed),
+                                       hidden, depth, stream_ptr()), "cips3d_nerf_pack_weights")
+    return packed
+
+
+def nerf_suggest_chunks(B, img_size, n_samples):
+    return int(_lib.load().cips3d_nerf_suggest_chunks(B, img_size, n_samples))
+
+
+def nerf_render(**kw):
+    """Fill cips3d_nerf_params from keyword tensors / ints and launch the fused renderer."""
+    lib = _lib.load()
+    p = _lib.NerfParams()
+    ptr_fields = ("cam_poses", "focals", "near_", "far_", "w_first", "packed", "w_view", "film", "layer_bias",
+                  "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta", "part")
+    for f in ptr_fields:
+        setattr(p, f, dev_ptr(kw[f], f))
+    p.perturb_u = dev_ptr(kw.get("perturb_u"), "perturb_u", True)
+    p.sdf = dev_ptr(kw.get("sdf"), "sdf", True)
+    for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
+        setattr(p, f, int(kw[f]))
+    check(lib.cips3d_nerf_render(C.byref(p), stream_ptr()), "cips3d_nerf_render")
+
+
+def nerf_finish(part, n_chunks, B, img_size, hidden):
+    lib = _lib.load()
+    dev = part.device
+    R = img_size * img_size
+    features = torch.empty(B, hidden, img_size, img_size, device=dev)
+    thumb = torch.empty(B, 3, img_size, img_size, device=dev)
+    xyz = torch.empty(B, 3, img_size, img_size, device=dev)
+    mask = torch.empty(B, 2, img_size, img_size, device=dev)
+    check(lib.cips3d_nerf_finish(dev_ptr(part), n_chunks, B, img_size, hidden, dev_ptr(features), dev_ptr(thumb),
+                                 dev_ptr(xyz), dev_ptr(mask), stream_ptr()), "cips3d_nerf_finish")
+    return features, thumb, xyz, mask
+
+
+def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(B * Cout * Cin * ksq, device=W.device, dtype=torch.float32)
+    flags = (MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0)
+    check(lib.cips3d_modulate_weights(dev_ptr(W, "W"), dev_ptr(s, "s") + 4 * s_offset, s_stride, dev_ptr(out), B, Cout, Cin,
+                                      ksq, float(scale), flags, stream_ptr()), "cips3d_modulate_weights")
+    return out
+
+
+def modconv1x1_supported(Cin, Cout, HW):
+    return bool(_lib.load().cips3d_modconv1x1_supported(Cin, Cout, HW))
+
+
+def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=0.0, bias=None, out=None):
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+    nb = 0
+    if noise is not None and noise.shape[0] == B and B > 1:
+        nb = H * W
+    if noise is not None and noise.shape[0] not in (1, B):
+        raise RuntimeError("noise batch must be 1 or B")
+    check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H * W, epilogue,
+                                dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias", True),
+                                stream_ptr()), "cips3d_modconv1x1")
+    return out
+
+
+def up2_fir_act(y_lo, fir, noise, noise_w, bias, out=None):
+    lib = _lib.load()
+    B, Cc, H, W = y_lo.shape
+    if out is None:
+        out = torch.empty(B, Cc, 2 * H, 2 * W, device=y_lo.device, dtype=torch.float32)
+    nb = 4 * H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    check(lib.cips3d_up2_fir_act(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(out), B, Cc, H, W,
+                                 dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias"), stream_ptr()),
+          "cips3d_up2_fir_act")
+    return out
+
+
+def noise_bias_act(x, noise, noise_w, bias):
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    nb = H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    check(lib.cips3d_noise_bias_act(dev_ptr(x, "x"), dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias"),
+                                    dev_ptr(out), B, Cc, H * W, stream_ptr()), "cips3d_noise_bias_act")
+    return out
+
+
+def torgb(x, wm, bias, skip=None, skip_up=False, fir=None, out=None):
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    if out is None:
+        out = torch.empty(B, 3, H, W, device=x.device, dtype=torch.float32)
+    check(lib.cips3d_torgb(dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(bias, "bias"), dev_ptr(skip, "skip", True),
+                           int(bool(skip_up)), dev_ptr(fir, "fir", True), dev_ptr(out), B, Cin, H, W, stream_ptr()),
+          "cips3d_torgb")
+    return out
+
+
+def modconv_kxk(x, wm, Cout, k, transpose2=False):
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    OH = 2 * H - 1 + k - 1 if transpose2 else H
+    OW = 2 * W - 1 + k - 1 if transpose2 else W
+    out = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+    check(lib.cips3d_modconv_kxk(dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(out), B, Cin, Cout, H, W, k,
+                                 int(bool(transpose2)), stream_ptr()), "cips3d_modconv_kxk")
+    return out

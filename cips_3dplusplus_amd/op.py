@@ -1,0 +1,154 @@
+"""Op-level Python API of the reference's `op` package on top of the HIP C ABI.
+
+Same names, arguments and error behaviour as /root/reference/exp/op/__init__.py:1-2:
+    fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2**0.5)     op/fused_act.py:104-119
+    FusedLeakyReLU(channel, bias=True, negative_slope=0.2, scale=2**0.5)     op/fused_act.py:87-101
+    upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))                       op/upfirdn2d.py:146-157
+The autograd wiring follows op/fused_act.py:20-84 and op/upfirdn2d.py:20-143: the backward of
+bias+leaky-ReLU is the same kernel in mode (act 3, grad 1) keyed on the saved OUTPUT, the backward
+of upfirdn2d is upfirdn2d with the flipped FIR and swapped up/down factors.
+
+Unlike the reference there is no pure-torch CPU branch: tensors must live on the GPU (see _lib).
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------ raw calls
+def bias_act_raw(x, bias, ref, act, grad, alpha, scale):
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    step_b = 1
+    for d in x.shape[2:]:
+        step_b *= d
+    size_b = bias.numel() if bias is not None and bias.numel() else 0
+    b_ptr = _lib.dev_ptr(bias.contiguous(), "bias") if size_b else None
+    r_ptr = _lib.dev_ptr(ref.contiguous(), "refer") if ref is not None and ref.numel() else None
+    _lib.check(lib.cips3d_fused_bias_act(_lib.dev_ptr(x, "input"), b_ptr, r_ptr, _lib.dev_ptr(out), x.numel(), step_b,
+                                         max(size_b, 1), act, grad, float(alpha), float(scale), _lib.stream_ptr()),
+               "cips3d_fused_bias_act")
+    return out
+
+
+def upfirdn2d_raw(x4, kernel, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0, pad_y1):
+    """x4: [major, in_h, in_w, minor] -> [major, out_h, out_w, minor] (the native binding's layout)."""
+    lib = _lib.load()
+    x4 = x4.contiguous()
+    kernel = kernel.contiguous()
+    major, in_h, in_w, minor = x4.shape
+    kh, kw = kernel.shape
+    out_h = (in_h * up_y + pad_y0 + pad_y1 - kh) // down_y + 1
+    out_w = (in_w * up_x + pad_x0 + pad_x1 - kw) // down_x + 1
+    out = torch.empty(major, out_h, out_w, minor, device=x4.device, dtype=x4.dtype)
+    _lib.check(lib.cips3d_upfirdn2d(_lib.dev_ptr(x4, "input"), _lib.dev_ptr(kernel, "kernel"), _lib.dev_ptr(out), major,
+                                    in_h, in_w, minor, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_x1, pad_y0,
+                                    pad_y1, _lib.stream_ptr()), "cips3d_upfirdn2d")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ fused leaky relu
+class _FusedLeakyReLUBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, out, has_bias, negative_slope, scale):
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        grad_input = bias_act_raw(grad_output, None, out, 3, 1, negative_slope, scale)
+        if has_bias:
+            dims = [0] + list(range(2, grad_input.ndim))
+            grad_bias = grad_input.sum(dims).detach()
+        else:
+            grad_bias = grad_output.new_empty(0)
+        return grad_input, grad_bias
+
+    @staticmethod
+    def backward(ctx, gg_input, gg_bias):
+        out, = ctx.saved_tensors
+        gg_out = bias_act_raw(gg_input, gg_bias, out, 3, 1, ctx.negative_slope, ctx.scale)
+        return gg_out, None, None, None, None
+
+
+class _FusedLeakyReLU(Function):
+    @staticmethod
+    def forward(ctx, input, bias, negative_slope, scale):
+        ctx.has_bias = bias is not None
+        out = bias_act_raw(input, bias, None, 3, 0, negative_slope, scale)
+        ctx.save_for_backward(out)
+        ctx.negative_slope, ctx.scale = negative_slope, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        out, = ctx.saved_tensors
+        grad_input, grad_bias = _FusedLeakyReLUBackward.apply(grad_output.contiguous(), out, ctx.has_bias,
+                                                              ctx.negative_slope, ctx.scale)
+        return grad_input, (grad_bias if ctx.has_bias else None), None, None
+
+
+def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    return _FusedLeakyReLU.apply(input, bias, negative_slope, scale)
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel, bias=True, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel)) if bias else None
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input):
+        return fused_leaky_relu(input, self.bias, self.negative_slope, self.scale)
+
+
+# ------------------------------------------------------------------------------------------ upfirdn2d
+class _UpFirDn2dBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, kernel, grad_kernel, up, down, pad, g_pad, in_size, out_size):
+        gx0, gx1, gy0, gy1 = g_pad
+        g = grad_output.reshape(-1, out_size[0], out_size[1], 1)
+        grad_input = upfirdn2d_raw(g, grad_kernel, down[0], down[1], up[0], up[1], gx0, gx1, gy0, gy1)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad, in_size, out_size)
+        return grad_input.view(in_size[0], in_size[1], in_size[2], in_size[3])
+
+    @staticmethod
+    def backward(ctx, gg_input):
+        kernel, = ctx.saved_tensors
+        up, down, pad, in_size, out_size = ctx.cfg
+        gg = gg_input.reshape(-1, in_size[2], in_size[3], 1)
+        gg_out = upfirdn2d_raw(gg, kernel, up[0], up[1], down[0], down[1], *pad)
+        return gg_out.view(in_size[0], in_size[1], out_size[0], out_size[1]), None, None, None, None, None, None, None, None
+
+
+class _UpFirDn2d(Function):
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        up_x, up_y = up
+        down_x, down_y = down
+        px0, px1, py0, py1 = pad
+        kh, kw = kernel.shape
+        _, channel, in_h, in_w = input.shape
+        ctx.in_size = input.shape
+        out_h = (in_h * up_y + py0 + py1 - kh) // down_y + 1
+        out_w = (in_w * up_x + px0 + px1 - kw) // down_x + 1
+        ctx.out_size = (out_h, out_w)
+        ctx.up, ctx.down, ctx.pad = (up_x, up_y), (down_x, down_y), (px0, px1, py0, py1)
+        ctx.g_pad = (kw - px0 - 1, in_w * up_x - out_w * down_x + px0 - up_x + 1,
+                     kh - py0 - 1, in_h * up_y - out_h * down_y + py0 - up_y + 1)
+        ctx.save_for_backward(kernel, torch.flip(kernel, [0, 1]))
+        out = upfirdn2d_raw(input.reshape(-1, in_h, in_w, 1), kernel, up_x, up_y, down_x, down_y, px0, px1, py0, py1)
+        return out.view(-1, channel, out_h, out_w)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, grad_kernel = ctx.saved_tensors
+        grad_input = _UpFirDn2dBackward.apply(grad_output.contiguous(), kernel, grad_kernel, ctx.up, ctx.down, ctx.pad,
+                                              ctx.g_pad, ctx.in_size, ctx.out_size)
+        return grad_input, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    return _UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -1,0 +1,211 @@
+/*
+ * cips3d_hip.h -- C ABI of libcips3d_hip.so: the MI355X (gfx950) implementation of the
+ * CIPS-3D++ generator-forward hot path.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers + sizes, no framework types; all pointers are DEVICE pointers to
+ *     contiguous fp32 (or int32 where stated) unless the name ends in `_host`;
+ *   - the caller allocates every output and keeps every buffer alive until the stream
+ *     has passed the call; nothing is allocated, freed or synchronised inside;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *   - returns 0 on success, a hipError_t (> 0) from the launch, or a negative CIPS3D_E_*
+ *     code for argument errors (nothing is launched in that case);
+ *   - stateless and re-entrant per stream.
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/exp/):
+ *   cips3d_fused_bias_act     op/fused_bias_act.cpp:11-20, op/fused_bias_act_kernel.cu:18-98
+ *   cips3d_upfirdn2d          op/upfirdn2d.cpp:12-23, op/upfirdn2d_kernel.cu:49-369
+ *   cips3d_linear*            models/model_v3.py:40-65,183-210 (MappingLinear/EqualLinear),
+ *                             cips3d/volume_renderer.py:15-35 (LinearLayer gamma/beta heads)
+ *   cips3d_camera_params      cips3d/nerf_utils.py:344-436,466-564
+ *   cips3d_nerf_*             cips3d/nerf_utils.py:18-338 + cips3d/volume_renderer.py:39-303
+ *   cips3d_modconv_* / torgb  models/model_v3.py:218-341,418-482
+ */
+#ifndef CIPS3D_HIP_H
+#define CIPS3D_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CIPS3D_ABI_VERSION 1
+
+#define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
+#define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
+
+int cips3d_abi_version(void);
+/* human-readable text for a return code of any entry point (static storage) */
+const char* cips3d_strerror(int code);
+
+/* ------------------------------------------------------------------ op level */
+
+/* out[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale.
+ * act: 1 = linear, 3 = leaky-relu(alpha).  grad: 0 = forward; 1 = first derivative w.r.t. x
+ * evaluated with `ref` (the saved forward OUTPUT) deciding the branch; 2 = second derivative (0).
+ * bias / ref may be NULL (absent).  Same contract as fused.fused_bias_act(input, bias, refer,
+ * act, grad, alpha, scale) with step_b = prod(dims[2:]). */
+int cips3d_fused_bias_act(const float* x, const float* bias, const float* ref, float* out,
+                          int64_t n, int64_t step_b, int64_t size_b,
+                          int act, int grad, float alpha, float scale, void* stream);
+
+/* Up-sample by zero insertion, pad / crop, FIR-filter (true convolution with `kernel`),
+ * down-sample.  input [major, in_h, in_w, minor] -> out [major, out_h, out_w, minor],
+ * out_h = (in_h*up_y + pad_y0 + pad_y1 - kernel_h) / down_y + 1 (same for w); the caller
+ * sizes `out` accordingly.  kernel [kernel_h, kernel_w] lives in device memory. */
+int cips3d_upfirdn2d(const float* input, const float* kernel, float* out,
+                     int64_t major, int in_h, int in_w, int minor, int kernel_h, int kernel_w,
+                     int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* ------------------------------------------------------------------ small dense layers */
+
+/* One dense layer on a batch of row vectors:
+ *   h      = pixelnorm ? x[b] * rsqrt(mean(x[b]^2) + 1e-8) : x[b]
+ *   y      = sum_i h[i] * (W[o][i] * w_scale) + bias[o] * b_scale          (bias may be NULL)
+ *   y      = lrelu ? leaky_relu(y, 0.2) * act_gain : y
+ *   y      = y * out_scale + out_shift
+ *   out    = trunc_mean ? trunc_mean[o] + trunc_psi * (y - trunc_mean[o]) : y
+ * x [B, x_stride] (first in_dim entries used), W [out_dim, in_dim], out [B, out_stride]. */
+int cips3d_linear(const float* x, int64_t x_stride, const float* W, const float* bias, float* out,
+                  int64_t out_stride, int B, int in_dim, int out_dim,
+                  float w_scale, float b_scale, int pixelnorm, int lrelu, float act_gain,
+                  float out_scale, float out_shift, const float* trunc_mean, float trunc_psi,
+                  void* stream);
+
+/* A table of independent dense layers evaluated in ONE launch (FiLM gamma/beta heads and the
+ * decoder's per-layer style modulations).  The table itself lives in device memory. */
+typedef struct cips3d_linear_desc {
+  const float* W;        /* [out_dim, in_dim] */
+  const float* bias;     /* [out_dim] or NULL */
+  const float* x;        /* row b at x + b * x_stride */
+  float* out;            /* row b at out + b * out_stride */
+  int64_t x_stride;
+  int64_t out_stride;
+  int32_t in_dim;
+  int32_t out_dim;
+  float w_scale;
+  float b_scale;
+  float out_scale;       /* applied after the bias: y * out_scale + out_shift */
+  float out_shift;
+  int32_t row_begin;     /* exclusive prefix sum of out_dim over the table */
+  int32_t pad_;
+} cips3d_linear_desc;
+
+int cips3d_linear_table(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int B,
+                        void* stream);
+
+/* ------------------------------------------------------------------ camera */
+
+/* locations [B,2] = (azim, elev); fov_deg [B] or NULL (then fov_deg_scalar); up [B,3] or NULL
+ * (then (0,1,0)).  Writes extrinsics [B,3,4] = [R^T | T], focal/near/far [B]. */
+int cips3d_camera_params(const float* locations, const float* fov_deg, float fov_deg_scalar,
+                         const float* up, float dist_radius, int img_size, int B,
+                         float* extrinsics, float* focal, float* near_, float* far_, void* stream);
+
+/* ------------------------------------------------------------------ NeRF renderer */
+
+/* Re-pack the FiLM-SIREN weight matrices into the MFMA operand order the render kernel streams
+ * (once per weight update).  hidden = H (multiple of 32, <= 256), depth = D >= 1.
+ *   w_hidden : D-1 matrices [H,H] (pts_linears.1..D-1.weight), concatenated
+ *   w_view   : [H, H+3] (views_linears.weight)
+ * packed     : D * H*H floats  (hidden layers 1..D-1, then the H x H part of the view layer). */
+int cips3d_nerf_pack_weights(const float* w_hidden, const float* w_view, float* packed,
+                             int hidden, int depth, void* stream);
+
+typedef struct cips3d_nerf_params {
+  /* geometry, per view */
+  const float* cam_poses;   /* [B,3,4] */
+  const float* focals;      /* [B] */
+  const float* near_;       /* [B] */
+  const float* far_;        /* [B] */
+  const float* perturb_u;   /* [B, img*img] per-ray uniform in [0,1) or NULL (perturb = False) */
+  /* network (all device pointers straight into the module's parameters) */
+  const float* w_first;     /* [H,3]    pts_linears.0.weight */
+  const float* packed;      /* cips3d_nerf_pack_weights output */
+  const float* w_view;      /* [H,H+3]  views_linears.weight (columns H..H+2 = view direction) */
+  const float* film;        /* [B, D+1, 2, H]: gamma = 15*g+30, beta = 0.25*b per layer */
+  const float* layer_bias;  /* [D+1, H]: pts_linears.i.bias rows, then views_linears.bias */
+  const float* w_sigma;     /* [H]      sigma_linear.weight */
+  const float* w_rgb;       /* [3,H]    rgb_linear.weight */
+  const float* b_sigma;     /* [1] */
+  const float* b_rgb;       /* [3] */
+  const float* sigmoid_beta;/* [1] */
+  int32_t B, img_size, n_samples, hidden, depth;
+  int32_t static_viewdirs;
+  int32_t n_chunks;         /* sample chunks per ray (partials per ray) */
+  int32_t pad_;
+  /* outputs */
+  float* part;              /* [n_chunks, B, H+8, R] partial composites (see nerf.hip) */
+  float* sdf;               /* [B, R, n_samples] or NULL */
+} cips3d_nerf_params;
+
+/* Chunk count the render kernel wants for (B, n_samples): enough workgroups to fill the chip. */
+int cips3d_nerf_suggest_chunks(int B, int img_size, int n_samples);
+/* floats needed for `part` */
+int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int n_chunks);
+
+/* rays -> samples -> FiLM-SIREN MLP (fp32 MFMA) -> per-chunk alpha compositing. */
+int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream);
+
+/* Ordered combination of the chunk partials into the final maps:
+ *   features [B,H,R] (channel-major = NCHW), thumb_rgb [B,3,R], xyz [B,3,R], mask [B,2,R]. */
+int cips3d_nerf_finish(const float* part, int n_chunks, int B, int img_size, int hidden,
+                       float* features, float* thumb_rgb, float* xyz, float* mask, void* stream);
+
+/* ------------------------------------------------------------------ decoder */
+
+/* Modulated (and optionally demodulated) weights of one conv for every sample:
+ *   wm[b][o][i][t] = scale * W[o][i][t] * s[b][i];  wm[b][o] *= rsqrt(sum wm[b][o]^2 + 1e-8)
+ * W [Cout, Cin, k*k], s [B, s_stride] (first Cin used), wm [B, Cout, Cin, k*k].
+ * flags: bit 0 = demodulate; bit 1 = emit the MFMA A-fragment order cips3d_modconv1x1 consumes
+ * (k = 1, Cout % 32 == 0, Cin % 8 == 0):
+ *   wm[b][o/32][i/8][((i&1)<<5 | (o&31))*4 + ((i&7)>>1)]. */
+#define CIPS3D_MOD_DEMODULATE 1
+#define CIPS3D_MOD_PACKED     2
+int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
+                            int B, int Cout, int Cin, int ksq, float scale, int flags,
+                            void* stream);
+
+/* 1 when cips3d_modconv1x1 tiles this shape (Cin % 32 == 0, Cout % 32 == 0, HW % 4 == 0). */
+int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW);
+
+/* 1x1 modulated convolution as a per-sample GEMM with a fused epilogue:
+ *   y[b][o][n] = sum_i wm[b][o][i] * x[b][i][n]
+ *   epilogue 0: out = y                                              (raw, feeds the FIR up-sampler)
+ *   epilogue 1: out = lrelu(y + noise_w * noise[n] + bias[o], 0.2) * sqrt(2)
+ * x [B,Cin,HW], wm in the PACKED order above, out [B,Cout,HW], noise [HW] (noise_bstride = 0) or
+ * per-sample [B,HW] (noise_bstride = HW). */
+int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
+                      int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
+                      float noise_w, const float* bias, void* stream);
+
+/* 2x FIR up-sampling of a low-resolution conv result fused with the StyledConv epilogue:
+ *   u   = upfirdn2d(y_lo, fir, up=2, pad=(2,1))      (fir = outer([1,3,3,1])/64*4, [4,4] device)
+ *   out = lrelu(u + noise_w * noise + bias[c], 0.2) * sqrt(2)
+ * y_lo [B,C,H,W] -> out [B,C,2H,2W]. */
+int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
+                       const float* noise, int64_t noise_bstride, float noise_w, const float* bias,
+                       void* stream);
+
+/* StyledConv epilogue on its own (used after the k x k path):
+ *   out = lrelu(x + noise_w * noise + bias[c], 0.2) * sqrt(2);  x/out [B,C,HW]. */
+int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, float noise_w,
+                          const float* bias, float* out, int B, int C, int64_t HW, void* stream);
+
+/* ToRGB: out[b][c][n] = sum_i wm[b][c][i] * x[b][i][n] + bias[c] + skip_term, where skip_term is
+ * absent (skip NULL), skip[b][c][n] (skip_up = 0) or upfirdn2d(skip, fir, up=2, pad=(2,1)) taken
+ * from the half-resolution skip [B,3,H/2,W/2] (skip_up = 1).  x [B,Cin,H,W], wm [B,3,Cin]. */
+int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,
+                 const float* fir, float* out, int B, int Cin, int H, int W, void* stream);
+
+/* General k x k modulated convolution (k odd, padding k/2), direct form; used for k = 3 configs.
+ * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
+int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
+                       int H, int W, int k, int transpose2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CIPS3D_HIP_H */
