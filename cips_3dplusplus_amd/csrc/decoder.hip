@@ -314,6 +314,41 @@ __global__ void __launch_bounds__(256) torgb_kernel(const float* __restrict__ x,
   }
 }
 
+// any H, W (no 16-byte alignment): one pixel per thread
+__global__ void __launch_bounds__(256) torgb_scalar_kernel(const float* __restrict__ x, const float* __restrict__ wm,
+                                                           const float* __restrict__ bias, const float* __restrict__ skip,
+                                                           int skip_up, const float* __restrict__ fir,
+                                                           float* __restrict__ out, int B, int Cin, int H, int W) {
+  float kf[16];
+  if (skip && skip_up) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
+  }
+  const int64_t HW = (int64_t)H * W;
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / HW);
+    const int64_t n = idx % HW;
+    const float* xb = x + (int64_t)b * Cin * HW + n;
+    const float* w = wm + (int64_t)b * 3 * Cin;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < Cin; ++i) {
+      const float v = xb[(int64_t)i * HW];
+      acc[0] = fmaf(w[i], v, acc[0]); acc[1] = fmaf(w[Cin + i], v, acc[1]); acc[2] = fmaf(w[2 * Cin + i], v, acc[2]);
+    }
+    const int oy = (int)(n / W), ox = (int)(n % W);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float o = acc[c] + bias[c];
+      if (skip) {
+        if (skip_up) o += up2_tap(skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2), H / 2, W / 2, oy, ox, kf);
+        else o += skip[((int64_t)b * 3 + c) * HW + n];
+      }
+      out[((int64_t)b * 3 + c) * HW + n] = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // direct k x k (generality path: k = 3 configs, channel counts the MFMA kernel does not tile)
 // ------------------------------------------------------------------------------------------------
@@ -417,8 +452,14 @@ extern "C" int cips3d_torgb(const float* x, const float* wm, const float* bias, 
                             const float* fir, float* out, int B, int Cin, int H, int W, void* stream) {
   if (!x || !wm || !bias || !out || B < 0 || Cin <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
   if (skip && skip_up && (!fir || (H % 2) || (W % 2))) return CIPS3D_E_BADARG;
-  if (((int64_t)H * W) % 4 != 0 || W % 4 != 0) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
+  if (W % 4 != 0) {
+    int64_t bs = ceil_div<int64_t>((int64_t)B * H * W, 256);
+    if (bs > 16384) bs = 16384;
+    hipLaunchKernelGGL(torgb_scalar_kernel, dim3((unsigned)bs), dim3(256), 0, as_stream(stream), x, wm, bias, skip,
+                       skip_up, fir, out, B, Cin, H, W);
+    return cips3d_launch_status();
+  }
   const int64_t quads = (int64_t)H * W / 4;
   int64_t bx = ceil_div<int64_t>(quads, 256);
   if (bx > 4096) bx = 4096;
