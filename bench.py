@@ -1,0 +1,168 @@
+"""Benchmark of the generator-forward hot path: rendered views / second.
+
+    python bench.py [--gpus N --steps K --warmup W] [--res 1024 --depth 2 --n-samples 24 --batch 1]
+
+One step = one `Generator.forward` over one batch of synthetic views with inputs resident in HBM
+(mapping -> fused NeRF render -> decoder -> rgb in device memory), i.e. the loop body of the
+reference's `test__rendering_time` (/root/reference/exp/tests/test_cips3dpp.py:709-748): FFHQ 1024^2
+release recipe (N_layers_renderer=2, 1x1 modulated convs), batch 1, 64x64 rays x 24 samples,
+perturb=True, fresh decoder noise every call, random-init (synthetic) weights, fp32.
+For N > 1 GPUs (launched with torch.distributed.run) every rank renders its own batch per step and the
+images are gathered to rank 0 over RCCL inside the timed region (weak scaling).
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PUBLISHED_VIEWS_PER_S = 46.93085418313323   # test__rendering_time docstring, unknown CUDA GPU
+MFMA_F32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+
+
+def nerf_flops_per_point(H, D):
+    # first layer + (D-1) hidden + view layer (H+3 inputs) + sigma head + rgb head
+    return 2 * 3 * H + (D - 1) * 2 * H * H + 2 * (H + 3) * H + 2 * H * 1 + 2 * H * 3
+
+
+def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=25.0):
+    """The oracle (CPU port of the reference path) timed on this host on the same workload."""
+    from cips_3dplusplus_amd import weights
+    from oracle import path as O
+    import cips_3dplusplus_amd as pkg
+    torch.manual_seed(0)
+    G = pkg.Generator(**cfg)
+    sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
+    del G
+    cores = torch.get_num_threads()
+    g = torch.Generator().manual_seed(12345)
+    zs = [torch.randn(batch, 256, generator=g), torch.randn(batch, 256, generator=g)]
+    cam = O.camera_params(torch.zeros(batch, 2), 64, 6, 0.12)
+    times = []
+    t_all = time.perf_counter()
+    with torch.no_grad():
+        for it in range(6):
+            nb = O.create_noise_bufs(cfg, 64, generator=g)
+            u = torch.rand(batch, 64, 64, 1, generator=g)
+            t0 = time.perf_counter()
+            O.generator_forward(sd, cfg, zs, cam[0], cam[1], 64, cam[2], cam[3], nerf_cfg, nb, perturb_u=u)
+            times.append(time.perf_counter() - t0)
+            if it >= 1 and time.perf_counter() - t_all > seconds_budget:
+                break
+    timed = times[1:] if len(times) > 1 else times   # first call is the warm-up
+    per_view = sum(timed) / len(timed) / batch
+    return {"value": 1.0 / per_view, "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"{len(timed)} forward(s) of the same workload after 1 warm-up ({per_view * 1e3:.0f} ms/view)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--depth", type=int, default=2)
+    ap.add_argument("--n-samples", type=int, default=24)
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--deterministic", action="store_true", help="perturb off + fixed noise buffers (demo semantics)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs, hip
+    from cips_3dplusplus_amd.camera import Camera
+    from cips_3dplusplus_amd.multiview import gather_views
+
+    cfg = configs.ffhq_G_cfg(a.res, a.depth)
+    nerf_cfg = {"N_samples": a.n_samples, "perturb": not a.deterministic, "static_viewdirs": False}
+    G = pkg.build_generator(cfg, dev, seed=0)
+    B = a.batch
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    zs = [torch.randn(B, 256, device=dev, generator=gen), torch.randn(B, 256, device=dev, generator=gen)]
+    locs = torch.zeros(B, 2, device=dev) if B == 1 else torch.randn(B, 2, device=dev, generator=gen) * torch.tensor([0.3, 0.15], device=dev)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, dev, locations=locs, **{k: v for k, v in configs.FFHQ_CAM_CFG.items()
+                                                                               if k in ("fov_ang", "dist_radius")})
+    noise_bufs = G.create_noise_bufs(64, dev) if a.deterministic else None
+
+    def step():
+        r = G(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1, noise_bufs=noise_bufs,
+              nerf_cfg=nerf_cfg)
+        rgb = r["rgb"]
+        if world > 1:
+            gather_views(rgb, B * world)
+        return rgb
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    hip.KERNEL_EVENTS["nerf_render"] = []
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events = hip.KERNEL_EVENTS.pop("nerf_render")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+
+    if rank == 0:
+        views = a.steps * B * world
+        value = views / elapsed
+        kern_ms = sum(s.elapsed_time(t) for s, t in events) / max(1, len(events))
+        H = cfg["renderer_cfg"]["hidden_dim"]
+        flops = B * 64 * 64 * a.n_samples * nerf_flops_per_point(H, a.depth)
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        published_cfg = (a.res == 1024 and a.depth == 2 and a.n_samples == 24 and B == 1 and not a.deterministic)
+        line = {
+            "metric": "rendered views/sec at FFHQ 1024^2 (generator forward: 64x64-ray NeRF + StyleGAN2 decoder)",
+            "value": value, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": (value / PUBLISHED_VIEWS_PER_S) if published_cfg else None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ffhq_r{a.res}_nerf64x64x{a.n_samples}_D{a.depth}_B{B}_fp32 "
+                                   f"(test__rendering_time loop body: perturb={not a.deterministic}, "
+                                   f"{'fixed' if a.deterministic else 'fresh'} decoder noise, random-init weights)",
+                       "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
+                       "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
+            "roofline": {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
+                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "avg_launch_ms": kern_ms, "flop_per_launch": flops},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, {**nerf_cfg, "perturb": True}, B)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

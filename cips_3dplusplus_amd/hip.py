@@ -13,6 +13,20 @@ from ._lib import dev_ptr, stream_ptr, check
 MOD_DEMODULATE = 1
 MOD_PACKED = 2
 
+# bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
+# events are recorded on the stream the kernel is launched on (torch's current stream).
+KERNEL_EVENTS = {}
+
+
+def _timed(name):
+    lst = KERNEL_EVENTS.get(name)
+    if lst is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    lst.append(ev)
+    ev[0].record()
+    return ev
+
 
 def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False, lrelu=False, act_gain=1.0,
            out_scale=1.0, out_shift=0.0, trunc_mean=None, trunc_psi=1.0):
@@ -120,7 +134,10 @@ def nerf_render(**kw):
     p.sdf = dev_ptr(kw.get("sdf"), "sdf", True)
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))
+    ev = _timed("nerf_render")
     check(lib.cips3d_nerf_render(C.byref(p), stream_ptr()), "cips3d_nerf_render")
+    if ev:
+        ev[1].record()
 
 
 def nerf_finish(part, n_chunks, B, img_size, hidden):
