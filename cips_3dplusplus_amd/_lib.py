@@ -26,6 +26,12 @@ class LinearDesc(C.Structure):
                 ("pad_", C.c_int32)]
 
 
+class ModulateDesc(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("s", C.c_void_p), ("out", C.c_void_p), ("s_stride", C.c_int64),
+                ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksq", C.c_int32), ("flags", C.c_int32),
+                ("scale", C.c_float), ("row_begin", C.c_int32)]
+
+
 class NerfParams(C.Structure):
     _fields_ = [("cam_poses", C.c_void_p), ("focals", C.c_void_p), ("near_", C.c_void_p), ("far_", C.c_void_p),
                 ("perturb_u", C.c_void_p),
@@ -55,6 +61,7 @@ _SIGS = {
     "cips3d_nerf_finish": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_modulate_weights": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int, c_f32, c_int,
                                         C.c_void_p]),
+    "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
     "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32,
                                   c_f32p, C.c_void_p]),

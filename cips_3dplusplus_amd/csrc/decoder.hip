@@ -26,16 +26,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   packed (ksq == 1, Cout % 32 == 0, Cin % 8 == 0): MFMA A order
 //           wmp[b][ot][kq][lane][j] = wm[b][ot*32 + (lane&31)][8*kq + 2*j + (lane>>5)]
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) modulate_kernel(const float* __restrict__ W, const float* __restrict__ s,
-                                                       int64_t s_stride, float* __restrict__ wm, int B, int Cout,
-                                                       int Cin, int ksq, float scale, int demod, int packed) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= (int64_t)B * Cout) return;
-  const int b = (int)(row / Cout), o = (int)(row % Cout);
+__device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb,
+                                             float* __restrict__ wm, int b, int o, int Cout, int Cin, int ksq,
+                                             float scale, int demod, int packed, int lane) {
   const int len = Cin * ksq;
   const float* w = W + (int64_t)o * len;
-  const float* sb = s + (int64_t)b * s_stride;
   float ss = 0.f;
   if (demod) {
     for (int e = lane; e < len; e += 64) {
@@ -56,6 +51,33 @@ __global__ void __launch_bounds__(256) modulate_kernel(const float* __restrict__
       wm[((int64_t)b * Cout + o) * len + e] = v;
     }
   }
+}
+
+__global__ void __launch_bounds__(256) modulate_kernel(const float* __restrict__ W, const float* __restrict__ s,
+                                                       int64_t s_stride, float* __restrict__ wm, int B, int Cout,
+                                                       int Cin, int ksq, float scale, int demod, int packed) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Cout) return;
+  const int b = (int)(row / Cout), o = (int)(row % Cout);
+  modulate_row(W, s + (int64_t)b * s_stride, wm, b, o, Cout, Cin, ksq, scale, demod, packed, lane);
+}
+
+// every conv of the decoder in one launch: grid.x covers the table's rows, grid.y the samples
+__global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modulate_desc* __restrict__ table, int n_desc,
+                                                             int total_rows) {
+  const int lane = threadIdx.x & 63;
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= total_rows) return;
+  const int b = blockIdx.y;
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid].row_begin <= grow) lo = mid; else hi = mid - 1;
+  }
+  const cips3d_modulate_desc d = table[lo];
+  modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
+               d.flags & 1, (d.flags >> 1) & 1, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -194,9 +216,10 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
 // 2x polyphase FIR up-sampler (upfirdn2d up=2, pad=(2,1), 4x4 taps) + noise + bias + leaky-ReLU.
 // Each thread produces 4 consecutive output pixels of one row (16-byte store).
 // ------------------------------------------------------------------------------------------------
+// single tap set for one output pixel; taps come from memory (runtime parity => no register array)
 __device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, int W, int oy, int ox,
-                                         const float (&kf)[16]) {
-  // u[y][x] = in[(y-2)/2][(x-2)/2] on even (y-2),(x-2); out = sum_{ky,kx} u[oy+ky][ox+kx] * kf[ky][kx]
+                                         const float* __restrict__ fir) {
+  // u[y][x] = in[(y-2)/2][(x-2)/2] on even (y-2),(x-2); out = sum_{ky,kx} u[oy+ky][ox+kx] * fir[3-ky][3-kx]
   const int ky0 = oy & 1, kx0 = ox & 1;        // first tap with (oy+ky-2) even
   float acc = 0.f;
 #pragma unroll
@@ -209,10 +232,47 @@ __device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, i
       const int kx = kx0 + 2 * c;
       const int ix = (ox + kx - 2) >> 1;
       if (ix < 0 || ix >= W) continue;
-      acc = fmaf(src[(int64_t)iy * W + ix], kf[ky * 4 + kx], acc);
+      acc = fmaf(src[(int64_t)iy * W + ix], fir[15 - (ky * 4 + kx)], acc);
     }
   }
   return acc;
+}
+
+// 2 x 4 output block (rows 2*iy, 2*iy+1; columns 4*qx .. 4*qx+3) from the 3 x 4 input patch
+// rows iy-1..iy+1, columns 2*qx-1..2*qx+2.  All tap indices are compile-time constants.
+__device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, int W, int iy, int qx,
+                                          const float (&kf)[16], float (&o)[2][4]) {
+  const int c = 2 * qx;
+  float v[3][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int y = iy - 1 + r;
+    const bool yok = (y >= 0) && (y < H);
+    const float* row = src + (int64_t)(yok ? y : 0) * W;
+    // middle pair is 8-byte aligned (c even, W even)
+    float2 mid = make_float2(0.f, 0.f);
+    if (yok) mid = *reinterpret_cast<const float2*>(row + c);
+    v[r][1] = mid.x; v[r][2] = mid.y;
+    v[r][0] = (yok && c - 1 >= 0) ? row[c - 1] : 0.f;
+    v[r][3] = (yok && c + 2 < W) ? row[c + 2] : 0.f;
+  }
+#pragma unroll
+  for (int py = 0; py < 2; ++py) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int px = j & 1;
+      const int col0 = (j + 1) >> 1;                 // j=0 -> v0,v1 ; j=1,2 -> v1,v2 ; j=3 -> v2,v3
+      float acc = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int ky = py + 2 * a;
+        const int r = py + a;                        // py=0: rows iy-1, iy ; py=1: rows iy, iy+1
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) acc = fmaf(v[r][col0 + bb], kf[ky * 4 + px + 2 * bb], acc);
+      }
+      o[py][j] = acc;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restrict__ y_lo, const float* __restrict__ fir,
@@ -222,27 +282,32 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
   float kf[16];   // flipped taps: kf[ky][kx] = fir[3-ky][3-kx]
 #pragma unroll
   for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
-  const int OW = 2 * W, OH = 2 * H;
-  const int qw = OW / 4;                                   // quads per output row (W >= 2)
-  const int64_t total = (int64_t)B * C * OH * qw;
+  const int OW = 2 * W;
+  const int qw = W / 2;                                    // 4-pixel output quads per row
+  const int64_t total = (int64_t)B * C * H * qw;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = idx;
     const int qx = (int)(t % qw); t /= qw;
-    const int oy = (int)(t % OH); t /= OH;
+    const int iy = (int)(t % H); t /= H;
     const int c = (int)(t % C);
     const int b = (int)(t / C);
     const float* src = y_lo + ((int64_t)b * C + c) * H * W;
     const float bs = bias[c];
-    const int ox0 = qx * 4;
-    float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (noise) nz = *reinterpret_cast<const float4*>(noise + (int64_t)b * noise_bstride + (int64_t)oy * OW + ox0);
-    float4 o;
-    o.x = lrelu02((up2_tap(src, H, W, oy, ox0 + 0, kf) + noise_w * nz.x) + bs) * 1.41421356237309515f;
-    o.y = lrelu02((up2_tap(src, H, W, oy, ox0 + 1, kf) + noise_w * nz.y) + bs) * 1.41421356237309515f;
-    o.z = lrelu02((up2_tap(src, H, W, oy, ox0 + 2, kf) + noise_w * nz.z) + bs) * 1.41421356237309515f;
-    o.w = lrelu02((up2_tap(src, H, W, oy, ox0 + 3, kf) + noise_w * nz.w) + bs) * 1.41421356237309515f;
-    *reinterpret_cast<float4*>(out + (((int64_t)b * C + c) * OH + oy) * OW + ox0) = o;
+    float o[2][4];
+    up2_block(src, H, W, iy, qx, kf, o);
+    float* dst = out + (((int64_t)b * C + c) * 2 * H + 2 * iy) * OW + 4 * qx;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (noise) nz = *reinterpret_cast<const float4*>(noise + (int64_t)b * noise_bstride + (int64_t)(2 * iy + py) * OW + 4 * qx);
+      float4 r;
+      r.x = lrelu02((o[py][0] + noise_w * nz.x) + bs) * 1.41421356237309515f;
+      r.y = lrelu02((o[py][1] + noise_w * nz.y) + bs) * 1.41421356237309515f;
+      r.z = lrelu02((o[py][2] + noise_w * nz.z) + bs) * 1.41421356237309515f;
+      r.w = lrelu02((o[py][3] + noise_w * nz.w) + bs) * 1.41421356237309515f;
+      *reinterpret_cast<float4*>(dst + (int64_t)py * OW) = r;
+    }
   }
 }
 
@@ -272,11 +337,6 @@ __global__ void __launch_bounds__(256) torgb_kernel(const float* __restrict__ x,
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 3 * Cin; i += 256) s_w[i] = wm[(int64_t)b * 3 * Cin + i];
   __syncthreads();
-  float kf[16];
-  if (skip && skip_up) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
-  }
   const int64_t HW = (int64_t)H * W;
   const int64_t quads = HW / 4;
   const float* xb = x + (int64_t)b * Cin * HW;
@@ -300,10 +360,10 @@ __global__ void __launch_bounds__(256) torgb_kernel(const float* __restrict__ x,
         if (skip_up) {
           const int oy = (int)((q * 4) / W), ox0 = (int)((q * 4) % W);
           const float* sp = skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2);
-          o.x += up2_tap(sp, H / 2, W / 2, oy, ox0 + 0, kf);
-          o.y += up2_tap(sp, H / 2, W / 2, oy, ox0 + 1, kf);
-          o.z += up2_tap(sp, H / 2, W / 2, oy, ox0 + 2, kf);
-          o.w += up2_tap(sp, H / 2, W / 2, oy, ox0 + 3, kf);
+          o.x += up2_tap(sp, H / 2, W / 2, oy, ox0 + 0, fir);
+          o.y += up2_tap(sp, H / 2, W / 2, oy, ox0 + 1, fir);
+          o.z += up2_tap(sp, H / 2, W / 2, oy, ox0 + 2, fir);
+          o.w += up2_tap(sp, H / 2, W / 2, oy, ox0 + 3, fir);
         } else {
           const float4 sv = *reinterpret_cast<const float4*>(skip + ((int64_t)b * 3 + c) * HW + q * 4);
           o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
@@ -314,16 +374,75 @@ __global__ void __launch_bounds__(256) torgb_kernel(const float* __restrict__ x,
   }
 }
 
+// Channel-split variant: a workgroup owns 256/S quads, its S thread slices each reduce Cin/S channels and
+// the partial sums meet in LDS.  Keeps every CU busy at low resolution (64^2 x 512 channels is only 1024
+// quads) and multiplies the loads in flight per CU at high resolution.
+template <int S>
+__global__ void __launch_bounds__(256) torgb_split_kernel(const float* __restrict__ x, const float* __restrict__ wm,
+                                                          const float* __restrict__ bias, const float* __restrict__ skip,
+                                                          int skip_up, const float* __restrict__ fir,
+                                                          float* __restrict__ out, int B, int Cin, int H, int W) {
+  constexpr int QB = 256 / S;
+  extern __shared__ __attribute__((aligned(16))) float s_mem[];   // [256][12] partials, then [3][Cin] weights
+  float* s_part = s_mem;
+  float* s_w = s_mem + 256 * 12;
+  const int b = blockIdx.y;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * Cin; i += 256) s_w[i] = wm[(int64_t)b * 3 * Cin + i];
+  __syncthreads();
+  const int64_t HW = (int64_t)H * W;
+  const int64_t quads = HW / 4;
+  const int ql = tid % QB, sl = tid / QB;
+  const int64_t q = (int64_t)blockIdx.x * QB + ql;
+  const bool qok = q < quads;
+  const float* xb = x + (int64_t)b * Cin * HW + (qok ? q : 0) * 4;
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f), g = r, bl = r;
+#pragma unroll 4
+  for (int i = sl; i < Cin; i += S) {
+    const float4 v = *reinterpret_cast<const float4*>(xb + (int64_t)i * HW);
+    const float w0 = s_w[i], w1 = s_w[Cin + i], w2 = s_w[2 * Cin + i];
+    r.x = fmaf(w0, v.x, r.x); r.y = fmaf(w0, v.y, r.y); r.z = fmaf(w0, v.z, r.z); r.w = fmaf(w0, v.w, r.w);
+    g.x = fmaf(w1, v.x, g.x); g.y = fmaf(w1, v.y, g.y); g.z = fmaf(w1, v.z, g.z); g.w = fmaf(w1, v.w, g.w);
+    bl.x = fmaf(w2, v.x, bl.x); bl.y = fmaf(w2, v.y, bl.y); bl.z = fmaf(w2, v.z, bl.z); bl.w = fmaf(w2, v.w, bl.w);
+  }
+  float4* pp = reinterpret_cast<float4*>(s_part) + (sl * QB + ql) * 3;
+  pp[0] = r; pp[1] = g; pp[2] = bl;
+  __syncthreads();
+  if (tid < QB * 3) {
+    const int c = tid / QB, q2 = tid % QB;
+    const int64_t qq = (int64_t)blockIdx.x * QB + q2;
+    if (qq < quads) {
+      float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(s_part)[(k * QB + q2) * 3 + c];
+        o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      }
+      const float bs = bias[c];
+      o.x += bs; o.y += bs; o.z += bs; o.w += bs;
+      if (skip) {
+        if (skip_up) {
+          const int oy = (int)((qq * 4) / W), ox0 = (int)((qq * 4) % W);
+          const float* sp = skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2);
+          o.x += up2_tap(sp, H / 2, W / 2, oy, ox0 + 0, fir);
+          o.y += up2_tap(sp, H / 2, W / 2, oy, ox0 + 1, fir);
+          o.z += up2_tap(sp, H / 2, W / 2, oy, ox0 + 2, fir);
+          o.w += up2_tap(sp, H / 2, W / 2, oy, ox0 + 3, fir);
+        } else {
+          const float4 sv = *reinterpret_cast<const float4*>(skip + ((int64_t)b * 3 + c) * HW + qq * 4);
+          o.x += sv.x; o.y += sv.y; o.z += sv.z; o.w += sv.w;
+        }
+      }
+      *reinterpret_cast<float4*>(out + ((int64_t)b * 3 + c) * HW + qq * 4) = o;
+    }
+  }
+}
+
 // any H, W (no 16-byte alignment): one pixel per thread
 __global__ void __launch_bounds__(256) torgb_scalar_kernel(const float* __restrict__ x, const float* __restrict__ wm,
                                                            const float* __restrict__ bias, const float* __restrict__ skip,
                                                            int skip_up, const float* __restrict__ fir,
                                                            float* __restrict__ out, int B, int Cin, int H, int W) {
-  float kf[16];
-  if (skip && skip_up) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
-  }
   const int64_t HW = (int64_t)H * W;
   const int64_t total = (int64_t)B * HW;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -341,7 +460,7 @@ __global__ void __launch_bounds__(256) torgb_scalar_kernel(const float* __restri
     for (int c = 0; c < 3; ++c) {
       float o = acc[c] + bias[c];
       if (skip) {
-        if (skip_up) o += up2_tap(skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2), H / 2, W / 2, oy, ox, kf);
+        if (skip_up) o += up2_tap(skip + ((int64_t)b * 3 + c) * (H / 2) * (W / 2), H / 2, W / 2, oy, ox, fir);
         else o += skip[((int64_t)b * 3 + c) * HW + n];
       }
       out[((int64_t)b * 3 + c) * HW + n] = o;
@@ -403,6 +522,15 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   return cips3d_launch_status();
 }
 
+extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B,
+                                     void* stream) {
+  if (!table_dev || n_desc <= 0 || total_rows <= 0 || B < 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(modulate_table_kernel, dim3((unsigned)ceil_div(total_rows, 4), (unsigned)B), dim3(256), 0,
+                     as_stream(stream), table_dev, n_desc, total_rows);
+  return cips3d_launch_status();
+}
+
 extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
   return (Cin % 32 == 0) && (Cout % 32 == 0) && (HW % 4 == 0) && HW >= 4;
 }
@@ -429,7 +557,7 @@ extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* ou
   if (!y_lo || !fir || !out || !bias || B < 0 || C <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
   if (W % 2 != 0) return CIPS3D_E_UNSUPP;     // 16-byte output quads
   if (B == 0) return 0;
-  const int64_t total = (int64_t)B * C * (2 * H) * (2 * W / 4);
+  const int64_t total = (int64_t)B * C * H * (W / 2);
   int64_t blocks = ceil_div<int64_t>(total, 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(up2_fir_act_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), y_lo, fir, out, B,
@@ -461,6 +589,19 @@ extern "C" int cips3d_torgb(const float* x, const float* wm, const float* bias, 
     return cips3d_launch_status();
   }
   const int64_t quads = (int64_t)H * W / 4;
+  {
+    const size_t lds = sizeof(float) * (256 * 12 + 3 * (size_t)Cin);
+    if (quads <= 32768 && Cin >= 64) {
+      hipLaunchKernelGGL(torgb_split_kernel<16>, dim3((unsigned)ceil_div<int64_t>(quads, 16), (unsigned)B), dim3(256), lds,
+                         as_stream(stream), x, wm, bias, skip, skip_up, fir, out, B, Cin, H, W);
+      return cips3d_launch_status();
+    }
+    if (Cin >= 16) {
+      hipLaunchKernelGGL(torgb_split_kernel<4>, dim3((unsigned)ceil_div<int64_t>(quads, 64), (unsigned)B), dim3(256), lds,
+                         as_stream(stream), x, wm, bias, skip, skip_up, fir, out, B, Cin, H, W);
+      return cips3d_launch_status();
+    }
+  }
   int64_t bx = ceil_div<int64_t>(quads, 256);
   if (bx > 4096) bx = 4096;
   hipLaunchKernelGGL(torgb_kernel, dim3((unsigned)bx, (unsigned)B), dim3(256), sizeof(float) * 3 * Cin,

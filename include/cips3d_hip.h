@@ -168,6 +168,21 @@ int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, fl
                             int B, int Cout, int Cin, int ksq, float scale, int flags,
                             void* stream);
 
+/* The same for a table of convs in ONE launch (the whole decoder).  The table lives in device memory;
+ * `s` already points at the conv's slice of the style-modulation buffer. */
+typedef struct cips3d_modulate_desc {
+  const float* W;        /* [Cout, Cin, ksq] */
+  const float* s;        /* row b at s + b * s_stride */
+  float* out;            /* [B, Cout*Cin*ksq] (plain or packed per flags) */
+  int64_t s_stride;
+  int32_t Cout, Cin, ksq, flags;
+  float scale;
+  int32_t row_begin;     /* exclusive prefix sum of Cout over the table */
+} cips3d_modulate_desc;
+
+int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B,
+                          void* stream);
+
 /* 1 when cips3d_modconv1x1 tiles this shape (Cin % 32 == 0, Cout % 32 == 0, HW % 4 == 0). */
 int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW);
 
