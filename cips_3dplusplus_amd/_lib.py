@@ -50,7 +50,7 @@ _SIGS = {
                                       C.c_void_p]),
     "cips3d_upfirdn2d": (c_int, [c_f32p, c_f32p, c_f32p, c_i64] + [c_int] * 13 + [C.c_void_p]),
     "cips3d_linear": (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int,
-                              c_int, c_f32, c_f32, c_f32, c_f32p, c_f32, C.c_void_p]),
+                              c_int, c_f32, c_f32, c_f32, c_f32p, c_f32, c_int, c_i64, C.c_void_p]),
     "cips3d_linear_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_camera_params": (c_int, [c_f32p, c_f32p, c_f32, c_f32p, c_f32, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_void_p]),
@@ -63,15 +63,18 @@ _SIGS = {
                                         C.c_void_p]),
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
-    "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32,
+    "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
                                   c_f32p, C.c_void_p]),
-    "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32, c_f32p,
+    "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32p, c_f32p,
                                    C.c_void_p]),
-    "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
+    "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cips3d_sizeof_plan": (c_i64, []),
+    "cips3d_sizeof_io": (c_i64, []),
 }
 
 EXPORTED = tuple(_SIGS)

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
 struct GemmArgs {
   const float* x; const float* wmp; float* out;
   int B, Cin, Cout; int64_t HW;
-  int epilogue; const float* noise; int64_t noise_bstride; float noise_w; const float* bias;
+  int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
 };
 
 template <int WM, int WN, int WGM, int WGN, int BK>
@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) modconv1x1_kernel(GemmArgs a) {
     const int64_t n = n0 + (wn_i * WN + j) * 32 + jn;
     if (n >= HW) continue;
     float nz = 0.f;
-    if (a.epilogue == 1 && a.noise) nz = a.noise_w * a.noise[(int64_t)b * a.noise_bstride + n];
+    if (a.epilogue == 1 && a.noise && a.noise_w) nz = a.noise_w[0] * a.noise[(int64_t)b * a.noise_bstride + n];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int obase = m0 + (wm_i * WM + i) * 32;
@@ -278,7 +278,8 @@ __device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, 
 __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restrict__ y_lo, const float* __restrict__ fir,
                                                           float* __restrict__ out, int B, int C, int H, int W,
                                                           const float* __restrict__ noise, int64_t noise_bstride,
-                                                          float noise_w, const float* __restrict__ bias) {
+                                                          const float* __restrict__ nwp, const float* __restrict__ bias) {
+  const float noise_w = (noise && nwp) ? nwp[0] : 0.f;
   float kf[16];   // flipped taps: kf[ky][kx] = fir[3-ky][3-kx]
 #pragma unroll
   for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
@@ -313,9 +314,10 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
 
 // StyledConv epilogue on its own (generality path): out = lrelu(x + noise_w*noise + bias[c], 0.2)*sqrt(2)
 __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ noise,
-                                                             int64_t noise_bstride, float noise_w,
+                                                             int64_t noise_bstride, const float* __restrict__ nwp,
                                                              const float* __restrict__ bias, float* __restrict__ out,
                                                              int B, int C, int64_t HW) {
+  const float noise_w = (noise && nwp) ? nwp[0] : 0.f;
   const int64_t total = (int64_t)B * C * HW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t n = i % HW;
@@ -536,7 +538,7 @@ extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
 }
 
 extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
-                                 int epilogue, const float* noise, int64_t noise_bstride, float noise_w,
+                                 int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                                  const float* bias, void* stream) {
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   if (epilogue != 0 && epilogue != 1) return CIPS3D_E_BADARG;
@@ -552,7 +554,7 @@ extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, in
 }
 
 extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
-                                  const float* noise, int64_t noise_bstride, float noise_w, const float* bias,
+                                  const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                                   void* stream) {
   if (!y_lo || !fir || !out || !bias || B < 0 || C <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
   if (W % 2 != 0) return CIPS3D_E_UNSUPP;     // 16-byte output quads
@@ -565,7 +567,7 @@ extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* ou
   return cips3d_launch_status();
 }
 
-extern "C" int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, float noise_w,
+extern "C" int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, const float* noise_w,
                                      const float* bias, float* out, int B, int C, int64_t HW, void* stream) {
   if (!x || !bias || !out || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;

@@ -1,0 +1,105 @@
+// cips3d_generator_forward: the whole generator forward (reference models/model_v3.py:875-1042) enqueued
+// by ONE host call.  At batch 1 a 1024^2 view is ~60 kernels of 5-300 us; issuing them from Python costs
+// ~20 us each (more than the GPU time of most of them), issuing them from here costs a hipLaunchKernel
+// each, and the call can be captured into a hipGraph by the caller because nothing here allocates,
+// synchronises or touches anything but `stream`.
+#include "common.h"
+
+#define TRY(expr)            \
+  do {                       \
+    const int rc_ = (expr);  \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+extern "C" int64_t cips3d_sizeof_plan(void) { return (int64_t)sizeof(cips3d_generator_plan); }
+extern "C" int64_t cips3d_sizeof_io(void) { return (int64_t)sizeof(cips3d_forward_io); }
+
+extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io,
+                                        void* stream) {
+  if (!plan || !io) return CIPS3D_E_BADARG;
+  const cips3d_generator_plan& P = *plan;
+  const cips3d_forward_io& IO = *io;
+  if (P.B <= 0 || P.n_map_r > CIPS3D_MAX_MAP_LAYERS || P.n_map_d > CIPS3D_MAX_MAP_LAYERS ||
+      P.n_dec_layers > CIPS3D_MAX_DEC_LAYERS || P.n_dec_layers < 2)
+    return CIPS3D_E_BADARG;
+  if (!IO.cam_poses || !IO.focals || !IO.near_ || !IO.far_ || !IO.rgb || !IO.thumb || !IO.xyz || !IO.mask)
+    return CIPS3D_E_BADARG;
+  const int B = P.B;
+  const int D = P.nerf.depth;
+  const bool trunc = IO.mean_r && IO.mean_d && IO.trunc_psi < 1.f;
+
+  // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot
+  if (IO.z_r) {
+    const float* x = IO.z_r;
+    int64_t xs = P.z_dim;
+    for (int i = 0; i < P.n_map_r; ++i) {
+      const bool last = i == P.n_map_r - 1;
+      const int in_dim = i == 0 ? P.z_dim : P.style_dim_r;
+      float* out = last ? P.styles_r : P.lat[i & 1];
+      TRY(cips3d_linear(x, xs, P.map_r_w[i], P.map_r_b[i], out, last ? (int64_t)(D + 1) * P.style_dim_r : P.style_dim_r,
+                        B, in_dim, P.style_dim_r, 1.f, 1.f, 0, 1, 1.f, 1.f, 0.f, (last && trunc) ? IO.mean_r : nullptr,
+                        IO.trunc_psi, last ? D + 1 : 1, P.style_dim_r, stream));
+      x = out; xs = P.style_dim_r;
+    }
+  }
+  if (IO.z_d) {
+    const float* x = IO.z_d;
+    int64_t xs = P.z_dim;
+    for (int i = 0; i < P.n_map_d; ++i) {
+      const bool last = i == P.n_map_d - 1;
+      const int in_dim = P.map_d_in[i];
+      float* out = last ? P.styles_d : P.lat[i & 1];
+      const float w_scale = (1.f / sqrtf((float)in_dim)) * P.map_d_lr_mul;
+      TRY(cips3d_linear(x, xs, P.map_d_w[i], P.map_d_b[i], out, last ? (int64_t)P.n_latent * P.style_dim_d : P.style_dim_d,
+                        B, in_dim, P.style_dim_d, w_scale, P.map_d_lr_mul, i == 0 ? 1 : 0, 1, 1.41421356237309515f, 1.f,
+                        0.f, (last && trunc) ? IO.mean_d : nullptr, IO.trunc_psi, last ? P.n_latent : 1, P.style_dim_d,
+                        stream));
+      x = out; xs = P.style_dim_d;
+    }
+  }
+
+  // ---- style heads: FiLM gamma/beta of every SIREN layer; every decoder modulation; modulated weights
+  TRY(cips3d_linear_table(P.film_table, P.film_n, P.film_rows, B, stream));
+  TRY(cips3d_linear_table(P.mod_table, P.mod_n, P.mod_rows, B, stream));
+  TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, stream));
+
+  // ---- NeRF: rays -> samples -> FiLM-SIREN -> compositing
+  cips3d_nerf_params np = P.nerf;
+  np.cam_poses = IO.cam_poses; np.focals = IO.focals; np.near_ = IO.near_; np.far_ = IO.far_;
+  np.perturb_u = IO.perturb_u; np.sdf = IO.sdf;
+  if (IO.ev_nerf_start) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_start), as_stream(stream));
+  TRY(cips3d_nerf_render(&np, stream));
+  if (IO.ev_nerf_stop) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_stop), as_stream(stream));
+  TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, P.features, IO.thumb, IO.xyz, IO.mask, stream));
+
+  // ---- decoder (model_v3.py:592-637)
+  const float* x = P.features;
+  const float* skip = nullptr;
+  int act_i = 0, skip_i = 0;
+  for (int li = 0; li < P.n_dec_layers; ++li) {
+    const cips3d_dec_layer& L = P.layers[li];
+    const bool last = li == P.n_dec_layers - 1;
+    if (L.kind == 0 || L.kind == 1) {
+      const float* nz = L.noise_index >= 0 ? IO.noise[L.noise_index] : nullptr;
+      const int64_t nbs = L.noise_index >= 0 ? IO.noise_bstride[L.noise_index] : 0;
+      float* out = P.act[act_i];
+      if (L.kind == 0) {
+        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 1, nz, nbs, L.noise_w, L.bias, stream));
+      } else {
+        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0, nullptr, nullptr,
+                              stream));
+        TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));
+      }
+      x = out;
+      act_i ^= 1;
+    } else if (L.kind == 2 || L.kind == 3) {
+      float* out = last ? IO.rgb : P.skip[skip_i];
+      TRY(cips3d_torgb(x, L.wm, L.bias, skip, L.kind == 3 ? 1 : 0, L.fir, out, B, L.Cin, L.H, L.W, stream));
+      skip = out;
+      skip_i ^= 1;
+    } else {
+      return CIPS3D_E_BADARG;
+    }
+  }
+  return 0;
+}

@@ -48,7 +48,7 @@ __device__ __forceinline__ void dot_rows(const float* __restrict__ w, const floa
 struct LinearArgs {
   const float* x; int64_t x_stride; const float* W; const float* bias; float* out; int64_t out_stride;
   int B, in_dim, out_dim; float w_scale, b_scale; int pixelnorm, lrelu; float act_gain, out_scale, out_shift;
-  const float* trunc_mean; float trunc_psi;
+  const float* trunc_mean; float trunc_psi; int out_repeat; int64_t out_repeat_stride;
 };
 
 __global__ void __launch_bounds__(256) linear_kernel(LinearArgs a) {
@@ -84,7 +84,8 @@ __global__ void __launch_bounds__(256) linear_kernel(LinearArgs a) {
         if (a.lrelu) y = lrelu02(y) * a.act_gain;
         y = fmaf(y, a.out_scale, a.out_shift);
         if (a.trunc_mean) { const float m = a.trunc_mean[row]; y = fmaf(a.trunc_psi, y - m, m); }
-        a.out[(int64_t)(b0 + j) * a.out_stride + row] = y;
+        for (int r = 0; r < a.out_repeat; ++r)   // broadcast of one latent to every layer's style slot
+          a.out[(int64_t)(b0 + j) * a.out_stride + r * a.out_repeat_stride + row] = y;
       }
     }
   }
@@ -125,11 +126,12 @@ __global__ void __launch_bounds__(256) linear_table_kernel(const cips3d_linear_d
 extern "C" int cips3d_linear(const float* x, int64_t x_stride, const float* W, const float* bias, float* out,
                              int64_t out_stride, int B, int in_dim, int out_dim, float w_scale, float b_scale,
                              int pixelnorm, int lrelu, float act_gain, float out_scale, float out_shift,
-                             const float* trunc_mean, float trunc_psi, void* stream) {
-  if (!x || !W || !out || B < 0 || in_dim <= 0 || out_dim <= 0) return CIPS3D_E_BADARG;
+                             const float* trunc_mean, float trunc_psi, int out_repeat, int64_t out_repeat_stride,
+                             void* stream) {
+  if (!x || !W || !out || B < 0 || in_dim <= 0 || out_dim <= 0 || out_repeat < 1) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   LinearArgs a{x, x_stride, W, bias, out, out_stride, B, in_dim, out_dim, w_scale, b_scale, pixelnorm, lrelu,
-               act_gain, out_scale, out_shift, trunc_mean, trunc_psi};
+               act_gain, out_scale, out_shift, trunc_mean, trunc_psi, out_repeat, out_repeat_stride};
   hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(out_dim, 4)), dim3(256), 0, as_stream(stream), a);
   return cips3d_launch_status();
 }

@@ -176,15 +176,6 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection(project=project_noise)
         self.bias = nn.Parameter(torch.zeros(1, out_channel, 1, 1))     # present in checkpoints, unused in forward
         self.activate = op.FusedLeakyReLU(out_channel)
-        self._nw = None
-
-    def noise_weight(self):
-        """Host copy of the scalar NoiseInjection.weight (one device read per weight update)."""
-        p = self.noise.weight
-        key = (p.data_ptr(), p._version)
-        if self._nw is None or self._nw[0] != key:
-            self._nw = (key, float(p.detach().cpu()))
-        return self._nw[1]
 
     def forward(self, input, style, noise=None, transform=None, mesh_path=None, wm=None):
         B, Cin, H, W = input.shape
@@ -194,7 +185,7 @@ class StyledConv(nn.Module):
         if noise is None:
             noise = torch.randn(B, 1, Ho, Wo, device=x.device)
         noise = noise.contiguous()
-        nw = self.noise_weight()
+        nw = self.noise.weight          # device scalar, read by the kernels
         if conv.fast(H * W):
             if wm is None:
                 wm = conv.modulated_weight(style, packed=True)

@@ -132,6 +132,54 @@ class Generator(nn.Module):
             noise_bufs = [None] * self.decoder.num_layers
         return noise_bufs
 
+    # ---------------------------------------------------------------- one-call forward
+    def _forward_plan(self, B, img_size, N, static):
+        """cips3d_generator_forward plan for this shape, or None when the configuration cannot be planned
+        (k=3 / untiled channel counts use the per-op path below)."""
+        from . import plan as _plan
+        if not hasattr(self, "_plans"):
+            self._plans = {}
+        key = (B, img_size, N, static)
+        ent = self._plans.get(key, 0)
+        if ent is None:
+            return None
+        if ent == 0 or ent.key != _plan.ForwardPlan.weights_key(self):
+            try:
+                ent = _plan.ForwardPlan(self, B, img_size, N, static)
+            except _plan.PlanUnsupported:
+                ent = None
+            self._plans[key] = ent
+        return ent
+
+    def _planned_forward(self, plan, zs, cam_poses, focals, near, far, perturb_u, noise_bufs, truncation, style_render,
+                         style_decoder, return_sdf, return_xyz):
+        from . import hip
+        B = plan.B
+        z_r = z_d = mean_r = mean_d = None
+        if style_render is not None and style_decoder is not None:
+            plan.styles_r.copy_(style_render)       # explicit W+ styles bypass the mapping networks
+            plan.styles_d.copy_(style_decoder)
+        else:
+            z_r, z_d = zs[0].float().contiguous(), zs[1].float().contiguous()
+            if truncation < 1:
+                mean_r = self.style_render_mean.reshape(-1).contiguous()
+                mean_d = self.style_decoder_mean.reshape(-1).contiguous()
+        events = None
+        lst = hip.KERNEL_EVENTS.get("nerf_render")
+        if lst is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(); ev[1].record()          # materialise the hipEvent_t handles
+            lst.append(ev)
+            events = (ev[0].cuda_event, ev[1].cuda_event)
+        rgb, thumb, xyz, mask, sdf = plan.run(
+            z_r, z_d, cam_poses.float().contiguous(), focals.float().reshape(B).contiguous(),
+            near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
+            None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
+            float(truncation), mean_r, mean_d, return_sdf, events)
+        return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
+                "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
+                "mask": mask[:, [0]], "depth": mask[:, [1]]}
+
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
     def forward(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
@@ -148,9 +196,6 @@ class Generator(nn.Module):
             raise NotImplementedError("project_noise needs pytorch3d mesh rendering; unused by released configs")
         # N_rays_forward / N_samples_forward only bound activation memory in the reference; the fused kernel
         # never materialises per-point activations, so they are accepted and ignored.
-        style_render, style_decoder = self.mapping_networks(
-            zs=zs, truncation=truncation, inject_index=inject_index, style_render=style_render,
-            style_decoder=style_decoder, recompute_mean=recompute_mean)
         noise_bufs = self.get_noise_bufs(noise_bufs, randomize_noise)
 
         B = cam_poses.shape[0]
@@ -164,6 +209,21 @@ class Generator(nn.Module):
         def per_view(v):
             return v if torch.is_tensor(v) else torch.full((B, 1, 1), float(v), device=dev)
 
+        static = bool(nerf_cfg.get("static_viewdirs", False))
+        plan = self._forward_plan(B, img_size, N, static)
+        if (style_render is None) != (style_decoder is None):
+            raise NotImplementedError
+        if plan is not None and inject_index is None:
+            if style_render is None and truncation < 1 and (
+                    recompute_mean or not hasattr(self, "style_render_mean") or not hasattr(self, "style_decoder_mean")):
+                self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, dev)
+            return self._planned_forward(plan, zs, cam_poses, per_view(focals), per_view(near), per_view(far), perturb_u,
+                                         noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz)
+
+        # ---- per-op path (k=3 / untiled shapes / style mixing): same kernels, launched one by one
+        style_render, style_decoder = self.mapping_networks(
+            zs=zs, truncation=truncation, inject_index=inject_index, style_render=style_render,
+            style_decoder=style_decoder, recompute_mean=recompute_mean)
         thumb_rgb, features, sdf, mask, xyz = self.renderer.render(
             cam_poses, per_view(focals), per_view(near), per_view(far), style_render, img_size, N,
             perturb_u=perturb_u, static_viewdirs=nerf_cfg.get("static_viewdirs", False), return_sdf=return_sdf)

@@ -29,7 +29,7 @@ def _timed(name):
 
 
 def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False, lrelu=False, act_gain=1.0,
-           out_scale=1.0, out_shift=0.0, trunc_mean=None, trunc_psi=1.0):
+           out_scale=1.0, out_shift=0.0, trunc_mean=None, trunc_psi=1.0, out_repeat=1, out_repeat_stride=0):
     """x [B,in] -> [B,out]; see cips3d_linear."""
     lib = _lib.load()
     B, in_dim = x.shape
@@ -38,7 +38,8 @@ def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False,
         out = torch.empty(B, out_dim, device=x.device, dtype=torch.float32)
     check(lib.cips3d_linear(dev_ptr(x, "x"), x.stride(0), dev_ptr(W, "W"), dev_ptr(bias, "bias", True), dev_ptr(out, "out"),
                             out.stride(0), B, in_dim, out_dim, w_scale, b_scale, int(pixelnorm), int(lrelu), act_gain,
-                            out_scale, out_shift, dev_ptr(trunc_mean, "trunc_mean", True), trunc_psi, stream_ptr()),
+                            out_scale, out_shift, dev_ptr(trunc_mean, "trunc_mean", True), trunc_psi, out_repeat, out_repeat_stride,
+                            stream_ptr()),
           "cips3d_linear")
     return out
 
@@ -167,7 +168,7 @@ def modconv1x1_supported(Cin, Cout, HW):
     return bool(_lib.load().cips3d_modconv1x1_supported(Cin, Cout, HW))
 
 
-def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=0.0, bias=None, out=None):
+def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None):
     lib = _lib.load()
     B, Cin, H, W = x.shape
     if out is None:
@@ -178,7 +179,7 @@ def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=0.0, bias=Non
     if noise is not None and noise.shape[0] not in (1, B):
         raise RuntimeError("noise batch must be 1 or B")
     check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H * W, epilogue,
-                                dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias", True),
+                                dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
                                 stream_ptr()), "cips3d_modconv1x1")
     return out
 
@@ -190,7 +191,7 @@ def up2_fir_act(y_lo, fir, noise, noise_w, bias, out=None):
         out = torch.empty(B, Cc, 2 * H, 2 * W, device=y_lo.device, dtype=torch.float32)
     nb = 4 * H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
     check(lib.cips3d_up2_fir_act(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(out), B, Cc, H, W,
-                                 dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias"), stream_ptr()),
+                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias"), stream_ptr()),
           "cips3d_up2_fir_act")
     return out
 
@@ -200,7 +201,7 @@ def noise_bias_act(x, noise, noise_w, bias):
     B, Cc, H, W = x.shape
     out = torch.empty_like(x)
     nb = H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
-    check(lib.cips3d_noise_bias_act(dev_ptr(x, "x"), dev_ptr(noise, "noise", True), nb, float(noise_w), dev_ptr(bias, "bias"),
+    check(lib.cips3d_noise_bias_act(dev_ptr(x, "x"), dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias"),
                                     dev_ptr(out), B, Cc, H * W, stream_ptr()), "cips3d_noise_bias_act")
     return out
 

@@ -1,0 +1,255 @@
+"""Host side of cips3d_generator_forward: builds the plan (device pointers into a Generator's
+parameters + a persistent workspace) once per (batch, img_size, N_samples, static_viewdirs) and fills
+the small per-call io struct.  One ctypes call then enqueues the whole forward.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, hip
+from ._lib import dev_ptr
+
+MAX_MAP = 8
+MAX_DEC = 40
+
+
+class DecLayer(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("noise_index", C.c_int32), ("wm", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
+                ("fir", C.c_void_p)]
+
+
+class GeneratorPlan(C.Structure):
+    _fields_ = [("B", C.c_int32), ("z_dim", C.c_int32), ("n_map_r", C.c_int32), ("n_map_d", C.c_int32),
+                ("style_dim_r", C.c_int32), ("style_dim_d", C.c_int32), ("n_latent", C.c_int32),
+                ("n_dec_layers", C.c_int32),
+                ("map_r_w", C.c_void_p * MAX_MAP), ("map_r_b", C.c_void_p * MAX_MAP),
+                ("map_d_w", C.c_void_p * MAX_MAP), ("map_d_b", C.c_void_p * MAX_MAP),
+                ("map_d_in", C.c_int32 * MAX_MAP), ("map_d_lr_mul", C.c_float), ("pad0_", C.c_int32),
+                ("lat", C.c_void_p * 2), ("styles_r", C.c_void_p), ("styles_d", C.c_void_p),
+                ("film_table", C.c_void_p), ("film_n", C.c_int32), ("film_rows", C.c_int32),
+                ("mod_table", C.c_void_p), ("mod_n", C.c_int32), ("mod_rows", C.c_int32),
+                ("wm_table", C.c_void_p), ("wm_n", C.c_int32), ("wm_rows", C.c_int32),
+                ("nerf", _lib.NerfParams), ("features", C.c_void_p),
+                ("layers", DecLayer * MAX_DEC),
+                ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("skip", C.c_void_p * 2)]
+
+
+class ForwardIO(C.Structure):
+    _fields_ = [("z_r", C.c_void_p), ("z_d", C.c_void_p), ("mean_r", C.c_void_p), ("mean_d", C.c_void_p),
+                ("trunc_psi", C.c_float), ("pad_", C.c_int32),
+                ("cam_poses", C.c_void_p), ("focals", C.c_void_p), ("near_", C.c_void_p), ("far_", C.c_void_p),
+                ("perturb_u", C.c_void_p), ("sdf", C.c_void_p),
+                ("noise", C.c_void_p * MAX_DEC), ("noise_bstride", C.c_int64 * MAX_DEC),
+                ("rgb", C.c_void_p), ("thumb", C.c_void_p), ("xyz", C.c_void_p), ("mask", C.c_void_p),
+                ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p)]
+
+
+class PlanUnsupported(RuntimeError):
+    """The configuration cannot be planned (k != 1 or channel counts the MFMA GEMM does not tile)."""
+
+
+def _upload(array):
+    raw = bytes(memoryview(array))
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+
+
+class ForwardPlan:
+    def __init__(self, G, B, img_size, N_samples, static_viewdirs, n_chunks=None):
+        lib = _lib.load()
+        if lib.cips3d_sizeof_plan() != C.sizeof(GeneratorPlan) or lib.cips3d_sizeof_io() != C.sizeof(ForwardIO):
+            raise RuntimeError("cips3d_generator_plan / cips3d_forward_io layout mismatch between python and the library")
+        dev = G.renderer.sigmoid_beta.device
+        ren, dec = G.renderer, G.decoder
+        D, H = ren.N_layers_renderer, ren.hidden_dim
+        self.B, self.img_size, self.N, self.static = B, img_size, N_samples, bool(static_viewdirs)
+        self.device = dev
+        self._keep = []
+        p = GeneratorPlan()
+        p.B, p.z_dim = B, G.z_dim
+        p.style_dim_r, p.style_dim_d = ren.style_dim, dec.style_dim
+        p.n_latent = dec.n_latent
+
+        # ---- mapping networks
+        map_r = list(G.style)
+        map_d = list(G.style_decoder)[1:]
+        if len(map_r) > MAX_MAP or len(map_d) > MAX_MAP:
+            raise PlanUnsupported("too many mapping layers")
+        p.n_map_r, p.n_map_d = len(map_r), len(map_d)
+        for i, l in enumerate(map_r):
+            p.map_r_w[i], p.map_r_b[i] = dev_ptr(l.weight), dev_ptr(l.bias)
+        for i, l in enumerate(map_d):
+            p.map_d_w[i], p.map_d_b[i] = dev_ptr(l.weight), dev_ptr(l.bias)
+            p.map_d_in[i] = l.weight.shape[1]
+        p.map_d_lr_mul = float(map_d[0].lr_mul)
+        lat_w = max(p.style_dim_r, p.style_dim_d, p.z_dim)
+        lat = torch.empty(2, B, lat_w, device=dev)
+        p.lat[0], p.lat[1] = lat[0].data_ptr(), lat[1].data_ptr()
+
+        # ---- FiLM heads (renderer owns styles staging + film + table)
+        styles_r, film, film_tab = ren._film_table(B, dev)
+        if film_tab._dev is None:
+            film_tab._upload()
+        p.styles_r = styles_r.data_ptr()
+        p.film_table, p.film_n, p.film_rows = film_tab._dev.data_ptr(), len(film_tab._descs), film_tab._rows
+        self.styles_r = styles_r
+
+        # ---- decoder modulations
+        styles_d, s_buf, mod_tab, offs, total = dec._style_table(B, dev)
+        if mod_tab._dev is None:
+            mod_tab._upload()
+        p.styles_d = styles_d.data_ptr()
+        p.mod_table, p.mod_n, p.mod_rows = mod_tab._dev.data_ptr(), len(mod_tab._descs), mod_tab._rows
+        self.styles_d = styles_d
+
+        # ---- decoder layer list + modulated-weight table
+        from .decoder import StyledConv
+        seq = dec._mod_layers()
+        if len(seq) > MAX_DEC:
+            raise PlanUnsupported("too many decoder layers")
+        res = img_size
+        wm_sizes, layer_info = [], []
+        noise_idx = 0
+        max_act, max_lo, max_skip = 0, 1, 1
+        for idx, (m, _) in enumerate(seq):
+            conv = m.conv
+            if conv.kernel_size != 1:
+                raise PlanUnsupported("kernel_size != 1")
+            if isinstance(m, StyledConv):
+                if not conv.fast(res * res):
+                    raise PlanUnsupported(f"conv {conv.in_channel}->{conv.out_channel} @ {res}^2 not tiled by the MFMA GEMM")
+                kind = 1 if conv.upsample else 0
+                info = dict(kind=kind, Cin=conv.in_channel, Cout=conv.out_channel, H=res, W=res, noise_index=noise_idx,
+                            bias=m.activate.bias, noise_w=m.noise.weight, fir=conv.blur.kernel if conv.upsample else None,
+                            packed=True, conv=conv)
+                noise_idx += 1
+                if conv.upsample:
+                    max_lo = max(max_lo, B * conv.out_channel * res * res)
+                    res *= 2
+                info["Hout"] = res
+                max_act = max(max_act, B * conv.out_channel * res * res)
+            else:
+                up = bool(m.upsample)
+                if res % 4 != 0:
+                    raise PlanUnsupported("toRGB resolution not a multiple of 4")
+                info = dict(kind=3 if up else 2, Cin=conv.in_channel, Cout=3, H=res, W=res, noise_index=-1, bias=m.bias,
+                            noise_w=None, fir=m.upsample.kernel if up else None, packed=False, conv=conv, Hout=res)
+                max_skip = max(max_skip, B * 3 * res * res)
+            wm_sizes.append(B * conv.out_channel * conv.in_channel)
+            layer_info.append(info)
+        self.out_res = res
+        self.noise_sizes = [li["Hout"] for li in layer_info if li["kind"] in (0, 1)]
+        wm_buf = torch.empty(sum(wm_sizes), device=dev)
+        wm_tab = (_lib.ModulateDesc * len(seq))()
+        rows, woff = 0, 0
+        for idx, (info, off) in enumerate(zip(layer_info, offs)):
+            conv = info["conv"]
+            d = wm_tab[idx]
+            d.W = dev_ptr(conv.weight)
+            d.s = s_buf.data_ptr() + 4 * off
+            d.out = wm_buf.data_ptr() + 4 * woff
+            d.s_stride = total
+            d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
+            d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0)
+            d.scale = conv.scale
+            d.row_begin = rows
+            rows += conv.out_channel
+            L = p.layers[idx]
+            L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
+                                                              info["W"], info["noise_index"])
+            L.wm = d.out
+            L.bias = dev_ptr(info["bias"])
+            L.noise_w = dev_ptr(info["noise_w"], allow_none=True)
+            L.fir = dev_ptr(info["fir"], allow_none=True)
+            woff += wm_sizes[idx]
+        p.n_dec_layers = len(seq)
+        wm_tab_dev = _upload(wm_tab).to(dev)
+        p.wm_table, p.wm_n, p.wm_rows = wm_tab_dev.data_ptr(), len(seq), rows
+
+        # ---- renderer
+        packed, layer_bias = ren._derived_buffers()
+        net = ren.network
+        if n_chunks is None:
+            n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)
+        R = img_size * img_size
+        part = torch.empty(n_chunks, B, H + 8, R, device=dev)
+        features = torch.empty(B, H, img_size, img_size, device=dev)
+        n = p.nerf
+        n.w_first, n.packed, n.w_view = dev_ptr(net.pts_linears[0].weight), dev_ptr(packed), dev_ptr(net.views_linears.weight)
+        n.film, n.layer_bias = dev_ptr(film), dev_ptr(layer_bias)
+        n.w_sigma, n.w_rgb = dev_ptr(net.sigma_linear.weight), dev_ptr(net.rgb_linear.weight)
+        n.b_sigma, n.b_rgb = dev_ptr(net.sigma_linear.bias), dev_ptr(net.rgb_linear.bias)
+        n.sigmoid_beta = dev_ptr(ren.sigmoid_beta)
+        n.B, n.img_size, n.n_samples, n.hidden, n.depth = B, img_size, N_samples, H, D
+        n.static_viewdirs, n.n_chunks = int(self.static), n_chunks
+        n.part = part.data_ptr()
+        p.features = features.data_ptr()
+
+        # ---- decoder workspace
+        act = torch.empty(2, max_act, device=dev)
+        y_lo = torch.empty(max_lo, device=dev)
+        skip = torch.empty(2, max_skip, device=dev)
+        p.act[0], p.act[1] = act[0].data_ptr(), act[1].data_ptr()
+        p.y_lo = y_lo.data_ptr()
+        p.skip[0], p.skip[1] = skip[0].data_ptr(), skip[1].data_ptr()
+
+        self.plan = p
+        self.key = self.weights_key(G)
+        self._keep += [lat, film, film_tab, mod_tab, s_buf, wm_buf, wm_tab_dev, packed, layer_bias, part, features, act,
+                       y_lo, skip]
+        self.noise_total = sum(s * s for s in self.noise_sizes)
+
+    @staticmethod
+    def weights_key(G):
+        """Plans hold raw pointers: they die with any re-allocation of a parameter (.to(), load of new storage)
+        and with a change of the NeRF weights the packed copy was made from."""
+        ren = G.renderer
+        return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key())
+
+    def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
+            events=None):
+        lib = _lib.load()
+        B, S, dev = self.B, self.img_size, self.device
+        io = ForwardIO()
+        io.z_r = dev_ptr(z_r, "zs[0]", allow_none=True)
+        io.z_d = dev_ptr(z_d, "zs[1]", allow_none=True)
+        io.mean_r = dev_ptr(mean_r, "style_render_mean", allow_none=True)
+        io.mean_d = dev_ptr(mean_d, "style_decoder_mean", allow_none=True)
+        io.trunc_psi = float(trunc_psi)
+        io.cam_poses, io.focals = dev_ptr(cam_poses, "cam_poses"), dev_ptr(focals, "focals")
+        io.near_, io.far_ = dev_ptr(near, "near"), dev_ptr(far, "far")
+        io.perturb_u = dev_ptr(perturb_u, "perturb_u", allow_none=True)
+        R = S * S
+        sdf = torch.empty(B, R, self.N, device=dev) if return_sdf else None
+        io.sdf = dev_ptr(sdf, "sdf", allow_none=True)
+        keep = None
+        if noise_bufs is None or all(nb is None for nb in noise_bufs):
+            # fresh N(0,1) noise for every layer and sample: one generator launch for the whole decoder
+            keep = torch.randn(B * self.noise_total, device=dev)
+            off = 0
+            for i, s in enumerate(self.noise_sizes):
+                io.noise[i] = keep.data_ptr() + 4 * off
+                io.noise_bstride[i] = s * s
+                off += B * s * s
+        else:
+            if len(noise_bufs) != len(self.noise_sizes):
+                raise RuntimeError(f"expected {len(self.noise_sizes)} noise buffers, got {len(noise_bufs)}")
+            for i, (nb, s) in enumerate(zip(noise_bufs, self.noise_sizes)):
+                if nb is None:
+                    nb = torch.randn(B, 1, s, s, device=dev)
+                if tuple(nb.shape[-2:]) != (s, s) or nb.shape[0] not in (1, B):
+                    raise RuntimeError(f"noise buffer {i} has shape {tuple(nb.shape)}, expected (1|{B},1,{s},{s})")
+                io.noise[i] = dev_ptr(nb, f"noise_bufs[{i}]")
+                io.noise_bstride[i] = s * s if (nb.shape[0] == B and B > 1) else 0
+        rgb = torch.empty(B, 3, self.out_res, self.out_res, device=dev)
+        thumb = torch.empty(B, 3, S, S, device=dev)
+        xyz = torch.empty(B, 3, S, S, device=dev)
+        mask = torch.empty(B, 2, S, S, device=dev)
+        io.rgb, io.thumb, io.xyz, io.mask = rgb.data_ptr(), thumb.data_ptr(), xyz.data_ptr(), mask.data_ptr()
+        if events is not None:
+            io.ev_nerf_start, io.ev_nerf_stop = events
+        _lib.check(lib.cips3d_generator_forward(C.byref(self.plan), C.byref(io), _lib.stream_ptr()),
+                   "cips3d_generator_forward")
+        if sdf is not None:
+            sdf = sdf.view(B, S, S, self.N, 1)
+        return rgb, thumb, xyz, mask, sdf

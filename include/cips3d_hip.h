@@ -67,12 +67,14 @@ int cips3d_upfirdn2d(const float* input, const float* kernel, float* out,
  *   y      = lrelu ? leaky_relu(y, 0.2) * act_gain : y
  *   y      = y * out_scale + out_shift
  *   out    = trunc_mean ? trunc_mean[o] + trunc_psi * (y - trunc_mean[o]) : y
+ * and the result is written out_repeat (>= 1) times, copy r at out + r * out_repeat_stride (the
+ * `w.unsqueeze(1).repeat(1, n_latent, 1)` of the mapping networks, models/model_v3.py:1367,1416).
  * x [B, x_stride] (first in_dim entries used), W [out_dim, in_dim], out [B, out_stride]. */
 int cips3d_linear(const float* x, int64_t x_stride, const float* W, const float* bias, float* out,
                   int64_t out_stride, int B, int in_dim, int out_dim,
                   float w_scale, float b_scale, int pixelnorm, int lrelu, float act_gain,
                   float out_scale, float out_shift, const float* trunc_mean, float trunc_psi,
-                  void* stream);
+                  int out_repeat, int64_t out_repeat_stride, void* stream);
 
 /* A table of independent dense layers evaluated in ONE launch (FiLM gamma/beta heads and the
  * decoder's per-layer style modulations).  The table itself lives in device memory. */
@@ -194,19 +196,19 @@ int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW);
  * per-sample [B,HW] (noise_bstride = HW). */
 int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
                       int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
-                      float noise_w, const float* bias, void* stream);
+                      const float* noise_w, const float* bias, void* stream);
 
 /* 2x FIR up-sampling of a low-resolution conv result fused with the StyledConv epilogue:
  *   u   = upfirdn2d(y_lo, fir, up=2, pad=(2,1))      (fir = outer([1,3,3,1])/64*4, [4,4] device)
  *   out = lrelu(u + noise_w * noise + bias[c], 0.2) * sqrt(2)
  * y_lo [B,C,H,W] -> out [B,C,2H,2W]. */
 int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
-                       const float* noise, int64_t noise_bstride, float noise_w, const float* bias,
+                       const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
                        void* stream);
 
 /* StyledConv epilogue on its own (used after the k x k path):
  *   out = lrelu(x + noise_w * noise + bias[c], 0.2) * sqrt(2);  x/out [B,C,HW]. */
-int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, float noise_w,
+int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstride, const float* noise_w,
                           const float* bias, float* out, int B, int C, int64_t HW, void* stream);
 
 /* ToRGB: out[b][c][n] = sum_i wm[b][c][i] * x[b][i][n] + bias[c] + skip_term, where skip_term is
@@ -219,6 +221,78 @@ int cips3d_torgb(const float* x, const float* wm, const float* bias, const float
  * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
 int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
                        int H, int W, int k, int transpose2, void* stream);
+
+/* ------------------------------------------------------------------ whole forward, one call */
+
+/* The generator forward (models/model_v3.py:875-1042) as ONE host call that enqueues every kernel of
+ * the path on `stream`: mapping networks -> FiLM heads -> fused NeRF render -> finish -> all decoder
+ * style modulations + weight modulations (two table launches) -> per layer GEMM / FIR / toRGB.
+ * The plan is built once per (module, batch size, N_samples) by the host binding: it holds device
+ * pointers into the module's parameters and into a persistent workspace; the per-call tensors travel
+ * in cips3d_forward_io.  Only 1x1 convolutions whose shapes cips3d_modconv1x1_supported accepts can be
+ * planned (every released v10 config); other configurations use the per-op entry points. */
+#define CIPS3D_MAX_MAP_LAYERS 8
+#define CIPS3D_MAX_DEC_LAYERS 40
+
+typedef struct cips3d_dec_layer {
+  int32_t kind;            /* 0 StyledConv, 1 StyledConv with 2x up-sampling, 2 ToRGB, 3 ToRGB + up-sampled skip */
+  int32_t Cin, Cout, H, W; /* H, W = INPUT resolution of the layer (ToRGB: its own resolution) */
+  int32_t noise_index;     /* index into cips3d_forward_io.noise (StyledConv) or -1 */
+  const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
+  const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */
+  const float* noise_w;    /* NoiseInjection.weight [1] (StyledConv) */
+  const float* fir;        /* 4x4 FIR (blur.kernel / upsample.kernel) for kinds 1 and 3 */
+} cips3d_dec_layer;
+
+typedef struct cips3d_generator_plan {
+  int32_t B, z_dim, n_map_r, n_map_d, style_dim_r, style_dim_d, n_latent, n_dec_layers;
+  /* mapping networks: MappingLinear x n_map_r (lrelu gain 1), PixelNorm + EqualLinear x n_map_d (gain sqrt 2) */
+  const float* map_r_w[CIPS3D_MAX_MAP_LAYERS]; const float* map_r_b[CIPS3D_MAX_MAP_LAYERS];
+  const float* map_d_w[CIPS3D_MAX_MAP_LAYERS]; const float* map_d_b[CIPS3D_MAX_MAP_LAYERS];
+  int32_t map_d_in[CIPS3D_MAX_MAP_LAYERS];
+  float map_d_lr_mul;
+  int32_t pad0_;
+  float* lat[2];                 /* ping-pong [B, max(style_dim_r, style_dim_d, z_dim)] */
+  float* styles_r;               /* [B, D+1, style_dim_r] */
+  float* styles_d;               /* [B, n_latent, style_dim_d] */
+  /* style heads */
+  const cips3d_linear_desc* film_table; int32_t film_n, film_rows;     /* -> nerf.film */
+  const cips3d_linear_desc* mod_table; int32_t mod_n, mod_rows;        /* -> s_buf */
+  const cips3d_modulate_desc* wm_table; int32_t wm_n, wm_rows;         /* s_buf -> wm buffers */
+  /* renderer: everything but the per-call camera / perturbation pointers is pre-filled */
+  cips3d_nerf_params nerf;
+  float* features;               /* [B, H, S, S] NeRF feature map = decoder input */
+  /* decoder */
+  cips3d_dec_layer layers[CIPS3D_MAX_DEC_LAYERS];
+  float* act[2];                 /* activation ping-pong, each >= B * max(C*H*W) floats */
+  float* y_lo;                   /* low-resolution GEMM result feeding the FIR up-sampler */
+  float* skip[2];                /* RGB skip ping-pong, each >= B*3*Hout*Wout floats */
+} cips3d_generator_plan;
+
+typedef struct cips3d_forward_io {
+  const float* z_r;        /* [B, z_dim] or NULL when styles_r of the plan was filled by the caller */
+  const float* z_d;        /* [B, z_dim] or NULL (same for styles_d) */
+  const float* mean_r;     /* [style_dim_r] truncation mean or NULL (truncation = 1) */
+  const float* mean_d;     /* [style_dim_d] */
+  float trunc_psi;
+  int32_t pad_;
+  const float* cam_poses; const float* focals; const float* near_; const float* far_;   /* [B,...] */
+  const float* perturb_u;  /* [B, R] or NULL */
+  float* sdf;              /* [B, R, N] or NULL */
+  const float* noise[CIPS3D_MAX_DEC_LAYERS];      /* per StyledConv: [1 or B][Hout*Wout] or NULL */
+  int64_t noise_bstride[CIPS3D_MAX_DEC_LAYERS];   /* 0 (shared) or Hout*Wout */
+  float* rgb;              /* [B, 3, Hout, Wout] final image (written by the last ToRGB) */
+  float* thumb;            /* [B, 3, S, S] */
+  float* xyz;              /* [B, 3, S, S] */
+  float* mask;             /* [B, 2, S, S]: background weight, -|xyz| */
+  void* ev_nerf_start;     /* optional hipEvent_t recorded on `stream` right before / after the render kernel */
+  void* ev_nerf_stop;
+} cips3d_forward_io;
+
+int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io, void* stream);
+/* sizeof() of the two structs as the library sees them (layout check for foreign-language bindings) */
+int64_t cips3d_sizeof_plan(void);
+int64_t cips3d_sizeof_io(void);
 
 #ifdef __cplusplus
 }
