@@ -37,6 +37,26 @@
 // partials only (n_chunks * (H+8) * 4 B per ray).
 #include "common.h"
 
+#ifdef CIPS3D_STAMPS
+// Diagnostic build only (never in the shipped library): per-phase cycle sums of wave 0 of every workgroup.
+__device__ unsigned long long g_nerf_stamps[8];
+#define STAMP(i)                                                                         \
+  do {                                                                                   \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
+    if (wave == 0 && lane == 0) atomicAdd(&g_nerf_stamps[i], t_ - t_prev_);              \
+    t_prev_ = __builtin_amdgcn_s_memtime();                                              \
+  } while (0)
+extern "C" int cips3d_debug_read_stamps(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_nerf_stamps), 64);
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_stamps), z, 64);
+  return 0;
+}
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -123,35 +143,53 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
   constexpr int H = NT * 16;
   constexpr int TILE = 16 * H;          // floats of one o-tile's A fragments
   constexpr int SLAB = TILE * TPS;
-#pragma unroll
-  for (int sl = 0; sl < NT / TPS; ++sl) {
+  constexpr int STEPS = NT / TPS;
+  constexpr int R = TPS * 4;            // output registers produced per step
+  // The slab-step loop is a REAL loop: one step's code (TPS*H/4 MFMAs + epilogue) is ~3 KB, the fully
+  // unrolled layer was ~25 KB and the whole kernel ~70 KB, more than the instruction cache can hold across
+  // one sample pass.  Output registers cannot be indexed by the (run-time) step, so the step always writes
+  // the LAST R registers of Y / FA and the array is rotated down by R; after STEPS steps every element is
+  // back in natural order.
+#pragma unroll 1
+  for (int sl = 0; sl < STEPS; ++sl) {
     if (ring.seq + 1 < ring.seq_end) {
       const int nxt = (ring.seq + 1) % ring.per_sample;
       stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
     }
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
+    const int o_base = sl * (TPS * 16) + q4o;          // this lane's first output unit of the step
+    // The TPS o-tiles of the slab are independent accumulator chains, interleaved so that one wave alone
+    // covers the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
+    f32x4 acc[TPS];
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
-      const int t = sl * TPS + tt;
-      const int o4 = t * 16 + q4o;        // this lane's 4 consecutive output units
-      f32x4 acc;
+      const int o4 = o_base + tt * 16;
       if (VIEW) {
         const f32x4 wx = *reinterpret_cast<const f32x4*>(s_wd + o4);
         const f32x4 wy = *reinterpret_cast<const f32x4*>(s_wd + H + o4);
         const f32x4 wz = *reinterpret_cast<const f32x4*>(s_wd + 2 * H + o4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = fmaf(wz[i], vz, fmaf(wy[i], vy, wx[i] * vx));
+        for (int i = 0; i < 4; ++i) acc[tt][i] = fmaf(wz[i], vz, fmaf(wy[i], vy, wx[i] * vx));
       } else {
-        acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      const float* tile = slab + tt * TILE;
+    }
 #pragma unroll
-      for (int q4 = 0; q4 < H / 16; ++q4) {
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(tile + (q4 * 64 + lane) * 4);
+    for (int q4 = 0; q4 < H / 16; ++q4) {
+      f32x4 a4[TPS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], X[4 * q4 + j], acc, 0, 0, 0);
-      }
+      for (int tt = 0; tt < TPS; ++tt)
+        a4[tt] = *reinterpret_cast<const f32x4*>(slab + tt * TILE + (q4 * 64 + lane) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tt = 0; tt < TPS; ++tt)
+          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt][j], X[4 * q4 + j], acc[tt], 0, 0, 0);
+    }
+    float res[R];
+#pragma unroll
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int o4 = o_base + tt * 16;
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + o4);
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(film_l + H + o4);
       if (VIEW) {
@@ -160,16 +198,28 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_wc + 2 * H + o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float f = sin_accurate(fmaf(g4[i], acc[i], c4[i]));
-          FA[t * 4 + i] = fmaf(wgt, f, FA[t * 4 + i]);
+          const float f = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
+          res[tt * 4 + i] = fmaf(wgt, f, FA[tt * 4 + i]);     // FA[0..R) currently holds this step's units
           chead[0] = fmaf(w0[i], f, chead[0]);
           chead[1] = fmaf(w1[i], f, chead[1]);
           chead[2] = fmaf(w2[i], f, chead[2]);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) Y[t * 4 + i] = sin_accurate(fmaf(g4[i], acc[i], c4[i]));
+        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
       }
+    }
+    // rotate: drop the first R registers, append this step's results
+    if (VIEW) {
+#pragma unroll
+      for (int k = 0; k < NT * 4 - R; ++k) FA[k] = FA[k + R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) FA[NT * 4 - R + k] = res[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NT * 4 - R; ++k) Y[k] = Y[k + R];
+#pragma unroll
+      for (int k = 0; k < R; ++k) Y[NT * 4 - R + k] = res[k];
     }
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
@@ -179,7 +229,7 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
 }
 
 template <int NT, int TPS>
-__global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
+__global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) {
   constexpr int H = NT * 16;
   constexpr int SLAB = 16 * H * TPS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -217,19 +267,19 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
     // FiLM table: s_film[l][0][o] = gamma, s_film[l][1][o] = gamma * bias_l[o] + beta, so that
     // sin(gamma * (W x + bias) + beta) = sin(gamma * (W x) + c) costs one FMA per unit.
     const float* film_b = P.film + (int64_t)b * L * 2 * H;
-    for (int i = tid; i < L * H; i += 512) {
+    for (int i = tid; i < L * H; i += WAVES * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
       s_film[(l * 2) * H + o] = gm;
       s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]);
     }
-    for (int i = tid; i < 3 * H; i += 512) {
+    for (int i = tid; i < 3 * H; i += WAVES * 64) {
       const int k = i / H, o = i - k * H;
       s_w0[i] = P.w_first[o * 3 + k];
       s_wd[i] = P.w_view[o * (H + 3) + H + k];
       s_wc[i] = P.w_rgb[i];
     }
-    for (int i = tid; i < H; i += 512) s_ws[i] = P.w_sigma[i];
+    for (int i = tid; i < H; i += WAVES * 64) s_ws[i] = P.w_sigma[i];
   }
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
@@ -287,6 +337,10 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
   __syncthreads();
 
   const int s_begin = c * a.chunk;
+#ifdef CIPS3D_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
+  STAMP(0);   // prologue
   for (int si = 0; si < a.chunk; ++si) {
     const int sg = s_begin + si;
     const bool live = ray_ok && sg < N;
@@ -317,6 +371,7 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
       }
     }
     float chead[3] = {0.f, 0.f, 0.f};
+    STAMP(1);   // sample setup + layer 0
     // ---- hidden layers 1 .. D-1
     for (int l = 1; l < D; ++l) {
       mfma_layer<NT, TPS, false>(X, Y, FA, 0.f, chead, ring, s_film + l * 2 * H, s_wd, s_wc, vx, vy, vz, wave,
@@ -324,6 +379,7 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
 #pragma unroll
       for (int i = 0; i < NT * 4; ++i) X[i] = Y[i];
     }
+    STAMP(2);   // hidden layers
     // ---- sigma head on h_D (volume_renderer.py:148)
     float sdf = 0.f;
 #pragma unroll
@@ -343,6 +399,7 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
     const float w = live ? alpha * T : 0.f;
     if (live) T *= (1.f - alpha) + 1e-10f;
 
+    STAMP(3);   // sigma head + weight
     // ---- view layer -> features, folded into FA; rgb head partial sums
     mfma_layer<NT, TPS, true>(X, Y, FA, w, chead, ring, s_film + D * 2 * H, s_wd, s_wc, vx, vy, vz, wave, lane,
                               q4o);
@@ -351,12 +408,14 @@ __global__ void __launch_bounds__(512, 2) nerf_render_kernel(NerfArgs a) {
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
     c0 += b_rgb0; c1 += b_rgb1; c2 += b_rgb2;
 
+    STAMP(4);   // view layer
     cr = fmaf(w, sigmoidf_acc(c0), cr); cg = fmaf(w, sigmoidf_acc(c1), cg); cb = fmaf(w, sigmoidf_acc(c2), cb);
     ax = fmaf(w, ptx, ax); ay = fmaf(w, pty, ay); az = fmaf(w, ptz, az);
     if (sg == N - 1) wlast = w;
     if (P.sdf && live && qd == 0) P.sdf[((int64_t)b * R + ray) * N + sg] = sdf;
   }
 
+  STAMP(5);   // last compositing tail
   // ---- write the chunk partial: part[c][b][ch][ray]
   if (ray_ok) {
     float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray;
@@ -430,7 +489,7 @@ int launch_render(const NerfArgs& a, hipStream_t st) {
     attr_set = true;
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
-  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS>), dim3((unsigned)wgs), dim3(512), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
   return cips3d_launch_status();
 }
 

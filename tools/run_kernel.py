@@ -1,0 +1,69 @@
+"""Run one piece of the path in isolation (for rocprofv3 counter passes).
+    python tools/run_kernel.py nerf|gemm64|forward [--iters N] [--depth D] [--n-samples N]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cips_3dplusplus_amd as pkg
+from cips_3dplusplus_amd import configs, hip
+from cips_3dplusplus_amd.camera import Camera
+
+ap = argparse.ArgumentParser()
+ap.add_argument("what")
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--depth", type=int, default=2)
+ap.add_argument("--n-samples", type=int, default=24)
+ap.add_argument("--res", type=int, default=1024)
+ap.add_argument("--batch", type=int, default=1)
+a = ap.parse_args()
+dev = "cuda"
+cfg = configs.ffhq_G_cfg(a.res, a.depth)
+G = pkg.build_generator(cfg, dev, seed=0)
+B = a.batch
+e, f, n, fa, _ = Camera.generate_camera_params(64, dev, locations=torch.zeros(B, 2, device=dev))
+torch.manual_seed(0)
+if a.what == "nerf":
+    styles = torch.randn(B, a.depth + 1, 256, device=dev)
+    fn = lambda: G.renderer.render(e, f, n, fa, styles, 64, a.n_samples)
+elif a.what == "gemm64":
+    import cips_3dplusplus_amd.decoder as dec
+    sc = G.decoder.convs[0]
+    x = torch.randn(B, 512, 64, 64, device=dev)
+    st = torch.randn(B, 512, device=dev)
+    nz = torch.randn(1, 1, 64, 64, device=dev)
+    wm = sc.conv.modulated_weight(st, packed=True)
+    fn = lambda: sc(x, st, noise=nz, wm=wm)
+else:
+    zs = [torch.randn(B, 256, device=dev), torch.randn(B, 256, device=dev)]
+    ncfg = dict(N_samples=a.n_samples, perturb=True, static_viewdirs=False)
+    fn = lambda: G(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, nerf_cfg=ncfg)
+for _ in range(3):
+    fn()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    fn()
+torch.cuda.synchronize()
+print(f"{a.what}: {(time.perf_counter() - t0) / a.iters * 1e3:.3f} ms/iter (host wall)")
+if a.what == "nerf":
+    hip.KERNEL_EVENTS["nerf_render"] = []
+    for _ in range(a.iters):
+        fn()
+    torch.cuda.synchronize()
+    ev = hip.KERNEL_EVENTS.pop("nerf_render")
+    ts = sorted(s.elapsed_time(t) for s, t in ev)
+    print(f"  nerf_render kernel: median {ts[len(ts)//2]*1e3:.1f} us  min {ts[0]*1e3:.1f} us")
+if a.what == "nerf":
+    import ctypes
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH) if hasattr(pkg, "_lib") else None
+    from cips_3dplusplus_amd import _lib as L
+    raw = ctypes.CDLL(L.LIB_PATH)
+    if hasattr(raw, "cips3d_debug_read_stamps"):
+        buf = (ctypes.c_ulonglong * 8)()
+        raw.cips3d_debug_read_stamps(buf)
+        fn(); 
+        raw.cips3d_debug_read_stamps(buf)
+        nwg = 256 * a.batch
+        names = ["prologue", "setup+layer0", "hidden", "sigma+weight", "view", "tail"]
+        tot = sum(buf[:6])
+        for nme, v in zip(names, buf[:6]):
+            print(f"  {nme:14s} {v / nwg:10.0f} cycles/wg  {100.0 * v / tot:5.1f}%")
