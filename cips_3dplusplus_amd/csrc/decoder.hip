@@ -13,6 +13,8 @@
 // Rooflines: 64^2 / 128^2 stages are MFMA-bound (2*Cin*Cout flop per pixel against (Cin+Cout)*4 B);
 // >= 256^2 stages, the FIR up-sampler and ToRGB are HBM-bound: every kernel reads its input once and
 // writes its output once with >= 128-byte row segments.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -547,6 +549,19 @@ extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, in
   if (B == 0) return 0;
   GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias};
   hipStream_t st = as_stream(stream);
+  static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
+  if (dbg_cfg && Cout % 128 == 0) {
+    switch (dbg_cfg) {
+      case 1: return launch_gemm<1, 2, 2, 2, 32>(a, st);
+      case 2: return launch_gemm<1, 1, 2, 2, 32>(a, st);
+      case 3: return launch_gemm<1, 1, 2, 2, 64>(a, st);
+      case 4: return launch_gemm<2, 1, 2, 2, 32>(a, st);
+      case 5: return launch_gemm<2, 2, 2, 2, 32>(a, st);
+      case 6: return launch_gemm<1, 2, 1, 4, 16>(a, st);
+      case 7: return launch_gemm<1, 1, 1, 4, 32>(a, st);
+      case 8: return launch_gemm<1, 1, 4, 1, 32>(a, st);
+    }
+  }
   if (Cout % 128 == 0 && Cout <= 128) return launch_gemm<2, 2, 2, 2, 32>(a, st);   // 128 x 128: x read once
   if (Cout % 64 == 0 && Cout > 128) return launch_gemm<1, 2, 2, 2, 32>(a, st);     // 64 x 128
   if (Cout == 64) return launch_gemm<2, 2, 1, 4, 16>(a, st);                        // 64 x 256
