@@ -25,8 +25,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // weight modulation.  One wave per (b, o).
 //   plain : wm[b][o][i*ksq + t]
-//   packed (ksq == 1, Cout % 32 == 0, Cin % 8 == 0): MFMA A order
-//           wmp[b][ot][kq][lane][j] = wm[b][ot*32 + (lane&31)][8*kq + 2*j + (lane>>5)]
+//   packed (ksq == 1, Cout % 16 == 0, Cin % 16 == 0): A-fragment order of v_mfma_f32_16x16x4_f32
+//           wmp[b][ot][kq][lane][j] = wm[b][ot*16 + (lane&15)][16*kq + 4*j + (lane>>4)]
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb,
                                              float* __restrict__ wm, int b, int o, int Cout, int Cin, int ksq,
@@ -47,8 +47,8 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
     if (demod) v *= d;
     if (packed) {
       const int i = e;  // ksq == 1
-      const int ot = o >> 5, kq = i >> 3, j = (i & 7) >> 1, hh = i & 1;
-      wm[(((int64_t)b * (Cout >> 5) + ot) * (Cin >> 3) + kq) * 256 + ((hh << 5) | (o & 31)) * 4 + j] = v;
+      const int ot = o >> 4, kq = i >> 4, j = (i >> 2) & 3, q = i & 3;
+      wm[(((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = v;
     } else {
       wm[((int64_t)b * Cout + o) * len + e] = v;
     }
@@ -83,8 +83,12 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
 }
 
 // ------------------------------------------------------------------------------------------------
-// 1x1 modulated conv as GEMM.  Workgroup tile BM x BN, BK-deep stages through a 2-slot LDS ring filled
-// by LDS-DMA (A: packed fragments, linear copy; B: BK rows of BN pixels).  Wave tile = WM x WN MFMA tiles.
+// 1x1 modulated conv as GEMM on v_mfma_f32_16x16x4_f32.  Workgroup tile BM x BN, BK-deep stages through a
+// 2-slot LDS ring filled by LDS-DMA (A: packed fragments, linear copy; B: BK rows of BN pixels).
+// A wave owns WM o-tiles (16 rows each) x 64 pixels.  Its four 16-pixel column tiles are INTERLEAVED over
+// the pixels (lane j of column tile c holds pixel 4*j + c), so ONE ds_read_b128 per k-step delivers the
+// B fragments of all four column tiles (a per-MFMA ds_read_b32 made the kernel LDS-issue bound at one
+// wave per SIMD), and the epilogue stores 16 bytes per lane.
 // ------------------------------------------------------------------------------------------------
 struct GemmArgs {
   const float* x; const float* wmp; float* out;
@@ -92,18 +96,31 @@ struct GemmArgs {
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
 };
 
-template <int WM, int WN, int WGM, int WGN, int BK>
-__global__ void __launch_bounds__(256) modconv1x1_kernel(GemmArgs a) {
-  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+// s_waitcnt immediate that waits until at most n vector-memory operations of this wave are outstanding
+// (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt / lgkmcnt fields left at "no wait")
+__device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+template <int WM, int WGM, int WGN, int BK, int NS>
+__global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) {
+  constexpr int NW = WGM * WGN;               // waves per workgroup: 8 = two per SIMD, so one wave's DMA issue,
+                                              // waits and fragment reads run under the partner's MFMAs
+  constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
   constexpr int A_STAGE = BM * BK;            // floats
   constexpr int B_STAGE = BK * BN;
   constexpr int STAGE = A_STAGE + B_STAGE;
   constexpr int A_PIECES = A_STAGE / 256;     // 1-KiB pieces
   constexpr int B_PIECES = B_STAGE / 256;
   constexpr int PIECES = A_PIECES + B_PIECES;
-  constexpr int KQ = BK / 8;                  // A pieces per o-tile per stage
-  static_assert(WGM * WGN == 4, "four waves");
-  __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];
+  constexpr int PW = PIECES / NW;             // LDS-DMA instructions per wave per stage
+  constexpr int KQ = BK / 16;                 // A pieces per o-tile per stage
+  static_assert(NW == 4 || NW == 8, "four or eight waves");
+  static_assert(PIECES % NW == 0, "every wave must issue the same number of DMA pieces (counted vmcnt)");
+  static_assert(NS >= 2 && NS <= 4, "ring depth");
+  // NS-slot ring, NS-1 stages in flight: the LDS-DMA lands ~1.1 us after issue, so ONE 24 KB stage in
+  // flight caps a CU at ~22 GB/s (Little's law) -- below what the MFMA pipe consumes (measured: 63 % of
+  // peak at any tile shape).  Waits are counted (vmcnt(N) leaves the younger stages in flight) and the
+  // barrier is the raw s_barrier: __syncthreads() would drain every outstanding DMA.
+  __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,17 +135,16 @@ __global__ void __launch_bounds__(256) modconv1x1_kernel(GemmArgs a) {
   const float* xb = a.x + (int64_t)b * K * HW;
   const float* ab = a.wmp + (int64_t)b * a.Cout * K;   // packed: [ot][kq][256]
 
-  auto stage_load = [&](int st, int slot) {
-    float* dstA = lds + slot * STAGE;
+  auto stage_load = [&](int st) {
+    float* dstA = lds + (st % NS) * STAGE;
     float* dstB = dstA + A_STAGE;
     const int k0 = st * BK;
 #pragma unroll
-    for (int j = 0; j < (PIECES + 3) / 4; ++j) {
-      const int piece = j * 4 + wave;
-      if (PIECES % 4 != 0 && piece >= PIECES) break;
+    for (int j = 0; j < PW; ++j) {
+      const int piece = j * NW + wave;
       if (piece < A_PIECES) {
         const int ot_l = piece / KQ, kq_l = piece % KQ;
-        const float* src = ab + ((int64_t)((m0 >> 5) + ot_l) * (K >> 3) + (k0 >> 3) + kq_l) * 256 + lane * 4;
+        const float* src = ab + ((int64_t)((m0 >> 4) + ot_l) * (K >> 4) + (k0 >> 4) + kq_l) * 256 + lane * 4;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
       } else {
@@ -144,73 +160,97 @@ __global__ void __launch_bounds__(256) modconv1x1_kernel(GemmArgs a) {
     }
   };
 
-  f32x16 acc[WM][WN];
+  const int q = lane >> 4, jn = lane & 15;
+  // epilogue operands first (registers, ordinary loads, consumed only after the main loop)
+  const int64_t ncol = n0 + wn_i * 64 + jn * 4;            // this lane's 4 consecutive pixels
+  f32x4 nz4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4[WM];
+  if (a.epilogue == 1) {
+    if (a.noise && a.noise_w && ncol < HW) {
+      nz4 = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)b * a.noise_bstride + ncol);
+      const float nw = a.noise_w[0];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) nz4[c] *= nw;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+      bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    // retire them now so that the counted waits below see DMA pieces only
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+
+  f32x4 acc[WM][4];
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int j = 0; j < WN; ++j)
+    for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: NS-1 stages in flight
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nstage) stage_load(s0);
 
-  stage_load(0, 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-
-  const int hh = lane >> 5, jn = lane & 31;
   for (int st = 0; st < nstage; ++st) {
-    if (st + 1 < nstage) stage_load(st + 1, (st + 1) & 1);
-    const float* sA = lds + (st & 1) * STAGE;
-    const float* sB = sA + A_STAGE;
+    // stage st must have landed; stages st+1 .. st+NS-2 (as far as they exist) stay in flight
+    int younger = nstage - 1 - st;
+    if (younger > NS - 2) younger = NS - 2;
+    if (younger >= 2) __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PW));
+    else if (younger == 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PW));
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __builtin_amdgcn_s_barrier();      // every wave's pieces of stage st landed; everyone is done with stage st-1
+    if (st + NS - 1 < nstage) stage_load(st + NS - 1);    // refills the slot stage st-1 was read from
+    const float* sA = lds + (st % NS) * STAGE;
+    const float* sB = sA + A_STAGE + wn_i * 64 + jn * 4;
+    // Issue every fragment read of the stage first (12 x ds_read_b128 for BK = 32, WM = 2), then run the MFMAs
+    // back to back behind counted lgkmcnt waits: with one wave per SIMD a read-then-wait per MFMA group
+    // leaves the matrix pipe idle for an LDS round trip every 16 MFMAs (measured 64 % busy).
+    f32x4 afr[KQ][WM], bfr[KQ][4];
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) {
-      f32x4 a4[WM];
 #pragma unroll
       for (int i = 0; i < WM; ++i)
-        a4[i] = *reinterpret_cast<const f32x4*>(sA + ((wm_i * WM + i) * KQ + kq) * 256 + lane * 4);
+        afr[kq][i] = *reinterpret_cast<const f32x4*>(sA + ((wm_i * WM + i) * KQ + kq) * 256 + lane * 4);
 #pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const int krow = kq * 8 + j4 * 2 + hh;
-        float bf[WN];
+      for (int j4 = 0; j4 < 4; ++j4)   // k row 16*kq + 4*j4 + q, pixels 4*jn..4*jn+3 = B fragments of the 4 column tiles
+        bfr[kq][j4] = *reinterpret_cast<const f32x4*>(sB + (kq * 16 + j4 * 4 + q) * BN);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks each read back in front of its first MFMA
 #pragma unroll
-        for (int j = 0; j < WN; ++j) bf[j] = sB[krow * BN + (wn_i * WN + j) * 32 + jn];
+    for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][j4], bf[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], bfr[kq][j4][c], acc[i][c], 0, 0, 0);
+    // all LDS reads of this stage retired before the slot can be refilled after the next barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
-  // ---- epilogue: D layout -> out[b][o][n]; lanes 0-31 / 32-63 write two 128-byte row segments
-  float* ob = a.out + (int64_t)b * a.Cout * HW;
+  // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4*q + r][pixel ncol + c]
+  if (ncol >= HW) return;
+  float* ob = a.out + (int64_t)b * a.Cout * HW + ncol;
 #pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int64_t n = n0 + (wn_i * WN + j) * 32 + jn;
-    if (n >= HW) continue;
-    float nz = 0.f;
-    if (a.epilogue == 1 && a.noise && a.noise_w) nz = a.noise_w[0] * a.noise[(int64_t)b * a.noise_bstride + n];
+  for (int i = 0; i < WM; ++i) {
+    const int obase = m0 + (wm_i * WM + i) * 16 + 4 * q;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-      const int obase = m0 + (wm_i * WM + i) * 32;
+    for (int r = 0; r < 4; ++r) {
+      f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      if (a.epilogue == 1) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = obase + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        float v = acc[i][j][r];
-        if (a.epilogue == 1) v = lrelu02((v + nz) + a.bias[o]) * 1.41421356237309515f;
-        ob[(int64_t)o * HW + n] = v;
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c]) + bias4[i][r]) * 1.41421356237309515f;
       }
+      *reinterpret_cast<f32x4*>(ob + (int64_t)(obase + r) * HW) = v;
     }
   }
 }
 
-template <int WM, int WN, int WGM, int WGN, int BK>
+template <int WM, int WGM, int WGN, int BK, int NS>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
-  constexpr int BM = 32 * WM * WGM, BN = 32 * WN * WGN;
+  constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
   dim3 grid((unsigned)ceil_div<int64_t>(a.HW, BN), (unsigned)(a.Cout / BM), (unsigned)a.B);
-  hipLaunchKernelGGL((modconv1x1_kernel<WM, WN, WGM, WGN, BK>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -552,20 +592,19 @@ extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, in
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
   if (dbg_cfg && Cout % 128 == 0) {
     switch (dbg_cfg) {
-      case 1: return launch_gemm<1, 2, 2, 2, 32>(a, st);
-      case 2: return launch_gemm<1, 1, 2, 2, 32>(a, st);
-      case 3: return launch_gemm<1, 1, 2, 2, 64>(a, st);
-      case 4: return launch_gemm<2, 1, 2, 2, 32>(a, st);
-      case 5: return launch_gemm<2, 2, 2, 2, 32>(a, st);
-      case 6: return launch_gemm<1, 2, 1, 4, 16>(a, st);
-      case 7: return launch_gemm<1, 1, 1, 4, 32>(a, st);
-      case 8: return launch_gemm<1, 1, 4, 1, 32>(a, st);
+      case 1: return launch_gemm<2, 2, 2, 32, 4>(a, st);    // 64 x 128, 4 waves
+      case 2: return launch_gemm<1, 4, 2, 32, 4>(a, st);    // 64 x 128, 8 waves
+      case 3: return launch_gemm<2, 4, 2, 32, 3>(a, st);    // 128 x 128, 8 waves
+      case 4: return launch_gemm<1, 4, 2, 32, 2>(a, st);    // 64 x 128, 8 waves, 1 stage in flight
+      case 5: return launch_gemm<2, 2, 4, 32, 3>(a, st);    // 64 x 256, 8 waves
+      case 6: return launch_gemm<1, 8, 1, 32, 4>(a, st);    // 128 x 64, 8 waves
+      case 7: return launch_gemm<1, 2, 2, 32, 4>(a, st);    // 32 x 128, 4 waves
     }
   }
-  if (Cout % 128 == 0 && Cout <= 128) return launch_gemm<2, 2, 2, 2, 32>(a, st);   // 128 x 128: x read once
-  if (Cout % 64 == 0 && Cout > 128) return launch_gemm<1, 2, 2, 2, 32>(a, st);     // 64 x 128
-  if (Cout == 64) return launch_gemm<2, 2, 1, 4, 16>(a, st);                        // 64 x 256
-  return launch_gemm<1, 2, 1, 4, 16>(a, st);                                        // 32 x 256 (any Cout % 32 == 0)
+  if (Cout >= 256 && Cout % 64 == 0) return launch_gemm<1, 4, 2, 32, 2>(a, st);   // 64 x 128 tiles, 8 waves
+  if (Cout == 128) return launch_gemm<1, 8, 1, 32, 4>(a, st);                     // all 128 rows: x read once
+  if (Cout == 64) return launch_gemm<1, 4, 2, 32, 4>(a, st);                      // 64 x 128
+  return launch_gemm<1, 2, 2, 32, 4>(a, st);                                      // 32 x 128 (any Cout % 32 == 0)
 }
 
 extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,

@@ -178,7 +178,7 @@ class Generator(nn.Module):
             float(truncation), mean_r, mean_d, return_sdf, events)
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
                 "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
-                "mask": mask[:, [0]], "depth": mask[:, [1]]}
+                "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
 
     # ---------------------------------------------------------------- forward
     @torch.no_grad()
@@ -235,6 +235,6 @@ class Generator(nn.Module):
             "eikonal_term": None,
             "sdf": sdf if return_sdf else None,
             "xyz": xyz if return_xyz else None,
-            "mask": mask[:, [0]],
-            "depth": mask[:, [1]],
+            "mask": mask[:, 0:1].contiguous(),
+            "depth": mask[:, 1:2].contiguous(),
         }

@@ -162,8 +162,8 @@ int cips3d_nerf_finish(const float* part, int n_chunks, int B, int img_size, int
  *   wm[b][o][i][t] = scale * W[o][i][t] * s[b][i];  wm[b][o] *= rsqrt(sum wm[b][o]^2 + 1e-8)
  * W [Cout, Cin, k*k], s [B, s_stride] (first Cin used), wm [B, Cout, Cin, k*k].
  * flags: bit 0 = demodulate; bit 1 = emit the MFMA A-fragment order cips3d_modconv1x1 consumes
- * (k = 1, Cout % 32 == 0, Cin % 8 == 0):
- *   wm[b][o/32][i/8][((i&1)<<5 | (o&31))*4 + ((i&7)>>1)]. */
+ * (k = 1, Cout % 16 == 0, Cin % 16 == 0; A operand of v_mfma_f32_16x16x4_f32, four k-steps per 16 bytes):
+ *   wm[b][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
 #define CIPS3D_MOD_DEMODULATE 1
 #define CIPS3D_MOD_PACKED     2
 int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
