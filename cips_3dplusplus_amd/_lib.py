@@ -68,6 +68,10 @@ _SIGS = {
     "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32p, c_f32p,
                                    C.c_void_p]),
     "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_fused_up_conv_supported": (c_int, [c_int, c_int, c_int]),
+    "cips3d_fused_up_conv": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
+                                     c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int,
+                                     C.c_void_p]),
     "cips3d_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

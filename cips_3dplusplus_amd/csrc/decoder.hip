@@ -551,6 +551,207 @@ __global__ void __launch_bounds__(256) modconv_kxk_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused up-sampling stage:  y_lo --(2x FIR + noise1 + bias1 + lrelu)--> act1 --(1x1 modconv, noise2 + bias2
+// + lrelu)--> out2 --(ToRGB + bias + FIR-upsampled skip)--> rgb, one kernel.  act1 (the largest tensor of
+// the stage) only ever exists as LDS B-operand stages; out2 is stored only when a later stage needs it
+// (never for the last stage, which then writes 12 B per pixel instead of moving ~540 B).
+//   workgroup = 8 waves: WGM wave rows cover ALL C output channels (so ToRGB reduces inside the
+//   workgroup, deterministically), WGN waves cover WGN image rows of 64 pixels.
+//   per 32-channel K stage: every thread builds 2x4-pixel blocks of act1 from a 3x4 patch of y_lo (VALU),
+//   writes them to the LDS stage the MFMAs of the next step read; A fragments come straight from L2.
+// ------------------------------------------------------------------------------------------------
+struct FusedArgs {
+  const float* y_lo; const float* fir; const float* noise1; int64_t nbs1; const float* nw1; const float* bias1;
+  const float* wm2; const float* noise2; int64_t nbs2; const float* nw2; const float* bias2; float* out2;
+  const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
+  int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
+};
+
+template <int C, int WM, int WGM, int WGN>
+__global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
+  constexpr int TH = WGN, BN = TH * 64, BK = 32, NSTAGE = C / BK, NBUF = NSTAGE > 1 ? 2 : 1;
+  constexpr int KQ = BK / 16;
+  static_assert(WGM * WGN == 8 && 16 * WM * WGM == C && TH % 2 == 0, "tile shape");
+  constexpr int NBLK = (TH / 2) * 16;            // 2x4 blocks per channel in the tile
+  constexpr int BPT = BK * NBLK / 512;           // blocks per thread per stage
+  static_assert((BK * NBLK) % 512 == 0, "block split");
+  __shared__ __attribute__((aligned(16))) float sB[NBUF * BK * BN];
+  __shared__ __attribute__((aligned(16))) float s_nz1[BN];
+  __shared__ __attribute__((aligned(16))) float s_red[WGM * 3 * BN];
+  __shared__ float s_wrgb[3 * C];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm_i = wave / WGN, wn_i = wave % WGN;
+  const int q = lane >> 4, jn = lane & 15;
+  const int b = blockIdx.z;
+  const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W;
+  const int tiles_x = OW / 64;
+  const int ox0 = (blockIdx.x % tiles_x) * 64, oy0 = (blockIdx.x / tiles_x) * TH;
+  const int64_t HWlo = (int64_t)H * W, HWo = (int64_t)OH * OW;
+
+  float kf[16];   // flipped taps
+#pragma unroll
+  for (int i = 0; i < 16; ++i) kf[i] = a.fir[15 - i];
+  // noise of the first conv for this tile (scaled), ToRGB weights
+  if (tid < BN / 4) {
+    const int r = tid / 16, x4 = tid % 16;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (a.noise1 && a.nw1) {
+      v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + (int64_t)(oy0 + r) * OW + ox0 + x4 * 4);
+      const float nw = a.nw1[0];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] *= nw;
+    }
+    *reinterpret_cast<f32x4*>(s_nz1 + r * 64 + x4 * 4) = v;
+  }
+  if (a.wm_rgb)
+    for (int i = tid; i < 3 * C; i += 512) s_wrgb[i] = a.wm_rgb[(int64_t)b * 3 * C + i];
+  __syncthreads();
+
+  // act1 blocks of one K stage -> LDS
+  auto produce = [&](int st, float* dst) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      const int g = tid + 512 * u;
+      const int ch = g / NBLK, rem = g % NBLK;
+      const int by = rem / 16, qx = rem % 16;
+      const int cg = st * BK + ch;
+      float o[2][4];
+      up2_block(a.y_lo + ((int64_t)b * C + cg) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, kf, o);
+      const float bs = a.bias1[cg];
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * 64 + qx * 4);
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * 1.41421356237309515f;
+        *reinterpret_cast<f32x4*>(dst + ch * BN + (2 * by + py) * 64 + qx * 4) = v;
+      }
+    }
+  };
+
+  f32x4 acc[WM][4];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
+  produce(0, sB);
+  __syncthreads();
+#pragma unroll 1
+  for (int st = 0; st < NSTAGE; ++st) {
+    const float* cur = sB + (NBUF > 1 ? (st & 1) : 0) * BK * BN + wn_i * 64 + jn * 4;
+    f32x4 afr[KQ][WM];
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        afr[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + st * KQ + kq) * 256 + lane * 4);
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(cur + (kq * 16 + j4 * 4 + q) * BN);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], b4[c], acc[i][c], 0, 0, 0);
+      }
+    if (NBUF > 1 && st + 1 < NSTAGE) produce(st + 1, sB + ((st + 1) & 1) * BK * BN);
+    __syncthreads();
+  }
+
+  // ---- epilogue of conv2: this lane holds channels o = (wm_i*WM+i)*16 + 4q + r at pixels (oy, ox .. ox+3)
+  const int oy = oy0 + wn_i, ox = ox0 + jn * 4;
+  f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
+  if (a.noise2 && a.nw2) {
+    nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
+    const float nw = a.nw2[0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nz2[c] *= nw;
+  }
+  float prgb[3][4];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int obase = (wm_i * WM + i) * 16 + 4 * q;
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias2 + obase);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[r]) * 1.41421356237309515f;
+      if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((int64_t)b * C + obase + r) * HWo + (int64_t)oy * OW + ox) = v;
+      if (a.wm_rgb) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float w = s_wrgb[ch * C + obase + r];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) prgb[ch][c] = fmaf(w, v[c], prgb[ch][c]);
+        }
+      }
+    }
+  }
+  if (!a.wm_rgb) return;
+  // ---- ToRGB: reduce over the 4 lane quarters, then over the WGM wave rows through LDS
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = prgb[ch][c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      prgb[ch][c] = v;
+    }
+  if (q == 0) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + wn_i * 64 + jn * 4) =
+          f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+  }
+  __syncthreads();
+  if (wm_i == 0 && q < 3) {          // quarter q finishes colour channel q
+    const int ch = q;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < WGM; ++m) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (m * 3 + ch) * BN + wn_i * 64 + jn * 4);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] += t[c];
+    }
+    const float bs = a.bias_rgb[ch];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += bs;
+    if (a.skip) {
+      if (a.skip_up) {
+        const float* sp = a.skip + ((int64_t)b * 3 + ch) * HWlo;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += up2_tap(sp, H, W, oy, ox + c, a.fir);
+      } else {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + ch) * HWo + (int64_t)oy * OW + ox);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += sv[c];
+      }
+    }
+    *reinterpret_cast<f32x4*>(a.rgb + ((int64_t)b * 3 + ch) * HWo + (int64_t)oy * OW + ox) = v;
+  }
+}
+
+template <int C, int WM, int WGM, int WGN>
+int launch_fused(const FusedArgs& a, hipStream_t st) {
+  dim3 grid((unsigned)((2 * a.W / 64) * (2 * a.H / WGN)), 1, (unsigned)a.B);
+  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN>), grid, dim3(512), 0, st, a);
+  return cips3d_launch_status();
+}
+
 }  // namespace
 
 extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm, int B, int Cout,
@@ -630,6 +831,32 @@ extern "C" int cips3d_noise_bias_act(const float* x, const float* noise, int64_t
   hipLaunchKernelGGL(noise_bias_act_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, noise,
                      noise_bstride, noise_w, bias, out, B, C, HW);
   return cips3d_launch_status();
+}
+
+extern "C" int cips3d_fused_up_conv_supported(int C, int H, int W) {
+  return (C == 32 || C == 64 || C == 128 || C == 256) && W % 32 == 0 && H % 2 == 0 && H >= 2;
+}
+
+extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
+                                    const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
+                                    int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
+                                    const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
+                                    float* rgb, int B, int C, int H, int W, void* stream) {
+  if (!y_lo || !fir || !bias1 || !wm2 || !bias2 || B < 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
+  if (!out2 && !wm_rgb) return CIPS3D_E_BADARG;
+  if (wm_rgb && (!bias_rgb || !rgb)) return CIPS3D_E_BADARG;
+  if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
+              wm_rgb, bias_rgb, skip, skip_up, rgb, B, H, W};
+  hipStream_t st = as_stream(stream);
+  switch (C) {
+    case 32: return launch_fused<32, 1, 2, 4>(a, st);
+    case 64: return launch_fused<64, 2, 2, 4>(a, st);
+    case 128: return launch_fused<128, 2, 4, 2>(a, st);
+    case 256: return launch_fused<256, 4, 4, 2>(a, st);
+  }
+  return CIPS3D_E_UNSUPP;
 }
 
 extern "C" int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,

@@ -83,6 +83,30 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       const float* nz = L.noise_index >= 0 ? IO.noise[L.noise_index] : nullptr;
       const int64_t nbs = L.noise_index >= 0 ? IO.noise_bstride[L.noise_index] : 0;
       float* out = P.act[act_i];
+      // up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] with equal widths: low-res GEMM, then ONE fused
+      // kernel for FIR + act -> conv2 + act -> ToRGB (+ FIR-upsampled skip); the full-resolution intermediate
+      // never reaches HBM and the last stage stores only the image
+      if (L.kind == 1 && li + 2 < P.n_dec_layers && P.layers[li + 1].kind == 0 && P.layers[li + 2].kind == 3 &&
+          P.layers[li + 1].Cin == L.Cout && P.layers[li + 1].Cout == L.Cout && P.layers[li + 2].Cin == L.Cout &&
+          cips3d_fused_up_conv_supported(L.Cout, L.H, L.W)) {
+        const cips3d_dec_layer& L2 = P.layers[li + 1];
+        const cips3d_dec_layer& L3 = P.layers[li + 2];
+        const bool stage_last = li + 2 == P.n_dec_layers - 1;
+        const float* nz2 = L2.noise_index >= 0 ? IO.noise[L2.noise_index] : nullptr;
+        const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
+        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0, nullptr, nullptr,
+                              stream));
+        float* out2 = stage_last ? nullptr : P.act[act_i];
+        float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
+        TRY(cips3d_fused_up_conv(P.y_lo, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
+                                 L3.wm, L3.bias, skip, 1, rgb, B, L.Cout, L.H, L.W, stream));
+        x = out2;
+        act_i ^= 1;
+        skip = rgb;
+        skip_i ^= 1;
+        li += 2;
+        continue;
+      }
       if (L.kind == 0) {
         TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 1, nz, nbs, L.noise_w, L.bias, stream));
       } else {

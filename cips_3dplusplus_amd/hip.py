@@ -226,3 +226,24 @@ def modconv_kxk(x, wm, Cout, k, transpose2=False):
     check(lib.cips3d_modconv_kxk(dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(out), B, Cin, Cout, H, W, k,
                                  int(bool(transpose2)), stream_ptr()), "cips3d_modconv_kxk")
     return out
+
+
+def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
+                  skip=None, skip_up=True, want_out2=True):
+    """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv)."""
+    lib = _lib.load()
+    B, Cc, H, W = y_lo.shape
+    dev = y_lo.device
+    out2 = torch.empty(B, Cc, 2 * H, 2 * W, device=dev) if want_out2 else None
+    rgb = torch.empty(B, 3, 2 * H, 2 * W, device=dev) if wm_rgb is not None else None
+
+    def bs(nz):
+        return 4 * H * W if (nz is not None and nz.shape[0] == B and B > 1) else 0
+
+    check(lib.cips3d_fused_up_conv(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
+                                   dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
+                                   dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
+                                   dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
+                                   dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True), int(bool(skip_up)),
+                                   dev_ptr(rgb, "rgb", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv")
+    return out2, rgb

@@ -217,6 +217,20 @@ int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstr
 int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,
                  const float* fir, float* out, int B, int Cin, int H, int W, void* stream);
 
+/* One kernel for a whole up-sampling stage after its low-resolution GEMM (models/model_v3.py:618-630 for a
+ * stage in `upsample_list`):
+ *   act1 = lrelu(upfirdn2d(y_lo, fir, up=2, pad=(2,1)) + nw1*noise1 + bias1) * sqrt(2)     (never stored)
+ *   out2 = lrelu(wm2 (1x1) act1 + nw2*noise2 + bias2) * sqrt(2)            -> out2 [B,C,2H,2W] unless NULL
+ *   rgb  = wm_rgb (3 x C) out2 + bias_rgb + (skip_up ? upfirdn2d(skip) : skip)   -> rgb [B,3,2H,2W] unless wm_rgb NULL
+ * y_lo [B,C,H,W]; wm2 in the PACKED order of cips3d_modulate_weights, wm_rgb plain [B,3,C]; skip [B,3,H,W] when
+ * skip_up else [B,3,2H,2W] (or NULL).  C in {32,64,128,256}, W % 32 == 0, H % 2 == 0. */
+int cips3d_fused_up_conv_supported(int C, int H, int W);
+int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
+                         const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
+                         int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
+                         const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up, float* rgb,
+                         int B, int C, int H, int W, void* stream);
+
 /* General k x k modulated convolution (k odd, padding k/2), direct form; used for k = 3 configs.
  * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
 int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,

@@ -347,3 +347,39 @@ def test_planned_forward_equals_per_op_path(golden):
     # random-noise / perturbed call runs and is finite
     d = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, nerf_cfg=dict(N_samples=6, perturb=True))
     assert torch.isfinite(d["rgb"]).all()
+
+
+@pytest.mark.parametrize("C,H,B,last", [(32, 32, 1, True), (64, 32, 2, False), (128, 32, 1, False), (256, 32, 1, False),
+                                        (32, 64, 1, False)])
+def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
+    """cips3d_fused_up_conv = StyledConv(up) FIR part + StyledConv + ToRGB(up) of one stage, against the oracle."""
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(C + H)
+    S = 64
+    c1 = dec.StyledConv(C, C, 1, S, upsample=True)
+    c2 = dec.StyledConv(C, C, 1, S)
+    tr = dec.ToRGB(C, S, upsample=True)
+    for m in (c1, c2):
+        m.noise.weight.data.fill_(0.25)
+        m.activate.bias.data = torch.randn(C) * 0.2
+    tr.bias.data = torch.randn(1, 3, 1, 1) * 0.1
+    sd = {}
+    for nm, m in (("c1", c1), ("c2", c2), ("tr", tr)):
+        sd.update({f"{nm}.{k}": v.clone() for k, v in m.state_dict().items()})
+    x = torch.randn(B, C, H, H)
+    st = [torch.randn(B, S) for _ in range(3)]
+    n1, n2 = torch.randn(1, 1, 2 * H, 2 * H), torch.randn(B, 1, 2 * H, 2 * H)
+    skip = torch.randn(B, 3, H, H)
+    r1 = O.styled_conv(sd, "c1", x, st[0], n1, upsample=True)
+    r2 = O.styled_conv(sd, "c2", r1, st[1], n2)
+    r3 = O.to_rgb(sd, "tr", r2, st[2], skip, upsample=True)
+    c1, c2, tr = c1.to(DEV), c2.to(DEV), tr.to(DEV)
+    y_lo = hip.modconv1x1(cu(x), c1.conv.modulated_weight(cu(st[0]), packed=True), C, epilogue=0)
+    out2, rgb = hip.fused_up_conv(y_lo, c1.conv.blur.kernel, cu(n1), c1.noise.weight, c1.activate.bias,
+                                  c2.conv.modulated_weight(cu(st[1]), packed=True), cu(n2), c2.noise.weight,
+                                  c2.activate.bias, tr.conv.modulated_weight(cu(st[2]), packed=False), tr.bias, cu(skip),
+                                  skip_up=True, want_out2=not last)
+    scale = max(1.0, float(r2.abs().max()))
+    if not last:
+        assert maxdiff(out2.cpu(), r2) < 3e-5 * scale
+    assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
