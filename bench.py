@@ -92,7 +92,7 @@ def main():
     import cips_3dplusplus_amd as pkg
     from cips_3dplusplus_amd import configs, hip
     from cips_3dplusplus_amd.camera import Camera
-    from cips_3dplusplus_amd.multiview import gather_views
+    from cips_3dplusplus_amd.multiview import gather_views_async
 
     cfg = configs.ffhq_G_cfg(a.res, a.depth)
     nerf_cfg = {"N_samples": a.n_samples, "perturb": not a.deterministic, "static_viewdirs": False}
@@ -105,16 +105,27 @@ def main():
                                                                                if k in ("fov_ang", "dist_radius")})
     noise_bufs = G.create_noise_bufs(64, dev) if a.deterministic else None
 
+    pending = [None]
+
     def step():
         r = G(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1, noise_bufs=noise_bufs,
               nerf_cfg=nerf_cfg)
         rgb = r["rgb"]
         if world > 1:
-            gather_views(rgb, B * world)
+            # the one exchange step of the path: finished images -> rank 0.  uint8 on the device first (what the
+            # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
+            # step i overlaps the rendering of step i+1.
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = gather_views_async(hip.rgb_to_uint8(rgb), B * world)
         return rgb
 
     def barrier():
         if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
+            torch.cuda.synchronize()
             torch.distributed.barrier()
         torch.cuda.synchronize()
 

@@ -68,7 +68,47 @@ int launch_bias_act(const float* x, const float* bias, const float* ref, float* 
   return cips3d_launch_status();
 }
 
+// image post-step of the multi-view loop (render_video_web_v10.py:1825-1826, tl2 img_tensor_to_pil): clamp to
+// [-1, 1], map to [0, 255], round to nearest -> uint8.  16 pixels-bytes per thread (4 x float4 in, one 16-B store).
+__global__ void __launch_bounds__(256) rgb_to_u8_kernel(const float* __restrict__ x, uint8_t* __restrict__ out,
+                                                        int64_t n16, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(x)[i * 4 + k];
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      uint32_t pk = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float c = fminf(fmaxf(f[j], -1.f), 1.f);
+        pk |= (uint32_t)__float2int_rn((c + 1.f) * 127.5f) << (8 * j);
+      }
+      w[k] = pk;
+    }
+    reinterpret_cast<uint4*>(out)[i] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // tail (n % 16 elements), one thread
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t e = n16 * 16; e < n; ++e) {
+      const float c = fminf(fmaxf(x[e], -1.f), 1.f);
+      out[e] = (uint8_t)__float2int_rn((c + 1.f) * 127.5f);
+    }
+}
+
 }  // namespace
+
+extern "C" int cips3d_rgb_to_uint8(const float* rgb, uint8_t* out, int64_t n, void* stream) {
+  if (n == 0) return 0;
+  if (!rgb || !out || n < 0) return CIPS3D_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(rgb) | reinterpret_cast<uintptr_t>(out)) & 15) return CIPS3D_E_UNSUPP;
+  const int64_t n16 = n / 16;
+  int64_t blocks = ceil_div<int64_t>(n16 > 0 ? n16 : 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(rgb_to_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), rgb, out, n16, n);
+  return cips3d_launch_status();
+}
 
 extern "C" int cips3d_fused_bias_act(const float* x, const float* bias, const float* ref, float* out,
                                      int64_t n, int64_t step_b, int64_t size_b, int act, int grad,

@@ -569,13 +569,14 @@ struct FusedArgs {
 };
 
 template <int C, int WM, int WGM, int WGN>
-__global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
+__global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs a) {
+  constexpr int NT = 64 * WGM * WGN;            // threads: 8 waves, or 4 for the narrow last stage (more workgroups per CU)
   constexpr int TH = WGN, BN = TH * 64, BK = 32, NSTAGE = C / BK, NBUF = NSTAGE > 1 ? 2 : 1;
   constexpr int KQ = BK / 16;
-  static_assert(WGM * WGN == 8 && 16 * WM * WGM == C && TH % 2 == 0, "tile shape");
+  static_assert((WGM * WGN == 8 || WGM * WGN == 4) && 16 * WM * WGM == C && TH % 2 == 0, "tile shape");
   constexpr int NBLK = (TH / 2) * 16;            // 2x4 blocks per channel in the tile
-  constexpr int BPT = BK * NBLK / 512;           // blocks per thread per stage
-  static_assert((BK * NBLK) % 512 == 0, "block split");
+  constexpr int BPT = BK * NBLK / NT;            // blocks per thread per stage
+  static_assert((BK * NBLK) % NT == 0, "block split");
   __shared__ __attribute__((aligned(16))) float sB[NBUF * BK * BN];
   __shared__ __attribute__((aligned(16))) float s_nz1[BN];
   __shared__ __attribute__((aligned(16))) float s_red[WGM * 3 * BN];
@@ -591,6 +592,27 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
   const int tiles_x = OW / 64;
   const int ox0 = (blockIdx.x % tiles_x) * 64, oy0 = (blockIdx.x / tiles_x) * TH;
   const int64_t HWlo = (int64_t)H * W, HWo = (int64_t)OH * OW;
+
+  // Everything that does not depend on a barrier is requested first, so the workgroup pays ONE global-memory
+  // latency up front instead of one per phase: conv2's first A fragments, its noise / bias, the FIR taps.
+  const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
+  f32x4 afr_next[KQ][WM];
+#pragma unroll
+  for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+      afr_next[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + kq) * 256 + lane * 4);
+  const int oy = oy0 + wn_i, ox = ox0 + jn * 4;
+  f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
+  if (a.noise2 && a.nw2) {
+    nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
+    const float nw = a.nw2[0];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) nz2[c] *= nw;
+  }
+  f32x4 bias4[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) bias4[i] = *reinterpret_cast<const f32x4*>(a.bias2 + (wm_i * WM + i) * 16 + 4 * q);
 
   float kf[16];   // flipped taps
 #pragma unroll
@@ -608,14 +630,14 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
     *reinterpret_cast<f32x4*>(s_nz1 + r * 64 + x4 * 4) = v;
   }
   if (a.wm_rgb)
-    for (int i = tid; i < 3 * C; i += 512) s_wrgb[i] = a.wm_rgb[(int64_t)b * 3 * C + i];
+    for (int i = tid; i < 3 * C; i += NT) s_wrgb[i] = a.wm_rgb[(int64_t)b * 3 * C + i];
   __syncthreads();
 
   // act1 blocks of one K stage -> LDS
   auto produce = [&](int st, float* dst) {
 #pragma unroll
     for (int u = 0; u < BPT; ++u) {
-      const int g = tid + 512 * u;
+      const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / 16, qx = rem % 16;
       const int cg = st * BK + ch;
@@ -639,7 +661,6 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
   produce(0, sB);
   __syncthreads();
 #pragma unroll 1
@@ -649,8 +670,15 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
-      for (int i = 0; i < WM; ++i)
-        afr[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + st * KQ + kq) * 256 + lane * 4);
+      for (int i = 0; i < WM; ++i) afr[kq][i] = afr_next[kq][i];
+    if (st + 1 < NSTAGE) {   // next stage's A fragments travel under this stage's MFMAs
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          afr_next[kq][i] = *reinterpret_cast<const f32x4*>(
+              ab + ((int64_t)(wm_i * WM + i) * (C / 16) + (st + 1) * KQ + kq) * 256 + lane * 4);
+    }
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
@@ -667,14 +695,6 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
   }
 
   // ---- epilogue of conv2: this lane holds channels o = (wm_i*WM+i)*16 + 4q + r at pixels (oy, ox .. ox+3)
-  const int oy = oy0 + wn_i, ox = ox0 + jn * 4;
-  f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
-  if (a.noise2 && a.nw2) {
-    nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
-    const float nw = a.nw2[0];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) nz2[c] *= nw;
-  }
   float prgb[3][4];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
@@ -683,12 +703,11 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int obase = (wm_i * WM + i) * 16 + 4 * q;
-    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(a.bias2 + obase);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[r]) * 1.41421356237309515f;
+      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * 1.41421356237309515f;
       if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((int64_t)b * C + obase + r) * HWo + (int64_t)oy * OW + ox) = v;
       if (a.wm_rgb) {
 #pragma unroll
@@ -748,7 +767,7 @@ __global__ void __launch_bounds__(512) fused_up_conv_kernel(FusedArgs a) {
 template <int C, int WM, int WGM, int WGN>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   dim3 grid((unsigned)((2 * a.W / 64) * (2 * a.H / WGN)), 1, (unsigned)a.B);
-  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN>), grid, dim3(512), 0, st, a);
+  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -851,7 +870,7 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
               wm_rgb, bias_rgb, skip, skip_up, rgb, B, H, W};
   hipStream_t st = as_stream(stream);
   switch (C) {
-    case 32: return launch_fused<32, 1, 2, 4>(a, st);
+    case 32: return launch_fused<32, 1, 2, 2>(a, st);
     case 64: return launch_fused<64, 2, 2, 4>(a, st);
     case 128: return launch_fused<128, 2, 4, 2>(a, st);
     case 256: return launch_fused<256, 4, 4, 2>(a, st);

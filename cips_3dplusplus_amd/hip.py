@@ -247,3 +247,12 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
                                    dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True), int(bool(skip_up)),
                                    dev_ptr(rgb, "rgb", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv")
     return out2, rgb
+
+
+def rgb_to_uint8(rgb):
+    """[-1,1] float image -> uint8 (clamp, scale, round to nearest) on the device."""
+    lib = _lib.load()
+    x = rgb.contiguous()
+    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib.cips3d_rgb_to_uint8(dev_ptr(x, "rgb"), out.data_ptr(), x.numel(), stream_ptr()), "cips3d_rgb_to_uint8")
+    return out

@@ -38,6 +38,40 @@ def gather_views(local, n_views, dst=0, group=None):
     return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(outs, counts)], 0)
 
 
+class PendingGather:
+    """Handle of an asynchronous gather: the collective runs on the communicator's stream while the caller keeps
+    rendering; `wait()` orders the current stream after it and (on dst) returns the assembled tensor."""
+
+    def __init__(self, work, outs, counts, keep):
+        self.work, self.outs, self.counts, self.keep = work, outs, counts, keep
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        if self.outs is None:
+            return None
+        return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(self.outs, self.counts)], 0)
+
+
+def gather_views_async(local, n_views, dst=0, group=None):
+    """gather_views without blocking the compute stream (used to overlap the image gather of step i with the
+    rendering of step i+1)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return PendingGather(None, [local], [(0, local.shape[0])], None)
+    ws, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [view_slice(n_views, r, ws) for r in range(ws)]
+    cap = max(hi - lo for lo, hi in counts)
+    buf = local
+    if local.shape[0] < cap:
+        pad = torch.zeros((cap - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        buf = torch.cat([local, pad], 0)
+    buf = buf.contiguous()
+    outs = [torch.empty_like(buf) for _ in range(ws)] if rank == dst else None
+    work = dist.gather(buf, outs, dst=dst, group=group, async_op=True)
+    return PendingGather(work, outs, counts if rank == dst else None, buf)
+
+
 def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, chunk=1):
     """render_fn(lo, hi) -> dict of tensors whose dim 0 is the view index for views [lo, hi).
     Every rank renders its block in `chunk`-view calls; the entries named in `keys` are gathered to dst."""

@@ -59,6 +59,10 @@ int cips3d_upfirdn2d(const float* input, const float* kernel, float* out,
                      int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
 
+/* Image post-step of the demo loops (clamp [-1,1] -> [0,255], round to nearest): out[i] = u8((clamp(x)+1)*127.5).
+ * Both pointers 16-byte aligned.  Used before the multi-GPU gather (4x fewer bytes over xGMI). */
+int cips3d_rgb_to_uint8(const float* rgb, uint8_t* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ small dense layers */
 
 /* One dense layer on a batch of row vectors:

@@ -383,3 +383,13 @@ def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
     if not last:
         assert maxdiff(out2.cpu(), r2) < 3e-5 * scale
     assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
+
+
+def test_rgb_to_uint8():
+    x = torch.randn(2, 3, 37, 41) * 0.8
+    x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -3.0, 3.0])
+    y = hip.rgb_to_uint8(cu(x)).cpu()
+    ref = ((x.clamp(-1, 1) + 1) * 127.5).round().to(torch.uint8)
+    assert y.dtype == torch.uint8 and y.shape == x.shape
+    assert int((y.int() - ref.int()).abs().max()) <= 1     # ties may round differently by one ulp of the product
+    assert float((y != ref).float().mean()) < 1e-3

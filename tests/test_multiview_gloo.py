@@ -27,7 +27,7 @@ def _worker(rank, world, port, n_views, chunk, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from cips_3dplusplus_amd.multiview import gather_views, render_views_sharded, view_slice
+    from cips_3dplusplus_amd.multiview import gather_views, gather_views_async, render_views_sharded, view_slice
     lo, hi = view_slice(n_views, rank, world)
 
     def render(a, b):
@@ -49,6 +49,12 @@ def _worker(rank, world, port, n_views, chunk, q):
         exp = torch.cat([torch.full((view_slice(n_views, r, world)[1] - view_slice(n_views, r, world)[0], 2), float(r))
                          for r in range(world)])
         ok &= bool((g == exp).all())
+    pg = gather_views_async(torch.full((hi - lo, 3), float(rank + 1)), n_views)
+    ga = pg.wait()
+    if rank == 0:
+        ok &= ga.shape[0] == n_views and float(ga[0, 0]) == 1.0 and float(ga[-1, 0]) == float(world)
+    else:
+        ok &= ga is None
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
