@@ -152,6 +152,12 @@ def main():
         flops = B * 64 * 64 * a.n_samples * nerf_flops_per_point(H, a.depth)
         achieved = flops / (kern_ms * 1e-3) / 1e12
         published_cfg = (a.res == 1024 and a.depth == 2 and a.n_samples == 24 and B == 1 and not a.deterministic)
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE and
+        # WRITE_SIZE cannot share a pass with timing); the committed summary is quoted for the matching config.
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_pmc_nerf_traffic.json")
+        if a.depth == 2 and a.n_samples == 24 and B == 1 and os.path.exists(tp):
+            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
         line = {
             "metric": "rendered views/sec at FFHQ 1024^2 (generator forward: 64x64-ray NeRF + StyleGAN2 decoder)",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -165,7 +171,7 @@ def main():
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
             "roofline": {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_ms": kern_ms, "flop_per_launch": flops},
         }
         if world == 1 and not a.no_cpu_baseline:
