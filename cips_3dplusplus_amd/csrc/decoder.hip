@@ -280,24 +280,25 @@ __device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, i
   return acc;
 }
 
-// 2 x 4 output block (rows 2*iy, 2*iy+1; columns 4*qx .. 4*qx+3) from the 3 x 4 input patch
-// rows iy-1..iy+1, columns 2*qx-1..2*qx+2.  All tap indices are compile-time constants.
-__device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, int W, int iy, int qx,
-                                          const float (&kf)[16], float (&o)[2][4]) {
+// 3 x 4 input patch (rows iy-1..iy+1, columns 2*qx-1..2*qx+2, zero outside the image) of the 2 x 4 output block
+// at rows 2*iy, 2*iy+1, columns 4*qx .. 4*qx+3
+__device__ __forceinline__ void up2_load(const float* __restrict__ src, int H, int W, int iy, int qx, float (&v)[3][4]) {
   const int c = 2 * qx;
-  float v[3][4];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const int y = iy - 1 + r;
     const bool yok = (y >= 0) && (y < H);
     const float* row = src + (int64_t)(yok ? y : 0) * W;
-    // middle pair is 8-byte aligned (c even, W even)
-    float2 mid = make_float2(0.f, 0.f);
+    float2 mid = make_float2(0.f, 0.f);           // middle pair is 8-byte aligned (c even, W even)
     if (yok) mid = *reinterpret_cast<const float2*>(row + c);
     v[r][1] = mid.x; v[r][2] = mid.y;
     v[r][0] = (yok && c - 1 >= 0) ? row[c - 1] : 0.f;
     v[r][3] = (yok && c + 2 < W) ? row[c + 2] : 0.f;
   }
+}
+
+// polyphase FIR of the patch; all tap indices are compile-time constants
+__device__ __forceinline__ void up2_fir(const float (&v)[3][4], const float (&kf)[16], float (&o)[2][4]) {
 #pragma unroll
   for (int py = 0; py < 2; ++py) {
 #pragma unroll
@@ -315,6 +316,13 @@ __device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, 
       o[py][j] = acc;
     }
   }
+}
+
+__device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, int W, int iy, int qx,
+                                          const float (&kf)[16], float (&o)[2][4]) {
+  float v[3][4];
+  up2_load(src, H, W, iy, qx, v);
+  up2_fir(v, kf, o);
 }
 
 __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restrict__ y_lo, const float* __restrict__ fir,
@@ -568,15 +576,18 @@ struct FusedArgs {
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
 };
 
-template <int C, int WM, int WGM, int WGN>
+template <int C, int WM, int WGM, int WGN, int RW, int BK>
 __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs a) {
-  constexpr int NT = 64 * WGM * WGN;            // threads: 8 waves, or 4 for the narrow last stage (more workgroups per CU)
-  constexpr int TH = WGN, BN = TH * 64, BK = 32, NSTAGE = C / BK, NBUF = NSTAGE > 1 ? 2 : 1;
-  constexpr int KQ = BK / 16;
-  static_assert((WGM * WGN == 8 || WGM * WGN == 4) && 16 * WM * WGM == C && TH % 2 == 0, "tile shape");
-  constexpr int NBLK = (TH / 2) * 16;            // 2x4 blocks per channel in the tile
+  // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
+  // workgroup are stacked vertically: pixel tile TH x TW.
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int CW = 64 / RW, TH = RW * WGN, TW = CW, BN = TH * TW;
+  constexpr int NSTAGE = C / BK, NBUF = NSTAGE > 1 ? 2 : 1, KQ = BK / 16;
+  constexpr int LPR = CW / 4;                    // lanes (pixel quads) per image row of the wave tile
+  static_assert((WGM * WGN == 8 || WGM * WGN == 4) && 16 * WM * WGM == C && TH % 2 == 0 && C % BK == 0, "tile shape");
+  constexpr int NBLK = (TH / 2) * (TW / 4);      // 2x4 blocks per channel in the tile
   constexpr int BPT = BK * NBLK / NT;            // blocks per thread per stage
-  static_assert((BK * NBLK) % NT == 0, "block split");
+  static_assert((BK * NBLK) % NT == 0 && BPT >= 1, "block split");
   __shared__ __attribute__((aligned(16))) float sB[NBUF * BK * BN];
   __shared__ __attribute__((aligned(16))) float s_nz1[BN];
   __shared__ __attribute__((aligned(16))) float s_red[WGM * 3 * BN];
@@ -587,14 +598,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
   const int lane = tid & 63;
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int q = lane >> 4, jn = lane & 15;
+  const int lrow = jn / LPR, lx4 = jn % LPR;
+  const int nloc = (wn_i * RW + lrow) * TW + lx4 * 4;     // this lane's first pixel inside the tile
   const int b = blockIdx.z;
   const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W;
-  const int tiles_x = OW / 64;
-  const int ox0 = (blockIdx.x % tiles_x) * 64, oy0 = (blockIdx.x / tiles_x) * TH;
+  const int tiles_x = OW / TW;
+  const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
   const int64_t HWlo = (int64_t)H * W, HWo = (int64_t)OH * OW;
+  const int oy = oy0 + wn_i * RW + lrow, ox = ox0 + lx4 * 4;
 
-  // Everything that does not depend on a barrier is requested first, so the workgroup pays ONE global-memory
-  // latency up front instead of one per phase: conv2's first A fragments, its noise / bias, the FIR taps.
+  // Everything that does not depend on a barrier is requested first: conv2's first A fragments, its noise / bias.
   const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
   f32x4 afr_next[KQ][WM];
 #pragma unroll
@@ -602,7 +615,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
 #pragma unroll
     for (int i = 0; i < WM; ++i)
       afr_next[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + kq) * 256 + lane * 4);
-  const int oy = oy0 + wn_i, ox = ox0 + jn * 4;
   f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
   if (a.noise2 && a.nw2) {
     nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
@@ -617,9 +629,54 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
   float kf[16];   // flipped taps
 #pragma unroll
   for (int i = 0; i < 16; ++i) kf[i] = a.fir[15 - i];
+  // the lanes that will finish a colour channel (wave row 0, quarter = channel) fetch their skip operands now
+  const bool rgb_lane = a.wm_rgb && wm_i == 0 && q < 3;
+  float skp[3][4];
+  f32x4 skv = {0.f, 0.f, 0.f, 0.f};
+  float rgb_bias = 0.f;
+  if (rgb_lane) {
+    rgb_bias = a.bias_rgb[q];
+    if (a.skip) {
+      if (a.skip_up) up2_load(a.skip + ((int64_t)b * 3 + q) * HWlo, H, W, oy >> 1, ox >> 2, skp);
+      else skv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + q) * HWo + (int64_t)oy * OW + ox);
+    }
+  }
+
+  // FIR patches of one K stage: loaded early (before the MFMAs that precede their use), filtered late
+  float pv[BPT][3][4];
+  auto patch_load = [&](int st) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      const int g = tid + NT * u;
+      const int ch = g / NBLK, rem = g % NBLK;
+      const int by = rem / (TW / 4), qx = rem % (TW / 4);
+      up2_load(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+    }
+  };
+  auto patch_store = [&](int st, float* dst) {
+#pragma unroll
+    for (int u = 0; u < BPT; ++u) {
+      const int g = tid + NT * u;
+      const int ch = g / NBLK, rem = g % NBLK;
+      const int by = rem / (TW / 4), qx = rem % (TW / 4);
+      float o[2][4];
+      up2_fir(pv[u], kf, o);
+      const float bs = a.bias1[st * BK + ch];
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * TW + qx * 4);
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * 1.41421356237309515f;
+        *reinterpret_cast<f32x4*>(dst + ch * BN + (2 * by + py) * TW + qx * 4) = v;
+      }
+    }
+  };
+  patch_load(0);
+
   // noise of the first conv for this tile (scaled), ToRGB weights
   if (tid < BN / 4) {
-    const int r = tid / 16, x4 = tid % 16;
+    const int r = tid / (TW / 4), x4 = tid % (TW / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (a.noise1 && a.nw1) {
       v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + (int64_t)(oy0 + r) * OW + ox0 + x4 * 4);
@@ -627,33 +684,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] *= nw;
     }
-    *reinterpret_cast<f32x4*>(s_nz1 + r * 64 + x4 * 4) = v;
+    *reinterpret_cast<f32x4*>(s_nz1 + r * TW + x4 * 4) = v;
   }
   if (a.wm_rgb)
     for (int i = tid; i < 3 * C; i += NT) s_wrgb[i] = a.wm_rgb[(int64_t)b * 3 * C + i];
   __syncthreads();
-
-  // act1 blocks of one K stage -> LDS
-  auto produce = [&](int st, float* dst) {
-#pragma unroll
-    for (int u = 0; u < BPT; ++u) {
-      const int g = tid + NT * u;
-      const int ch = g / NBLK, rem = g % NBLK;
-      const int by = rem / 16, qx = rem % 16;
-      const int cg = st * BK + ch;
-      float o[2][4];
-      up2_block(a.y_lo + ((int64_t)b * C + cg) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, kf, o);
-      const float bs = a.bias1[cg];
-#pragma unroll
-      for (int py = 0; py < 2; ++py) {
-        const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * 64 + qx * 4);
-        f32x4 v;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * 1.41421356237309515f;
-        *reinterpret_cast<f32x4*>(dst + ch * BN + (2 * by + py) * 64 + qx * 4) = v;
-      }
-    }
-  };
 
   f32x4 acc[WM][4];
 #pragma unroll
@@ -661,23 +696,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  produce(0, sB);
+  patch_store(0, sB);
   __syncthreads();
 #pragma unroll 1
   for (int st = 0; st < NSTAGE; ++st) {
-    const float* cur = sB + (NBUF > 1 ? (st & 1) : 0) * BK * BN + wn_i * 64 + jn * 4;
+    const float* cur = sB + (NBUF > 1 ? (st & 1) : 0) * BK * BN + nloc;
     f32x4 afr[KQ][WM];
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
       for (int i = 0; i < WM; ++i) afr[kq][i] = afr_next[kq][i];
-    if (st + 1 < NSTAGE) {   // next stage's A fragments travel under this stage's MFMAs
+    if (st + 1 < NSTAGE) {   // next stage's operands travel under this stage's MFMAs
 #pragma unroll
       for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
         for (int i = 0; i < WM; ++i)
           afr_next[kq][i] = *reinterpret_cast<const f32x4*>(
               ab + ((int64_t)(wm_i * WM + i) * (C / 16) + (st + 1) * KQ + kq) * 256 + lane * 4);
+      patch_load(st + 1);
     }
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
@@ -690,7 +726,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
           for (int c = 0; c < 4; ++c)
             acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], b4[c], acc[i][c], 0, 0, 0);
       }
-    if (NBUF > 1 && st + 1 < NSTAGE) produce(st + 1, sB + ((st + 1) & 1) * BK * BN);
+    if (NBUF > 1 && st + 1 < NSTAGE) patch_store(st + 1, sB + ((st + 1) & 1) * BK * BN);
     __syncthreads();
   }
 
@@ -733,41 +769,42 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
   if (q == 0) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-      *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + wn_i * 64 + jn * 4) =
+      *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) =
           f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
   }
   __syncthreads();
-  if (wm_i == 0 && q < 3) {          // quarter q finishes colour channel q
+  if (rgb_lane) {                     // quarter q finishes colour channel q
     const int ch = q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < WGM; ++m) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (m * 3 + ch) * BN + wn_i * 64 + jn * 4);
+      const f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (m * 3 + ch) * BN + nloc);
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] += t[c];
     }
-    const float bs = a.bias_rgb[ch];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] += bs;
+    for (int c = 0; c < 4; ++c) v[c] += rgb_bias;
     if (a.skip) {
       if (a.skip_up) {
-        const float* sp = a.skip + ((int64_t)b * 3 + ch) * HWlo;
+        float so[2][4];
+        up2_fir(skp, kf, so);
+        const int py = oy & 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] += up2_tap(sp, H, W, oy, ox + c, a.fir);
+        for (int c = 0; c < 4; ++c) v[c] += py ? so[1][c] : so[0][c];
       } else {
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + ch) * HWo + (int64_t)oy * OW + ox);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] += sv[c];
+        for (int c = 0; c < 4; ++c) v[c] += skv[c];
       }
     }
     *reinterpret_cast<f32x4*>(a.rgb + ((int64_t)b * 3 + ch) * HWo + (int64_t)oy * OW + ox) = v;
   }
 }
 
-template <int C, int WM, int WGM, int WGN>
+template <int C, int WM, int WGM, int WGN, int RW, int BK>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-  dim3 grid((unsigned)((2 * a.W / 64) * (2 * a.H / WGN)), 1, (unsigned)a.B);
-  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  constexpr int TH = RW * WGN, TW = 64 / RW;
+  dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
+  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -870,10 +907,10 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
               wm_rgb, bias_rgb, skip, skip_up, rgb, B, H, W};
   hipStream_t st = as_stream(stream);
   switch (C) {
-    case 32: return launch_fused<32, 1, 2, 2>(a, st);
-    case 64: return launch_fused<64, 2, 2, 4>(a, st);
-    case 128: return launch_fused<128, 2, 4, 2>(a, st);
-    case 256: return launch_fused<256, 4, 4, 2>(a, st);
+    case 32: return launch_fused<32, 1, 2, 2, 1, 32>(a, st);      // 2 rows x 64, 4 waves
+    case 64: return launch_fused<64, 2, 2, 2, 1, 32>(a, st);      // 2 rows x 64, 4 waves
+    case 128: return launch_fused<128, 2, 4, 2, 1, 32>(a, st);    // 2 rows x 64
+    case 256: return launch_fused<256, 2, 8, 1, 2, 64>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
   }
   return CIPS3D_E_UNSUPP;
 }
