@@ -150,6 +150,7 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
   // one sample pass.  Output registers cannot be indexed by the (run-time) step, so the step always writes
   // the LAST R registers of Y / FA and the array is rotated down by R; after STEPS steps every element is
   // back in natural order.
+  const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
 #pragma unroll 1
   for (int sl = 0; sl < STEPS; ++sl) {
     if (ring.seq + 1 < ring.seq_end) {
@@ -186,6 +187,15 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
         for (int tt = 0; tt < TPS; ++tt)
           acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt][j], X[4 * q4 + j], acc[tt], 0, 0, 0);
     }
+    // Epilogue stagger.  Waves w and w + WAVES/2 share a SIMD and meet at every slab barrier; with the barrier
+    // after the FiLM/sine epilogue both would run its ~250 VALU instructions together while the matrix pipe
+    // idles.  The upper half of the waves takes the step barrier BEFORE its epilogue instead, which then overlaps
+    // the partner wave's next-step MFMAs, and the partner's epilogue overlaps this wave's MFMA tail.  Either
+    // position is after this wave's last read of slot (seq&1) and before its next stage_slab into it.
+    if (late_epilogue) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's piece of slab seq+1 has landed
+      __syncthreads();
+    }
     float res[R];
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
@@ -209,6 +219,11 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
         for (int i = 0; i < 4; ++i) res[tt * 4 + i] = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
       }
     }
+    // The sink pass would otherwise move the sines below the barrier that follows (undoing the stagger): make
+    // the results opaque here.
+#pragma unroll
+    for (int k = 0; k < R; ++k) asm volatile("" : "+v"(res[k]));
+    if (VIEW) asm volatile("" : "+v"(chead[0]), "+v"(chead[1]), "+v"(chead[2]));
     // rotate: drop the first R registers, append this step's results
     if (VIEW) {
 #pragma unroll
@@ -222,8 +237,10 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
       for (int k = 0; k < R; ++k) Y[NT * 4 - R + k] = res[k];
     }
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
-    __syncthreads();
+    if (!late_epilogue) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
+      __syncthreads();
+    }
     ++ring.seq;
   }
 }
