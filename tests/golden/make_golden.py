@@ -308,13 +308,47 @@ def g_full():
     save("full_size", **out)
 
 
+# ---------------------------------------------------------------- 10. on-disk formats
+def g_ckpt_tiny():
+    """A checkpoint directory and an inversion file as the reference's writers lay them out, holding the
+    reference generator's own tensors: G_ema.pth = state_dict of the imported reference Generator
+    (scripts/train_v10.py:496-523 via tl2 save_models(save_module=False)); w.pth = the dict of
+    models/projector_v10.py:1044-1055.  config_command.yaml is written by hand in the structure the loaders read
+    (`list(load_yaml(...).values())[0].G_cfg`, tests/test_cips3dpp.py:705-706): tl2's dumper is not vendored."""
+    import yaml
+    d = os.path.join(HERE, "ckpt_tiny")
+    os.makedirs(d, exist_ok=True)
+    cfg = configs.tiny_G_cfg(hidden=32, N_layers_renderer=2, kernel_size=1)
+    G = ref.Generator(**cfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    G.load_state_dict(weights.synth_state_dict(shapes, seed=7), strict=True)
+    torch.save(G.state_dict(), os.path.join(d, "G_ema.pth"))
+    block = {"G_cfg": {"register_modules": ["exp.cips3d.models.model_v3"],
+                       "name": "exp.cips3d.models.model_v3.Generator", **cfg},
+             "G_kwargs": {"cam_cfg": dict(configs.FFHQ_CAM_CFG), "nerf_cfg": dict(configs.TRAIN_NERF_CFG)}}
+    with open(os.path.join(d, "config_command.yaml"), "w") as f:
+        yaml.safe_dump({"train_cips3d_ffhq_v10": block}, f, sort_keys=False)
+    g = torch.Generator().manual_seed(21)
+    w_dec = torch.zeros(2, G.decoder.n_latent, 32)
+    w_dec[1] = 1.0
+    torch.save({
+        "azim": torch.tensor([0.25, -0.25]), "elev": torch.tensor([0.05, 0.05]),
+        "w_render_opt": torch.zeros(1, G.N_layers_renderer + 1, 32), "w_decoder_opt": w_dec,
+        "render_state_dict": G.renderer.state_dict(), "decoder_state_dict": G.decoder.state_dict(),
+        "noise_bufs": [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(8, "cpu")],
+        "padding": 0,
+    }, os.path.join(d, "w.pth"))
+    for fn in sorted(os.listdir(d)):
+        print(f"ckpt_tiny/{fn}: {os.path.getsize(os.path.join(d, fn)) / 1024:.1f} KB")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     jobs = dict(camera=g_camera, rays=g_rays, siren=g_siren, ops=g_ops, modconv=g_modconv,
-                tiny_generator=g_tiny_generator)
+                tiny_generator=g_tiny_generator, ckpt_tiny=g_ckpt_tiny)
     if a.full:
         jobs["full_size"] = g_full
     for name, fn in jobs.items():
