@@ -77,6 +77,15 @@ _SIGS = {
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
+    "cips3d_linear_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_int, c_int, c_int, c_f32, c_f32,
+                                  c_int, c_f32, c_f32, c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_modulate_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_int, c_f32, c_int, c_f32p,
+                                    c_f32p, c_i64, C.c_void_p]),
+    "cips3d_pack_weights": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_gemm_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
+                                          c_int, c_i64, C.c_void_p]),
+    "cips3d_torgb_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),

@@ -1,0 +1,171 @@
+"""Differentiable form of the generator path: one torch.autograd.Function per HIP forward op, each with an explicit
+HIP backward (csrc/backward.hip, csrc/nerf_bwd.hip).  torch's autograd engine is only the tape that orders the calls
+and sums fan-out gradients; the reference relies on the same engine (`loss.backward()` in
+/root/reference/exp/cips3d/models/projector_v10.py:1203-1209).
+
+Used by `Generator.forward` when gradients are enabled and something that reaches the output requires them
+(flip inversion: camera angles, W+ styles, decoder parameters, noise buffers — projector_v10.py:985-1009).
+"""
+import torch
+from torch.autograd import Function
+
+from . import hip, op
+
+
+def _c(t):
+    return t.contiguous() if t is not None else None
+
+
+class LinearFn(Function):
+    """hip.linear without PixelNorm / truncation: EqualLinear, MappingLinear, LinearLayer."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, w_scale, b_scale, lrelu, act_gain, out_scale, out_shift):
+        x = _c(x.float())
+        y = hip.linear(x, W, bias, w_scale=w_scale, b_scale=b_scale, lrelu=lrelu, act_gain=act_gain, out_scale=out_scale,
+                       out_shift=out_shift)
+        ctx.save_for_backward(x, W, y if lrelu else None)
+        ctx.cfg = (w_scale, b_scale, lrelu, act_gain, out_scale, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, y = ctx.saved_tensors
+        w_scale, b_scale, lrelu, act_gain, out_scale, has_bias = ctx.cfg
+        nx, nW, nb = ctx.needs_input_grad[:3]
+        dx, dW, db = hip.linear_bwd(x, W, _c(dy), out=y, w_scale=w_scale, b_scale=b_scale, lrelu=lrelu, act_gain=act_gain,
+                                    out_scale=out_scale, need_dx=nx, need_dW=nW, need_db=nb and has_bias)
+        return dx, dW, db, None, None, None, None, None, None
+
+
+def linear(x, W, bias=None, w_scale=1.0, b_scale=1.0, lrelu=False, act_gain=1.0, out_scale=1.0, out_shift=0.0):
+    return LinearFn.apply(x, W, bias, float(w_scale), float(b_scale), bool(lrelu), float(act_gain), float(out_scale),
+                          float(out_shift))
+
+
+class ModulateFn(Function):
+    """ModulatedConv2d weight modulation (k = 1): W [1,Cout,Cin,1,1], s [B,Cin] -> wm [B,Cout,Cin]."""
+
+    @staticmethod
+    def forward(ctx, W, s, scale, demodulate):
+        _, Cout, Cin, kh, kw = W.shape
+        if kh * kw != 1:
+            raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
+        s = _c(s)
+        wm = hip.modulate_weights(W, s, s.shape[1], s.shape[0], Cout, Cin, 1, scale, demodulate, packed=False)
+        ctx.save_for_backward(W, s)
+        ctx.cfg = (Cout, Cin, scale, demodulate)
+        return wm.view(s.shape[0], Cout, Cin)
+
+    @staticmethod
+    def backward(ctx, dwm):
+        W, s = ctx.saved_tensors
+        Cout, Cin, scale, demodulate = ctx.cfg
+        dW, ds = hip.modulate_bwd(dwm.contiguous().clone(), W, s, Cout, Cin, 1, scale, demodulate,
+                                  need_dW=ctx.needs_input_grad[0])
+        return dW, ds, None, None
+
+
+class Conv1x1Fn(Function):
+    """Per-sample GEMM y[b] = wm[b] x[b] (x [B,Cin,H,W]); backward = the same GEMM on wm^T + the pixel-contraction GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, wm):
+        x = _c(x)
+        wm = _c(wm)
+        Cout = wm.shape[1]
+        y = hip.modconv1x1(x, hip.pack_weights(wm), Cout, epilogue=0)
+        ctx.save_for_backward(x, wm)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved_tensors
+        dy = _c(dy)
+        dx = dwm = None
+        if ctx.needs_input_grad[0]:
+            dx = hip.modconv1x1(dy, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0)
+        if ctx.needs_input_grad[1]:
+            dwm = hip.gemm_wgrad(dy, x)
+        return dx, dwm
+
+
+class NoiseBiasActFn(Function):
+    """NoiseInjection + FusedLeakyReLU: y = lrelu(x + nw*noise + bias_c)*sqrt2."""
+
+    @staticmethod
+    def forward(ctx, x, noise, noise_w, bias):
+        x = _c(x)
+        noise = _c(noise)
+        y = hip.noise_bias_act(x, noise, noise_w, bias)
+        ctx.save_for_backward(y, noise, noise_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, noise, noise_w = ctx.saved_tensors
+        _, n_noise, n_nw, n_b = ctx.needs_input_grad
+        dx, dnoise, dnw, db = hip.noise_bias_act_bwd(_c(dy), y, noise, noise_w, need_dnoise=n_noise, need_dnw=n_nw, need_db=n_b)
+        return dx, dnoise, dnw, db
+
+
+class ToRGBFn(Function):
+    """rgb = wm x + bias (+ skip, already at the output resolution)."""
+
+    @staticmethod
+    def forward(ctx, x, wm, bias, skip):
+        x = _c(x)
+        wm = _c(wm)
+        rgb = hip.torgb(x, wm, bias, skip=_c(skip), skip_up=False)
+        ctx.save_for_backward(x, wm)
+        ctx.has_skip = skip is not None
+        return rgb
+
+    @staticmethod
+    def backward(ctx, drgb):
+        x, wm = ctx.saved_tensors
+        drgb = _c(drgb)
+        dx, dwm, db = hip.torgb_bwd(drgb, x, wm, need_db=ctx.needs_input_grad[2])
+        return dx, dwm, db.view(1, 3, 1, 1) if db is not None else None, (drgb if ctx.has_skip else None)
+
+
+# ------------------------------------------------------------------------------------------ decoder, differentiable walk
+def styled_conv(sc, x, style, noise):
+    """StyledConv (models/model_v3.py:444-454) as a chain of differentiable HIP ops."""
+    conv = sc.conv
+    mod = conv.modulation
+    s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
+    wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate)
+    y = Conv1x1Fn.apply(x, wm)
+    if conv.upsample:
+        y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
+    if noise is None:
+        noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], device=y.device)
+    return NoiseBiasActFn.apply(y, noise, sc.noise.weight, sc.activate.bias)
+
+
+def to_rgb(tr, x, style, skip):
+    conv = tr.conv
+    mod = conv.modulation
+    s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
+    wm = ModulateFn.apply(conv.weight, s, conv.scale, False)
+    if skip is not None and tr.upsample:
+        skip = tr.upsample(skip)            # op.upfirdn2d, differentiable
+    return ToRGBFn.apply(x, wm, tr.bias, skip)
+
+
+def decoder_forward(dec, features, styles, noise=None):
+    """Decoder.forward (models/model_v3.py:592-637) with gradients."""
+    if dec.kernel_size != 1:
+        raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
+    if noise is None:
+        noise = [None] * dec.num_layers
+    out = styled_conv(dec.conv1, features, styles[:, 0], noise[0])
+    skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None)
+    i = 1
+    for st in range(len(dec.to_rgbs)):
+        out = styled_conv(dec.convs[2 * st], out, styles[:, i], noise[2 * st + 1])
+        out = styled_conv(dec.convs[2 * st + 1], out, styles[:, i + 1], noise[2 * st + 2])
+        skip = to_rgb(dec.to_rgbs[st], out, styles[:, i + 2], skip)
+        i += 2
+    return skip

@@ -1,0 +1,391 @@
+// Backward building blocks of the generator path (flip inversion, reference
+// models/projector_v10.py:211-277,915-1216 drives `loss.backward()` through Generator.forward).
+//
+// The reference gets every one of these from PyTorch autograd over cuBLAS/cuDNN; here each forward op has an explicit
+// HIP backward, chained on the host by torch.autograd.Function objects (cips_3dplusplus_amd/autograd.py):
+//   cips3d_linear_bwd            EqualLinear / MappingLinear / LinearLayer   (model_v3.py:40-65,183-210; volume_renderer.py:15-35)
+//   cips3d_modulate_bwd          weight modulation + demodulation            (model_v3.py:267-278)
+//   cips3d_pack_weights          plain [B,M,K] -> MFMA A-fragment order, optionally of the transpose (data-gradient GEMM)
+//   cips3d_gemm_wgrad            dW[b] = dY[b] X[b]^T over the pixels, fp32 MFMA, split over pixel chunks
+//   cips3d_noise_bias_act_bwd    NoiseInjection + FusedLeakyReLU             (model_v3.py:327-341; fused_act.py:20-84)
+//   cips3d_torgb_bwd             ToRGB (C -> 3 modulated conv + bias)        (model_v3.py:469-482)
+// The data gradient of the 1x1 convolution is cips3d_modconv1x1 itself on the packed transpose; the gradient of the FIR
+// up-sampler is cips3d_upfirdn2d with swapped factors and flipped taps (upfirdn2d.py:20-143).
+//
+// Rooflines: the element-wise kernels and the reductions are HBM-bound (each activation read once, each gradient
+// written once); cips3d_gemm_wgrad is MFMA work (2*M*K flop per pixel) fed straight from global memory -- both
+// operands are pixel-contiguous, so a float4 per lane IS four k-slices of v_mfma_f32_16x16x4_f32 and no LDS
+// transpose is needed.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// ------------------------------------------------------------------------------------------------ linear
+struct LinBwd {
+  const float* x; int64_t x_stride; const float* W; const float* out; int64_t out_stride; const float* dout;
+  int64_t dout_stride; int B, in_dim, out_dim; float w_scale, b_scale; int lrelu; float act_gain, out_scale;
+  float* dx; int64_t dx_stride; float* dW; float* dbias;
+};
+
+// d(pre-activation) of y = (lrelu?(pre) * gain) * out_scale + out_shift, pre = x W^T w_scale + b b_scale
+__device__ __forceinline__ float lin_dpre(const LinBwd& a, int b, int o) {
+  float g = a.dout[(int64_t)b * a.dout_stride + o] * a.out_scale;
+  if (a.lrelu) g *= a.act_gain * (a.out[(int64_t)b * a.out_stride + o] > 0.f ? 1.f : 0.2f);
+  return g;
+}
+
+__global__ void __launch_bounds__(256) linear_bwd_dw_kernel(LinBwd a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)a.out_dim * a.in_dim) return;
+  const int o = (int)(e / a.in_dim), i = (int)(e % a.in_dim);
+  float acc = 0.f;
+  for (int b = 0; b < a.B; ++b) acc = fmaf(lin_dpre(a, b, o), a.x[(int64_t)b * a.x_stride + i], acc);
+  a.dW[e] = acc * a.w_scale;
+}
+
+__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(LinBwd a) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)a.B * a.in_dim) return;
+  const int b = (int)(e / a.in_dim), i = (int)(e % a.in_dim);
+  float acc = 0.f;
+  for (int o = 0; o < a.out_dim; ++o) acc = fmaf(lin_dpre(a, b, o), a.W[(int64_t)o * a.in_dim + i], acc);
+  a.dx[(int64_t)b * a.dx_stride + i] = acc * a.w_scale;
+}
+
+__global__ void __launch_bounds__(256) linear_bwd_db_kernel(LinBwd a) {
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  if (o >= a.out_dim) return;
+  float acc = 0.f;
+  for (int b = 0; b < a.B; ++b) acc += lin_dpre(a, b, o);
+  a.dbias[o] = acc * a.b_scale;
+}
+
+// ------------------------------------------------------------------------------------------------ modulation
+// wm[b][o][e] = u * d,  u = scale W[o][e] s[b][e/ksq],  d = rsqrt(sum_e u^2 + 1e-8) (demodulate) or 1.
+// One wave per (b, o): du = dwm d - d^3 u <dwm, u>, written over dwm.
+__global__ void __launch_bounds__(256) modulate_bwd_du_kernel(float* __restrict__ dwm, const float* __restrict__ W,
+                                                              const float* __restrict__ s, int64_t s_stride, int B,
+                                                              int Cout, int len, int ksq, float scale, int demod) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)B * Cout || !demod) return;
+  const int b = (int)(row / Cout), o = (int)(row % Cout);
+  const float* w = W + (int64_t)o * len;
+  const float* sb = s + (int64_t)b * s_stride;
+  float* g = dwm + row * len;
+  float ss = 0.f, dot = 0.f;
+  for (int e = lane; e < len; e += 64) {
+    const float u = (scale * w[e]) * sb[e / ksq];
+    ss = fmaf(u, u, ss);
+    dot = fmaf(g[e], u, dot);
+  }
+  ss = wave_sum(ss);
+  dot = wave_sum(dot);
+  const float d = rsqrtf(ss + 1e-8f);
+  const float c = d * d * d * dot;
+  for (int e = lane; e < len; e += 64) {
+    const float u = (scale * w[e]) * sb[e / ksq];
+    g[e] = fmaf(g[e], d, -c * u);
+  }
+}
+
+// dW[o][e] = scale sum_b du[b][o][e] s[b][e/ksq]
+__global__ void __launch_bounds__(256) modulate_bwd_dw_kernel(const float* __restrict__ du, const float* __restrict__ s,
+                                                              int64_t s_stride, int B, int Cout, int len, int ksq,
+                                                              float scale, float* __restrict__ dW) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)Cout * len) return;
+  const int i = (int)(e % len) / ksq;
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc = fmaf(du[(int64_t)b * Cout * len + e], s[(int64_t)b * s_stride + i], acc);
+  dW[e] = acc * scale;
+}
+
+// ds[b][i] = scale sum_o sum_t du[b][o][i*ksq+t] W[o][i*ksq+t]
+__global__ void __launch_bounds__(256) modulate_bwd_ds_kernel(const float* __restrict__ du, const float* __restrict__ W,
+                                                              int B, int Cout, int Cin, int ksq, float scale,
+                                                              float* __restrict__ ds, int64_t ds_stride) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * Cin) return;
+  const int b = (int)(e / Cin), i = (int)(e % Cin);
+  const int len = Cin * ksq;
+  float acc = 0.f;
+  for (int o = 0; o < Cout; ++o)
+    for (int t = 0; t < ksq; ++t)
+      acc = fmaf(du[((int64_t)b * Cout + o) * len + i * ksq + t], W[(int64_t)o * len + i * ksq + t], acc);
+  ds[(int64_t)b * ds_stride + i] = acc * scale;
+}
+
+// ------------------------------------------------------------------------------------------------ packing
+// out = A-fragment order (see decoder.hip: modulate_row) of wm[b] (M x K) or of its transpose (K x M).
+__global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ wm, float* __restrict__ out, int B, int M,
+                                                   int K, int transpose) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)B * M * K) return;
+  const int b = (int)(e / ((int64_t)M * K));
+  const int r = (int)((e / K) % M), c = (int)(e % K);       // element wm[b][r][c]
+  const int o = transpose ? c : r, i = transpose ? r : c;   // (row, column) of the packed matrix
+  const int OM = transpose ? K : M, OK = transpose ? M : K;
+  const int ot = o >> 4, kq = i >> 4, j = (i >> 2) & 3, q = i & 3;
+  out[(((int64_t)b * (OM >> 4) + ot) * (OK >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = wm[e];
+}
+
+// ------------------------------------------------------------------------------------------------ weight-gradient GEMM
+// dwm[b][m][k] = sum_p dy[b][m][p] x[b][k][p].  A workgroup = 4 waves = 2 x 2 wave tiles of 32 x 32 outputs; every
+// wave walks the same pixel chunk.  Lane (r = lane & 15, q = lane >> 4) loads float4 = pixels p0 + 4q .. 4q+3 of row r:
+// component j of all lanes forms one k-slice {p0 + 4q' + j} -- the same permutation of the pixels on both operands,
+// which a contraction does not see.  Partial sums of the chunks meet in dwm through fp32 atomics.
+__global__ void __launch_bounds__(256) gemm_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         float* __restrict__ dwm, int M, int K, int64_t P,
+                                                         int64_t chunk) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int kblocks = ceil_div(K, 64);
+  const int mb = blockIdx.x / kblocks, kb = blockIdx.x % kblocks;
+  const int m0 = mb * 64 + (wave >> 1) * 32, k0 = kb * 64 + (wave & 1) * 32;
+  if (m0 >= M || k0 >= K) return;
+  const int b = blockIdx.z;
+  const int64_t p_begin = (int64_t)blockIdx.y * chunk;
+  const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;
+  const float* a0 = dy + ((int64_t)b * M + m0 + r) * P + 4 * q;
+  const float* a1 = a0 + 16 * P;
+  const float* b0 = x + ((int64_t)b * K + k0 + r) * P + 4 * q;
+  const float* b1 = b0 + 16 * P;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t p = p_begin; p < p_end; p += 16) {
+    const bool ok = p + 4 * q < p_end;          // P % 4 == 0, chunk % 16 == 0: a float4 is all-in or all-out
+    const f32x4 va0 = ok ? *reinterpret_cast<const f32x4*>(a0 + p) : zero;
+    const f32x4 va1 = ok ? *reinterpret_cast<const f32x4*>(a1 + p) : zero;
+    const f32x4 vb0 = ok ? *reinterpret_cast<const f32x4*>(b0 + p) : zero;
+    const f32x4 vb1 = ok ? *reinterpret_cast<const f32x4*>(b1 + p) : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[j], vb0[j], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va0[j], vb1[j], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1[j], vb0[j], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(va1[j], vb1[j], acc[1][1], 0, 0, 0);
+    }
+  }
+  // D layout: register t of lane (r, q) = C[4q + t][r]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        unsafeAtomicAdd(dwm + ((int64_t)b * M + m0 + 16 * i + 4 * q + t) * K + k0 + 16 * j + r, acc[i][j][t]);
+}
+
+// ------------------------------------------------------------------------------------------------ noise + bias + leaky-ReLU
+// y = lrelu(x + nw noise + bias_c) sqrt2  =>  dx = dy sqrt2 (y > 0 ? 1 : 0.2);  dbias_c = sum_{b,p} dx.
+// grid (pixel blocks, C, B): one block reduces its 1024 pixels of one channel.
+__global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                      float* __restrict__ dx, float* __restrict__ dbias, int C,
+                                                      int64_t HW) {
+  __shared__ float sh[4];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int64_t base = ((int64_t)b * C + c) * HW;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  float sum = 0.f;
+  if (p0 < HW) {    // HW % 4 == 0
+    const float4 g = *reinterpret_cast<const float4*>(dy + base + p0);
+    const float4 v = *reinterpret_cast<const float4*>(y + base + p0);
+    const float S = 1.41421356237309515f;
+    float4 o;
+    o.x = g.x * (v.x > 0.f ? S : 0.2f * S);
+    o.y = g.y * (v.y > 0.f ? S : 0.2f * S);
+    o.z = g.z * (v.z > 0.f ? S : 0.2f * S);
+    o.w = g.w * (v.w > 0.f ? S : 0.2f * S);
+    *reinterpret_cast<float4*>(dx + base + p0) = o;
+    sum = (o.x + o.y) + (o.z + o.w);
+  }
+  sum = block_sum_256(sum, sh);
+  if (threadIdx.x == 0 && dbias) unsafeAtomicAdd(dbias + c, sum);
+}
+
+// dnoise[bn][p] = nw sum_{c (and b if the noise is shared)} dx[b][c][p];  dnw = sum_p noise[p] * (sum_c dx)
+__global__ void __launch_bounds__(256) noise_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ noise,
+                                                        int64_t noise_bstride, const float* __restrict__ noise_w,
+                                                        float* __restrict__ dnoise, float* __restrict__ dnw, int B, int C,
+                                                        int64_t HW) {
+  __shared__ float sh[4];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int b_lo = noise_bstride ? blockIdx.y : 0, b_hi = noise_bstride ? blockIdx.y + 1 : B;
+  float part = 0.f;
+  if (p < HW) {
+    float acc = 0.f;
+    for (int b = b_lo; b < b_hi; ++b)
+      for (int c = 0; c < C; ++c) acc += dx[((int64_t)b * C + c) * HW + p];
+    const int64_t np = (int64_t)(noise_bstride ? blockIdx.y : 0) * noise_bstride + p;
+    if (dnoise) dnoise[np] = acc * noise_w[0];
+    part = acc * noise[np];
+  }
+  part = block_sum_256(part, sh);
+  if (threadIdx.x == 0 && dnw) unsafeAtomicAdd(dnw, part);
+}
+
+// ------------------------------------------------------------------------------------------------ ToRGB
+// rgb[r][p] = sum_c wm[b][r][c] x[c][p] + bias_r (+ skip)
+//   dx[c][p] = sum_r wm[r][c] drgb[r][p];  dwm[b][r][c] = sum_p drgb[r][p] x[c][p];  dbias_r = sum_{b,p} drgb[r][p]
+__global__ void __launch_bounds__(256) torgb_bwd_kernel(const float* __restrict__ drgb, const float* __restrict__ x,
+                                                        const float* __restrict__ wm, float* __restrict__ dx,
+                                                        float* __restrict__ dwm, float* __restrict__ dbias, int C,
+                                                        int64_t HW) {
+  __shared__ float sh[4];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const float* g = drgb + (int64_t)b * 3 * HW;
+  const float w0 = wm[((int64_t)b * 3 + 0) * C + c], w1 = wm[((int64_t)b * 3 + 1) * C + c],
+              w2 = wm[((int64_t)b * 3 + 2) * C + c];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  if (p0 < HW) {
+    const float4 g0 = *reinterpret_cast<const float4*>(g + p0);
+    const float4 g1 = *reinterpret_cast<const float4*>(g + HW + p0);
+    const float4 g2 = *reinterpret_cast<const float4*>(g + 2 * HW + p0);
+    const int64_t xi = ((int64_t)b * C + c) * HW + p0;
+    const float4 xv = *reinterpret_cast<const float4*>(x + xi);
+    float4 o;
+    o.x = fmaf(w2, g2.x, fmaf(w1, g1.x, w0 * g0.x));
+    o.y = fmaf(w2, g2.y, fmaf(w1, g1.y, w0 * g0.y));
+    o.z = fmaf(w2, g2.z, fmaf(w1, g1.z, w0 * g0.z));
+    o.w = fmaf(w2, g2.w, fmaf(w1, g1.w, w0 * g0.w));
+    *reinterpret_cast<float4*>(dx + xi) = o;
+    s0 = fmaf(g0.w, xv.w, fmaf(g0.z, xv.z, fmaf(g0.y, xv.y, g0.x * xv.x)));
+    s1 = fmaf(g1.w, xv.w, fmaf(g1.z, xv.z, fmaf(g1.y, xv.y, g1.x * xv.x)));
+    s2 = fmaf(g2.w, xv.w, fmaf(g2.z, xv.z, fmaf(g2.y, xv.y, g2.x * xv.x)));
+    if (c == 0) {
+      t0 = (g0.x + g0.y) + (g0.z + g0.w);
+      t1 = (g1.x + g1.y) + (g1.z + g1.w);
+      t2 = (g2.x + g2.y) + (g2.z + g2.w);
+    }
+  }
+  s0 = block_sum_256(s0, sh); s1 = block_sum_256(s1, sh); s2 = block_sum_256(s2, sh);
+  if (threadIdx.x == 0) {
+    unsafeAtomicAdd(dwm + ((int64_t)b * 3 + 0) * C + c, s0);
+    unsafeAtomicAdd(dwm + ((int64_t)b * 3 + 1) * C + c, s1);
+    unsafeAtomicAdd(dwm + ((int64_t)b * 3 + 2) * C + c, s2);
+  }
+  if (c == 0 && dbias) {
+    t0 = block_sum_256(t0, sh); t1 = block_sum_256(t1, sh); t2 = block_sum_256(t2, sh);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(dbias + 0, t0); unsafeAtomicAdd(dbias + 1, t1); unsafeAtomicAdd(dbias + 2, t2); }
+  }
+}
+
+}  // namespace
+
+extern "C" int cips3d_linear_bwd(const float* x, int64_t x_stride, const float* W, const float* out, int64_t out_stride,
+                                 const float* dout, int64_t dout_stride, int B, int in_dim, int out_dim, float w_scale,
+                                 float b_scale, int lrelu, float act_gain, float out_scale, float* dx, int64_t dx_stride,
+                                 float* dW, float* dbias, void* stream) {
+  if (!x || !W || !dout || B < 0 || in_dim <= 0 || out_dim <= 0) return CIPS3D_E_BADARG;
+  if (lrelu && !out) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  LinBwd a{x, x_stride, W, out, out_stride, dout, dout_stride, B, in_dim, out_dim, w_scale, b_scale, lrelu, act_gain,
+           out_scale, dx, dx_stride, dW, dbias};
+  hipStream_t st = as_stream(stream);
+  if (dW)
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)out_dim * in_dim, 256)), dim3(256), 0,
+                       st, a);
+  if (dx)
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * in_dim, 256)), dim3(256), 0, st, a);
+  if (dbias) hipLaunchKernelGGL(linear_bwd_db_kernel, dim3((unsigned)ceil_div(out_dim, 256)), dim3(256), 0, st, a);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_modulate_bwd(float* dwm, const float* W, const float* s, int64_t s_stride, int B, int Cout, int Cin,
+                                   int ksq, float scale, int demodulate, float* dW, float* ds, int64_t ds_stride,
+                                   void* stream) {
+  if (!dwm || !W || !s || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  const int len = Cin * ksq;
+  if (demodulate)
+    hipLaunchKernelGGL(modulate_bwd_du_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * Cout, 4)), dim3(256), 0, st, dwm,
+                       W, s, s_stride, B, Cout, len, ksq, scale, demodulate);
+  if (dW)
+    hipLaunchKernelGGL(modulate_bwd_dw_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)Cout * len, 256)), dim3(256), 0, st,
+                       dwm, s, s_stride, B, Cout, len, ksq, scale, dW);
+  if (ds)
+    hipLaunchKernelGGL(modulate_bwd_ds_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * Cin, 256)), dim3(256), 0, st, dwm,
+                       W, B, Cout, Cin, ksq, scale, ds, ds_stride);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int transpose, void* stream) {
+  if (!wm || !packed || B < 0 || M <= 0 || K <= 0) return CIPS3D_E_BADARG;
+  if (M % 16 || K % 16) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * M * K, 256)), dim3(256), 0, as_stream(stream),
+                     wm, packed, B, M, K, transpose);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P, void* stream) {
+  if (!dy || !x || !dwm || B < 0 || M <= 0 || K <= 0 || P <= 0) return CIPS3D_E_BADARG;
+  if (M % 32 || K % 32 || P % 4) return CIPS3D_E_UNSUPP;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(dwm, 0, sizeof(float) * (size_t)B * M * K, st);
+  if (e != hipSuccess) return (int)e;
+  const int blocks = ceil_div(M, 64) * ceil_div(K, 64);
+  // enough pixel chunks for ~4 workgroups per CU, at least 256 pixels each
+  int64_t n_chunks = ceil_div<int64_t>(1024, (int64_t)blocks * B);
+  const int64_t max_chunks = ceil_div<int64_t>(P, 256);
+  if (n_chunks > max_chunks) n_chunks = max_chunks;
+  if (n_chunks < 1) n_chunks = 1;
+  int64_t chunk = ceil_div<int64_t>(ceil_div<int64_t>(P, n_chunks), 16) * 16;
+  n_chunks = ceil_div<int64_t>(P, chunk);
+  hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((unsigned)blocks, (unsigned)n_chunks, (unsigned)B), dim3(256), 0, st, dy, x, dwm,
+                     M, K, P, chunk);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const float* noise, int64_t noise_bstride,
+                                         const float* noise_w, float* dx, float* dnoise, float* dnoise_w, float* dbias,
+                                         int B, int C, int64_t HW, void* stream) {
+  if (!dy || !y || !dx || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if ((dnoise || dnoise_w) && (!noise || !noise_w)) return CIPS3D_E_BADARG;
+  if (HW % 4) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  if (dbias) { hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st, dy,
+                     y, dx, dbias, C, HW);
+  if (dnoise || dnoise_w) {
+    if (dnoise_w) { hipError_t e = hipMemsetAsync(dnoise_w, 0, sizeof(float), st); if (e != hipSuccess) return (int)e; }
+    hipLaunchKernelGGL(noise_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 256), (unsigned)(noise_bstride ? B : 1)),
+                       dim3(256), 0, st, dx, noise, noise_bstride, noise_w, dnoise, dnoise_w, B, C, HW);
+  }
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_torgb_bwd(const float* drgb, const float* x, const float* wm, float* dx, float* dwm, float* dbias,
+                                int B, int C, int64_t HW, void* stream) {
+  if (!drgb || !x || !wm || !dx || !dwm || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (HW % 4) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(dwm, 0, sizeof(float) * (size_t)B * 3 * C, st);
+  if (e != hipSuccess) return (int)e;
+  if (dbias) { e = hipMemsetAsync(dbias, 0, sizeof(float) * 3, st); if (e != hipSuccess) return (int)e; }
+  hipLaunchKernelGGL(torgb_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st,
+                     drgb, x, wm, dx, dwm, dbias, C, HW);
+  return cips3d_launch_status();
+}

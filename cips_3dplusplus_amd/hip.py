@@ -256,3 +256,82 @@ def rgb_to_uint8(rgb):
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     check(lib.cips3d_rgb_to_uint8(dev_ptr(x, "rgb"), out.data_ptr(), x.numel(), stream_ptr()), "cips3d_rgb_to_uint8")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- backward entry points
+def linear_bwd(x, W, dout, out=None, w_scale=1.0, b_scale=1.0, lrelu=False, act_gain=1.0, out_scale=1.0, need_dx=True,
+               need_dW=True, need_db=True):
+    lib = _lib.load()
+    B, in_dim = x.shape
+    out_dim = W.shape[0]
+    dev = x.device
+    dx = torch.empty(B, in_dim, device=dev) if need_dx else None
+    dW = torch.empty(out_dim, in_dim, device=dev) if need_dW else None
+    db = torch.empty(out_dim, device=dev) if need_db else None
+    check(lib.cips3d_linear_bwd(dev_ptr(x, "x"), x.stride(0), dev_ptr(W, "W"), dev_ptr(out, "out", True),
+                                out.stride(0) if out is not None else 0, dev_ptr(dout, "dout"), dout.stride(0), B, in_dim,
+                                out_dim, w_scale, b_scale, int(lrelu), act_gain, out_scale, dev_ptr(dx, "dx", True), in_dim,
+                                dev_ptr(dW, "dW", True), dev_ptr(db, "db", True), stream_ptr()), "cips3d_linear_bwd")
+    return dx, dW, db
+
+
+def modulate_bwd(dwm, W, s, Cout, Cin, ksq, scale, demodulate, need_dW=True):
+    """dwm [B,Cout,Cin*ksq] is consumed (scratch).  Returns (dW shaped like W or None, ds [B,Cin])."""
+    lib = _lib.load()
+    B = s.shape[0]
+    dW = torch.empty_like(W) if need_dW else None
+    ds = torch.empty(B, Cin, device=W.device)
+    check(lib.cips3d_modulate_bwd(dev_ptr(dwm, "dwm"), dev_ptr(W, "W"), dev_ptr(s, "s"), s.stride(0), B, Cout, Cin, ksq,
+                                  float(scale), int(bool(demodulate)), dev_ptr(dW, "dW", True), dev_ptr(ds), Cin, stream_ptr()),
+          "cips3d_modulate_bwd")
+    return dW, ds
+
+
+def pack_weights(wm, transpose=False):
+    """wm [B,M,K] -> packed A fragments of wm (or of wm^T)."""
+    lib = _lib.load()
+    B, M, K = wm.shape
+    out = torch.empty(B * M * K, device=wm.device)
+    check(lib.cips3d_pack_weights(dev_ptr(wm, "wm"), dev_ptr(out), B, M, K, int(bool(transpose)), stream_ptr()),
+          "cips3d_pack_weights")
+    return out
+
+
+def gemm_wgrad(dy, x):
+    """dy [B,M,...], x [B,K,...] (same trailing pixels) -> dwm [B,M,K]."""
+    lib = _lib.load()
+    B, M = dy.shape[:2]
+    K = x.shape[1]
+    P = dy[0, 0].numel()
+    dwm = torch.empty(B, M, K, device=dy.device)
+    check(lib.cips3d_gemm_wgrad(dev_ptr(dy, "dy"), dev_ptr(x, "x"), dev_ptr(dwm), B, M, K, P, stream_ptr()), "cips3d_gemm_wgrad")
+    return dwm
+
+
+def noise_bias_act_bwd(dy, y, noise, noise_w, need_dnoise=False, need_dnw=True, need_db=True):
+    lib = _lib.load()
+    B, Cc = y.shape[:2]
+    HW = y[0, 0].numel()
+    dev = y.device
+    dx = torch.empty_like(y)
+    nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    dnoise = torch.empty_like(noise) if (need_dnoise and noise is not None) else None
+    dnw = torch.empty(1, device=dev) if (need_dnw and noise is not None) else None
+    db = torch.empty(Cc, device=dev) if need_db else None
+    check(lib.cips3d_noise_bias_act_bwd(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(noise, "noise", True), nb,
+                                        dev_ptr(noise_w, "noise_w", True), dev_ptr(dx), dev_ptr(dnoise, "dnoise", True),
+                                        dev_ptr(dnw, "dnw", True), dev_ptr(db, "db", True), B, Cc, HW, stream_ptr()),
+          "cips3d_noise_bias_act_bwd")
+    return dx, dnoise, dnw, db
+
+
+def torgb_bwd(drgb, x, wm, need_db=True):
+    lib = _lib.load()
+    B, Cc = x.shape[:2]
+    HW = x[0, 0].numel()
+    dx = torch.empty_like(x)
+    dwm = torch.empty(B, 3, Cc, device=x.device)
+    db = torch.empty(3, device=x.device) if need_db else None
+    check(lib.cips3d_torgb_bwd(dev_ptr(drgb, "drgb"), dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(dx), dev_ptr(dwm),
+                               dev_ptr(db, "db", True), B, Cc, HW, stream_ptr()), "cips3d_torgb_bwd")
+    return dx, dwm, db

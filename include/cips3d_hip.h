@@ -312,6 +312,48 @@ int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_for
 int64_t cips3d_sizeof_plan(void);
 int64_t cips3d_sizeof_io(void);
 
+/* ------------------------------------------------------------------ backward of the path
+ * The flip-inversion loop (reference models/projector_v10.py:211-277,1058-1216) calls loss.backward() through
+ * Generator.forward; the reference gets these gradients from PyTorch autograd over cuBLAS/cuDNN and from the backward
+ * wiring of its two native ops (op/fused_act.py:20-84, op/upfirdn2d.py:20-143).  Each entry below is the explicit
+ * backward of one forward entry point; torch.autograd.Function objects on the host chain them.
+ * Gradient outputs are OVERWRITTEN (not accumulated); NULL output pointers skip that gradient. */
+
+/* Backward of cips3d_linear (pixelnorm = 0, no truncation):  y = act(x W^T w_scale + bias b_scale) * out_scale + shift,
+ * act = leaky-ReLU(0.2) * act_gain when lrelu (then `out` = the forward output, whose sign selects the slope).
+ * dx [B,in], dW [out,in], dbias [out].  (models/model_v3.py:40-65,183-210; cips3d/volume_renderer.py:15-35) */
+int cips3d_linear_bwd(const float* x, int64_t x_stride, const float* W, const float* out, int64_t out_stride,
+                      const float* dout, int64_t dout_stride, int B, int in_dim, int out_dim, float w_scale,
+                      float b_scale, int lrelu, float act_gain, float out_scale, float* dx, int64_t dx_stride,
+                      float* dW, float* dbias, void* stream);
+
+/* Backward of cips3d_modulate_weights (models/model_v3.py:267-278).  dwm [B,Cout,Cin*ksq] holds dL/dwm on entry and is
+ * used as scratch (it holds dL/du on return, u = the modulated weight before demodulation).
+ * dW [Cout,Cin*ksq] (summed over the batch), ds [B,Cin] with row stride ds_stride. */
+int cips3d_modulate_bwd(float* dwm, const float* W, const float* s, int64_t s_stride, int B, int Cout, int Cin, int ksq,
+                        float scale, int demodulate, float* dW, float* ds, int64_t ds_stride, void* stream);
+
+/* wm [B,M,K] plain -> the MFMA A-fragment order cips3d_modconv1x1 consumes; transpose != 0 packs wm[b]^T (K x M),
+ * which turns cips3d_modconv1x1 into the data-gradient GEMM dx = wm^T dy.  M, K multiples of 16. */
+int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int transpose, void* stream);
+
+/* Weight gradient of the 1x1 convolution: dwm[b][m][k] = sum_p dy[b][m][p] * x[b][k][p]  (dy [B,M,P], x [B,K,P]).
+ * M, K multiples of 32, P multiple of 4, 16-byte aligned pointers.  Pixel chunks are summed with fp32 atomics, so the
+ * last bits depend on the execution order (as cuDNN's default weight-gradient algorithms do). */
+int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P, void* stream);
+
+/* Backward of cips3d_noise_bias_act / the epilogue of StyledConv (models/model_v3.py:327-341; op/fused_act.py:20-84):
+ * y = lrelu(x + noise_w*noise + bias_c)*sqrt2.  dx [B,C,HW] (may alias dy), dnoise [1 or B][HW] (layout of `noise`),
+ * dnoise_w [1], dbias [C]. */
+int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const float* noise, int64_t noise_bstride,
+                              const float* noise_w, float* dx, float* dnoise, float* dnoise_w, float* dbias, int B, int C,
+                              int64_t HW, void* stream);
+
+/* Backward of cips3d_torgb without the skip (its gradient is drgb itself; the FIR up-sampling of the skip is
+ * cips3d_upfirdn2d): dx [B,C,HW], dwm [B,3,C], dbias [3].  (models/model_v3.py:469-482) */
+int cips3d_torgb_bwd(const float* drgb, const float* x, const float* wm, float* dx, float* dwm, float* dbias, int B, int C,
+                     int64_t HW, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,140 @@
+"""GPU parity of the backward path: HIP backward kernels, chained by cips_3dplusplus_amd.autograd,
+vs torch autograd through the CPU oracle on the same seeded inputs, and vs gradients of the imported reference
+(tests/golden/backward.npz).  Gradient tolerance: 2e-4 of the gradient's own max-abs (+1e-6), fp32 accumulation order
+differs (fp32 atomics in the reductions)."""
+import pytest
+import torch
+
+import cips_3dplusplus_amd as pkg
+from cips_3dplusplus_amd import autograd as AG
+from cips_3dplusplus_amd import configs, hip
+from oracle import path as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cu(t):
+    return t.to(DEV).contiguous()
+
+
+def close(a, b, rel=2e-4, what=""):
+    a = a.detach().cpu().reshape(b.shape)
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= rel * scale + 1e-6, f"{what}: err {err:.3e} vs scale {scale:.3e}"
+
+
+def leaf(t):
+    return t.clone().requires_grad_(True)
+
+
+def test_linear_bwd():
+    g = torch.Generator().manual_seed(1)
+    for (B, i, o, lrelu) in ((2, 64, 48, False), (3, 512, 256, True), (1, 32, 512, False)):
+        x, W, b, dy = torch.randn(B, i, generator=g), torch.randn(o, i, generator=g), torch.randn(o, generator=g), \
+            torch.randn(B, o, generator=g)
+        ws, bs, gain, osc, osh = 0.37, 0.01, 2 ** 0.5, 15.0, 30.0
+        if lrelu:
+            osc, osh = 1.0, 0.0
+        xr, Wr, br = leaf(x), leaf(W), leaf(b)
+        pre = xr @ (Wr * ws).t() + br * bs
+        y = (torch.nn.functional.leaky_relu(pre, 0.2) * gain if lrelu else pre) * osc + osh
+        y.backward(dy)
+        xg, Wg, bg = leaf(cu(x)), leaf(cu(W)), leaf(cu(b))
+        yg = AG.linear(xg, Wg, bg, w_scale=ws, b_scale=bs, lrelu=lrelu, act_gain=gain, out_scale=osc, out_shift=osh)
+        close(yg, y.detach(), 1e-5, "y")
+        yg.backward(cu(dy))
+        close(xg.grad, xr.grad, what="dx"); close(Wg.grad, Wr.grad, what="dW"); close(bg.grad, br.grad, what="db")
+
+
+@pytest.mark.parametrize("cin,cout,hw,up,B,per_sample_noise", [
+    (32, 32, 16, False, 2, False), (64, 32, 16, True, 1, False), (128, 64, 8, True, 2, True), (96, 160, 6, False, 2, False),
+    (256, 512, 12, False, 1, False)])
+def test_styled_conv_bwd_vs_oracle(cin, cout, hw, up, B, per_sample_noise):
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(cin + cout + hw)
+    sc = dec.StyledConv(cin, cout, 1, 64, upsample=up)
+    sc.noise.weight.data.fill_(0.3)
+    sc.activate.bias.data = torch.randn(cout) * 0.2
+    sd = {"m." + k: leaf(v) if v.is_floating_point() and "kernel" not in k else v.clone() for k, v in sc.state_dict().items()}
+    x, st = torch.randn(B, cin, hw, hw), torch.randn(B, 64)
+    ho = 2 * hw if up else hw
+    nz = torch.randn(B if per_sample_noise else 1, 1, ho, ho)
+    dy = torch.randn(B, cout, ho, ho)
+    xr, sr, nr = leaf(x), leaf(st), leaf(nz)
+    ref = O.styled_conv(sd, "m", xr, sr, nr, upsample=up)
+    ref.backward(dy)
+    sc = sc.to(DEV)
+    xg, sg, ng = leaf(cu(x)), leaf(cu(st)), leaf(cu(nz))
+    y = AG.styled_conv(sc, xg, sg, ng)
+    close(y, ref.detach(), 3e-5, "y")
+    y.backward(cu(dy))
+    close(xg.grad, xr.grad, what="dx"); close(sg.grad, sr.grad, what="dstyle"); close(ng.grad, nr.grad, what="dnoise")
+    for name, p in sc.named_parameters():
+        if name == "bias":            # present in checkpoints, unused in forward (model_v3.py:440)
+            assert p.grad is None
+            continue
+        close(p.grad, sd["m." + name].grad, what=name)
+
+
+@pytest.mark.parametrize("up", [False, True])
+def test_to_rgb_bwd_vs_oracle(up):
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(3 + up)
+    C, hw, B = 64, 16, 2
+    tr = dec.ToRGB(C, 32, upsample=up)
+    tr.bias.data = torch.randn(1, 3, 1, 1)
+    sd = {"m." + k: leaf(v) if "kernel" not in k else v.clone() for k, v in tr.state_dict().items()}
+    x, st = torch.randn(B, C, hw, hw), torch.randn(B, 32)
+    skip = torch.randn(B, 3, hw // 2 if up else hw, hw // 2 if up else hw)
+    dy = torch.randn(B, 3, hw, hw)
+    xr, sr, kr = leaf(x), leaf(st), leaf(skip)
+    ref = O.to_rgb(sd, "m", xr, sr, kr, upsample=up)
+    ref.backward(dy)
+    tr = tr.to(DEV)
+    xg, sg, kg = leaf(cu(x)), leaf(cu(st)), leaf(cu(skip))
+    y = AG.to_rgb(tr, xg, sg, kg)
+    close(y, ref.detach(), 3e-5, "rgb")
+    y.backward(cu(dy))
+    close(xg.grad, xr.grad, what="dx"); close(sg.grad, sr.grad, what="dstyle"); close(kg.grad, kr.grad, what="dskip")
+    for name, p in tr.named_parameters():
+        close(p.grad, sd["m." + name].grad, what=name)
+
+
+def test_decoder_bwd_vs_oracle():
+    cfg = configs.tiny_G_cfg(32, 2, 1)
+    G = pkg.build_generator(cfg, DEV, seed=5)
+    for sc in [G.decoder.conv1] + list(G.decoder.convs):
+        sc.noise.weight.data.fill_(0.2)
+    sd = {k: (leaf(v.cpu()) if v.is_floating_point() and "kernel" not in k else v.cpu().clone())
+          for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    B, S = 2, 8
+    feat = torch.randn(B, 32, S, S, generator=g)
+    styles = torch.randn(B, G.decoder.n_latent, 32, generator=g)
+    noise = [torch.randn(*b.shape, generator=g) for b in G.decoder.create_noise_bufs(S, "cpu")]
+    fr, sr = leaf(feat), leaf(styles)
+    nr = [leaf(n) for n in noise]
+    ref = O.decoder_forward(sd, cfg, fr, sr, nr)
+    tgt = torch.randn(ref.shape, generator=g)
+    ((ref - tgt) ** 2).mean().backward()
+    fg, sg = leaf(cu(feat)), leaf(cu(styles))
+    ng = [leaf(cu(n)) for n in noise]
+    for p in G.decoder.parameters():
+        p.requires_grad_(True)
+    out = AG.decoder_forward(G.decoder, fg, sg, ng)
+    close(out, ref.detach(), 1e-4, "rgb")
+    ((out - cu(tgt)) ** 2).mean().backward()
+    close(fg.grad, fr.grad, what="dfeatures"); close(sg.grad, sr.grad, what="dstyles")
+    for i in range(len(ng)):
+        close(ng[i].grad, nr[i].grad, what=f"dnoise{i}")
+    checked = 0
+    for name, p in G.decoder.named_parameters():
+        r = sd["decoder." + name].grad
+        if r is None:
+            assert p.grad is None, name
+            continue
+        close(p.grad, r, what=name)
+        checked += 1
+    assert checked > 30
