@@ -43,6 +43,12 @@ class NerfParams(C.Structure):
                 ("part", C.c_void_p), ("sdf", C.c_void_p)]
 
 
+class NerfBwdGeom(C.Structure):
+    _fields_ = [("cam_poses", C.c_void_p), ("focals", C.c_void_p), ("near_", C.c_void_p), ("far_", C.c_void_p),
+                ("perturb_u", C.c_void_p), ("B", C.c_int32), ("img_size", C.c_int32), ("n_samples", C.c_int32),
+                ("static_viewdirs", C.c_int32)]
+
+
 _SIGS = {
     "cips3d_abi_version": (c_int, []),
     "cips3d_strerror": (C.c_char_p, [c_int]),
@@ -86,6 +92,18 @@ _SIGS = {
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
                                           c_int, c_i64, C.c_void_p]),
     "cips3d_torgb_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_nerf_bwd_points": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                                       C.c_void_p]),
+    "cips3d_nerf_bwd_film": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_f32p, c_int, c_int, c_int,
+                                     c_i64, C.c_void_p]),
+    "cips3d_nerf_bwd_heads": (c_int, [c_f32p, c_f32p, c_int, c_int, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_dot": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_composite": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_film_grad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_nerf_bwd_camera": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_camera_params_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, C.c_void_p]),
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),

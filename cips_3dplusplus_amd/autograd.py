@@ -169,3 +169,64 @@ def decoder_forward(dec, features, styles, noise=None):
         skip = to_rgb(dec.to_rgbs[st], out, styles[:, i + 2], skip)
         i += 2
     return skip
+
+
+# ------------------------------------------------------------------------------------------ camera + NeRF
+class CameraFn(Function):
+    """Camera.generate_camera_params for given `locations` (azim, elev), differentiable w.r.t. them."""
+
+    @staticmethod
+    def forward(ctx, locations, img_size, fov_ang, dist_radius, up):
+        extr, focal, near, far = hip.camera_params(locations, img_size, fov_ang, dist_radius, up=up)
+        ctx.save_for_backward(locations.detach(), up)
+        ctx.mark_non_differentiable(focal, near, far)
+        return extr, focal, near, far
+
+    @staticmethod
+    def backward(ctx, dextr, dfocal, dnear, dfar):
+        locations, up = ctx.saved_tensors
+        return hip.camera_params_bwd(locations, dextr, up).to(locations.dtype), None, None, None, None
+
+
+def film_table(renderer, styles):
+    """gamma / beta of every FiLM layer from the W+ styles (B, D+1, style_dim) -> [B, D+1, 2, H]
+    (cips3d/volume_renderer.py:66-67 through LinearLayer :15-35)."""
+    net = renderer.network
+    rows = []
+    for l, layer in enumerate(list(net.pts_linears) + [net.views_linears]):
+        st = styles[:, l]
+        gb = [linear(st, head.weight, head.bias, out_scale=float(head.std_init), out_shift=float(head.bias_init))
+              for head in (layer.gamma, layer.beta)]
+        rows.append(torch.stack(gb, 1))
+    return torch.stack(rows, 1)
+
+
+class NerfRenderFn(Function):
+    """VolumeFeatureRenderer.render with gradients w.r.t. the camera pose and the FiLM table.  Forward = the fused kernel;
+    backward = the materialised recompute of csrc/nerf_bwd.hip.  The renderer's own weights are treated as constants
+    (`optim_render_params: false` in the released inversion recipes, train_cips3d_compcars_v10.yaml:585)."""
+
+    @staticmethod
+    def forward(ctx, renderer, cam_poses, focals, near, far, film, perturb_u, img_size, n_samples, static_viewdirs):
+        thumb, features, _, mask, xyz = renderer.render(cam_poses.detach(), focals, near, far, None, img_size, n_samples,
+                                                        perturb_u=perturb_u, static_viewdirs=static_viewdirs, film=film)
+        ctx.renderer = renderer
+        ctx.cfg = (img_size, n_samples, static_viewdirs)
+        ctx.save_for_backward(cam_poses.detach(), focals, near, far, film.detach(), perturb_u)
+        ctx.mark_non_differentiable(mask, xyz)
+        return features, thumb, xyz, mask
+
+    @staticmethod
+    def backward(ctx, dfeat, dthumb, dxyz, dmask):
+        cam_poses, focals, near, far, film, perturb_u = ctx.saved_tensors
+        img_size, n_samples, static = ctx.cfg
+        r = ctx.renderer
+        _, layer_bias = r._derived_buffers()
+        B, H = cam_poses.shape[0], r.hidden_dim
+        if dfeat is None:
+            dfeat = torch.zeros(B, H, img_size, img_size, device=cam_poses.device)
+        if dthumb is None:
+            dthumb = torch.zeros(B, 3, img_size, img_size, device=cam_poses.device)
+        dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
+                                        layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())
+        return None, dcam, None, None, None, dfilm, None, None, None, None

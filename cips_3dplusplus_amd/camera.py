@@ -47,7 +47,12 @@ class Camera(object):
         fov = fov_ang
         if torch.is_tensor(fov_ang) and fov_ang.numel() not in (1, n):
             raise RuntimeError("fov_ang tensor must have 1 or B elements")
-        extr, focal, near, far = hip.camera_params(viewpoint.to(device), img_size, fov, dist_radius, up=up)
+        if torch.is_grad_enabled() and viewpoint.requires_grad:
+            # inversion: the pose is optimised through `locations` (projector_v10.py:227-232)
+            from .autograd import CameraFn
+            extr, focal, near, far = CameraFn.apply(viewpoint.to(device), img_size, fov, dist_radius, up)
+        else:
+            extr, focal, near, far = hip.camera_params(viewpoint.to(device), img_size, fov, dist_radius, up=up)
         return extr, focal, near, far, viewpoint
 
     @staticmethod

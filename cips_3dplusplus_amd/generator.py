@@ -181,12 +181,77 @@ class Generator(nn.Module):
                 "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
 
     # ---------------------------------------------------------------- forward
-    @torch.no_grad()
     def forward(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
                 path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
                 eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
                 N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
                 renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, **kwargs):
+        """model_v3.py:875-1042.  Inference runs the fused path without an autograd graph.  When gradients are enabled
+        and an INPUT tensor (cam_poses, style_render, style_decoder, a noise buffer) requires them -- the inversion loop,
+        projector_v10.py:211-277 -- the differentiable op chain of `autograd.py` is used instead; parameters with
+        requires_grad then receive gradients as well (decoder only: the renderer's weights are constants there)."""
+        kw = dict(zs=zs, cam_poses=cam_poses, focals=focals, img_size=img_size, near=near, far=far, truncation=truncation,
+                  inject_index=inject_index, path_reg=path_reg, style_render=style_render, style_decoder=style_decoder,
+                  noise_bufs=noise_bufs, randomize_noise=randomize_noise, eikonal_reg=eikonal_reg, return_sdf=return_sdf,
+                  return_xyz=return_xyz, N_rays_forward=N_rays_forward, N_rays_grad=N_rays_grad,
+                  N_samples_forward=N_samples_forward, nerf_cfg=nerf_cfg, recompute_mean=recompute_mean,
+                  project_noise=project_noise, mesh_path=mesh_path, renderer_detach=renderer_detach,
+                  sample_idx_h=sample_idx_h, sample_idx_w=sample_idx_w, perturb_u=perturb_u)
+        if torch.is_grad_enabled():
+            ins = [cam_poses, style_render, style_decoder] + list(noise_bufs or [])
+            if any(torch.is_tensor(t) and t.requires_grad for t in ins):
+                return self._forward_grad(**kw)
+        with torch.no_grad():
+            return self._forward_infer(**kw, **kwargs)
+
+    def _forward_grad(self, zs, cam_poses, focals, img_size, near, far, truncation, inject_index, path_reg, style_render,
+                      style_decoder, noise_bufs, randomize_noise, eikonal_reg, return_sdf, return_xyz, N_rays_forward,
+                      N_rays_grad, N_samples_forward, nerf_cfg, recompute_mean, project_noise, mesh_path, renderer_detach,
+                      sample_idx_h, sample_idx_w, perturb_u):
+        from . import autograd as AG
+        assert len(zs) == 2
+        if eikonal_reg or path_reg:
+            raise NotImplementedError("eikonal_reg / path_reg need double backward (training-only)")
+        if N_rays_grad is not None or sample_idx_h is not None or sample_idx_w is not None or project_noise:
+            raise NotImplementedError("ray sub-sampling / project_noise are training-only")
+        noise_bufs = self.get_noise_bufs(noise_bufs, randomize_noise)
+        B, dev = cam_poses.shape[0], cam_poses.device
+        N = int(nerf_cfg["N_samples"])
+        if nerf_cfg.get("perturb", False) and perturb_u is None:
+            perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)
+        if not nerf_cfg.get("perturb", False):
+            perturb_u = None
+        if style_render is None or style_decoder is None:
+            with torch.no_grad():       # z -> W+ is a constant of the inversion (styles are its leaves)
+                style_render, style_decoder = self.mapping_networks(
+                    zs=zs, truncation=truncation, inject_index=inject_index, style_render=style_render,
+                    style_decoder=style_decoder, recompute_mean=recompute_mean)
+
+        def per_view(v):
+            return (v if torch.is_tensor(v) else torch.full((B, 1, 1), float(v), device=dev)).detach()
+
+        static = bool(nerf_cfg.get("static_viewdirs", False))
+        film = AG.film_table(self.renderer, style_render)
+        features, thumb, xyz, mask = AG.NerfRenderFn.apply(
+            self.renderer, cam_poses.float(), per_view(focals), per_view(near), per_view(far), film,
+            None if perturb_u is None else perturb_u.detach(), img_size, N, static)
+        if self.renderer_detach if renderer_detach is None else renderer_detach:
+            features = features.detach()                                    # model_v3.py:1016-1017
+        rgb = AG.decoder_forward(self.decoder, features, style_decoder, noise_bufs)
+        sdf = None
+        if return_sdf:
+            with torch.no_grad():
+                sdf = self.renderer.render(cam_poses.detach(), per_view(focals), per_view(near), per_view(far), None, img_size,
+                                           N, perturb_u=perturb_u, static_viewdirs=static, return_sdf=True,
+                                           film=film.detach())[2]
+        return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None, "sdf": sdf,
+                "xyz": xyz if return_xyz else None, "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
+
+    def _forward_infer(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
+                       path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
+                       eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
+                       N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
+                       renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, **kwargs):
         assert len(zs) == 2
         if eikonal_reg or path_reg:
             raise NotImplementedError("eikonal_reg / path_reg are training-only (double backward); inference path here")

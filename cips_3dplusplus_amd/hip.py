@@ -335,3 +335,109 @@ def torgb_bwd(drgb, x, wm, need_db=True):
     check(lib.cips3d_torgb_bwd(dev_ptr(drgb, "drgb"), dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(dx), dev_ptr(dwm),
                                dev_ptr(db, "db", True), B, Cc, HW, stream_ptr()), "cips3d_torgb_bwd")
     return dx, dwm, db
+
+
+def camera_params_bwd(locations, dextr, up=None):
+    lib = _lib.load()
+    B = locations.shape[0]
+    loc = locations.detach().float().contiguous()
+    up_t = up.detach().float().contiguous() if up is not None else None
+    dloc = torch.empty(B, 2, device=loc.device)
+    check(lib.cips3d_camera_params_bwd(dev_ptr(loc, "locations"), dev_ptr(up_t, "up", True), dev_ptr(dextr.contiguous(), "dextr"),
+                                       B, dev_ptr(dloc), stream_ptr()), "cips3d_camera_params_bwd")
+    return dloc
+
+
+def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, film, layer_bias, img_size, n_samples,
+                  static_viewdirs, d_features, d_thumb):
+    """The materialised NeRF backward (see csrc/nerf_bwd.hip): returns (dfilm [B,L,2,H], dcam [B,3,4]).
+
+    net = SirenGenerator (weights), film [B,L,2,H], layer_bias [L,H]; d_features [B,H,S,S], d_thumb [B,3,S,S]."""
+    lib = _lib.load()
+    st = stream_ptr()
+    dev = cam_poses.device
+    B = cam_poses.shape[0]
+    H = net.W
+    D = net.D
+    L = D + 1
+    R = img_size * img_size
+    P = R * n_samples
+    fb = L * 2 * H
+    geom = _lib.NerfBwdGeom()
+    keep = [cam_poses.float().contiguous(), focals.float().reshape(B).contiguous(), near.float().reshape(B).contiguous(),
+            far.float().reshape(B).contiguous(),
+            None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous()]
+    geom.cam_poses, geom.focals, geom.near_, geom.far_ = (dev_ptr(t) for t in keep[:4])
+    geom.perturb_u = dev_ptr(keep[4], "perturb_u", True)
+    geom.B, geom.img_size, geom.n_samples, geom.static_viewdirs = B, img_size, n_samples, int(bool(static_viewdirs))
+    gp = C.byref(geom)
+    new = lambda *shape: torch.empty(*shape, device=dev)
+    film = film.contiguous()
+    film_l = lambda l: film.data_ptr() + 4 * (l * 2 * H)
+
+    # ---- forward recompute
+    ptsn, viewdirs = new(B, 3, P), new(B, 3, R)
+    pre = [new(B, H, P)] + [None] * (L - 1)
+    hh = [new(B, H, P) for _ in range(L)]
+    w_first = net.pts_linears[0].weight
+    check(lib.cips3d_nerf_bwd_points(gp, dev_ptr(w_first), layer_bias.data_ptr(), film_l(0), fb, H, dev_ptr(ptsn),
+                                     dev_ptr(pre[0]), dev_ptr(hh[0]), dev_ptr(viewdirs), st), "cips3d_nerf_bwd_points")
+    w_view = net.views_linears.weight                      # [H, H+3]
+    mats = [net.pts_linears[l].weight.detach() for l in range(1, D)] + [w_view.detach()[:, :H].contiguous()]
+    packed, packed_t = [], []
+    for Wl in mats:                                        # shared over the batch: replicate the (small) matrix
+        Wb = Wl.unsqueeze(0).expand(B, H, H).contiguous()
+        packed.append(pack_weights(Wb))
+        packed_t.append(pack_weights(Wb, transpose=True))
+
+    def gemm(x, pk):
+        return modconv1x1(x.view(B, H, P, 1), pk, H, epilogue=0).view(B, H, P)
+
+    for l in range(1, L):
+        acc = gemm(hh[l - 1], packed[l - 1])
+        is_view = l == D
+        check(lib.cips3d_nerf_bwd_film(dev_ptr(acc), dev_ptr(hh[l]), layer_bias.data_ptr() + 4 * l * H, film_l(l), fb,
+                                       (w_view.data_ptr() + 4 * H) if is_view else None, H + 3,
+                                       dev_ptr(viewdirs) if is_view else None, B, H, R, P, st), "cips3d_nerf_bwd_film")
+        pre[l] = acc
+    h_last, f = hh[D - 1], hh[D]
+    sdf, crgb, g = new(B, 1, P), new(B, 3, P), new(B, P)
+    check(lib.cips3d_nerf_bwd_heads(dev_ptr(h_last), dev_ptr(net.sigma_linear.weight), H, 1, dev_ptr(net.sigma_linear.bias), 1,
+                                    B, H, P, dev_ptr(sdf), st), "cips3d_nerf_bwd_heads")
+    check(lib.cips3d_nerf_bwd_heads(dev_ptr(f), dev_ptr(net.rgb_linear.weight), H, 1, dev_ptr(net.rgb_linear.bias), 3, B, H, P,
+                                    dev_ptr(crgb), st), "cips3d_nerf_bwd_heads")
+    dF = d_features.contiguous().view(B, H, R)
+    dth = d_thumb.contiguous().view(B, 3, R)
+    check(lib.cips3d_nerf_bwd_dot(dev_ptr(dF), dev_ptr(f), B, H, R, P, dev_ptr(g), st), "cips3d_nerf_bwd_dot")
+
+    # ---- compositing backward
+    wts, Tb, dsdf, dcrgb, ddnorm = new(B, P), new(B, P), new(B, P), new(B, 3, P), new(B, R)
+    check(lib.cips3d_nerf_bwd_composite(gp, dev_ptr(sdf), dev_ptr(crgb), dev_ptr(g), dev_ptr(dth), dev_ptr(sigmoid_beta),
+                                        dev_ptr(wts), dev_ptr(Tb), dev_ptr(dsdf), dev_ptr(dcrgb), dev_ptr(ddnorm), st),
+          "cips3d_nerf_bwd_composite")
+
+    # ---- MLP backward
+    dfilm = torch.zeros(B, L, 2, H, device=dev)
+    dfilm_l = lambda l: dfilm.data_ptr() + 4 * (l * 2 * H)
+    check(lib.cips3d_nerf_bwd_film_grad(dev_ptr(f), dev_ptr(pre[D]), film_l(D), fb, 1, None, None, dev_ptr(wts), dev_ptr(dF),
+                                        dev_ptr(net.rgb_linear.weight), dev_ptr(dcrgb), dfilm_l(D), B, H, R, P, st),
+          "cips3d_nerf_bwd_film_grad")
+    dpre = f
+    dvd_pt = new(B, 3, P)
+    check(lib.cips3d_nerf_bwd_heads(dev_ptr(dpre), w_view.data_ptr() + 4 * H, 1, H + 3, None, 3, B, H, P, dev_ptr(dvd_pt), st),
+          "cips3d_nerf_bwd_heads")
+    for l in range(D, 0, -1):
+        dh = gemm(dpre, packed_t[l - 1])                  # gradient w.r.t. h_{l-1}
+        first = l == D                                     # h_{D-1} also feeds the sigma head
+        check(lib.cips3d_nerf_bwd_film_grad(dev_ptr(dh), dev_ptr(pre[l - 1]), film_l(l - 1), fb, 0,
+                                            dev_ptr(net.sigma_linear.weight) if first else None,
+                                            dev_ptr(dsdf) if first else None, None, None, None, None, dfilm_l(l - 1), B, H, R,
+                                            P, st), "cips3d_nerf_bwd_film_grad")
+        dpre = dh
+    dptsn = new(B, 3, P)
+    check(lib.cips3d_nerf_bwd_heads(dev_ptr(dpre), dev_ptr(w_first), 1, 3, None, 3, B, H, P, dev_ptr(dptsn), st),
+          "cips3d_nerf_bwd_heads")
+    dcam = new(B, 3, 4)
+    check(lib.cips3d_nerf_bwd_camera(gp, dev_ptr(dptsn), dev_ptr(dvd_pt), dev_ptr(ddnorm), dev_ptr(dcam), st),
+          "cips3d_nerf_bwd_camera")
+    return dfilm, dcam

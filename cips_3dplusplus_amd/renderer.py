@@ -127,7 +127,7 @@ class VolumeFeatureRenderer(nn.Module):
 
     @torch.no_grad()
     def render(self, cam_poses, focals, near, far, styles, img_size, N_samples, perturb_u=None,
-               static_viewdirs=False, return_sdf=False, n_chunks=None):
+               static_viewdirs=False, return_sdf=False, n_chunks=None, film=None):
         """cam_poses (B,3,4), focals/near/far (B,1,1), styles (B,D+1,style_dim)
         -> thumb_rgb (B,3,S,S), features (B,H,S,S), sdf (B,S,S,N,1)|None, mask (B,2,S,S), xyz (B,3,S,S)"""
         B = cam_poses.shape[0]
@@ -135,9 +135,12 @@ class VolumeFeatureRenderer(nn.Module):
         D, H = self.N_layers_renderer, self.hidden_dim
         net = self.network
         packed, layer_bias = self._derived_buffers()
-        styles_buf, film, tab = self._film_table(B, dev)
-        styles_buf.copy_(styles)
-        tab.run(B)
+        if film is None:
+            styles_buf, film, tab = self._film_table(B, dev)
+            styles_buf.copy_(styles)
+            tab.run(B)
+        else:                       # FiLM table computed by the caller (differentiable path: autograd.film_table)
+            film = film.detach().float().contiguous()
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)
         R = img_size * img_size

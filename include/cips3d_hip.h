@@ -354,6 +354,54 @@ int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const float* nois
 int cips3d_torgb_bwd(const float* drgb, const float* x, const float* wm, float* dx, float* dwm, float* dbias, int B, int C,
                      int64_t HW, void* stream);
 
+/* ---- NeRF half, materialised backward (csrc/nerf_bwd.hip).  Replaces autograd through Render.prepare_nerf_inputs,
+ * SirenGenerator.forward and Render.volume_integration (cips3d/nerf_utils.py:18-338, cips3d/volume_renderer.py:39-160).
+ * Activations are recomputed layer by layer in the decoder's layout act[b][c][p], p = sample * R + ray (R = img_size^2,
+ * P = R * n_samples), so the hidden-layer GEMMs and their data gradients are cips3d_modconv1x1 (weights packed with
+ * cips3d_pack_weights, transposed for the gradient).  Sequence: cips_3dplusplus_amd/autograd.py:NerfRenderFn.backward. */
+typedef struct cips3d_nerf_bwd_geom {
+  const float* cam_poses;  /* [B,3,4] */
+  const float* focals;     /* [B] */
+  const float* near_;      /* [B] */
+  const float* far_;       /* [B] */
+  const float* perturb_u;  /* [B,R] or NULL */
+  int32_t B, img_size, n_samples, static_viewdirs;
+} cips3d_nerf_bwd_geom;
+
+/* rays -> ptsn [B,3,P] (normalised points), pre0 / h0 [B,H,P] (layer-0 pre-activation incl. bias, and its FiLM sine),
+ * viewdirs [B,3,R].  film points at layer 0 of the [B,L,2,H] table, film_bstride = L*2*H floats. */
+int cips3d_nerf_bwd_points(const cips3d_nerf_bwd_geom* geom, const float* w_first, const float* bias0, const float* film,
+                           int film_bstride, int H, float* ptsn, float* pre0, float* h0, float* viewdirs, void* stream);
+/* acc [B,H,P] (GEMM output) -> pre = acc + bias_c (+ wd[c*wd_stride + 0..2] . viewdir[ray]) in place; h = sin(gamma pre + beta) */
+int cips3d_nerf_bwd_film(float* acc, float* h, const float* bias, const float* film, int film_bstride, const float* wd,
+                         int wd_stride, const float* viewdirs, int B, int H, int R, int64_t P, void* stream);
+/* out[b][r][p] = sum_c Wm[r*row_stride + c*col_stride] * x[b][c][p] + bias[r], n_rows <= 4 (bias may be NULL) */
+int cips3d_nerf_bwd_heads(const float* x, const float* Wm, int row_stride, int col_stride, const float* bias, int n_rows,
+                          int B, int H, int64_t P, float* out, void* stream);
+/* g[b][p] = sum_c dF[b][c][ray(p)] * f[b][c][p] */
+int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H, int R, int64_t P, float* g, void* stream);
+/* volume integration forward + backward per ray: sdf [B,P], crgb [B,3,P] (rgb logits), g [B,P], dthumb [B,3,R]
+ * -> w [B,P] (compositing weights), dsdf [B,P], dcrgb [B,3,P], ddnorm [B,R] (d loss / d |rays_d|, which scales the
+ * sample spacing); T_scratch [B,P]. */
+int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* geom, const float* sdf, const float* crgb, const float* g,
+                              const float* dthumb, const float* sigmoid_beta, float* w, float* T_scratch, float* dsdf,
+                              float* dcrgb, float* ddnorm, void* stream);
+/* FiLM-sine backward, in place on buf [B,H,P]:
+ *   mode 0: buf = dh (+ w_sigma[c]*dsdf[p] when w_sigma != NULL)            -> buf = d(pre)
+ *   mode 1: upstream = weights[p]*dF[c][ray] + sum_r w_rgb[r][c]*dcrgb[r][p] -> buf = d(pre)   (buf's old content unused)
+ * dfilm (same layout / stride as film, pointing at this layer) += sums for d(gamma), d(beta); zero it before the first call. */
+int cips3d_nerf_bwd_film_grad(float* buf, const float* pre, const float* film, int film_bstride, int mode,
+                              const float* w_sigma, const float* dsdf, const float* weights, const float* dF,
+                              const float* w_rgb, const float* dcrgb, float* dfilm, int B, int H, int R, int64_t P,
+                              void* stream);
+/* dptsn [B,3,P], dvd_pt [B,3,P] (d loss / d viewdir per point), ddnorm [B,R] -> dcam [B,3,4] */
+int cips3d_nerf_bwd_camera(const cips3d_nerf_bwd_geom* geom, const float* dptsn, const float* dvd_pt, const float* ddnorm,
+                           float* dcam, void* stream);
+/* Backward of cips3d_camera_params w.r.t. locations (azim, elev): dextrinsics [B,3,4] -> dlocations [B,2]
+ * (cips3d/nerf_utils.py:344-436,466-564; focal / near / far do not depend on the angles). */
+int cips3d_camera_params_bwd(const float* locations, const float* up, const float* dextrinsics, int B, float* dlocations,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

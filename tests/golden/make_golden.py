@@ -308,6 +308,46 @@ def g_full():
     save("full_size", **out)
 
 
+# ---------------------------------------------------------------- 9b. one inversion-like step: loss + gradients
+def g_backward():
+    """Forward + backward of the reference generator as the flip-inversion loop drives it
+    (models/projector_v10.py:211-277: camera from `locations`, W+ styles passed in, renderer_detach=False, batch = image +
+    flip) with a surrogate loss (VGG weights are not obtainable): mean((rgb-t)^2) + 50 mean((thumb-t_thumb)^2)."""
+    out = {"_src": "models/projector_v10.py:211-277 + models/model_v3.py:875-1042 under autograd (tiny G_cfg)"}
+    for tag, hidden, D, static in (("h32_d2", 32, 2, True), ("h32_d3", 32, 3, False)):
+        cfg = configs.tiny_G_cfg(hidden=hidden, N_layers_renderer=D, kernel_size=1)
+        G = ref.Generator(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+        G.load_state_dict(weights.synth_state_dict(shapes, seed=7), strict=True)
+        G.requires_grad_(False)
+        G.decoder.requires_grad_(True)
+        g = torch.Generator().manual_seed(31)
+        locs = torch.tensor([[0.3, 0.1], [-0.3, 0.1]]).requires_grad_(True)
+        w_r = (0.5 * torch.randn(2, D + 1, hidden, generator=g)).requires_grad_(True)
+        w_d = (0.5 * torch.randn(2, G.decoder.n_latent, 32, generator=g)).requires_grad_(True)
+        nb = [torch.randn(*b.shape, generator=g).requires_grad_(True) for b in G.create_noise_bufs(8, "cpu")]
+        t_rgb = torch.randn(2, 3, 32, 32, generator=g)
+        t_thumb = torch.randn(2, 3, 8, 8, generator=g)
+        ncfg = dict(N_samples=6, perturb=False, static_viewdirs=static)
+        with torch.enable_grad():
+            cam = ref_nerf.Camera.generate_camera_params(img_size=8, device="cpu", locations=locs, fov_ang=6, dist_radius=0.12)
+            r = G(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=cam[0], focals=cam[1], img_size=8,
+                  near=cam[2], far=cam[3], noise_bufs=nb, nerf_cfg=ncfg, renderer_detach=False)
+            loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
+            loss.backward()
+        out.update({f"{tag}.locs": locs.detach(), f"{tag}.w_r": w_r.detach(), f"{tag}.w_d": w_d.detach(),
+                    f"{tag}.t_rgb": t_rgb, f"{tag}.t_thumb": t_thumb, f"{tag}.loss": loss.detach(),
+                    f"{tag}.rgb": r["rgb"].detach(), f"{tag}.thumb": r["thumb_rgb"].detach(),
+                    f"{tag}.g.locs": locs.grad, f"{tag}.g.w_r": w_r.grad, f"{tag}.g.w_d": w_d.grad})
+        out.update({f"{tag}.noise{i}": b.detach() for i, b in enumerate(nb)})
+        out.update({f"{tag}.g.noise{i}": b.grad for i, b in enumerate(nb)})
+        for name, p in G.decoder.named_parameters():
+            if p.grad is not None:
+                out[f"{tag}.g.dec.{name}"] = p.grad
+        print(tag, "loss", float(loss), "|dlocs|", locs.grad.abs().max().item(), "|dw_r|", w_r.grad.abs().max().item())
+    save("backward", **out)
+
+
 # ---------------------------------------------------------------- 10. on-disk formats (SURVEY 8f row 3)
 def g_ckpt_tiny():
     """A checkpoint directory and an inversion file as the reference's writers lay them out, holding the
@@ -348,7 +388,7 @@ if __name__ == "__main__":
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
     jobs = dict(camera=g_camera, rays=g_rays, siren=g_siren, ops=g_ops, modconv=g_modconv,
-                tiny_generator=g_tiny_generator, ckpt_tiny=g_ckpt_tiny)
+                tiny_generator=g_tiny_generator, ckpt_tiny=g_ckpt_tiny, backward=g_backward)
     if a.full:
         jobs["full_size"] = g_full
     for name, fn in jobs.items():

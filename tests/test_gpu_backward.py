@@ -138,3 +138,99 @@ def test_decoder_bwd_vs_oracle():
         close(p.grad, r, what=name)
         checked += 1
     assert checked > 30
+
+
+# ------------------------------------------------------------------------------------------ camera, NeRF, generator
+def test_camera_bwd_vs_oracle():
+    from cips_3dplusplus_amd.camera import Camera
+    locs = torch.tensor([[0.3, 0.1], [-0.7, -0.2], [0.0, 0.0], [2.5, 0.6]])
+    g = torch.Generator().manual_seed(4)
+    dext = torch.randn(4, 3, 4, generator=g)
+    lr = leaf(locs)
+    O.camera_params(lr, 64, 6, 0.12)[0].backward(dext)
+    lg = leaf(cu(locs))
+    e = Camera.generate_camera_params(64, DEV, locations=lg, fov_ang=6, dist_radius=0.12)
+    assert e[0].requires_grad and not e[1].requires_grad
+    e[0].backward(cu(dext))
+    close(lg.grad, lr.grad, 1e-4, "dlocations")
+
+
+def _renderer_sd(G):
+    return {k: v.detach().cpu() for k, v in G.state_dict().items()}
+
+
+@pytest.mark.parametrize("D,static,perturb,N,S", [(2, False, False, 6, 8), (3, True, True, 5, 8), (2, False, True, 8, 16)])
+def test_nerf_render_bwd_vs_oracle(D, static, perturb, N, S):
+    cfg = configs.tiny_G_cfg(32, D, 1)
+    G = pkg.build_generator(cfg, DEV, seed=3)
+    sd = _renderer_sd(G)
+    g = torch.Generator().manual_seed(D + N)
+    B, R, H = 2, S * S, 32
+    locs = torch.tensor([[0.25, 0.1], [-0.4, -0.05]])
+    cam = O.camera_params(locs, S, 6, 0.12)
+    styles = 0.5 * torch.randn(B, D + 1, 32, generator=g)
+    u = torch.rand(B, S, S, 1, generator=g) if perturb else None
+    tF, tT = torch.randn(B, H, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
+    # oracle
+    cr, sr = leaf(cam[0]), leaf(styles)
+    rays_o, rays_d, viewdirs = O.rays_in_world(cam[1], S, cr, static)
+    z = O.z_vals(cam[2], cam[3], B, S, S, N, u)
+    pts = O.ray_points(rays_o, rays_d, z)
+    thumb, feat, sdf, mask, xyz = O.renderer_forward(sd, "renderer", pts.reshape(B, R, N, 3), rays_d.reshape(B, R, 3),
+                                                     viewdirs.reshape(B, R, 3), z.reshape(B, R, N), cam[2], cam[3], sr, D)
+    to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S)
+    loss = (to_img(feat) * tF).sum() + 3.0 * (to_img(thumb) * tT).sum()
+    loss.backward()
+    # HIP
+    cg, sg = leaf(cu(cam[0])), leaf(cu(styles))
+    film = AG.film_table(G.renderer, sg)
+    f_g, t_g, xyz_g, mask_g = AG.NerfRenderFn.apply(G.renderer, cg, cu(cam[1]), cu(cam[2]), cu(cam[3]), film,
+                                                    None if u is None else cu(u), S, N, static)
+    close(f_g, to_img(feat).detach(), 1e-4, "features"); close(t_g, to_img(thumb).detach(), 1e-4, "thumb")
+    ((f_g * cu(tF)).sum() + 3.0 * (t_g * cu(tT)).sum()).backward()
+    close(sg.grad, sr.grad, 3e-4, "dstyles")
+    close(cg.grad, cr.grad, 3e-4, "dcam_poses")
+
+
+@pytest.mark.parametrize("tag,D,static", [("h32_d2", 2, True), ("h32_d3", 3, False)])
+def test_generator_backward_golden(golden, tag, D, static):
+    """One inversion-like step: loss and every gradient vs the imported reference (tests/golden/backward.npz)."""
+    from cips_3dplusplus_amd.camera import Camera
+    fx, tiny = golden("backward"), golden("tiny_generator")
+    cfg = configs.tiny_G_cfg(32, D, 1)
+    G = pkg.build_generator(cfg, DEV, state_dict=tiny.sub(f"{tag}.sd."))
+    G.requires_grad_(False)
+    G.decoder.requires_grad_(True)
+    locs, w_r, w_d = leaf(cu(fx[f"{tag}.locs"])), leaf(cu(fx[f"{tag}.w_r"])), leaf(cu(fx[f"{tag}.w_d"]))
+    nb = [leaf(cu(fx[f"{tag}.noise{i}"])) for i in range(G.decoder.num_layers)]
+    e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=locs, fov_ang=6, dist_radius=0.12)
+    r = G(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=e, focals=f, img_size=8, near=n, far=fa,
+          noise_bufs=nb, nerf_cfg=dict(N_samples=6, perturb=False, static_viewdirs=static), renderer_detach=False)
+    close(r["rgb"], fx[f"{tag}.rgb"], 1e-4, "rgb"); close(r["thumb_rgb"], fx[f"{tag}.thumb"], 1e-4, "thumb")
+    loss = ((r["rgb"] - cu(fx[f"{tag}.t_rgb"])) ** 2).mean() + 50 * ((r["thumb_rgb"] - cu(fx[f"{tag}.t_thumb"])) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx[f"{tag}.loss"])) < 1e-4 * float(fx[f"{tag}.loss"])
+    close(locs.grad, fx[f"{tag}.g.locs"], 5e-4, "dlocs"); close(w_r.grad, fx[f"{tag}.g.w_r"], 5e-4, "dw_render")
+    close(w_d.grad, fx[f"{tag}.g.w_d"], 5e-4, "dw_decoder")
+    for i in range(len(nb)):
+        close(nb[i].grad, fx[f"{tag}.g.noise{i}"], 5e-4, f"dnoise{i}")
+    n_checked = 0
+    for name, p in G.decoder.named_parameters():
+        key = f"{tag}.g.dec.{name}"
+        if key in fx:
+            close(p.grad, fx[key], 5e-4, name)
+            n_checked += 1
+        else:
+            assert p.grad is None, name
+    assert n_checked > 30
+    assert all(p.grad is None for p in G.renderer.parameters())
+
+
+def test_inference_path_unchanged_without_input_grads():
+    """Parameters require grad by default; the fused no-graph path must still be the one that runs for plain inference."""
+    from cips_3dplusplus_amd.camera import Camera
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=1)
+    e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    zs = [torch.randn(1, 32, device=DEV), torch.randn(1, 32, device=DEV)]
+    r = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, nerf_cfg=dict(N_samples=6, perturb=False))
+    assert not r["rgb"].requires_grad

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from cips_3dplusplus_amd import configs
+from cips_3dplusplus_amd import configs, weights
 from conftest import maxdiff
 from oracle import path as O
 
@@ -150,3 +150,41 @@ def test_noise_buf_shapes():
     assert sizes == [64] * 9 + [128] * 2 + [256] * 2 + [512] * 2 + [1024] * 2
     lay = O.decoder_layout(cfg)
     assert lay["n_latent"] == 18 and lay["num_layers"] == 17
+
+
+@pytest.mark.parametrize("tag,D,static", [("h32_d2", 2, True), ("h32_d3", 3, False)])
+def test_oracle_autograd_matches_reference_gradients(golden, tag, D, static):
+    """The oracle under torch autograd reproduces loss and gradients of the imported reference for one inversion-like
+    step (tests/golden/make_golden.py:g_backward) -- this is what the GPU backward tests lean on."""
+    fx = golden("backward")
+    tiny = golden("tiny_generator")
+    cfg = configs.tiny_G_cfg(32, D, 1)
+    shapes = {k[len(f"{tag}.sd."):]: tuple(tiny[k].shape) for k in tiny.keys() if k.startswith(f"{tag}.sd.")}
+    sd = weights.synth_state_dict(shapes, seed=7)
+    sd = {k: (v.clone().requires_grad_(True) if k.startswith("decoder.") and v.is_floating_point() and "kernel" not in k
+              else v) for k, v in sd.items()}
+    locs = fx[f"{tag}.locs"].clone().requires_grad_(True)
+    w_r = fx[f"{tag}.w_r"].clone().requires_grad_(True)
+    w_d = fx[f"{tag}.w_d"].clone().requires_grad_(True)
+    n_noise = len([k for k in fx.keys() if k.startswith(f"{tag}.noise")])
+    nb = [fx[f"{tag}.noise{i}"].clone().requires_grad_(True) for i in range(n_noise)]
+    cam = O.camera_params(locs, 8, 6, 0.12)
+    r = O.generator_forward(sd, cfg, [None, None], cam[0], cam[1], 8, cam[2], cam[3],
+                            dict(N_samples=6, perturb=False, static_viewdirs=static), nb, style_render=w_r, style_decoder=w_d)
+    loss = ((r["rgb"] - fx[f"{tag}.t_rgb"]) ** 2).mean() + 50 * ((r["thumb_rgb"] - fx[f"{tag}.t_thumb"]) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx[f"{tag}.loss"])) < 1e-4 * float(fx[f"{tag}.loss"])
+
+    def close(a, b, what):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max()) + 1e-7, what
+
+    close(locs.grad, fx[f"{tag}.g.locs"], "locs"); close(w_r.grad, fx[f"{tag}.g.w_r"], "w_r")
+    close(w_d.grad, fx[f"{tag}.g.w_d"], "w_d")
+    for i in range(n_noise):
+        close(nb[i].grad, fx[f"{tag}.g.noise{i}"], f"noise{i}")
+    n = 0
+    for k in fx.keys():
+        if k.startswith(f"{tag}.g.dec."):
+            close(sd["decoder." + k[len(f"{tag}.g.dec."):]].grad, fx[k], k)
+            n += 1
+    assert n > 30
