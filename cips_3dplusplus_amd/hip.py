@@ -54,6 +54,11 @@ class LinearTable:
         self._dev = None
         self._keep = []
 
+    def __deepcopy__(self, memo):
+        # descriptors hold raw device pointers of the ORIGINAL module; the owners key their caches on parameter
+        # addresses and rebuild the table for a copied module
+        return LinearTable(self.device)
+
     def add(self, W, bias, x, x_stride, out, out_stride, w_scale=1.0, b_scale=1.0, out_scale=1.0, out_shift=0.0,
             x_offset=0, out_offset=0):
         out_dim, in_dim = W.shape

@@ -199,6 +199,13 @@ class ForwardPlan:
                        y_lo, skip]
         self.noise_total = sum(s * s for s in self.noise_sizes)
 
+    def __deepcopy__(self, memo):
+        """A copied generator owns new parameter storage: the copy of a plan is a tombstone whose key never matches,
+        so `Generator._forward_plan` rebuilds it (raw pointers must not be cloned)."""
+        dead = object.__new__(ForwardPlan)
+        dead.key = None
+        return dead
+
     @staticmethod
     def weights_key(G):
         """Plans hold raw pointers: they die with any re-allocation of a parameter (.to(), load of new storage)

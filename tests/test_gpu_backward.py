@@ -234,3 +234,39 @@ def test_inference_path_unchanged_without_input_grads():
     zs = [torch.randn(1, 32, device=DEV), torch.randn(1, 32, device=DEV)]
     r = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, nerf_cfg=dict(N_samples=6, perturb=False))
     assert not r["rgb"].requires_grad
+
+
+def test_flip_inversion_loop_reduces_loss():
+    """The optimisation loop of projector_v10.py:915-1280 over the HIP forward/backward: a target rendered at a known
+    pose / style is approached (pose phase: camera + NeRF style, decoder frozen; appearance phase: decoder too)."""
+    import copy
+    from cips_3dplusplus_amd.camera import Camera
+    from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss, cur_lr
+    assert cur_lr(0, 200) == 0.0 and abs(cur_lr(100, 200) - 1.0) < 1e-12 and cur_lr(199, 200) < 0.01
+    cfg = configs.tiny_G_cfg(32, 2, 1)
+    G = pkg.build_generator(cfg, DEV, seed=11)
+    G2 = copy.deepcopy(G)                                  # copies must not share plan / table pointers
+    cam_cfg = {"img_size": 8, "fov_ang": 6, "dist_radius": 0.12}
+    ncfg = {"N_samples": 6, "perturb": False, "static_viewdirs": True}
+    with torch.no_grad():
+        mr, md = G.get_mean_latent(512, DEV)
+        torch.manual_seed(0)
+        w_r = mr.reshape(1, 1, -1).repeat(2, 3, 1) + 0.3 * torch.randn(1, 3, 32, device=DEV)
+        w_d = md.reshape(1, 1, -1).repeat(2, G.decoder.n_latent, 1)
+        loc = torch.tensor([[0.35, 0.1], [-0.35, 0.1]], device=DEV)
+        e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=loc, fov_ang=6, dist_radius=0.12)
+        nb0 = [torch.zeros_like(b) for b in G.create_noise_bufs(8, DEV)]
+        tgt = G2(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=e, focals=f, img_size=8, near=n, far=fa,
+                 noise_bufs=nb0, nerf_cfg=ncfg)
+    proj = FlipProjector(G, DEV)
+    out = proj.project_wplus(cam_cfg, ncfg, surrogate_loss(tgt["rgb"], tgt["thumb_rgb"]), N_steps_pose=60, N_steps_app=30,
+                             lr_cam=0.02, lr_render_w=0.01, w_avg_samples=512, azim_init=(0.15, -0.15))
+    h = out["loss_history"]
+    assert float(h[-1]) < 0.35 * float(h[1]), (float(h[1]), float(h[-1]))
+    assert abs(float(out["azim"][0]) - 0.35) < 0.2 and abs(float(out["azim"][1]) + 0.35) < 0.2   # from +-0.15 towards +-0.35
+    assert set(out) >= {"azim", "elev", "w_render_opt", "w_decoder_opt", "render_state_dict", "decoder_state_dict",
+                        "noise_bufs", "padding"}
+    # the pose phase must not have touched the decoder; the appearance phase must have
+    d0, d1 = G.decoder.state_dict(), out["decoder_state_dict"]
+    assert any(not torch.equal(d0[k], d1[k]) for k in d0 if d0[k].is_floating_point())
+    assert all(torch.equal(a, b) for a, b in zip(G.renderer.state_dict().values(), out["render_state_dict"].values()))
