@@ -89,8 +89,8 @@ _SIGS = {
                                     c_f32p, c_i64, C.c_void_p]),
     "cips3d_pack_weights": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_gemm_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
-    "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
-                                          c_int, c_i64, C.c_void_p]),
+    "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_torgb_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_nerf_bwd_points": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                        C.c_void_p]),

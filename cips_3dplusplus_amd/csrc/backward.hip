@@ -54,13 +54,22 @@ __global__ void __launch_bounds__(256) linear_bwd_dw_kernel(LinBwd a) {
   a.dW[e] = acc * a.w_scale;
 }
 
-__global__ void __launch_bounds__(256) linear_bwd_dx_kernel(LinBwd a) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)a.B * a.in_dim) return;
-  const int b = (int)(e / a.in_dim), i = (int)(e % a.in_dim);
+// grid (ceil(in/64), B), 1024 threads = 64 input columns x 16 groups of output rows (W rows read with 256-byte segments)
+__global__ void __launch_bounds__(1024) linear_bwd_dx_kernel(LinBwd a) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 64 + lane;
   float acc = 0.f;
-  for (int o = 0; o < a.out_dim; ++o) acc = fmaf(lin_dpre(a, b, o), a.W[(int64_t)o * a.in_dim + i], acc);
-  a.dx[(int64_t)b * a.dx_stride + i] = acc * a.w_scale;
+  if (i < a.in_dim)
+    for (int o = grp; o < a.out_dim; o += 16) acc = fmaf(lin_dpre(a, b, o), a.W[(int64_t)o * a.in_dim + i], acc);
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && i < a.in_dim) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][lane];
+    a.dx[(int64_t)b * a.dx_stride + i] = t * a.w_scale;
+  }
 }
 
 __global__ void __launch_bounds__(256) linear_bwd_db_kernel(LinBwd a) {
@@ -113,18 +122,27 @@ __global__ void __launch_bounds__(256) modulate_bwd_dw_kernel(const float* __res
 }
 
 // ds[b][i] = scale sum_o sum_t du[b][o][i*ksq+t] W[o][i*ksq+t]
-__global__ void __launch_bounds__(256) modulate_bwd_ds_kernel(const float* __restrict__ du, const float* __restrict__ W,
-                                                              int B, int Cout, int Cin, int ksq, float scale,
-                                                              float* __restrict__ ds, int64_t ds_stride) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= (int64_t)B * Cin) return;
-  const int b = (int)(e / Cin), i = (int)(e % Cin);
+// grid (ceil(Cin/64), B), 1024 threads = 64 input channels x 16 groups of output rows
+__global__ void __launch_bounds__(1024) modulate_bwd_ds_kernel(const float* __restrict__ du, const float* __restrict__ W,
+                                                               int B, int Cout, int Cin, int ksq, float scale,
+                                                               float* __restrict__ ds, int64_t ds_stride) {
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 64 + lane;
   const int len = Cin * ksq;
   float acc = 0.f;
-  for (int o = 0; o < Cout; ++o)
-    for (int t = 0; t < ksq; ++t)
-      acc = fmaf(du[((int64_t)b * Cout + o) * len + i * ksq + t], W[(int64_t)o * len + i * ksq + t], acc);
-  ds[(int64_t)b * ds_stride + i] = acc * scale;
+  if (i < Cin)
+    for (int o = grp; o < Cout; o += 16)
+      for (int t = 0; t < ksq; ++t)
+        acc = fmaf(du[((int64_t)b * Cout + o) * len + i * ksq + t], W[(int64_t)o * len + i * ksq + t], acc);
+  part[grp][lane] = acc;
+  __syncthreads();
+  if (grp == 0 && i < Cin) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += part[g][lane];
+    ds[(int64_t)b * ds_stride + i] = t * scale;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ packing
@@ -196,13 +214,14 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(const float* __restrict
 // y = lrelu(x + nw noise + bias_c) sqrt2  =>  dx = dy sqrt2 (y > 0 ? 1 : 0.2);  dbias_c = sum_{b,p} dx.
 // grid (pixel blocks, C, B): one block reduces its 1024 pixels of one channel.
 __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                      float* __restrict__ dx, float* __restrict__ dbias, int C,
-                                                      int64_t HW) {
+                                                      float* __restrict__ dx, float* __restrict__ dbias,
+                                                      const float* __restrict__ noise, int64_t noise_bstride,
+                                                      float* __restrict__ dnw, int C, int64_t HW) {
   __shared__ float sh[4];
   const int c = blockIdx.y, b = blockIdx.z;
   const int64_t base = ((int64_t)b * C + c) * HW;
   const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  float sum = 0.f;
+  float sum = 0.f, nsum = 0.f;
   if (p0 < HW) {    // HW % 4 == 0
     const float4 g = *reinterpret_cast<const float4*>(dy + base + p0);
     const float4 v = *reinterpret_cast<const float4*>(y + base + p0);
@@ -214,30 +233,38 @@ __global__ void __launch_bounds__(256) act_bwd_kernel(const float* __restrict__ 
     o.w = g.w * (v.w > 0.f ? S : 0.2f * S);
     *reinterpret_cast<float4*>(dx + base + p0) = o;
     sum = (o.x + o.y) + (o.z + o.w);
+    if (dnw) {
+      const float4 nz = *reinterpret_cast<const float4*>(noise + (int64_t)b * noise_bstride + p0);
+      nsum = fmaf(o.w, nz.w, fmaf(o.z, nz.z, fmaf(o.y, nz.y, o.x * nz.x)));
+    }
   }
   sum = block_sum_256(sum, sh);
   if (threadIdx.x == 0 && dbias) unsafeAtomicAdd(dbias + c, sum);
+  if (dnw) {       // d noise_weight = sum_{b,c,p} dx * noise: per-channel partials (one hot address would serialise)
+    nsum = block_sum_256(nsum, sh);
+    if (threadIdx.x == 0) unsafeAtomicAdd(dnw + c, nsum);
+  }
 }
 
-// dnoise[bn][p] = nw sum_{c (and b if the noise is shared)} dx[b][c][p];  dnw = sum_p noise[p] * (sum_c dx)
-__global__ void __launch_bounds__(256) noise_bwd_kernel(const float* __restrict__ dx, const float* __restrict__ noise,
-                                                        int64_t noise_bstride, const float* __restrict__ noise_w,
-                                                        float* __restrict__ dnoise, float* __restrict__ dnw, int B, int C,
-                                                        int64_t HW) {
+__global__ void __launch_bounds__(256) sum_to_scalar_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
   __shared__ float sh[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += v[i];
+  acc = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
+// dnoise[bn][p] += nw sum_{c in chunk} dx[b][c][p]   (bn = b for per-sample noise, 0 for a shared buffer; dnoise zeroed by
+// the host call).  grid (ceil(HW/256), ceil(C/32), B)
+__global__ void __launch_bounds__(256) noise_bwd_kernel(const float* __restrict__ dx, int64_t noise_bstride,
+                                                        const float* __restrict__ noise_w, float* __restrict__ dnoise,
+                                                        int C, int64_t HW) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int b_lo = noise_bstride ? blockIdx.y : 0, b_hi = noise_bstride ? blockIdx.y + 1 : B;
-  float part = 0.f;
-  if (p < HW) {
-    float acc = 0.f;
-    for (int b = b_lo; b < b_hi; ++b)
-      for (int c = 0; c < C; ++c) acc += dx[((int64_t)b * C + c) * HW + p];
-    const int64_t np = (int64_t)(noise_bstride ? blockIdx.y : 0) * noise_bstride + p;
-    if (dnoise) dnoise[np] = acc * noise_w[0];
-    part = acc * noise[np];
-  }
-  part = block_sum_256(part, sh);
-  if (threadIdx.x == 0 && dnw) unsafeAtomicAdd(dnw, part);
+  if (p >= HW) return;
+  const int b = blockIdx.z, c0 = blockIdx.y * 32, c1 = min(C, c0 + 32);
+  float acc = 0.f;
+  for (int c = c0; c < c1; ++c) acc += dx[((int64_t)b * C + c) * HW + p];
+  unsafeAtomicAdd(dnoise + (int64_t)b * noise_bstride + p, acc * noise_w[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ ToRGB
@@ -303,7 +330,7 @@ extern "C" int cips3d_linear_bwd(const float* x, int64_t x_stride, const float* 
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)out_dim * in_dim, 256)), dim3(256), 0,
                        st, a);
   if (dx)
-    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * in_dim, 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)ceil_div(in_dim, 64), (unsigned)B), dim3(1024), 0, st, a);
   if (dbias) hipLaunchKernelGGL(linear_bwd_db_kernel, dim3((unsigned)ceil_div(out_dim, 256)), dim3(256), 0, st, a);
   return cips3d_launch_status();
 }
@@ -322,8 +349,8 @@ extern "C" int cips3d_modulate_bwd(float* dwm, const float* W, const float* s, i
     hipLaunchKernelGGL(modulate_bwd_dw_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)Cout * len, 256)), dim3(256), 0, st,
                        dwm, s, s_stride, B, Cout, len, ksq, scale, dW);
   if (ds)
-    hipLaunchKernelGGL(modulate_bwd_ds_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * Cin, 256)), dim3(256), 0, st, dwm,
-                       W, B, Cout, Cin, ksq, scale, ds, ds_stride);
+    hipLaunchKernelGGL(modulate_bwd_ds_kernel, dim3((unsigned)ceil_div(Cin, 64), (unsigned)B), dim3(1024), 0, st, dwm, W, B, Cout,
+                       Cin, ksq, scale, ds, ds_stride);
   return cips3d_launch_status();
 }
 
@@ -359,19 +386,23 @@ extern "C" int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, in
 
 extern "C" int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const float* noise, int64_t noise_bstride,
                                          const float* noise_w, float* dx, float* dnoise, float* dnoise_w, float* dbias,
-                                         int B, int C, int64_t HW, void* stream) {
+                                         float* scratch_c, int B, int C, int64_t HW, void* stream) {
   if (!dy || !y || !dx || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (dnoise_w && !scratch_c) return CIPS3D_E_BADARG;
   if ((dnoise || dnoise_w) && (!noise || !noise_w)) return CIPS3D_E_BADARG;
   if (HW % 4) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   hipStream_t st = as_stream(stream);
   if (dbias) { hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
+  if (dnoise_w) { hipError_t e = hipMemsetAsync(scratch_c, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st, dy,
-                     y, dx, dbias, C, HW);
-  if (dnoise || dnoise_w) {
-    if (dnoise_w) { hipError_t e = hipMemsetAsync(dnoise_w, 0, sizeof(float), st); if (e != hipSuccess) return (int)e; }
-    hipLaunchKernelGGL(noise_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 256), (unsigned)(noise_bstride ? B : 1)),
-                       dim3(256), 0, st, dx, noise, noise_bstride, noise_w, dnoise, dnoise_w, B, C, HW);
+                     y, dx, dbias, noise, noise_bstride, dnoise_w ? scratch_c : nullptr, C, HW);
+  if (dnoise_w) hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, scratch_c, C, dnoise_w);
+  if (dnoise) {
+    hipError_t e = hipMemsetAsync(dnoise, 0, sizeof(float) * (size_t)(noise_bstride ? B : 1) * HW, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(noise_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 256), (unsigned)ceil_div(C, 32), (unsigned)B),
+                       dim3(256), 0, st, dx, noise_bstride, noise_w, dnoise, C, HW);
   }
   return cips3d_launch_status();
 }

@@ -323,9 +323,11 @@ def noise_bias_act_bwd(dy, y, noise, noise_w, need_dnoise=False, need_dnw=True, 
     dnoise = torch.empty_like(noise) if (need_dnoise and noise is not None) else None
     dnw = torch.empty(1, device=dev) if (need_dnw and noise is not None) else None
     db = torch.empty(Cc, device=dev) if need_db else None
+    scratch = torch.empty(Cc, device=dev) if dnw is not None else None
     check(lib.cips3d_noise_bias_act_bwd(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(noise, "noise", True), nb,
                                         dev_ptr(noise_w, "noise_w", True), dev_ptr(dx), dev_ptr(dnoise, "dnoise", True),
-                                        dev_ptr(dnw, "dnw", True), dev_ptr(db, "db", True), B, Cc, HW, stream_ptr()),
+                                        dev_ptr(dnw, "dnw", True), dev_ptr(db, "db", True), dev_ptr(scratch, "scratch", True),
+                                        B, Cc, HW, stream_ptr()),
           "cips3d_noise_bias_act_bwd")
     return dx, dnoise, dnw, db
 

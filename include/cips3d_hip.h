@@ -344,10 +344,10 @@ int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, int B, int M,
 
 /* Backward of cips3d_noise_bias_act / the epilogue of StyledConv (models/model_v3.py:327-341; op/fused_act.py:20-84):
  * y = lrelu(x + noise_w*noise + bias_c)*sqrt2.  dx [B,C,HW] (may alias dy), dnoise [1 or B][HW] (layout of `noise`),
- * dnoise_w [1], dbias [C]. */
+ * dnoise_w [1], dbias [C]; scratch_c [C] is required with dnoise_w (per-channel partial sums). */
 int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const float* noise, int64_t noise_bstride,
-                              const float* noise_w, float* dx, float* dnoise, float* dnoise_w, float* dbias, int B, int C,
-                              int64_t HW, void* stream);
+                              const float* noise_w, float* dx, float* dnoise, float* dnoise_w, float* dbias,
+                              float* scratch_c, int B, int C, int64_t HW, void* stream);
 
 /* Backward of cips3d_torgb without the skip (its gradient is drgb itself; the FIR up-sampling of the skip is
  * cips3d_upfirdn2d): dx [B,C,HW], dwm [B,3,C], dbias [3].  (models/model_v3.py:469-482) */
