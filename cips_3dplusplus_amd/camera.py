@@ -97,3 +97,20 @@ def cameras_from_trajectory(traj, img_size, device, dist_radius=0.12, up=None):
                                                       fov_ang=traj[:, 2].contiguous(), dist_radius=dist_radius,
                                                       up=None if up is None else up.to(device))
     return e, f, n, fa
+
+
+def translate_rotate_cameras(n_frames, trans_max, img_size, device, fov_ang=6.0, dist_radius=0.12):
+    """render_video_web_v10.py:1587-1649: first a sideways translation of a frontal camera at z = 1
+    (x = trans_max sin(2 pi t), identity rotation), then an in-plane roll of the frontal camera (custom up vectors).
+    Returns (extrinsics [2n,3,4], trajectory [2n,3], focal, near, far)."""
+    t = torch.linspace(0, 1, n_frames)
+    ext_t = torch.zeros(n_frames, 3, 4, device=device)
+    ext_t[:, :, :3] = torch.eye(3, device=device)
+    ext_t[:, 0, 3] = (trans_max * torch.sin(t * 2 * math.pi)).to(device)
+    ext_t[:, 2, 3] = 1
+    traj = torch.zeros(n_frames, 3)
+    traj[:, 2] = fov_ang
+    _, f_t, n_t, fa_t = cameras_from_trajectory(traj, img_size, device, dist_radius)
+    ext_r, f_r, n_r, fa_r = cameras_from_trajectory(traj, img_size, device, dist_radius, up=roll_up_vectors(n_frames))
+    cat = lambda a, b: torch.cat([a, b], 0)
+    return cat(ext_t, ext_r), cat(traj, traj).to(device), cat(f_t, f_r), cat(n_t, n_r), cat(fa_t, fa_r)

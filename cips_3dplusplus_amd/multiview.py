@@ -97,3 +97,58 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
         else:
             result[k] = local
     return result
+
+
+def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, truncation_ratio=0.5, N_samples=128,
+                      zero_noise_bufs=False, noise_bufs=None, azim_range=(-0.77, 0.77), elev=0.0, circle=None,
+                      trans_max=0.04, only_rotate=False, chunk=1, gather=("rgb", "thumb_rgb", "xyz"), to_uint8=True,
+                      group=None):
+    """The frame loop of `_sample_multi_view_web` (render_video_web_v10.py:1651-1899) without the web page: one z pair,
+    one set of noise buffers, `perturb=False`, a camera trajectory (`yaw` / `circle` / `translate_rotate`), one
+    `G(...)` call per `chunk` frames with `truncation=truncation_ratio, return_xyz=True`.  With torch.distributed
+    initialised the frames are dealt to the ranks (contiguous blocks) and gathered to rank 0; `rgb` travels as uint8
+    (the `img_tensor_to_pil` step, :1825-1826) unless `to_uint8=False`.  Video encoding / mesh shading stay with the
+    caller (`gen_images.xyz_to_mesh` gives the surface of a frame's `xyz`)."""
+    from . import hip
+    from .camera import yaw_trajectory, circle_trajectory, cameras_from_trajectory, translate_rotate_cameras
+    dev = next(G.parameters()).device
+    img_size = cam_cfg["img_size"]
+    fov, dist_radius = cam_cfg.get("fov_ang", 6), cam_cfg.get("dist_radius", 0.12)
+    if view_mode == "yaw":
+        traj = yaw_trajectory(N_frames, azim_range, elev, fov)
+        ext, foc, near, far = cameras_from_trajectory(traj, img_size, dev, dist_radius)
+    elif view_mode == "circle":
+        c = circle or {}
+        traj = circle_trajectory(N_frames, c.get("azim_range", 0.5), c.get("elev_range", 0.0), c.get("fov_range", (6.0, 8.0)))
+        ext, foc, near, far = cameras_from_trajectory(traj, img_size, dev, dist_radius)
+    elif view_mode == "translate_rotate":
+        ext, traj, foc, near, far = translate_rotate_cameras(N_frames, trans_max, img_size, dev, fov, dist_radius)
+        if only_rotate:
+            ext, traj, foc, near, far = (t.chunk(2)[1] for t in (ext, traj, foc, near, far))
+    else:
+        raise ValueError(f"view_mode {view_mode!r}")
+    n_views = ext.shape[0]
+    ncfg = dict(nerf_cfg)
+    ncfg["perturb"] = False
+    ncfg["N_samples"] = N_samples
+    if noise_bufs is None:
+        noise_bufs = G.create_noise_bufs(img_size, dev)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            for b in noise_bufs:                   # every rank must draw the same buffers
+                dist.broadcast(b, src=0, group=group)
+    if zero_noise_bufs:
+        noise_bufs = [torch.zeros_like(b) for b in noise_bufs]
+
+    def render(a, b):
+        with torch.no_grad():
+            r = G(zs=zs, cam_poses=ext[a:b].contiguous(), focals=foc[a:b].contiguous(), img_size=img_size,
+                  near=near[a:b].contiguous(), far=far[a:b].contiguous(), noise_bufs=noise_bufs,
+                  truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True)
+        if to_uint8:
+            r = dict(r)
+            r["rgb"] = hip.rgb_to_uint8(r["rgb"])
+        return r
+
+    out = render_views_sharded(render, n_views, keys=gather, group=group, chunk=chunk)
+    out["trajectory"] = traj
+    return out

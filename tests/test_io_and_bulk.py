@@ -231,3 +231,47 @@ def test_gen_images_on_gpu(tmp_path):
     for i in range(2):
         img = torch.from_numpy(np.array(Image.open(files[i]))).permute(2, 0, 1)
         assert img.shape == u8[i].shape and torch.equal(img, u8[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n", [("yaw", 5), ("circle", 4), ("translate_rotate", 3)])
+def test_sample_multi_view_single_gpu(mode, n):
+    """Frame loop of _sample_multi_view_web vs frame-by-frame oracle renders (same z, noise, truncation means)."""
+    from cips_3dplusplus_amd import checkpoint, hip
+    from cips_3dplusplus_amd.multiview import sample_multi_view
+    from oracle import path as O
+    G, cfg = checkpoint.load_generator(CKPT, device="cuda")
+    ctor = checkpoint.generator_ctor_cfg(cfg["G_cfg"])
+    g = torch.Generator().manual_seed(8)
+    zs = [torch.randn(1, 32, generator=g), torch.randn(1, 32, generator=g)]
+    mr, md = 0.2 * torch.randn(1, 32, generator=g), 0.2 * torch.randn(1, 32, generator=g)
+    G.style_render_mean, G.style_decoder_mean = mr.cuda(), md.cuda()
+    nb = [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(8, "cpu")]
+    cam_cfg = {"img_size": 8, "fov_ang": 6, "dist_radius": 0.12}
+    out = sample_multi_view(G, cam_cfg, {"N_samples": 24, "static_viewdirs": True}, [z.cuda() for z in zs], view_mode=mode,
+                            N_frames=n, truncation_ratio=0.5, N_samples=6, noise_bufs=[b.cuda() for b in nb], to_uint8=False)
+    n_views = 2 * n if mode == "translate_rotate" else n
+    assert out["rgb"].shape[0] == n_views and out["trajectory"].shape == (n_views, 3)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    traj = out["trajectory"].cpu()
+    ups = None
+    if mode == "translate_rotate":
+        from cips_3dplusplus_amd.camera import roll_up_vectors
+        ups = roll_up_vectors(n)
+    for v in range(n_views):
+        if mode == "translate_rotate" and v < n:
+            import math
+            ext = torch.zeros(1, 3, 4); ext[0, :, :3] = torch.eye(3)
+            ext[0, 0, 3] = 0.04 * math.sin(2 * math.pi * v / (n - 1)); ext[0, 2, 3] = 1
+            cam = (ext,) + tuple(O.camera_params(torch.zeros(1, 2), 8, 6, 0.12)[1:4])
+        else:
+            up = None if ups is None else ups[v - n: v - n + 1]
+            cam = O.camera_params(traj[v:v + 1, :2], 8, float(traj[v, 2]), 0.12, up=up)
+        ref = O.generator_forward(sd, ctor, zs, cam[0], cam[1], 8, cam[2], cam[3],
+                                  dict(N_samples=6, perturb=False, static_viewdirs=True), nb, truncation=0.5,
+                                  style_render_mean=mr, style_decoder_mean=md, return_xyz=True)
+        for k in ("rgb", "thumb_rgb", "xyz"):
+            assert float((out[k][v].cpu() - ref[k][0]).abs().max()) < 2e-4, (mode, v, k)
+    u8 = sample_multi_view(G, cam_cfg, {"N_samples": 24, "static_viewdirs": True}, [z.cuda() for z in zs], view_mode=mode,
+                           N_frames=n, truncation_ratio=0.5, N_samples=6, noise_bufs=[b.cuda() for b in nb])
+    assert u8["rgb"].dtype == torch.uint8 and torch.equal(u8["rgb"], hip.rgb_to_uint8(out["rgb"]))
