@@ -17,6 +17,14 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 template <typename T>
 __host__ __device__ static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 
+// arguments of one cips3d_linear call (library-internal; linear.hip / forward.hip)
+struct cips3d_linear_args {
+  const float* x; int64_t x_stride; const float* W; const float* bias; float* out; int64_t out_stride;
+  int B, in_dim, out_dim; float w_scale, b_scale; int pixelnorm, lrelu; float act_gain, out_scale, out_shift;
+  const float* trunc_mean; float trunc_psi; int out_repeat; int64_t out_repeat_stride;
+};
+int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream);
+
 // floor division for possibly negative numerators (b > 0)
 __host__ __device__ static inline int floor_div_i(int a, int b) {
   int q = a / b;

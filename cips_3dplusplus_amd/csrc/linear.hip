@@ -45,15 +45,20 @@ __device__ __forceinline__ void dot_rows(const float* __restrict__ w, const floa
   for (int j = 0; j < BT; ++j) acc[j] = wave_sum(acc[j]);
 }
 
-struct LinearArgs {
-  const float* x; int64_t x_stride; const float* W; const float* bias; float* out; int64_t out_stride;
-  int B, in_dim, out_dim; float w_scale, b_scale; int pixelnorm, lrelu; float act_gain, out_scale, out_shift;
-  const float* trunc_mean; float trunc_psi; int out_repeat; int64_t out_repeat_stride;
-};
+__device__ __forceinline__ void linear_rows(const cips3d_linear_args& a, int row);
 
-__global__ void __launch_bounds__(256) linear_kernel(LinearArgs a) {
+__global__ void __launch_bounds__(256) linear_kernel(cips3d_linear_args a) {
+  linear_rows(a, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// two independent layers (the i-th layers of the two mapping networks) in one launch: blocks [0, blocks_a) run `a`
+__global__ void __launch_bounds__(256) linear_pair_kernel(cips3d_linear_args a, cips3d_linear_args b, int blocks_a) {
+  if ((int)blockIdx.x < blocks_a) linear_rows(a, blockIdx.x * 4 + (threadIdx.x >> 6));
+  else linear_rows(b, (blockIdx.x - blocks_a) * 4 + (threadIdx.x >> 6));
+}
+
+__device__ __forceinline__ void linear_rows(const cips3d_linear_args& a, int row) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.out_dim) return;
   const float* w = a.W + (int64_t)row * a.in_dim;
   const float b = a.bias ? a.bias[row] * a.b_scale : 0.f;
@@ -130,9 +135,16 @@ extern "C" int cips3d_linear(const float* x, int64_t x_stride, const float* W, c
                              void* stream) {
   if (!x || !W || !out || B < 0 || in_dim <= 0 || out_dim <= 0 || out_repeat < 1) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
-  LinearArgs a{x, x_stride, W, bias, out, out_stride, B, in_dim, out_dim, w_scale, b_scale, pixelnorm, lrelu,
-               act_gain, out_scale, out_shift, trunc_mean, trunc_psi, out_repeat, out_repeat_stride};
+  cips3d_linear_args a{x, x_stride, W, bias, out, out_stride, B, in_dim, out_dim, w_scale, b_scale, pixelnorm, lrelu,
+                       act_gain, out_scale, out_shift, trunc_mean, trunc_psi, out_repeat, out_repeat_stride};
   hipLaunchKernelGGL(linear_kernel, dim3(ceil_div(out_dim, 4)), dim3(256), 0, as_stream(stream), a);
+  return cips3d_launch_status();
+}
+
+// library-internal (forward.hip): two layers, one launch
+int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream) {
+  const int ba = ceil_div(a.out_dim, 4), bb = ceil_div(b.out_dim, 4);
+  hipLaunchKernelGGL(linear_pair_kernel, dim3(ba + bb), dim3(256), 0, as_stream(stream), a, b, ba);
   return cips3d_launch_status();
 }
 

@@ -478,18 +478,17 @@ __global__ void __launch_bounds__(256) nerf_finish_kernel(const float* __restric
     xyz[((int64_t)b * 3 + (ch - H - 3)) * R + ray] = acc;
   } else {
     mask[((int64_t)b * 2 + 0) * R + ray] = acc;
+    // depth = -|xyz| (second mask channel) needs all three xyz sums: this thread recombines them the same way
+    float Tq = 1.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float* pc = part + ((int64_t)(c * B + b) * CH) * R + ray;
+      ax = fmaf(Tq, pc[(int64_t)(H + 3) * R], ax);
+      ay = fmaf(Tq, pc[(int64_t)(H + 4) * R], ay);
+      az = fmaf(Tq, pc[(int64_t)(H + 5) * R], az);
+      Tq *= pc[(int64_t)(H + 7) * R];
+    }
+    mask[((int64_t)b * 2 + 1) * R + ray] = -sqrtf((ax * ax + ay * ay) + az * az);
   }
-}
-
-// depth = -|xyz| (second mask channel); separate tiny pass because it needs all three xyz sums
-__global__ void __launch_bounds__(256) nerf_depth_kernel(const float* __restrict__ xyz, float* __restrict__ mask,
-                                                         int B, int R) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)B * R) return;
-  const int b = (int)(i / R), ray = (int)(i % R);
-  const float x = xyz[((int64_t)b * 3 + 0) * R + ray], y = xyz[((int64_t)b * 3 + 1) * R + ray],
-              z = xyz[((int64_t)b * 3 + 2) * R + ray];
-  mask[((int64_t)b * 2 + 1) * R + ray] = -sqrtf((x * x + y * y) + z * z);
 }
 
 template <int NT, int TPS>
@@ -576,9 +575,5 @@ extern "C" int cips3d_nerf_finish(const float* part, int n_chunks, int B, int im
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(nerf_finish_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, st, part,
                      n_chunks, B, R, hidden, features, thumb_rgb, xyz, mask);
-  int rc = cips3d_launch_status();
-  if (rc) return rc;
-  hipLaunchKernelGGL(nerf_depth_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * R, 256)), dim3(256), 0, st,
-                     xyz, mask, B, R);
   return cips3d_launch_status();
 }

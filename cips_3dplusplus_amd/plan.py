@@ -26,7 +26,7 @@ class GeneratorPlan(C.Structure):
                 ("map_r_w", C.c_void_p * MAX_MAP), ("map_r_b", C.c_void_p * MAX_MAP),
                 ("map_d_w", C.c_void_p * MAX_MAP), ("map_d_b", C.c_void_p * MAX_MAP),
                 ("map_d_in", C.c_int32 * MAX_MAP), ("map_d_lr_mul", C.c_float), ("pad0_", C.c_int32),
-                ("lat", C.c_void_p * 2), ("styles_r", C.c_void_p), ("styles_d", C.c_void_p),
+                ("lat", C.c_void_p * 4), ("styles_r", C.c_void_p), ("styles_d", C.c_void_p),
                 ("film_table", C.c_void_p), ("film_n", C.c_int32), ("film_rows", C.c_int32),
                 ("mod_table", C.c_void_p), ("mod_n", C.c_int32), ("mod_rows", C.c_int32),
                 ("wm_table", C.c_void_p), ("wm_n", C.c_int32), ("wm_rows", C.c_int32),
@@ -83,8 +83,9 @@ class ForwardPlan:
             p.map_d_in[i] = l.weight.shape[1]
         p.map_d_lr_mul = float(map_d[0].lr_mul)
         lat_w = max(p.style_dim_r, p.style_dim_d, p.z_dim)
-        lat = torch.empty(2, B, lat_w, device=dev)
-        p.lat[0], p.lat[1] = lat[0].data_ptr(), lat[1].data_ptr()
+        lat = torch.empty(4, B, lat_w, device=dev)
+        for i in range(4):
+            p.lat[i] = lat[i].data_ptr()
 
         # ---- FiLM heads (renderer owns styles staging + film + table)
         styles_r, film, film_tab = ren._film_table(B, dev)

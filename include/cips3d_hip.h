@@ -221,6 +221,7 @@ int cips3d_noise_bias_act(const float* x, const float* noise, int64_t noise_bstr
 int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,
                  const float* fir, float* out, int B, int Cin, int H, int W, void* stream);
 
+
 /* One kernel for a whole up-sampling stage after its low-resolution GEMM (models/model_v3.py:618-630 for a
  * stage in `upsample_list`):
  *   act1 = lrelu(upfirdn2d(y_lo, fir, up=2, pad=(2,1)) + nw1*noise1 + bias1) * sqrt(2)     (never stored)
@@ -270,7 +271,7 @@ typedef struct cips3d_generator_plan {
   int32_t map_d_in[CIPS3D_MAX_MAP_LAYERS];
   float map_d_lr_mul;
   int32_t pad0_;
-  float* lat[2];                 /* ping-pong [B, max(style_dim_r, style_dim_d, z_dim)] */
+  float* lat[4];                 /* ping-pong [B, max(style_dim_r, style_dim_d, z_dim)]: [0,1] renderer chain, [2,3] decoder chain */
   float* styles_r;               /* [B, D+1, style_dim_r] */
   float* styles_d;               /* [B, n_latent, style_dim_d] */
   /* style heads */
