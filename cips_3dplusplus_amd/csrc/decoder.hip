@@ -576,8 +576,10 @@ struct FusedArgs {
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
 };
 
-template <int C, int WM, int WGM, int WGN, int RW, int BK>
-__global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs a) {
+// MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
+// store is serial, so throughput comes from co-resident workgroups).
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW>
+__global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
   constexpr int NT = 64 * WGM * WGN;
@@ -800,11 +802,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) fused_up_conv_kernel(FusedArgs
   }
 }
 
-template <int C, int WM, int WGM, int WGN, int RW, int BK>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -907,10 +909,11 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
               wm_rgb, bias_rgb, skip, skip_up, rgb, B, H, W};
   hipStream_t st = as_stream(stream);
   switch (C) {
-    case 32: return launch_fused<32, 1, 2, 2, 1, 32>(a, st);      // 2 rows x 64, 4 waves
-    case 64: return launch_fused<64, 2, 2, 2, 1, 32>(a, st);      // 2 rows x 64, 4 waves
-    case 128: return launch_fused<128, 2, 4, 2, 1, 32>(a, st);    // 2 rows x 64
-    case 256: return launch_fused<256, 2, 8, 1, 2, 64>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
+    // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
+    case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2
+    case 64: return launch_fused<64, 2, 2, 2, 1, 16, 4>(a, st);      // 2 rows x 64, 4 waves, BK 16     42 us @512^2
+    case 128: return launch_fused<128, 4, 2, 4, 1, 32, 2>(a, st);    // 4 rows x 64                     33 us @256^2
+    case 256: return launch_fused<256, 2, 8, 1, 2, 64, 2>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
   }
   return CIPS3D_E_UNSUPP;
 }
