@@ -39,8 +39,9 @@ class NerfParams(C.Structure):
                 ("layer_bias", C.c_void_p), ("w_sigma", C.c_void_p), ("w_rgb", C.c_void_p),
                 ("b_sigma", C.c_void_p), ("b_rgb", C.c_void_p), ("sigmoid_beta", C.c_void_p),
                 ("B", C.c_int32), ("img_size", C.c_int32), ("n_samples", C.c_int32), ("hidden", C.c_int32),
-                ("depth", C.c_int32), ("static_viewdirs", C.c_int32), ("n_chunks", C.c_int32), ("pad_", C.c_int32),
-                ("part", C.c_void_p), ("sdf", C.c_void_p)]
+                ("depth", C.c_int32), ("static_viewdirs", C.c_int32), ("n_chunks", C.c_int32), ("n_rays", C.c_int32),
+                ("part", C.c_void_p), ("sdf", C.c_void_p),
+                ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -66,6 +67,7 @@ _SIGS = {
     "cips3d_nerf_part_floats": (c_i64, [c_int, c_int, c_int, c_int]),
     "cips3d_nerf_render": (c_int, [C.POINTER(NerfParams), C.c_void_p]),
     "cips3d_nerf_finish": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_nerf_finish_rays": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_modulate_weights": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int, c_f32, c_int,
                                         C.c_void_p]),
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
@@ -83,6 +85,13 @@ _SIGS = {
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
+    "cips3d_rays_in_world": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_z_vals": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
+    "cips3d_ray_points": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_volume_integration": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_f32p,
+                                          c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_points_linear": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_f32p,
+                                     C.c_void_p]),
     "cips3d_linear_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_int, c_int, c_int, c_f32, c_f32,
                                   c_int, c_f32, c_f32, c_f32p, c_i64, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_modulate_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_int, c_f32, c_int, c_f32p,

@@ -245,7 +245,8 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
   }
 }
 
-template <int NT, int TPS>
+// XG: explicit-geometry instantiation (compile-time so that the camera-driven hot path keeps its register allocation)
+template <int NT, int TPS, bool XG>
 __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) {
   constexpr int H = NT * 16;
   constexpr int SLAB = 16 * H * TPS;
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int g = task_ok ? tv / P.n_chunks : 0;
   const int c = task_ok ? tv % P.n_chunks : 0;
   const int S = P.img_size;
-  const int R = S * S;
+  const int R = P.n_rays > 0 ? P.n_rays : S * S;
   const int ray = g * RAYS + pl;
   const bool ray_ok = task_ok && ray < R;
   const int rayc = ray < R ? ray : R - 1;
@@ -303,25 +304,34 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const float sig_beta = P.sigmoid_beta[0];
 
   // ---- ray setup (nerf_utils.py:38-66)
-  const float focal = P.focals[b];
   const float nearv = P.near_[b], farv = P.far_[b];
-  const float* cw = P.cam_poses + 12 * b;
-  const int pi = rayc / S, pj = rayc - pi * S;
-  const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
-  const float dcx = (px - (float)S * 0.5f) / focal;
-  const float dcy = -(py - (float)S * 0.5f) / focal;
-  const float dcz = -1.f;
-  const float dx = (dcx * cw[0] + dcy * cw[1]) + dcz * cw[2];
-  const float dy = (dcx * cw[4] + dcy * cw[5]) + dcz * cw[6];
-  const float dz = (dcx * cw[8] + dcy * cw[9]) + dcz * cw[10];
-  const float ox = cw[3], oy = cw[7], oz = cw[11];
-  float vx = P.static_viewdirs ? dcx : dx, vy = P.static_viewdirs ? dcy : dy, vz = P.static_viewdirs ? dcz : dz;
-  {
+  // explicit-geometry mode (VolumeFeatureRenderer.forward(pts, rays_d, viewdirs, z_vals, ...), volume_renderer.py:192-303):
+  // the caller's points / directions / depths are read instead of being generated from the camera
+  constexpr bool explicit_geom = XG;
+  const int64_t bray = (int64_t)b * R + rayc;
+  float dx, dy, dz, ox = 0.f, oy = 0.f, oz = 0.f, vx, vy, vz;
+  if (explicit_geom) {
+    dx = P.x_rays_d[bray * 3]; dy = P.x_rays_d[bray * 3 + 1]; dz = P.x_rays_d[bray * 3 + 2];
+    vx = P.x_viewdirs[bray * 3]; vy = P.x_viewdirs[bray * 3 + 1]; vz = P.x_viewdirs[bray * 3 + 2];
+  } else {
+    const float focal = P.focals[b];
+    const float* cw = P.cam_poses + 12 * b;
+    const int pi = rayc / S, pj = rayc - pi * S;
+    const float px = (float)pj + 0.5f, py = (float)pi + 0.5f;
+    const float dcx = (px - (float)S * 0.5f) / focal;
+    const float dcy = -(py - (float)S * 0.5f) / focal;
+    const float dcz = -1.f;
+    dx = (dcx * cw[0] + dcy * cw[1]) + dcz * cw[2];
+    dy = (dcx * cw[4] + dcy * cw[5]) + dcz * cw[6];
+    dz = (dcx * cw[8] + dcy * cw[9]) + dcz * cw[10];
+    ox = cw[3]; oy = cw[7]; oz = cw[11];
+    vx = P.static_viewdirs ? dcx : dx; vy = P.static_viewdirs ? dcy : dy; vz = P.static_viewdirs ? dcz : dz;
     const float n = fmaxf(sqrtf((vx * vx + vy * vy) + vz * vz), 1e-12f);
     vx /= n; vy /= n; vz /= n;
   }
   const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
-  const float u = P.perturb_u ? P.perturb_u[(int64_t)b * R + rayc] : 0.f;
+  const float u = (P.perturb_u && !explicit_geom) ? P.perturb_u[bray] : 0.f;
+  const float* xz = explicit_geom ? P.x_z_vals + bray * P.n_samples : nullptr;
   const float span = farv - nearv;
   const int N = P.n_samples;
   // torch.linspace(0, 1 - 1/N, N): symmetric evaluation around the midpoint
@@ -333,6 +343,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     return nearv * (1.f - t) + farv * t;
   };
   auto zsample = [&](int k) -> float {
+    if (xz) return xz[k < N ? k : N - 1];
     const float z0 = zbase(k);
     return P.perturb_u ? z0 + (zbase(k + 1) - z0) * u : z0;
   };
@@ -363,7 +374,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     const bool live = ray_ok && sg < N;
     const int sk = sg < N ? sg : N - 1;
     const float z = zsample(sk);
-    const float ptx = ox + dx * z, pty = oy + dy * z, ptz = oz + dz * z;
+    float ptx, pty, ptz;
+    if (explicit_geom) {
+      const float* pp = P.x_pts + (bray * N + sk) * 3;
+      ptx = pp[0]; pty = pp[1]; ptz = pp[2];
+    } else {
+      ptx = ox + dx * z; pty = oy + dy * z; ptz = oz + dz * z;
+    }
     const float nx = ptx * 2.f / span, ny = pty * 2.f / span, nz = ptz * 2.f / span;
     // Opaque zero folded into every table offset of this iteration: the tables are loop-invariant and
     // LICM would otherwise hoist ~5*H/4 registers of them out of the sample loop (and spill them).
@@ -491,22 +508,27 @@ __global__ void __launch_bounds__(256) nerf_finish_kernel(const float* __restric
   }
 }
 
-template <int NT, int TPS>
-int launch_render(const NerfArgs& a, hipStream_t st) {
+template <int NT, int TPS, bool XG>
+int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
   const size_t lds_bytes = sizeof(float) * (2 * 16 * H * TPS + (size_t)(P.depth + 1) * 2 * H + 10 * H);
   if (lds_bytes > 160 * 1024) return CIPS3D_E_UNSUPP;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
-  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
   return cips3d_launch_status();
+}
+
+template <int NT, int TPS>
+int launch_render(const NerfArgs& a, hipStream_t st) {
+  return a.p.x_pts ? launch_render_x<NT, TPS, true>(a, st) : launch_render_x<NT, TPS, false>(a, st);
 }
 
 }  // namespace
@@ -543,8 +565,10 @@ extern "C" int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int 
 extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if (!p) return CIPS3D_E_BADARG;
   const cips3d_nerf_params& P = *p;
-  if (!P.cam_poses || !P.focals || !P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
+  if (!P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
       !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || !P.sigmoid_beta || !P.part)
+    return CIPS3D_E_BADARG;
+  if (P.x_pts ? (!P.x_rays_d || !P.x_viewdirs || !P.x_z_vals || P.n_rays <= 0) : (!P.cam_poses || !P.focals || P.n_rays != 0))
     return CIPS3D_E_BADARG;
   if (P.B < 0 || P.img_size <= 0 || P.n_samples <= 0 || P.depth < 1 || P.n_chunks < 1 ||
       P.n_chunks > P.n_samples)
@@ -552,7 +576,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if (P.B == 0) return 0;
   NerfArgs a;
   a.p = P;
-  a.groups = ceil_div(P.img_size * P.img_size, RAYS);
+  a.groups = ceil_div(P.n_rays > 0 ? P.n_rays : P.img_size * P.img_size, RAYS);
   a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
   a.chunk = ceil_div(P.n_samples, P.n_chunks);
   hipStream_t st = as_stream(stream);
@@ -567,10 +591,16 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
 
 extern "C" int cips3d_nerf_finish(const float* part, int n_chunks, int B, int img_size, int hidden,
                                   float* features, float* thumb_rgb, float* xyz, float* mask, void* stream) {
-  if (!part || !features || !thumb_rgb || !xyz || !mask || n_chunks < 1 || B < 0 || img_size <= 0 || hidden <= 0)
+  if (img_size <= 0) return CIPS3D_E_BADARG;
+  return cips3d_nerf_finish_rays(part, n_chunks, B, img_size * img_size, hidden, features, thumb_rgb, xyz, mask, stream);
+}
+
+extern "C" int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, int hidden, float* features,
+                                       float* thumb_rgb, float* xyz, float* mask, void* stream) {
+  if (!part || !features || !thumb_rgb || !xyz || !mask || n_chunks < 1 || B < 0 || n_rays <= 0 || hidden <= 0)
     return CIPS3D_E_BADARG;
   if (B == 0) return 0;
-  const int R = img_size * img_size;
+  const int R = n_rays;
   const int64_t total = (int64_t)B * (hidden + 7) * R;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(nerf_finish_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, st, part,

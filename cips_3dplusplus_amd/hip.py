@@ -132,12 +132,17 @@ def nerf_render(**kw):
     """Fill cips3d_nerf_params from keyword tensors / ints and launch the fused renderer."""
     lib = _lib.load()
     p = _lib.NerfParams()
-    ptr_fields = ("cam_poses", "focals", "near_", "far_", "w_first", "packed", "w_view", "film", "layer_bias",
+    ptr_fields = ("near_", "far_", "w_first", "packed", "w_view", "film", "layer_bias",
                   "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta", "part")
     for f in ptr_fields:
         setattr(p, f, dev_ptr(kw[f], f))
+    for f in ("cam_poses", "focals"):
+        setattr(p, f, dev_ptr(kw.get(f), f, kw.get("x_pts") is not None))
     p.perturb_u = dev_ptr(kw.get("perturb_u"), "perturb_u", True)
     p.sdf = dev_ptr(kw.get("sdf"), "sdf", True)
+    for f in ("x_pts", "x_rays_d", "x_viewdirs", "x_z_vals"):          # explicit-geometry mode
+        setattr(p, f, dev_ptr(kw.get(f), f, True))
+    p.n_rays = int(kw.get("n_rays", 0))
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))
     ev = _timed("nerf_render")
@@ -146,9 +151,81 @@ def nerf_render(**kw):
         ev[1].record()
 
 
-def nerf_finish(part, n_chunks, B, img_size, hidden):
+def rays_in_world(cam_poses, focals, img_size, static_viewdirs=False):
+    """-> rays_o, rays_d, viewdirs, each [B,S,S,3] (Render.get_rays_in_world)."""
+    lib = _lib.load()
+    B = cam_poses.shape[0]
+    o, d, v = (torch.empty(B, img_size, img_size, 3, device=cam_poses.device) for _ in range(3))
+    check(lib.cips3d_rays_in_world(dev_ptr(cam_poses.float().contiguous(), "c2w"), dev_ptr(focals.float().reshape(B).contiguous(), "focal"),
+                                   img_size, int(bool(static_viewdirs)), B, dev_ptr(o), dev_ptr(d), dev_ptr(v), stream_ptr()),
+          "cips3d_rays_in_world")
+    return o, d, v
+
+
+def z_vals(near, far, B, R, N, perturb_u=None):
+    lib = _lib.load()
+    z = torch.empty(B, R, N, device=near.device)
+    u = None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous()
+    check(lib.cips3d_z_vals(dev_ptr(near.float().reshape(B).contiguous(), "near"), dev_ptr(far.float().reshape(B).contiguous(), "far"),
+                            dev_ptr(u, "u", True), B, R, N, dev_ptr(z), stream_ptr()), "cips3d_z_vals")
+    return z
+
+
+def ray_points(rays_o, rays_d, z, near=None, far=None, want_pts=True, want_normalized=False):
+    """rays [B,R,3], z [B,R,N] -> pts and/or normalised pts [B,R,N,3]."""
+    lib = _lib.load()
+    B, R, N = z.shape
+    dev = z.device
+    pts = torch.empty(B, R, N, 3, device=dev) if want_pts else None
+    ptsn = torch.empty(B, R, N, 3, device=dev) if want_normalized else None
+    nr = None if near is None else near.float().reshape(B).contiguous()
+    fr = None if far is None else far.float().reshape(B).contiguous()
+    check(lib.cips3d_ray_points(dev_ptr(rays_o, "rays_o"), dev_ptr(rays_d, "rays_d"), dev_ptr(z, "z_vals"), dev_ptr(nr, "near", True),
+                                dev_ptr(fr, "far", True), B, R, N, dev_ptr(pts, "pts", True), dev_ptr(ptsn, "ptsn", True),
+                                stream_ptr()), "cips3d_ray_points")
+    return pts, ptsn
+
+
+def volume_integration(rgb, sdf, features, z, rays_d, pts, sigmoid_beta):
+    """[n,N,3], [n,N], [n,N,C]|None, [n,N], [n,3], [n,N,3] -> rgb_map [n,3], feature_map [n,C]|None, xyz [n,3], mask [n,2]."""
+    lib = _lib.load()
+    n, N = z.shape
+    dev = z.device
+    Cc = features.shape[-1] if features is not None else 0
+    rgb_map, xyz, mask = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev), torch.empty(n, 2, device=dev)
+    fmap = torch.empty(n, Cc, device=dev) if features is not None else None
+    check(lib.cips3d_volume_integration(dev_ptr(rgb, "rgb"), dev_ptr(sdf, "sdf"), dev_ptr(features, "features", True),
+                                        dev_ptr(z, "z_vals"), dev_ptr(rays_d, "rays_d"), dev_ptr(pts, "pts"),
+                                        dev_ptr(sigmoid_beta, "sigmoid_beta"), n, N, Cc, dev_ptr(rgb_map),
+                                        dev_ptr(fmap, "feature_map", True), dev_ptr(xyz), dev_ptr(mask), stream_ptr()),
+          "cips3d_volume_integration")
+    return rgb_map, fmap, xyz, mask
+
+
+def points_linear(x, W, bias=None, film=None, out_scale=1.0, out_shift=0.0):
+    """x (b, ..., in) point-major -> (b, ..., out): LinearLayer (film None) or FiLMSiren (film [B,2,out] = gamma, beta)."""
+    lib = _lib.load()
+    xin = x.float().contiguous()
+    B, in_dim = xin.shape[0], xin.shape[-1]
+    n = xin.numel() // in_dim
+    out_dim = W.shape[0]
+    y = torch.empty(*xin.shape[:-1], out_dim, device=x.device)
+    check(lib.cips3d_points_linear(dev_ptr(xin, "x"), dev_ptr(W, "W"), dev_ptr(bias, "bias", True), dev_ptr(film, "film", True), n,
+                                   max(1, n // B), in_dim, out_dim, 0 if film is None else 1, float(out_scale), float(out_shift),
+                                   dev_ptr(y), stream_ptr()), "cips3d_points_linear")
+    return y
+
+
+def nerf_finish(part, n_chunks, B, img_size, hidden, n_rays=None):
     lib = _lib.load()
     dev = part.device
+    if n_rays is not None:           # explicit-geometry mode: a [B, C, n_rays, 1] "image"
+        features = torch.empty(B, hidden, n_rays, 1, device=dev)
+        thumb, xyz = torch.empty(B, 3, n_rays, 1, device=dev), torch.empty(B, 3, n_rays, 1, device=dev)
+        mask = torch.empty(B, 2, n_rays, 1, device=dev)
+        check(lib.cips3d_nerf_finish_rays(dev_ptr(part), n_chunks, B, n_rays, hidden, dev_ptr(features), dev_ptr(thumb),
+                                          dev_ptr(xyz), dev_ptr(mask), stream_ptr()), "cips3d_nerf_finish_rays")
+        return features, thumb, xyz, mask
     R = img_size * img_size
     features = torch.empty(B, hidden, img_size, img_size, device=dev)
     thumb = torch.empty(B, 3, img_size, img_size, device=dev)

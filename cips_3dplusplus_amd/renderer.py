@@ -37,6 +37,9 @@ class LinearLayer(nn.Module):
         self.std_init = std_init
 
     def forward(self, input):
+        if input.numel() // input.shape[-1] > 64:       # point tensors (b, ..., n, c): MFMA path
+            return hip.points_linear(input, self.weight, self.bias, out_scale=float(self.std_init),
+                                     out_shift=float(self.bias_init))
         x = input.reshape(-1, input.shape[-1]).contiguous()
         y = hip.linear(x, self.weight, self.bias, out_scale=float(self.std_init), out_shift=float(self.bias_init))
         return y.view(*input.shape[:-1], -1)
@@ -54,6 +57,13 @@ class FiLMSiren(nn.Module):
         self.gamma = LinearLayer(style_dim, out_channel, bias_init=30, std_init=15)
         self.beta = LinearLayer(style_dim, out_channel, bias_init=0, std_init=0.25)
 
+    @torch.no_grad()
+    def forward(self, input, style):
+        """volume_renderer.py:70-85: input (b, ..., in), style (b, style_dim) -> sin(gamma * (x W^T + b) + beta).
+        (The generator itself never materialises per-point activations: csrc/nerf.hip fuses all layers.)"""
+        film = torch.stack([self.gamma(style), self.beta(style)], 1).contiguous()       # [B, 2, out]
+        return hip.points_linear(input, self.weight, self.bias, film=film)
+
 
 class SirenGenerator(nn.Module):
     """volume_renderer.py:89-116 (construction order matters for seeded init parity)."""
@@ -67,6 +77,21 @@ class SirenGenerator(nn.Module):
         self.views_linears = FiLMSiren(input_ch_views + W, W, style_dim=style_dim)
         self.rgb_linear = LinearLayer(W, 3, freq_init=True)
         self.sigma_linear = LinearLayer(W, 1, freq_init=True)
+
+    @torch.no_grad()
+    def points_forward(self, x, styles):
+        """volume_renderer.py:133-160: x (b, ..., n, 3 + 3) = [normalised points, view dirs], styles (b, D+1, style_dim)
+        -> rgb (.., 3), sdf (.., 1), features (.., W), all per point (layer by layer, materialised)."""
+        pts, views = torch.split(x, [self.input_ch, self.input_ch_views], dim=-1)
+        h = pts.contiguous()
+        for i, layer in enumerate(self.pts_linears):
+            h = layer(h, styles[:, i])
+        sdf = self.sigma_linear(h)
+        feat = self.views_linears(torch.cat([h, views], -1), styles[:, -1])
+        return self.rgb_linear(feat), sdf, feat
+
+    def forward(self, x, styles, forward_points=None):
+        return self.points_forward(x=x, styles=styles)
 
 
 class VolumeFeatureRenderer(nn.Module):
@@ -159,8 +184,45 @@ class VolumeFeatureRenderer(nn.Module):
             sdf = sdf.view(B, img_size, img_size, N_samples, 1)
         return thumb, features, sdf, mask, xyz
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError(
-            "the point-list entry (pts, rays_d, viewdirs, z_vals) of the reference renderer is not exposed; "
-            "use VolumeFeatureRenderer.render(cam_poses, focals, near, far, styles, ...) which fuses ray "
-            "generation, the FiLM-SIREN MLP and compositing on the GPU")
+    @torch.no_grad()
+    def run_network(self, inputs, viewdirs, styles=None):
+        """volume_renderer.py:282-303: per-point (rgb, sdf, features) for normalised points + per-ray view directions."""
+        dirs = viewdirs.unsqueeze(-2).expand(inputs.shape)
+        return self.network(torch.cat([inputs, dirs], -1), styles=styles)
+
+    @torch.no_grad()
+    def forward(self, pts, rays_d, viewdirs, z_vals, near, far, styles=None, return_eikonal=False, N_samples_forward=None):
+        """The reference entry (volume_renderer.py:192-303): explicit sample points instead of a camera.
+        pts (b h w N 3) or (b hw N 3); rays_d / viewdirs (b h w 3) | (b hw 3); z_vals (b h w N) | (b hw N); near / far
+        (b 1 1); styles (b, D+1, style_dim) -> rgb_map (.., 3), feature_map (.., C), sdf (.., N, 1), mask (.., 2),
+        xyz (.., 3), eikonal_term (None).  Runs the same fused kernel in its explicit-geometry instantiation;
+        `N_samples_forward` (a memory bound of the reference) is accepted and ignored."""
+        if return_eikonal:
+            raise NotImplementedError("eikonal term needs double backward (training-only)")
+        B = pts.shape[0]
+        lead = pts.shape[:-2]
+        N = pts.shape[-2]
+        D, H = self.N_layers_renderer, self.hidden_dim
+        dev = pts.device
+        p = pts.float().reshape(B, -1, N, 3).contiguous()
+        R = p.shape[1]
+        d = rays_d.float().reshape(B, R, 3).contiguous()
+        v = viewdirs.float().reshape(B, R, 3).contiguous()
+        z = z_vals.float().reshape(B, R, N).contiguous()
+        net = self.network
+        packed, layer_bias = self._derived_buffers()
+        styles_buf, film, tab = self._film_table(B, dev)
+        styles_buf.copy_(styles)
+        tab.run(B)
+        n_chunks = max(1, min(N, hip.nerf_suggest_chunks(B, max(1, int(R ** 0.5)), N)))
+        part = torch.empty(n_chunks, B, H + 8, R, device=dev)
+        sdf = torch.empty(B, R, N, device=dev)
+        hip.nerf_render(near_=near.float().reshape(B).contiguous(), far_=far.float().reshape(B).contiguous(),
+                        w_first=net.pts_linears[0].weight, packed=packed, w_view=net.views_linears.weight, film=film,
+                        layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
+                        b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
+                        B=B, img_size=1, n_samples=N, hidden=H, depth=D, static_viewdirs=0, n_chunks=n_chunks, part=part,
+                        sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R)
+        features, thumb, xyz, mask = hip.nerf_finish(part, n_chunks, B, 1, H, n_rays=R)
+        to_rays = lambda t: t.view(B, t.shape[1], R).transpose(1, 2).reshape(*lead, t.shape[1]).contiguous()
+        return to_rays(thumb), to_rays(features), sdf.view(*lead, N, 1), to_rays(mask), to_rays(xyz), None

@@ -141,10 +141,16 @@ typedef struct cips3d_nerf_params {
   int32_t B, img_size, n_samples, hidden, depth;
   int32_t static_viewdirs;
   int32_t n_chunks;         /* sample chunks per ray (partials per ray) */
-  int32_t pad_;
+  int32_t n_rays;           /* 0: R = img_size^2 rays generated from the camera; > 0: explicit-geometry mode with R = n_rays */
   /* outputs */
   float* part;              /* [n_chunks, B, H+8, R] partial composites (see nerf.hip) */
   float* sdf;               /* [B, R, n_samples] or NULL */
+  /* explicit-geometry mode = the reference's VolumeFeatureRenderer.forward(pts, rays_d, viewdirs, z_vals, ...)
+   * (cips3d/volume_renderer.py:192-303): all four or none; cam_poses / focals / perturb_u are then unused */
+  const float* x_pts;       /* [B, R, n_samples, 3] un-normalised sample points */
+  const float* x_rays_d;    /* [B, R, 3] */
+  const float* x_viewdirs;  /* [B, R, 3] (already normalised) */
+  const float* x_z_vals;    /* [B, R, n_samples] */
 } cips3d_nerf_params;
 
 /* Chunk count the render kernel wants for (B, n_samples): enough workgroups to fill the chip. */
@@ -159,6 +165,9 @@ int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream);
  *   features [B,H,R] (channel-major = NCHW), thumb_rgb [B,3,R], xyz [B,3,R], mask [B,2,R]. */
 int cips3d_nerf_finish(const float* part, int n_chunks, int B, int img_size, int hidden,
                        float* features, float* thumb_rgb, float* xyz, float* mask, void* stream);
+/* the same for an arbitrary ray count per view (explicit-geometry mode): outputs are [B, C, n_rays] */
+int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, int hidden, float* features,
+                            float* thumb_rgb, float* xyz, float* mask, void* stream);
 
 /* ------------------------------------------------------------------ decoder */
 
@@ -312,6 +321,32 @@ int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_for
 /* sizeof() of the two structs as the library sees them (layout check for foreign-language bindings) */
 int64_t cips3d_sizeof_plan(void);
 int64_t cips3d_sizeof_io(void);
+
+/* ------------------------------------------------------------------ stand-alone renderer steps
+ * The fused kernel does these in registers; as separate entry points they give every method of the reference's `Render`
+ * class (cips3d/nerf_utils.py:11-338) a callable counterpart with the reference's tensor layouts. */
+/* Render.get_rays_in_world (:18-66): rays_o / rays_d / viewdirs [B,S,S,3] */
+int cips3d_rays_in_world(const float* cam_poses, const float* focals, int img_size, int static_viewdirs, int B,
+                         float* rays_o, float* rays_d, float* viewdirs, void* stream);
+/* Render.get_z_vals, offset-sampling branch (:69-121): z [B,R,N]; perturb_u [B,R] per-ray uniform or NULL */
+int cips3d_z_vals(const float* near_, const float* far_, const float* perturb_u, int B, int R, int N, float* z, void* stream);
+/* Render.get_points (+ Render.normalize_points when pts_normalized != NULL) (:124-170): [B,R,N,3]; either output may be NULL */
+int cips3d_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* near_, const float* far_, int B,
+                      int R, int N, float* pts, float* pts_normalized, void* stream);
+/* Render.volume_integration, with_sdf branch (:231-338): rgb [n_rays,N,3], sdf [n_rays,N], features [n_rays,N,C] or NULL,
+ * z_vals [n_rays,N], rays_d [n_rays,3], pts [n_rays,N,3] -> rgb_map [n_rays,3], feature_map [n_rays,C], xyz [n_rays,3],
+ * mask [n_rays,2] = (last weight, -|xyz|).  N <= 256, C % 4 == 0. */
+int cips3d_volume_integration(const float* rgb, const float* sdf, const float* features, const float* z_vals,
+                              const float* rays_d, const float* pts, const float* sigmoid_beta, int64_t n_rays, int N, int C,
+                              float* rgb_map, float* feature_map, float* xyz, float* mask, void* stream);
+
+/* Dense layer over a point-major tensor x [n_points, in] -> y [n_points, out] for the per-point module forwards of the
+ * reference when they are called directly (LinearLayer / FiLMSiren, cips3d/volume_renderer.py:15-85):
+ *   mode 0: y = out_scale * (x W^T + bias) + out_shift
+ *   mode 1: y = sin(gamma * (x W^T + bias) + beta), film = [B][2][out] (gamma, beta), batch = point / points_per_batch */
+int cips3d_points_linear(const float* x, const float* W, const float* bias, const float* film, int64_t n_points,
+                         int64_t points_per_batch, int in_dim, int out_dim, int mode, float out_scale, float out_shift,
+                         float* y, void* stream);
 
 /* ------------------------------------------------------------------ backward of the path
  * The flip-inversion loop (reference models/projector_v10.py:211-277,1058-1216) calls loss.backward() through

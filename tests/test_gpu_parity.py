@@ -393,3 +393,124 @@ def test_rgb_to_uint8():
     assert y.dtype == torch.uint8 and y.shape == x.shape
     assert int((y.int() - ref.int()).abs().max()) <= 1     # ties may round differently by one ulp of the product
     assert float((y != ref).float().mean()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ Render.* stand-alone steps
+def test_render_class_vs_oracle():
+    """nerf_utils.Render.{get_rays_in_world,get_z_vals,get_points,normalize_points,prepare_nerf_inputs} vs the oracle."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    g = torch.Generator().manual_seed(4)
+    B, S, N = 3, 12, 7
+    cam = O.camera_params(torch.tensor([[0.3, 0.1], [-0.9, -0.2], [0.0, 0.4]]), S, 9, 0.12)
+    for static in (False, True):
+        ro, rd, vd = O.rays_in_world(cam[1], S, cam[0], static)
+        o, d, v = Render.get_rays_in_world(cu(cam[1]), S, cu(cam[0]), static_viewdirs=static)
+        assert o.shape == (B, S, S, 3)
+        assert maxdiff(o.cpu(), ro) < 1e-6 and maxdiff(d.cpu(), rd) < 1e-6 and maxdiff(v.cpu(), vd) < 1e-6
+    u = torch.rand(B, S, S, 1, generator=g)
+    for pu in (None, u):
+        zr = O.z_vals(cam[2], cam[3], B, S, S, N, pu)
+        z = Render.get_z_vals(cu(cam[2]), cu(cam[3]), d, N, perturb=pu is not None, perturb_u=None if pu is None else cu(pu))
+        assert z.shape == (B, S, S, N) and maxdiff(z.cpu(), zr) < 2e-7
+    z = Render.get_z_vals(cu(cam[2]), cu(cam[3]), d, N, perturb=True)          # RNG site: one uniform per ray
+    lo = O.z_vals(cam[2], cam[3], B, S, S, N, torch.zeros(B, S, S, 1))
+    hi = O.z_vals(cam[2], cam[3], B, S, S, N, torch.ones(B, S, S, 1))
+    assert bool((z.cpu() >= lo - 1e-6).all()) and bool((z.cpu() <= hi + 1e-6).all())
+    pr = O.ray_points(ro, rd, zr)
+    pts = Render.get_points(o, d, cu(zr))
+    assert pts.shape == (B, S, S, N, 3) and maxdiff(pts.cpu(), pr) < 1e-6
+    assert maxdiff(Render.normalize_points(pts, cu(cam[2]), cu(cam[3])).cpu(), O.normalize_points(pr, cam[2], cam[3])) < 1e-5
+    p2, d2, v2, z2 = Render.prepare_nerf_inputs(cu(cam[1]), S, cu(cam[0]), cu(cam[2]), cu(cam[3]), N, perturb=True,
+                                                static_viewdirs=True, perturb_u=cu(u))
+    assert maxdiff(p2.cpu(), O.ray_points(ro, rd, O.z_vals(cam[2], cam[3], B, S, S, N, u))) < 1e-6
+    assert maxdiff(v2.cpu(), vd) < 1e-6
+
+
+@pytest.mark.parametrize("n,N,C", [(37, 6, 32), (130, 24, 256), (5, 1, 8)])
+def test_volume_integration_vs_oracle(n, N, C):
+    from cips_3dplusplus_amd.nerf_utils import Render
+    g = torch.Generator().manual_seed(n + N)
+    rgb, sdf, feat = torch.randn(2, n, N, 3, generator=g), 0.3 * torch.randn(2, n, N, 1, generator=g), \
+        torch.randn(2, n, N, C, generator=g)
+    z = torch.sort(torch.rand(2, n, N, generator=g) * 0.24 + 0.88, dim=-1).values
+    rays_d, pts = torch.randn(2, n, 3, generator=g), torch.randn(2, n, N, 3, generator=g)
+    beta = torch.tensor([0.1])
+    ref = O.volume_integration(rgb, sdf, feat, z, rays_d, pts, beta)
+    out = Render.volume_integration(cu(rgb), cu(sdf), cu(feat), cu(z), cu(rays_d), cu(pts), sigmoid_beta=cu(beta))
+    assert out[4] is None
+    for a, b, name in zip((out[0], out[1], out[2], out[3]), ref, ("rgb_map", "feature_map", "xyz", "mask")):
+        assert a.shape == b.shape, name
+        assert maxdiff(a.cpu(), b) < 2e-5 * max(1.0, float(b.abs().max())), name
+    out = Render.volume_integration(cu(rgb), cu(sdf), None, cu(z), cu(rays_d), cu(pts), sigmoid_beta=0.1)
+    assert out[1] is None and maxdiff(out[0].cpu(), ref[0]) < 2e-5
+
+
+@pytest.mark.parametrize("hidden,D,R,N", [(32, 2, 50, 5), (256, 2, 64, 6), (32, 3, 129, 8)])
+def test_renderer_explicit_points_entry_vs_oracle(hidden, D, R, N):
+    """VolumeFeatureRenderer.forward(pts, rays_d, viewdirs, z_vals, near, far, styles): the reference entry with
+    caller-made geometry (arbitrary ray count, rays that come from no camera)."""
+    cfg = configs.tiny_G_cfg(32, D, 1) if hidden == 32 else configs.ffhq_G_cfg(256, D)
+    G = pkg.build_generator(cfg, DEV, seed=2)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(R)
+    B = 2
+    S_dim = cfg["mapping_renderer_cfg"]["style_dim"]
+    rays_o = 0.2 * torch.randn(B, R, 3, generator=g) + torch.tensor([0.0, 0.0, 1.0])
+    rays_d = torch.randn(B, R, 3, generator=g) * 0.3 + torch.tensor([0.0, 0.0, -1.0])
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    z = torch.sort(torch.rand(B, R, N, generator=g) * 0.24 + 0.88, dim=-1).values
+    pts = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+    near, far = torch.full((B, 1, 1), 0.88), torch.full((B, 1, 1), 1.12)
+    styles = 0.5 * torch.randn(B, D + 1, S_dim, generator=g)
+    ref = O.renderer_forward(sd, "renderer", pts, rays_d, viewdirs, z, near, far, styles, D)   # rgb, feat, sdf, mask, xyz
+    out = G.renderer(cu(pts), cu(rays_d), cu(viewdirs), cu(z), cu(near), cu(far), styles=cu(styles))
+    assert out[5] is None
+    tol = 1e-4 if hidden == 256 else 3e-5
+    for a, b, name in zip(out[:5], ref, ("rgb_map", "feature_map", "sdf", "mask", "xyz")):
+        assert a.shape == b.shape, (name, a.shape, b.shape)
+        assert maxdiff(a.cpu(), b) < tol * max(1.0, float(b.abs().max())), name
+    # (b, h, w, ...) input layout
+    if R == 64:
+        o4 = G.renderer(cu(pts).view(B, 8, 8, N, 3), cu(rays_d).view(B, 8, 8, 3), cu(viewdirs).view(B, 8, 8, 3),
+                        cu(z).view(B, 8, 8, N), cu(near), cu(far), styles=cu(styles))
+        assert o4[1].shape == (B, 8, 8, hidden) and torch.equal(o4[1].reshape(B, R, hidden), out[1])
+
+
+def test_per_point_module_forwards_vs_oracle():
+    """FiLMSiren.forward / LinearLayer.forward on point tensors / SirenGenerator.points_forward / run_network, and the
+    piecewise pipeline of the reference (prepare_nerf_inputs -> normalize -> run_network -> volume_integration) against the
+    oracle and against the fused kernel."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    cfg = configs.tiny_G_cfg(32, 3, 1)
+    G = pkg.build_generator(cfg, DEV, seed=6)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    net = G.renderer.network
+    g = torch.Generator().manual_seed(12)
+    B, S, N, D = 2, 6, 5, 3
+    styles = 0.5 * torch.randn(B, D + 1, 32, generator=g)
+    x3 = torch.randn(B, S * S, N, 3, generator=g)
+    # one FiLM layer, K = 3 / 32 / 35 (first, hidden, view)
+    y = net.pts_linears[0](cu(x3), cu(styles[:, 0]))
+    assert maxdiff(y.cpu(), O.film_siren(sd, "renderer.network.pts_linears.0", x3, styles[:, 0])) < 2e-5
+    xh = torch.randn(B, S, S, N, 32, generator=g)
+    y = net.pts_linears[1](cu(xh), cu(styles[:, 1]))
+    assert y.shape == (B, S, S, N, 32)
+    assert maxdiff(y.cpu(), O.film_siren(sd, "renderer.network.pts_linears.1", xh, styles[:, 1])) < 2e-5
+    xv = torch.randn(B, S * S, N, 35, generator=g)
+    y = net.views_linears(cu(xv), cu(styles[:, -1]))
+    assert maxdiff(y.cpu(), O.film_siren(sd, "renderer.network.views_linears", xv, styles[:, -1])) < 2e-5
+    s1 = net.sigma_linear(cu(xh))
+    assert s1.shape == (B, S, S, N, 1) and maxdiff(s1.cpu(), O._affine(sd, "renderer.network.sigma_linear", xh)) < 1e-5
+    # whole per-point network
+    cam = O.camera_params(torch.tensor([[0.2, 0.1], [-0.5, 0.0]]), S, 6, 0.12)
+    pts, rays_d, viewdirs, z = Render.prepare_nerf_inputs(cu(cam[1]), S, cu(cam[0]), cu(cam[2]), cu(cam[3]), N, perturb=False)
+    ptsn = Render.normalize_points(pts, cu(cam[2]), cu(cam[3]))
+    rgb, sdf, feat = G.renderer.run_network(ptsn, viewdirs, styles=cu(styles))
+    ref = O.siren_points(sd, "renderer.network", ptsn.cpu(), viewdirs.cpu(), styles, D)
+    for a, b, name in zip((rgb, sdf, feat), ref, ("rgb", "sdf", "feat")):
+        assert a.shape == b.shape and maxdiff(a.cpu(), b) < 5e-5 * max(1.0, float(b.abs().max())), name
+    piece = Render.volume_integration(rgb, sdf, feat, z, rays_d, pts, sigmoid_beta=G.renderer.sigmoid_beta)
+    fused = G.renderer(pts, rays_d, viewdirs, z, cu(cam[2]), cu(cam[3]), styles=cu(styles))
+    for a, b, name in ((piece[0], fused[0], "rgb_map"), (piece[1], fused[1], "feature_map"), (piece[2], fused[4], "xyz"),
+                       (piece[3], fused[3], "mask")):
+        assert a.shape == b.shape and maxdiff(a, b) < 5e-5 * max(1.0, float(b.abs().max())), name
