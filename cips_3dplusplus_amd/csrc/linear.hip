@@ -126,7 +126,27 @@ __global__ void __launch_bounds__(256) linear_table_kernel(const cips3d_linear_d
   }
 }
 
+// PixelNorm as its own op (models/model_v3.py:32-37): one wave per row
+__global__ void __launch_bounds__(256) pixel_norm_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  const float* xr = x + (int64_t)row * C;
+  float s = 0.f;
+  for (int i = lane; i < C; i += 64) s = fmaf(xr[i], xr[i], s);
+  s = wave_sum(s);
+  const float r = rsqrtf(s / (float)C + 1e-8f);
+  for (int i = lane; i < C; i += 64) y[(int64_t)row * C + i] = xr[i] * r;
+}
+
 }  // namespace
+
+extern "C" int cips3d_pixel_norm(const float* x, float* y, int B, int C, void* stream) {
+  if (!x || !y || B < 0 || C <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(pixel_norm_kernel, dim3(ceil_div(B, 4)), dim3(256), 0, as_stream(stream), x, y, B, C);
+  return cips3d_launch_status();
+}
 
 extern "C" int cips3d_linear(const float* x, int64_t x_stride, const float* W, const float* bias, float* out,
                              int64_t out_stride, int B, int in_dim, int out_dim, float w_scale, float b_scale,

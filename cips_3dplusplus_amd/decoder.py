@@ -22,8 +22,14 @@ from . import hip, op
 class PixelNorm(nn.Module):
     """model_v3.py:32-37.  On the mapping path it is folded into the first EqualLinear launch."""
 
+    @torch.no_grad()
     def forward(self, input):
-        raise NotImplementedError("PixelNorm is fused into the first style_decoder layer (cips3d_linear pixelnorm=1)")
+        x = input.float().contiguous()
+        out = torch.empty_like(x)
+        lib = hip._lib.load()
+        hip.check(lib.cips3d_pixel_norm(hip.dev_ptr(x, "input"), hip.dev_ptr(out), x.shape[0], x.shape[1], hip.stream_ptr()),
+                  "cips3d_pixel_norm")
+        return out
 
 
 class MappingLinear(nn.Module):

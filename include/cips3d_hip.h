@@ -80,6 +80,10 @@ int cips3d_linear(const float* x, int64_t x_stride, const float* W, const float*
                   float out_scale, float out_shift, const float* trunc_mean, float trunc_psi,
                   int out_repeat, int64_t out_repeat_stride, void* stream);
 
+/* PixelNorm on its own (models/model_v3.py:32-37): y[b] = x[b] * rsqrt(mean(x[b]^2) + 1e-8).  The generator's mapping
+ * path folds it into its first cips3d_linear (pixelnorm = 1); this entry serves `G.style_decoder(z)` called as a module. */
+int cips3d_pixel_norm(const float* x, float* y, int B, int C, void* stream);
+
 /* A table of independent dense layers evaluated in ONE launch (FiLM gamma/beta heads and the
  * decoder's per-layer style modulations).  The table itself lives in device memory. */
 typedef struct cips3d_linear_desc {

@@ -514,3 +514,26 @@ def test_per_point_module_forwards_vs_oracle():
     for a, b, name in ((piece[0], fused[0], "rgb_map"), (piece[1], fused[1], "feature_map"), (piece[2], fused[4], "xyz"),
                        (piece[3], fused[3], "mask")):
         assert a.shape == b.shape and maxdiff(a, b) < 5e-5 * max(1.0, float(b.abs().max())), name
+
+
+def test_mapping_modules_callable_like_the_reference():
+    """`G.style(z)` / `G.style_decoder(z)` as plain module calls (projector_v10.py:313-315,351-353 computes the W means this
+    way with 10 000 rows), `get_ws`, `mapping_networks` with truncation."""
+    cfg = configs.tiny_G_cfg(32, 2, 1)
+    G = pkg.build_generator(cfg, DEV, seed=4)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(300, 32, generator=g)
+    wr = G.style(cu(z))
+    wd = G.style_decoder(cu(z))
+    ref_r = O.mapping_renderer(sd, cfg, z)[:, 0]
+    ref_d = O.mapping_decoder(sd, cfg, z)[:, 0]
+    assert maxdiff(wr.cpu(), ref_r) < 2e-5 and maxdiff(wd.cpu(), ref_d) < 2e-5
+    mr, md = wr.mean(0, keepdim=True), wd.mean(0, keepdim=True)
+    G.style_render_mean, G.style_decoder_mean = mr, md
+    z2 = [cu(torch.randn(2, 32, generator=g)), cu(torch.randn(2, 32, generator=g))]
+    s_r, s_d = G.mapping_networks(zs=z2, truncation=0.6, inject_index=None)
+    assert maxdiff(s_r.cpu(), O.mapping_renderer(sd, cfg, z2[0].cpu(), 0.6, mr.cpu())) < 2e-5
+    assert maxdiff(s_d.cpu(), O.mapping_decoder(sd, cfg, z2[1].cpu(), 0.6, md.cpu())) < 2e-5
+    assert s_r.shape == (2, 3, 32) and s_d.shape == (2, G.decoder.n_latent, 32)
+    assert G.z_dim == 32 and G.N_layers_renderer == 2 and "decoder" in G.module_name_list and "style" in G.module_name_list
