@@ -537,3 +537,35 @@ def test_mapping_modules_callable_like_the_reference():
     assert maxdiff(s_d.cpu(), O.mapping_decoder(sd, cfg, z2[1].cpu(), 0.6, md.cpu())) < 2e-5
     assert s_r.shape == (2, 3, 32) and s_d.shape == (2, G.decoder.n_latent, 32)
     assert G.z_dim == 32 and G.N_layers_renderer == 2 and "decoder" in G.module_name_list and "style" in G.module_name_list
+
+
+def test_forward_is_graph_capturable():
+    """cips3d_generator_forward neither allocates nor synchronises: the whole forward can be captured into a HIP graph and
+    replayed bit-identically (the path is GPU-bound, so this is a property, not a speed-up: DESIGN.md section 6)."""
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=9)
+    e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.tensor([[0.2, -0.1]], device=DEV))
+    zs = [torch.randn(1, 32, device=DEV), torch.randn(1, 32, device=DEV)]
+    nb = G.create_noise_bufs(8, DEV)
+    u = torch.rand(1, 8, 8, 1, device=DEV)
+
+    def fwd():
+        return G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, noise_bufs=nb, perturb_u=u,
+                 nerf_cfg=dict(N_samples=6, perturb=True, static_viewdirs=False))["rgb"]
+
+    ref = fwd().clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = fwd()
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    zs[0].add_(0.5)                      # new latent in the captured input buffer -> replay renders the new view
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, fwd())
