@@ -21,6 +21,24 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// bf16 compute mode of the GEMMs (BASELINE config 3: decoder in bf16 with fp32 accumulate).  Storage and data movement
+// stay fp32 and identical; only the fragments are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and fed to
+// v_mfma_f32_16x16x16_bf16.  The packed A layout gives lane (o, q) the channels 16kq + 4e + q (e = 0..3) of row o and the
+// B-fragment reads give lane (n, q) the same channels of pixel n, so element e of both operands is MFMA k = 4q + e:
+// one bf16 MFMA replaces the four fp32 MFMAs of a k-group.
+// Two-wide vector conversions compile to one v_cvt_pk_bf16_f32 per pair AND keep the compiler's hazard bookkeeping
+// (an inline-asm cvt feeding an MFMA loses the required wait state between the VALU write and the MFMA read: measured
+// wrong results).
+__device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a3) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const bf16x2_t lo = __builtin_convertvector(f32x2_t{a0, a1}, bf16x2_t);
+  const bf16x2_t hi = __builtin_convertvector(f32x2_t{a2, a3}, bf16x2_t);
+  return __builtin_bit_cast(s16x4, u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
+}
 
 // ------------------------------------------------------------------------------------------------
 // weight modulation.  One wave per (b, o).
@@ -94,13 +112,14 @@ struct GemmArgs {
   const float* x; const float* wmp; float* out;
   int B, Cin, Cout; int64_t HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
+  int bf16;
 };
 
 // s_waitcnt immediate that waits until at most n vector-memory operations of this wave are outstanding
 // (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt / lgkmcnt fields left at "no wait")
 __device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
-template <int WM, int WGM, int WGN, int BK, int NS>
+template <int WM, int WGM, int WGN, int BK, int NS, bool BF16 = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) {
   constexpr int NW = WGM * WGN;               // waves per workgroup: 8 = two per SIMD, so one wave's DMA issue,
                                               // waits and fragment reads run under the partner's MFMAs
@@ -215,6 +234,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
         bfr[kq][j4] = *reinterpret_cast<const f32x4*>(sB + (kq * 16 + j4 * 4 + q) * BN);
     }
     __builtin_amdgcn_sched_barrier(0);   // hipcc otherwise sinks each read back in front of its first MFMA
+    if (BF16) {
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq) {
+        s16x4 ah[WM], bh[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ah[i] = pack_bf16(afr[kq][i][0], afr[kq][i][1], afr[kq][i][2], afr[kq][i][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bh[c] = pack_bf16(bfr[kq][0][c], bfr[kq][1][c], bfr[kq][2][c], bfr[kq][3][c]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[c], acc[i][c], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
@@ -224,6 +258,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], bfr[kq][j4][c], acc[i][c], 0, 0, 0);
+    }
     // all LDS reads of this stage retired before the slot can be refilled after the next barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -250,7 +285,8 @@ template <int WM, int WGM, int WGN, int BK, int NS>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
   dim3 grid((unsigned)ceil_div<int64_t>(a.HW, BN), (unsigned)(a.Cout / BM), (unsigned)a.B);
-  hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -574,11 +610,12 @@ struct FusedArgs {
   const float* wm2; const float* noise2; int64_t nbs2; const float* nw2; const float* bias2; float* out2;
   const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
+  int bf16;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
@@ -718,7 +755,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       patch_load(st + 1);
     }
 #pragma unroll
-    for (int kq = 0; kq < KQ; ++kq)
+    for (int kq = 0; kq < KQ; ++kq) {
+      if (BF16) {
+        f32x4 b4[4];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) b4[j4] = *reinterpret_cast<const f32x4*>(cur + (kq * 16 + j4 * 4 + q) * BN);
+        s16x4 ah[WM], bh[4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) ah[i] = pack_bf16(afr[kq][i][0], afr[kq][i][1], afr[kq][i][2], afr[kq][i][3]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bh[c] = pack_bf16(b4[0][c], b4[1][c], b4[2][c], b4[3][c]);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[c], acc[i][c], 0, 0, 0);
+      } else {
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(cur + (kq * 16 + j4 * 4 + q) * BN);
@@ -728,6 +780,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           for (int c = 0; c < 4; ++c)
             acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], b4[c], acc[i][c], 0, 0, 0);
       }
+      }
+    }
     if (NBUF > 1 && st + 1 < NSTAGE) patch_store(st + 1, sB + ((st + 1) & 1) * BK * BN);
     __syncthreads();
   }
@@ -806,7 +860,8 @@ template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -842,11 +897,13 @@ extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, in
                                  int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                                  const float* bias, void* stream) {
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : 0;
+  epilogue &= ~CIPS3D_GEMM_BF16;
   if (epilogue != 0 && epilogue != 1) return CIPS3D_E_BADARG;
   if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
-  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias};
+  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16};
   hipStream_t st = as_stream(stream);
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
   if (dbg_cfg && Cout % 128 == 0) {
@@ -906,7 +963,7 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
-              wm_rgb, bias_rgb, skip, skip_up, rgb, B, H, W};
+              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0};
   hipStream_t st = as_stream(stream);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment

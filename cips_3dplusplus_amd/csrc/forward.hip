@@ -26,6 +26,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
     return CIPS3D_E_BADARG;
   const int B = P.B;
   const int D = P.nerf.depth;
+  const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
   const bool trunc = IO.mean_r && IO.mean_d && IO.trunc_psi < 1.f;
 
   // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot.  The two chains
@@ -105,12 +106,12 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const bool stage_last = li + 2 == P.n_dec_layers - 1;
         const float* nz2 = L2.noise_index >= 0 ? IO.noise[L2.noise_index] : nullptr;
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
-        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0, nullptr, nullptr,
-                              stream));
+        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
+                              nullptr, stream));
         float* out2 = stage_last ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
         TRY(cips3d_fused_up_conv(P.y_lo, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                 L3.wm, L3.bias, skip, 1, rgb, B, L.Cout, L.H, L.W, stream));
+                                 L3.wm, L3.bias, skip, 1 | gemm_flag, rgb, B, L.Cout, L.H, L.W, stream));
         x = out2;
         act_i ^= 1;
         skip = rgb;
@@ -119,10 +120,11 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         continue;
       }
       if (L.kind == 0) {
-        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 1, nz, nbs, L.noise_w, L.bias, stream));
-      } else {
-        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0, nullptr, nullptr,
+        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias,
                               stream));
+      } else {
+        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
+                              nullptr, stream));
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));
       }
       x = out;

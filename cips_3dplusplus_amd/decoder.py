@@ -182,6 +182,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection(project=project_noise)
         self.bias = nn.Parameter(torch.zeros(1, out_channel, 1, 1))     # present in checkpoints, unused in forward
         self.activate = op.FusedLeakyReLU(out_channel)
+        self.bf16 = False        # bf16 compute mode of the GEMM (Decoder.set_precision)
 
     def forward(self, input, style, noise=None, transform=None, mesh_path=None, wm=None):
         B, Cin, H, W = input.shape
@@ -196,9 +197,10 @@ class StyledConv(nn.Module):
             if wm is None:
                 wm = conv.modulated_weight(style, packed=True)
             if conv.upsample:
-                y_lo = hip.modconv1x1(x, wm, conv.out_channel, epilogue=0)
+                y_lo = hip.modconv1x1(x, wm, conv.out_channel, epilogue=0, bf16=self.bf16)
                 return hip.up2_fir_act(y_lo, conv.blur.kernel, noise, nw, self.activate.bias)
-            return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias)
+            return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias,
+                                  bf16=self.bf16)
         y = conv(x, style)
         return hip.noise_bias_act(y, noise, nw, self.activate.bias)
 
@@ -239,6 +241,7 @@ class Decoder(nn.Module):
                          1024: 16 * m}
         self.create_synthesis()
         self._tables = {}
+        self.bf16 = False
 
     def create_synthesis(self):
         self.log_in_size = int(math.log(self.size_start, 2))
@@ -262,6 +265,16 @@ class Decoder(nn.Module):
             self.to_rgbs.append(ToRGB(cout, self.style_dim, upsample=up))
         self.num_layers = (self.log_size - self.log_in_size) * 2 + 1
         self.n_latent = (self.log_size - self.log_in_size) * 2 + 2
+
+    def set_precision(self, precision):
+        """"fp32" (default, exact) or "bf16": every StyledConv GEMM rounds its operands to bf16 and accumulates in fp32
+        (BASELINE config 3).  Storage, ToRGB, FIR and the epilogues stay fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(precision)
+        self.bf16 = precision == "bf16"
+        for m in [self.conv1] + list(self.convs):
+            m.bf16 = self.bf16
+        return self
 
     def create_noise_bufs(self, start_size, device):
         """model_v3.py:639-666."""

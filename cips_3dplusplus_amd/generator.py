@@ -121,6 +121,13 @@ class Generator(nn.Module):
         return (w_r[:, None, :].repeat(1, self.N_layers_renderer + 1, 1),
                 w_d[:, None, :].repeat(1, self.decoder.n_latent, 1))
 
+    def set_decoder_precision(self, precision):
+        """"fp32" (default: exact fp32 MFMA, the reference's precision) or "bf16" (BASELINE config 3: the decoder's GEMM
+        operands are rounded to bf16 in registers, fp32 accumulate; the NeRF renderer stays fp32 because gamma ~ 30
+        re-amplifies input error in every SIREN layer)."""
+        self.decoder.set_precision(precision)
+        return self
+
     # ---------------------------------------------------------------- noise
     def create_noise_bufs(self, start_size, device):
         return self.decoder.create_noise_bufs(start_size=start_size, device=device)

@@ -250,7 +250,10 @@ def modconv1x1_supported(Cin, Cout, HW):
     return bool(_lib.load().cips3d_modconv1x1_supported(Cin, Cout, HW))
 
 
-def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None):
+GEMM_BF16 = 0x100      # CIPS3D_GEMM_BF16: bf16 compute mode of the decoder GEMMs (BASELINE config 3)
+
+
+def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False):
     lib = _lib.load()
     B, Cin, H, W = x.shape
     if out is None:
@@ -260,7 +263,8 @@ def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=No
         nb = H * W
     if noise is not None and noise.shape[0] not in (1, B):
         raise RuntimeError("noise batch must be 1 or B")
-    check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H * W, epilogue,
+    check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H * W,
+                                epilogue | (GEMM_BF16 if bf16 else 0),
                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
                                 stream_ptr()), "cips3d_modconv1x1")
     return out
@@ -311,7 +315,7 @@ def modconv_kxk(x, wm, Cout, k, transpose2=False):
 
 
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
-                  skip=None, skip_up=True, want_out2=True):
+                  skip=None, skip_up=True, want_out2=True, bf16=False):
     """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv)."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
@@ -326,7 +330,8 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
                                    dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
                                    dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
                                    dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
-                                   dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True), int(bool(skip_up)),
+                                   dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
+                                   int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0),
                                    dev_ptr(rgb, "rgb", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv")
     return out2, rgb
 

@@ -25,7 +25,7 @@ class GeneratorPlan(C.Structure):
                 ("n_dec_layers", C.c_int32),
                 ("map_r_w", C.c_void_p * MAX_MAP), ("map_r_b", C.c_void_p * MAX_MAP),
                 ("map_d_w", C.c_void_p * MAX_MAP), ("map_d_b", C.c_void_p * MAX_MAP),
-                ("map_d_in", C.c_int32 * MAX_MAP), ("map_d_lr_mul", C.c_float), ("pad0_", C.c_int32),
+                ("map_d_in", C.c_int32 * MAX_MAP), ("map_d_lr_mul", C.c_float), ("decoder_bf16", C.c_int32),
                 ("lat", C.c_void_p * 4), ("styles_r", C.c_void_p), ("styles_d", C.c_void_p),
                 ("film_table", C.c_void_p), ("film_n", C.c_int32), ("film_rows", C.c_int32),
                 ("mod_table", C.c_void_p), ("mod_n", C.c_int32), ("mod_rows", C.c_int32),
@@ -69,6 +69,7 @@ class ForwardPlan:
         p.B, p.z_dim = B, G.z_dim
         p.style_dim_r, p.style_dim_d = ren.style_dim, dec.style_dim
         p.n_latent = dec.n_latent
+        p.decoder_bf16 = int(bool(getattr(dec, "bf16", False)))
 
         # ---- mapping networks
         map_r = list(G.style)
@@ -212,7 +213,8 @@ class ForwardPlan:
         """Plans hold raw pointers: they die with any re-allocation of a parameter (.to(), load of new storage)
         and with a change of the NeRF weights the packed copy was made from."""
         ren = G.renderer
-        return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key())
+        return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key(),
+                bool(getattr(G.decoder, "bf16", False)))
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
             events=None):

@@ -183,6 +183,10 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  *   wm[b][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
 #define CIPS3D_MOD_DEMODULATE 1
 #define CIPS3D_MOD_PACKED     2
+/* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
+ * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
+ * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
+#define CIPS3D_GEMM_BF16      0x100
 int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
                             int B, int Cout, int Cin, int ksq, float scale, int flags,
                             void* stream);
@@ -283,7 +287,7 @@ typedef struct cips3d_generator_plan {
   const float* map_d_w[CIPS3D_MAX_MAP_LAYERS]; const float* map_d_b[CIPS3D_MAX_MAP_LAYERS];
   int32_t map_d_in[CIPS3D_MAX_MAP_LAYERS];
   float map_d_lr_mul;
-  int32_t pad0_;
+  int32_t decoder_bf16;          /* != 0: every decoder GEMM runs in the bf16 compute mode (CIPS3D_GEMM_BF16) */
   float* lat[4];                 /* ping-pong [B, max(style_dim_r, style_dim_d, z_dim)]: [0,1] renderer chain, [2,3] decoder chain */
   float* styles_r;               /* [B, D+1, style_dim_r] */
   float* styles_d;               /* [B, n_latent, style_dim_d] */

@@ -246,8 +246,14 @@ def mean_latents(sd, cfg, z_render, z_decoder):
 
 
 # --------------------------------------------------------------------------- decoder
-def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False):
-    """models/model_v3.py:218-314 (plain and up-sampling branches)."""
+def _bf16_round(t):
+    """round-to-nearest-even to bfloat16 and back (the operand rounding of the bf16 compute mode, BASELINE config 3)"""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False, bf16_gemm=False):
+    """models/model_v3.py:218-314 (plain and up-sampling branches).  bf16_gemm (not in the reference): both GEMM operands
+    are rounded to bf16, accumulation stays fp32 -- the restatement the bf16 decoder mode is checked against."""
     B, Cin, H, W = x.shape
     weight = sd[prefix + ".weight"]            # (1, Cout, Cin, k, k)
     Cout, k = weight.shape[1], weight.shape[3]
@@ -255,6 +261,8 @@ def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False):
     w = (1 / math.sqrt(Cin * k * k)) * weight * s
     if demodulate:
         w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).view(B, Cout, 1, 1, 1)
+    if bf16_gemm:
+        w, x = _bf16_round(w), _bf16_round(x)
     if upsample:
         wt = w.transpose(1, 2).reshape(B * Cin, Cout, k, k)
         y = F.conv_transpose2d(x.reshape(1, B * Cin, H, W), wt, padding=0, stride=2, groups=B)
@@ -265,9 +273,9 @@ def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False):
     return y.view(B, Cout, y.shape[2], y.shape[3])
 
 
-def styled_conv(sd, prefix, x, style, noise, upsample=False):
+def styled_conv(sd, prefix, x, style, noise, upsample=False, bf16_gemm=False):
     """models/model_v3.py:418-454 with NoiseInjection :327-341 (explicit noise only)."""
-    y = modulated_conv2d(sd, prefix + ".conv", x, style, demodulate=True, upsample=upsample)
+    y = modulated_conv2d(sd, prefix + ".conv", x, style, demodulate=True, upsample=upsample, bf16_gemm=bf16_gemm)
     y = y + sd[prefix + ".noise.weight"] * noise
     return fused_leaky_relu(y, sd[prefix + ".activate.bias"])
 
@@ -307,16 +315,16 @@ def create_noise_bufs(cfg, start_size, generator=None, dtype=torch.float32):
     return [torch.randn(1, 1, s, s, generator=generator, dtype=dtype) for s in sizes]
 
 
-def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder"):
+def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder", bf16_gemm=False):
     """models/model_v3.py:592-637."""
     lay = decoder_layout(cfg)
-    out = styled_conv(sd, prefix + ".conv1", features, styles[:, 0], noise[0])
+    out = styled_conv(sd, prefix + ".conv1", features, styles[:, 0], noise[0], bf16_gemm=bf16_gemm)
     skip = to_rgb(sd, prefix + ".to_rgb1", out, styles[:, 1])
     i = 1
     for s, st in enumerate(lay["stages"]):
         out = styled_conv(sd, f"{prefix}.convs.{2 * s}", out, styles[:, i], noise[2 * s + 1],
-                          upsample=st["up"])
-        out = styled_conv(sd, f"{prefix}.convs.{2 * s + 1}", out, styles[:, i + 1], noise[2 * s + 2])
+                          upsample=st["up"], bf16_gemm=bf16_gemm)
+        out = styled_conv(sd, f"{prefix}.convs.{2 * s + 1}", out, styles[:, i + 1], noise[2 * s + 2], bf16_gemm=bf16_gemm)
         skip = to_rgb(sd, f"{prefix}.to_rgbs.{s}", out, styles[:, i + 2], skip, upsample=st["up"])
         i += 2
     return skip
@@ -326,7 +334,7 @@ def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder"):
 def generator_forward(sd, cfg, zs, cam_poses, focals, img_size, near, far, nerf_cfg,
                       noise_bufs, truncation=1.0, style_render=None, style_decoder=None,
                       style_render_mean=None, style_decoder_mean=None, perturb_u=None,
-                      return_sdf=False, return_xyz=False):
+                      return_sdf=False, return_xyz=False, bf16_decoder=False):
     """models/model_v3.py:875-1042 for the inference configuration (explicit noise_bufs,
     injected perturbation/means).  Returns the ret_maps dict."""
     D = cfg["renderer_cfg"]["N_layers_renderer"]
@@ -345,7 +353,7 @@ def generator_forward(sd, cfg, zs, cam_poses, focals, img_size, near, far, nerf_
         z.reshape(B, R, N), near, far, style_render, D)
     to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S).contiguous()
     features = to_img(feat)
-    rgb = decoder_forward(sd, cfg, features, style_decoder, noise_bufs)
+    rgb = decoder_forward(sd, cfg, features, style_decoder, noise_bufs, bf16_gemm=bf16_decoder)
     mask_img = to_img(mask)
     return {
         "rgb": rgb, "thumb_rgb": to_img(thumb), "style_decoder": None, "eikonal_term": None,

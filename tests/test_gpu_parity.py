@@ -569,3 +569,81 @@ def test_forward_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, fwd())
+
+
+# ------------------------------------------------------------------------------------------ bf16 decoder mode (config 3)
+def _psnr(a, b):
+    mse = float(((a - b) ** 2).mean())
+    peak = float(b.max() - b.min())
+    return 10.0 * math.log10(peak * peak / max(mse, 1e-30))
+
+
+@pytest.mark.parametrize("cin,cout,hw,up,B", [(32, 32, 16, False, 2), (64, 32, 16, True, 1), (512, 512, 8, False, 1),
+                                               (128, 128, 16, True, 2), (256, 256, 16, True, 1)])
+def test_bf16_gemm_mode_vs_bf16_oracle(cin, cout, hw, up, B):
+    """bf16 compute mode of StyledConv (operands rounded to bf16, fp32 accumulate) vs the oracle with the same rounding."""
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(cin + cout + hw + 1)
+    sc = dec.StyledConv(cin, cout, 1, 64, upsample=up)
+    sc.noise.weight.data.fill_(0.3)
+    sc.activate.bias.data = torch.randn(cout) * 0.2
+    sd = {"m." + k: v.clone() for k, v in sc.state_dict().items()}
+    x, st = torch.randn(B, cin, hw, hw), torch.randn(B, 64)
+    ho = 2 * hw if up else hw
+    nz = torch.randn(1, 1, ho, ho)
+    sc = sc.to(DEV)
+    sc.bf16 = True
+    y = sc(cu(x), cu(st), noise=cu(nz))
+    ref16 = O.styled_conv(sd, "m", x, st, nz, upsample=up, bf16_gemm=True)
+    ref32 = O.styled_conv(sd, "m", x, st, nz, upsample=up)
+    scale = max(1.0, float(ref32.abs().max()))
+    # the device rounds the MODULATED weight to bf16 exactly like the oracle; what differs is the fp32 accumulation order
+    # and, rarely, one-ulp ties of the fp32 modulation feeding the rounding
+    assert maxdiff(y.cpu(), ref16) < 2e-3 * scale
+    assert float((y.cpu() - ref16).abs().mean()) < 5e-5 * scale
+    assert maxdiff(y.cpu(), ref32) > 1e-4 * scale           # and it is really the reduced-precision path
+    assert _psnr(y.cpu(), ref32) > 40.0
+
+
+def test_bf16_decoder_generator(golden):
+    """Config 3 semantics on the tiny and the 256^2 generator: planned path == per-op path; close to the bf16 oracle;
+    PSNR against the exact fp32 result reported and bounded."""
+    fx, tag = golden("tiny_generator"), "h32_d2"
+    cfg = _tiny_cfg(tag)
+    G = pkg.build_generator(cfg, DEV, state_dict=fx.sub(f"{tag}.sd."))
+    zs = [cu(fx[f"{tag}.z0"]), cu(fx[f"{tag}.z1"])]
+    e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=cu(fx[f"{tag}.locs"]))
+    nb = [cu(fx[f"{tag}.noise{i}"]) for i in range(G.decoder.num_layers)]
+    ncfg = dict(N_samples=6, perturb=False, static_viewdirs=False)
+    r32 = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, noise_bufs=nb, nerf_cfg=ncfg)["rgb"].clone()
+    G.set_decoder_precision("bf16")
+    r16 = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, noise_bufs=nb, nerf_cfg=ncfg)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    cam = O.camera_params(fx[f"{tag}.locs"], 8, 6, 0.12)
+    ref16 = O.generator_forward(sd, cfg, [z.cpu() for z in zs], cam[0], cam[1], 8, cam[2], cam[3], ncfg,
+                                [b.cpu() for b in nb], bf16_decoder=True)
+    scale = float(ref16["rgb"].abs().max())
+    assert maxdiff(r16["rgb"].cpu(), ref16["rgb"]) < 5e-3 * scale
+    assert maxdiff(r16["thumb_rgb"].cpu(), ref16["thumb_rgb"]) < 1e-5          # the renderer stays fp32
+    assert _psnr(r16["rgb"], r32) > 35.0 and not torch.equal(r16["rgb"], r32)
+    # planned (one-call) path and per-op path agree in bf16 mode too
+    s_r, s_d = G.mapping_networks(zs=zs, truncation=1, inject_index=None)
+    thumb, feats, _, _, _ = G.renderer.render(e, f, n, fa, s_r, 8, 6)
+    per_op = G.decoder(features=feats, styles=s_d, noise=nb)
+    assert maxdiff(per_op, r16["rgb"]) < 2e-4 * scale
+    G.set_decoder_precision("fp32")
+    assert torch.equal(G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, noise_bufs=nb, nerf_cfg=ncfg)["rgb"], r32)
+    # release-size generator, batch 4 (the configuration of BASELINE config 3 at 256^2 to keep the test short)
+    G2 = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=1)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    z2 = [torch.randn(4, 256, device=DEV, generator=g), torch.randn(4, 256, device=DEV, generator=g)]
+    e2, f2, n2, fa2, _ = Camera.generate_camera_params(64, DEV, locations=0.3 * torch.randn(4, 2, device=DEV, generator=g))
+    nb2 = G2.create_noise_bufs(64, DEV)
+    kw = dict(zs=z2, cam_poses=e2, focals=f2, img_size=64, near=n2, far=fa2, noise_bufs=nb2,
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    a32 = G2(**kw)["rgb"].clone()
+    G2.set_decoder_precision("bf16")
+    a16 = G2(**kw)["rgb"]
+    psnr = _psnr(a16, a32)
+    print(f"bf16 decoder vs fp32, 256^2 B=4: PSNR {psnr:.1f} dB, max-abs {maxdiff(a16, a32):.3e} on range {float(a32.abs().max()):.2f}")
+    assert psnr > 35.0
