@@ -647,3 +647,30 @@ def test_bf16_decoder_generator(golden):
     psnr = _psnr(a16, a32)
     print(f"bf16 decoder vs fp32, 256^2 B=4: PSNR {psnr:.1f} dB, max-abs {maxdiff(a16, a32):.3e} on range {float(a32.abs().max()):.2f}")
     assert psnr > 35.0
+
+
+@pytest.mark.parametrize("hidden,D,S,N,B,static,perturb,trunc", [
+    (64, 2, 8, 5, 3, False, True, 1.0), (128, 3, 12, 7, 1, True, False, 0.7), (32, 1, 16, 1, 2, False, False, 1.0),
+    (64, 4, 20, 9, 2, True, True, 0.5), (32, 2, 4, 24, 5, False, True, 1.0)])
+def test_generator_shape_sweep_vs_oracle(hidden, D, S, N, B, static, perturb, trunc):
+    """Widths / depths / ray-grid sizes / sample counts / batch sizes off the released recipe: whole generator vs oracle."""
+    cfg = configs.tiny_G_cfg(hidden, D, 1)
+    G = pkg.build_generator(cfg, DEV, seed=hidden + D)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(S * N + B)
+    zs = [torch.randn(B, hidden, generator=g), torch.randn(B, hidden, generator=g)]
+    locs = torch.stack([0.5 * torch.randn(B, generator=g), 0.2 * torch.randn(B, generator=g)], 1)
+    nb = [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(S, "cpu")]
+    mr, md = 0.2 * torch.randn(1, hidden, generator=g), 0.2 * torch.randn(1, 32, generator=g)
+    u = torch.rand(B, S, S, 1, generator=g) if perturb else None
+    ncfg = dict(N_samples=N, perturb=perturb, static_viewdirs=static)
+    G.style_render_mean, G.style_decoder_mean = cu(mr), cu(md)
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=cu(locs), fov_ang=12, dist_radius=0.3)
+    r = G(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=S, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+          truncation=trunc, nerf_cfg=ncfg, return_sdf=True, return_xyz=True, perturb_u=None if u is None else cu(u))
+    cam = O.camera_params(locs, S, 12, 0.3)
+    ref = O.generator_forward(sd, cfg, zs, cam[0], cam[1], S, cam[2], cam[3], ncfg, nb, truncation=trunc,
+                              style_render_mean=mr, style_decoder_mean=md, perturb_u=u, return_sdf=True, return_xyz=True)
+    for k in ("rgb", "thumb_rgb", "sdf", "xyz", "mask", "depth"):
+        assert r[k].shape == ref[k].shape, k
+        assert maxdiff(r[k].cpu(), ref[k]) < 2e-4 * max(1.0, float(ref[k].abs().max())), k
