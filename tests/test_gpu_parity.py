@@ -674,3 +674,45 @@ def test_generator_shape_sweep_vs_oracle(hidden, D, S, N, B, static, perturb, tr
     for k in ("rgb", "thumb_rgb", "sdf", "xyz", "mask", "depth"):
         assert r[k].shape == ref[k].shape, k
         assert maxdiff(r[k].cpu(), ref[k]) < 2e-4 * max(1.0, float(ref[k].abs().max())), k
+
+
+def test_full_size_properties():
+    """Size-independent properties at the BASELINE size (1024^2, D=2, N=24), where the oracle is too slow to run inside the
+    GPU suite: batch elements are independent (B=2 == two B=1 calls to fp32 round-off), repeat runs are bitwise identical,
+    compositing weights are probabilities, thumb_rgb is inside [-1,1], depth = -|xyz|, and the same forward through the
+    per-op path agrees with the one-call plan."""
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=0)
+    g = torch.Generator(device=DEV).manual_seed(77)
+    zs = [torch.randn(2, 256, device=DEV, generator=g), torch.randn(2, 256, device=DEV, generator=g)]
+    locs = torch.tensor([[0.3, 0.1], [-0.5, -0.1]], device=DEV)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=locs)
+    nb = G.create_noise_bufs(64, DEV)
+    u = torch.rand(2, 64, 64, 1, device=DEV, generator=g)
+    ncfg = dict(N_samples=24, perturb=True, static_viewdirs=False)
+
+    def run(sl):
+        return G(zs=[z[sl] for z in zs], cam_poses=e[sl], focals=f[sl], img_size=64, near=n[sl], far=fa[sl], noise_bufs=nb,
+                 perturb_u=u[sl], nerf_cfg=ncfg, return_xyz=True, return_sdf=True)
+
+    both = {k: v.clone() for k, v in run(slice(0, 2)).items() if v is not None}
+    again = run(slice(0, 2))
+    for k in both:
+        assert torch.equal(both[k], again[k]), f"{k}: repeat run differs"
+    for b in range(2):
+        one = run(slice(b, b + 1))
+        for k in both:
+            # not bitwise: the sample-chunk count of the NeRF kernel depends on B (fewer chunks per ray at larger B), so the
+            # chunk partials are combined in a different association
+            assert maxdiff(both[k][b:b + 1], one[k]) < 2e-5 * max(1.0, float(one[k].abs().max())), \
+                f"{k}: batch element {b} depends on its neighbours"
+    assert float(both["thumb_rgb"].abs().max()) <= 1.0 + 1e-6
+    assert float(both["mask"].min()) >= 0.0 and float(both["mask"].max()) <= 1.0 + 1e-6
+    assert maxdiff(both["depth"], -both["xyz"].norm(dim=1, keepdim=True)) < 1e-6
+    assert both["rgb"].shape == (2, 3, 1024, 1024) and bool(torch.isfinite(both["rgb"]).all())
+    # per-op path (module by module, python launches) == one-call planned path
+    s_r, s_d = G.mapping_networks(zs=zs, truncation=1, inject_index=None)
+    thumb, feats, _, _, _ = G.renderer.render(e, f, n, fa, s_r, 64, 24, perturb_u=u)
+    assert torch.equal(thumb, both["thumb_rgb"])
+    rgb_ops = G.decoder(features=feats, styles=s_d, noise=nb)
+    assert maxdiff(rgb_ops, both["rgb"]) < 2e-4 * float(both["rgb"].abs().max())
