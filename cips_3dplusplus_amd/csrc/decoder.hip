@@ -51,17 +51,26 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
                                              float scale, int demod, int packed, int lane) {
   const int len = Cin * ksq;
   const float* w = W + (int64_t)o * len;
+  constexpr int MAXV = 16;                 // rows up to 1024 values stay in registers between the two passes
+  const bool cached = len <= 64 * MAXV;
+  float vreg[MAXV];
   float ss = 0.f;
-  if (demod) {
+  if (cached) {
+#pragma unroll
+    for (int m = 0; m < MAXV; ++m) {
+      const int e = lane + 64 * m;
+      vreg[m] = e < len ? (scale * w[e]) * sb[e / ksq] : 0.f;
+      ss = fmaf(vreg[m], vreg[m], ss);
+    }
+  } else if (demod) {
     for (int e = lane; e < len; e += 64) {
       const float v = (scale * w[e]) * sb[e / ksq];
       ss = fmaf(v, v, ss);
     }
-    ss = wave_sum(ss);
   }
+  if (demod) ss = wave_sum(ss);
   const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
-  for (int e = lane; e < len; e += 64) {
-    float v = (scale * w[e]) * sb[e / ksq];
+  auto put = [&](int e, float v) {
     if (demod) v *= d;
     if (packed) {
       const int i = e;  // ksq == 1
@@ -70,6 +79,15 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
     } else {
       wm[((int64_t)b * Cout + o) * len + e] = v;
     }
+  };
+  if (cached) {
+#pragma unroll
+    for (int m = 0; m < MAXV; ++m) {
+      const int e = lane + 64 * m;
+      if (e < len) put(e, vreg[m]);
+    }
+  } else {
+    for (int e = lane; e < len; e += 64) put(e, (scale * w[e]) * sb[e / ksq]);
   }
 }
 

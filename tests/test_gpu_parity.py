@@ -23,6 +23,11 @@ def cu(t):
     return t.to(DEV).contiguous()
 
 
+def _dec_mod():
+    import cips_3dplusplus_amd.decoder as dec      # lazily exported sub-module: import it explicitly
+    return dec
+
+
 # ------------------------------------------------------------------------------------------ ops
 def test_upfirdn2d_golden(golden):
     fx = golden("ops")
@@ -199,7 +204,7 @@ def test_modulated_conv_golden_generality_path(golden):
     for tag in fx["mc_names"]:
         tag = str(tag)
         k = 3 if tag.startswith("k3") else 1
-        m = pkg.decoder.ModulatedConv2d(8, 12, k, 16, demodulate="_d1" in tag, upsample="_up1" in tag)
+        m = _dec_mod().ModulatedConv2d(8, 12, k, 16, demodulate="_d1" in tag, upsample="_up1" in tag)
         m.load_state_dict(fx.sub(f"mc_{tag}.sd."))
         m = m.to(DEV)
         y = m(cu(fx[f"mc_{tag}.x"]), cu(fx[f"mc_{tag}.style"]))
