@@ -121,6 +121,24 @@ class Generator(nn.Module):
         return (w_r[:, None, :].repeat(1, self.N_layers_renderer + 1, 1),
                 w_d[:, None, :].repeat(1, self.decoder.n_latent, 1))
 
+    @torch.no_grad()
+    def rays_forward(self, N_rays_forward, pts, rays_d, viewdirs, z_vals, near, far, style_render, style_decoder=None,
+                     noise_bufs=None, eikonal_reg=False, cam_poses=None, project_noise=False, mesh_path=None,
+                     renderer_detach=None, N_samples_forward=None):
+        """model_v3.py:1201-1268: the NeRF half for caller-made geometry, pts (b, hw, n, 3) etc. -> thumb_rgb (b, hw, 3),
+        sdf (b, hw, n, 1), mask (b, hw, 2), xyz (b, hw, 3), features (b, hw, C), eikonal_term.  The reference loops over
+        `N_rays_forward`-sized ray chunks to bound memory; the fused kernel keeps no per-point activations, so one call
+        covers all rays (the chunk size is accepted and ignored)."""
+        if eikonal_reg:
+            raise NotImplementedError("eikonal_reg needs double backward (training-only)")
+        thumb, feats, sdf, mask, xyz, eik = self.renderer(pts=pts, rays_d=rays_d, viewdirs=viewdirs, z_vals=z_vals, near=near,
+                                                          far=far, styles=style_render)
+        return thumb, sdf, mask, xyz, feats, eik
+
+    def init_forward(self, *args, **kwargs):
+        raise NotImplementedError("init_forward / mlp_init_pass is the SDF sphere-initialisation pass of training "
+                                  "(model_v3.py:1449-1470, volume_renderer.py: mlp_init_pass): out of scope")
+
     def set_decoder_precision(self, precision):
         """"fp32" (default: exact fp32 MFMA, the reference's precision) or "bf16" (BASELINE config 3: the decoder's GEMM
         operands are rounded to bf16 in registers, fp32 accumulate; the NeRF renderer stays fp32 because gamma ~ 30

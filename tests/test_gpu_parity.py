@@ -721,3 +721,26 @@ def test_full_size_properties():
     assert torch.equal(thumb, both["thumb_rgb"])
     rgb_ops = G.decoder(features=feats, styles=s_d, noise=nb)
     assert maxdiff(rgb_ops, both["rgb"]) < 2e-4 * float(both["rgb"].abs().max())
+
+
+def test_generator_rays_forward_equals_fused_forward():
+    """Generator.rays_forward on Render.prepare_nerf_inputs == the NeRF half of Generator.forward (the reference's own
+    decomposition, model_v3.py:941-1003)."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=8)
+    B, S, N = 2, 8, 6
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.3, 0.1], [-0.2, 0.0]], device=DEV))
+    zs = [torch.randn(B, 32, device=DEV), torch.randn(B, 32, device=DEV)]
+    nb = G.create_noise_bufs(S, DEV)
+    full = G(zs=zs, cam_poses=e, focals=f, img_size=S, near=n, far=fa, noise_bufs=nb, return_xyz=True, return_sdf=True,
+             nerf_cfg=dict(N_samples=N, perturb=False, static_viewdirs=False))
+    s_r, s_d = G.mapping_networks(zs=zs, truncation=1, inject_index=None)
+    pts, rays_d, viewdirs, z = Render.prepare_nerf_inputs(f, S, e, n, fa, N, perturb=False)
+    flat = lambda t: t.reshape(B, S * S, *t.shape[3:])
+    thumb, sdf, mask, xyz, feats, eik = G.rays_forward(None, flat(pts), flat(rays_d), flat(viewdirs), flat(z), n, fa, s_r)
+    img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S)
+    assert eik is None and feats.shape == (B, S * S, 32)
+    assert maxdiff(img(thumb), full["thumb_rgb"]) < 2e-6 and maxdiff(img(xyz), full["xyz"]) < 2e-6
+    assert maxdiff(img(mask)[:, 0:1], full["mask"]) < 2e-6 and maxdiff(sdf.view(B, S, S, N, 1), full["sdf"]) < 2e-6
+    rgb = G.decoder(features=img(feats).contiguous(), styles=s_d, noise=nb)
+    assert maxdiff(rgb, full["rgb"]) < 1e-4
