@@ -139,36 +139,66 @@ __global__ void __launch_bounds__(256) film_kernel(float* __restrict__ acc, floa
 }
 
 // ---------------------------------------------------------------------------------------------- channel heads
-// out[b][r][p] = sum_c Wm[r*rs + c*cs] x[b][c][p] + bias[r]   (nr <= 4).  grid (ceil(P/256), B)
+// out[b][r][p] = sum_c Wm[r*rs + c*cs] x[b][c][p] + bias[r]   (nr <= 4).  grid (ceil(P/1024), B); a thread owns 4 consecutive
+// points (16-byte loads, 8 channels in flight)
 __global__ void __launch_bounds__(256) heads_kernel(const float* __restrict__ x, const float* __restrict__ Wm, int rs, int cs,
                                                     const float* __restrict__ bias, int nr, int H, int64_t P,
                                                     float* __restrict__ out) {
   const int b = blockIdx.y;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* xp = x + (int64_t)b * H * P + p;
-  for (int c = 0; c < H; ++c) {
-    const float v = xp[(int64_t)c * P];
+  const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p >= P) return;                                   // P % 4 == 0
+  float4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (r < nr) acc[r] = fmaf(Wm[r * rs + c * cs], v, acc[r]);
+  for (int r = 0; r < 4; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float* xp = x + (int64_t)b * H * P + p;
+  for (int c0 = 0; c0 < H; c0 += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = c0 + u < H ? *reinterpret_cast<const float4*>(xp + (int64_t)(c0 + u) * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (c0 + u >= H) break;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < nr) {
+          const float w = Wm[r * rs + (c0 + u) * cs];
+          acc[r].x = fmaf(w, v[u].x, acc[r].x); acc[r].y = fmaf(w, v[u].y, acc[r].y);
+          acc[r].z = fmaf(w, v[u].z, acc[r].z); acc[r].w = fmaf(w, v[u].w, acc[r].w);
+        }
+    }
   }
-  for (int r = 0; r < nr; ++r) out[((int64_t)b * nr + r) * P + p] = acc[r] + (bias ? bias[r] : 0.f);
+  for (int r = 0; r < nr; ++r) {
+    const float bs = bias ? bias[r] : 0.f;
+    *reinterpret_cast<float4*>(out + ((int64_t)b * nr + r) * P + p) =
+        make_float4(acc[r].x + bs, acc[r].y + bs, acc[r].z + bs, acc[r].w + bs);
+  }
 }
 
-// g[b][p] = sum_c dF[b][c][ray] f[b][c][p]
+// g[b][p] = sum_c dF[b][c][ray] f[b][c][p];  4 consecutive points (= 4 consecutive rays of one sample) per thread
 __global__ void __launch_bounds__(256) dot_kernel(const float* __restrict__ dF, const float* __restrict__ f, int H, int R,
                                                   int64_t P, float* __restrict__ g) {
   const int b = blockIdx.y;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t p = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (p >= P) return;
-  const int ray = (int)(p % R);
+  const int ray = (int)(p % R);                       // R % 4 == 0: the four points share the sample
   const float* fp = f + (int64_t)b * H * P + p;
   const float* dp = dF + (int64_t)b * H * R + ray;
-  float acc = 0.f;
-  for (int c = 0; c < H; ++c) acc = fmaf(dp[(int64_t)c * R], fp[(int64_t)c * P], acc);
-  g[(int64_t)b * P + p] = acc;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c0 = 0; c0 < H; c0 += 4) {
+    float4 a[4], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = c0 + u < H;
+      a[u] = ok ? *reinterpret_cast<const float4*>(fp + (int64_t)(c0 + u) * P) : make_float4(0.f, 0.f, 0.f, 0.f);
+      d[u] = ok ? *reinterpret_cast<const float4*>(dp + (int64_t)(c0 + u) * R) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      acc.x = fmaf(d[u].x, a[u].x, acc.x); acc.y = fmaf(d[u].y, a[u].y, acc.y);
+      acc.z = fmaf(d[u].z, a[u].z, acc.z); acc.w = fmaf(d[u].w, a[u].w, acc.w);
+    }
+  }
+  *reinterpret_cast<float4*>(g + (int64_t)b * P + p) = acc;
 }
 
 // ---------------------------------------------------------------------------------------------- compositing fwd + bwd
@@ -426,7 +456,8 @@ extern "C" int cips3d_nerf_bwd_heads(const float* x, const float* Wm, int row_st
                                      int n_rows, int B, int H, int64_t P, float* out, void* stream) {
   if (!x || !Wm || !out || n_rows < 1 || n_rows > 4 || B < 0 || H <= 0 || P <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
-  hipLaunchKernelGGL(heads_kernel, dim3((unsigned)ceil_div<int64_t>(P, 256), (unsigned)B), dim3(256), 0, as_stream(stream), x, Wm,
+  if (P % 4) return CIPS3D_E_UNSUPP;
+  hipLaunchKernelGGL(heads_kernel, dim3((unsigned)ceil_div<int64_t>(P, 1024), (unsigned)B), dim3(256), 0, as_stream(stream), x, Wm,
                      row_stride, col_stride, bias, n_rows, H, P, out);
   return cips3d_launch_status();
 }
@@ -434,7 +465,8 @@ extern "C" int cips3d_nerf_bwd_heads(const float* x, const float* Wm, int row_st
 extern "C" int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H, int R, int64_t P, float* g, void* stream) {
   if (!dF || !f || !g || B < 0 || H <= 0 || R <= 0 || P <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
-  hipLaunchKernelGGL(dot_kernel, dim3((unsigned)ceil_div<int64_t>(P, 256), (unsigned)B), dim3(256), 0, as_stream(stream), dF, f, H,
+  if (P % 4 || R % 4) return CIPS3D_E_UNSUPP;
+  hipLaunchKernelGGL(dot_kernel, dim3((unsigned)ceil_div<int64_t>(P, 1024), (unsigned)B), dim3(256), 0, as_stream(stream), dF, f, H,
                      R, P, g);
   return cips3d_launch_status();
 }
