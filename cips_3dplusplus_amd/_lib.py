@@ -75,6 +75,9 @@ _SIGS = {
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
     "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
                                   c_f32p, C.c_void_p]),
+    "cips3d_modconv1x1_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
+                                        c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "cips3d_torgb_reduce": (c_int, [c_f32p, c_int, C.c_void_p, c_int, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),
     "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32p, c_f32p,
                                    C.c_void_p]),
     "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),

@@ -131,6 +131,10 @@ struct GemmArgs {
   int B, Cin, Cout; int64_t HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
   int bf16;
+  // optional: the ToRGB that follows this conv, folded into the epilogue.  Every workgroup writes the partial sums of its
+  // BM output rows, rgb_part[blockIdx.y][b][3][HW]; cips3d_torgb_reduce adds the row blocks (and layers) in a fixed order.
+  const float* rgb_w;       // plain [B][3][Cout] modulated ToRGB weights (no demodulation)
+  float* rgb_part;          // [Cout/BM][B][3][HW]
 };
 
 // s_waitcnt immediate that waits until at most n vector-memory operations of this wave are outstanding
@@ -282,8 +286,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   }
 
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4*q + r][pixel ncol + c]
-  if (ncol >= HW) return;
+  const bool col_ok = ncol < HW;
+  if (!col_ok && !a.rgb_part) return;
   float* ob = a.out + (int64_t)b * a.Cout * HW + ncol;
+  float prgb[3][4];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int obase = m0 + (wm_i * WM + i) * 16 + 4 * q;
@@ -294,8 +304,48 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c]) + bias4[i][r]) * 1.41421356237309515f;
       }
-      *reinterpret_cast<f32x4*>(ob + (int64_t)(obase + r) * HW) = v;
+      if (col_ok) *reinterpret_cast<f32x4*>(ob + (int64_t)(obase + r) * HW) = v;
+      if (a.rgb_part) {
+        const float* w = a.rgb_w + (int64_t)b * 3 * a.Cout + obase + r;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+          const float wc = w[ch * a.Cout];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) prgb[ch][c] = fmaf(wc, v[c], prgb[ch][c]);
+        }
+      }
     }
+  }
+  if (!a.rgb_part) return;
+  // ---- ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows through
+  // LDS (the ring is free: every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = prgb[ch][c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      prgb[ch][c] = v;
+    }
+  __syncthreads();
+  float* s_red = lds;                                   // [WGM][3][BN]
+  const int nloc = wn_i * 64 + jn * 4;
+  if (q == 0) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) = f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+  }
+  __syncthreads();
+  if (wm_i == 0 && q < 3 && col_ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < WGM; ++m) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(s_red + (m * 3 + q) * BN + nloc);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] += t[c];
+    }
+    *reinterpret_cast<f32x4*>(a.rgb_part + (((int64_t)blockIdx.y * a.B + b) * 3 + q) * HW + ncol) = v;
   }
 }
 
@@ -914,6 +964,24 @@ extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
 extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
                                  int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                                  const float* bias, void* stream) {
+  return cips3d_modconv1x1_torgb(x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, nullptr,
+                                 nullptr, nullptr, stream);
+}
+
+// rows per workgroup of the tile configuration cips3d_modconv1x1 picks for this Cout (= row blocks of the ToRGB partials)
+static int gemm_block_rows(int Cout) {
+  if (Cout >= 256 && Cout % 64 == 0) return 64;
+  if (Cout == 128) return 128;
+  if (Cout == 64) return 64;
+  return 32;
+}
+
+extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
+                                       int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
+                                       const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks,
+                                       void* stream) {
+  if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
+  if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / gemm_block_rows(Cout) : 0;
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : 0;
   epilogue &= ~CIPS3D_GEMM_BF16;
@@ -921,10 +989,10 @@ extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, in
   if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
-  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16};
+  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, rgb_w, rgb_part};
   hipStream_t st = as_stream(stream);
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
-  if (dbg_cfg && Cout % 128 == 0) {
+  if (dbg_cfg && !rgb_part && Cout % 128 == 0) {      // (the ToRGB fold needs the default tiling: gemm_block_rows)
     switch (dbg_cfg) {
       case 1: return launch_gemm<2, 2, 2, 32, 4>(a, st);    // 64 x 128, 4 waves
       case 2: return launch_gemm<1, 4, 2, 32, 4>(a, st);    // 64 x 128, 8 waves
@@ -991,6 +1059,70 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
     case 256: return launch_fused<256, 2, 8, 1, 2, 64, 2>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
   }
   return CIPS3D_E_UNSUPP;
+}
+
+// out = skip + sum_s part[s] + sum_k bias_k : the fixed-order fold of the ToRGB partial sums written by
+// cips3d_modconv1x1_torgb (slots = layers x row blocks, each [B][3][HW]).  One float4 per thread.
+struct RgbReduceArgs {
+  const float* part; int n_slots; int n_bias; const float* bias[CIPS3D_TORGB_FOLD_MAX]; const float* skip; float* out;
+  int64_t n4, HW4, slot_stride;
+};
+
+// block = 64 float4 positions x 4 slot groups: group g adds slots g, g+4, ... (independent loads in flight), the groups
+// meet in LDS in a fixed order.
+__global__ void __launch_bounds__(256) torgb_reduce_kernel(RgbReduceArgs a) {
+  __shared__ f32x4 s_p[4][64];
+  const int pl = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + pl;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (i < a.n4) {
+    for (int s0 = g; s0 < a.n_slots; s0 += 16) {
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        t[u] = s0 + 4 * u < a.n_slots ? *reinterpret_cast<const f32x4*>(a.part + (s0 + 4 * u) * a.slot_stride + i * 4)
+                                      : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += t[u][c];
+    }
+  }
+  s_p[g][pl] = v;
+  __syncthreads();
+  if (g != 0 || i >= a.n4) return;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const f32x4 t = s_p[k][pl];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += t[c];
+  }
+  const int ch = (int)((i / a.HW4) % 3);
+  float bs = 0.f;
+  for (int k = 0; k < a.n_bias; ++k) bs += a.bias[k][ch];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] += bs;
+  if (a.skip) {
+    const f32x4 sk = *reinterpret_cast<const f32x4*>(a.skip + i * 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] += sk[c];
+  }
+  *reinterpret_cast<f32x4*>(a.out + i * 4) = v;
+}
+
+extern "C" int cips3d_torgb_reduce(const float* part, int n_slots, const float* const* biases, int n_bias, const float* skip,
+                                   float* out, int B, int64_t HW, void* stream) {
+  if (!part || !out || n_slots < 1 || n_bias < 0 || n_bias > CIPS3D_TORGB_FOLD_MAX || (n_bias && !biases) || B < 0 || HW <= 0)
+    return CIPS3D_E_BADARG;
+  if (HW % 4) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  RgbReduceArgs a{};
+  a.part = part; a.n_slots = n_slots; a.n_bias = n_bias;
+  for (int k = 0; k < n_bias; ++k) a.bias[k] = biases[k];
+  a.skip = skip; a.out = out;
+  a.n4 = (int64_t)B * 3 * HW / 4; a.HW4 = HW / 4; a.slot_stride = (int64_t)B * 3 * HW;
+  hipLaunchKernelGGL(torgb_reduce_kernel, dim3((unsigned)ceil_div<int64_t>(a.n4, 64)), dim3(256), 0, as_stream(stream), a);
+  return cips3d_launch_status();
 }
 
 extern "C" int cips3d_torgb(const float* x, const float* wm, const float* bias, const float* skip, int skip_up,

@@ -88,6 +88,18 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const float* x = P.features;
   const float* skip = nullptr;
   int act_i = 0, skip_i = 0;
+  // ToRGB folding: a non-up-sampling ToRGB that follows a StyledConv is computed from that conv's registers (partial sums
+  // per row block, cips3d_modconv1x1_torgb); the slots of consecutive such layers are folded by ONE cips3d_torgb_reduce
+  // when their sum is first needed (the skip chain at an unchanged resolution is a plain sum).
+  int fold_slots = 0, fold_nb = 0, fold_H = 0, fold_W = 0;
+  const float* fold_bias[CIPS3D_TORGB_FOLD_MAX];
+  auto fold_flush = [&](float* dst) -> int {
+    if (fold_slots == 0) return 0;
+    const int rc = cips3d_torgb_reduce(P.rgb_part, fold_slots, fold_bias, fold_nb, skip, dst, B, (int64_t)fold_H * fold_W, stream);
+    skip = dst;
+    fold_slots = fold_nb = 0;
+    return rc;
+  };
   for (int li = 0; li < P.n_dec_layers; ++li) {
     const cips3d_dec_layer& L = P.layers[li];
     const bool last = li == P.n_dec_layers - 1;
@@ -95,6 +107,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       const float* nz = L.noise_index >= 0 ? IO.noise[L.noise_index] : nullptr;
       const int64_t nbs = L.noise_index >= 0 ? IO.noise_bstride[L.noise_index] : 0;
       float* out = P.act[act_i];
+      if (L.kind == 1 && fold_slots) {          // resolution changes: the folded sum becomes the skip of this stage
+        TRY(fold_flush(P.skip[skip_i]));
+        skip_i ^= 1;
+      }
       // up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] with equal widths: low-res GEMM, then ONE fused
       // kernel for FIR + act -> conv2 + act -> ToRGB (+ FIR-upsampled skip); the full-resolution intermediate
       // never reaches HBM and the last stage stores only the image
@@ -120,8 +136,24 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         continue;
       }
       if (L.kind == 0) {
-        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias,
-                              stream));
+        const cips3d_dec_layer* T = li + 1 < P.n_dec_layers ? &P.layers[li + 1] : nullptr;
+        const int64_t hw = (int64_t)L.H * L.W;
+        const bool fold = T && T->kind == 2 && li + 1 != P.n_dec_layers - 1 && T->Cin == L.Cout && hw % 4 == 0 && P.rgb_part &&
+                          fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
+                          (fold_slots == 0 || (fold_H == L.H && fold_W == L.W)) && !gemm_flag;
+        if (fold) {
+          int nblk = 0;
+          TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias, T->wm,
+                                      P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, stream));
+          fold_slots += nblk;
+          fold_bias[fold_nb++] = T->bias;
+          fold_H = L.H; fold_W = L.W;
+          x = out;
+          act_i ^= 1;
+          ++li;                                  // the ToRGB layer is done (its sum is pending in the slots)
+          continue;
+        }
+        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias, stream));
       } else {
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
                               nullptr, stream));
@@ -130,6 +162,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       x = out;
       act_i ^= 1;
     } else if (L.kind == 2 || L.kind == 3) {
+      if (fold_slots) {                          // a ToRGB that could not be folded: settle the pending sum first
+        TRY(fold_flush(P.skip[skip_i]));
+        skip_i ^= 1;
+      }
       float* out = last ? IO.rgb : P.skip[skip_i];
       TRY(cips3d_torgb(x, L.wm, L.bias, skip, L.kind == 3 ? 1 : 0, L.fir, out, B, L.Cin, L.H, L.W, stream));
       skip = out;

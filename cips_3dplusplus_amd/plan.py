@@ -32,7 +32,8 @@ class GeneratorPlan(C.Structure):
                 ("wm_table", C.c_void_p), ("wm_n", C.c_int32), ("wm_rows", C.c_int32),
                 ("nerf", _lib.NerfParams), ("features", C.c_void_p),
                 ("layers", DecLayer * MAX_DEC),
-                ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("skip", C.c_void_p * 2)]
+                ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("skip", C.c_void_p * 2), ("rgb_part", C.c_void_p),
+                ("rgb_part_slots", C.c_int64)]
 
 
 class ForwardIO(C.Structure):
@@ -194,6 +195,14 @@ class ForwardPlan:
         p.act[0], p.act[1] = act[0].data_ptr(), act[1].data_ptr()
         p.y_lo = y_lo.data_ptr()
         p.skip[0], p.skip[1] = skip[0].data_ptr(), skip[1].data_ptr()
+        # ToRGB layers at the input resolution fold into the epilogue of the conv that feeds them (forward.hip): one slot
+        # of [B,3,S,S] per row block per layer
+        n_fold = sum(1 for i, li in enumerate(layer_info) if li["kind"] == 2 and i > 0 and layer_info[i - 1]["kind"] == 0
+                     and li["H"] == img_size)
+        slots = 16 * n_fold
+        rgb_part = torch.empty(max(1, slots) * B * 3 * img_size * img_size, device=dev)
+        p.rgb_part, p.rgb_part_slots = rgb_part.data_ptr(), slots
+        self._keep.append(rgb_part)
 
         self.plan = p
         self.key = self.weights_key(G)

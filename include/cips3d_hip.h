@@ -219,6 +219,21 @@ int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Ci
                       int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
                       const float* noise_w, const float* bias, void* stream);
 
+/* The same GEMM with the ToRGB that FOLLOWS this conv folded into its epilogue (models/model_v3.py:602-632: ToRGB reads
+ * the conv's output): every workgroup also writes the partial sums of its block of output rows,
+ *   rgb_part[row_block][b][r][n] = sum_{o in block} rgb_w[b][r][o] * out[b][o][n]      (rgb_w plain [B,3,Cout])
+ * and *n_row_blocks receives the number of row blocks (slots) written.  cips3d_torgb_reduce folds the slots of one or
+ * several such layers, their biases and the skip image in a FIXED order (deterministic), replacing cips3d_torgb launches
+ * that re-read the activations.  rgb_w == rgb_part == NULL: plain cips3d_modconv1x1. */
+#define CIPS3D_TORGB_FOLD_MAX 8
+int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW, int epilogue,
+                            const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
+                            const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
+/* out[b][r][n] = skip[b][r][n] + sum_{s < n_slots} part[s][b][r][n] + sum_{k < n_bias} biases[k][r]
+ * (part = consecutive slots of [B,3,HW]; biases = HOST array of device pointers to [3]; skip may be NULL) */
+int cips3d_torgb_reduce(const float* part, int n_slots, const float* const* biases, int n_bias, const float* skip, float* out,
+                        int B, int64_t HW, void* stream);
+
 /* 2x FIR up-sampling of a low-resolution conv result fused with the StyledConv epilogue:
  *   u   = upfirdn2d(y_lo, fir, up=2, pad=(2,1))      (fir = outer([1,3,3,1])/64*4, [4,4] device)
  *   out = lrelu(u + noise_w * noise + bias[c], 0.2) * sqrt(2)
@@ -303,6 +318,8 @@ typedef struct cips3d_generator_plan {
   float* act[2];                 /* activation ping-pong, each >= B * max(C*H*W) floats */
   float* y_lo;                   /* low-resolution GEMM result feeding the FIR up-sampler */
   float* skip[2];                /* RGB skip ping-pong, each >= B*3*Hout*Wout floats */
+  float* rgb_part;               /* ToRGB partial-sum slots, each [B,3,H0*W0] at the input resolution (or NULL: no folding) */
+  int64_t rgb_part_slots;        /* capacity in slots */
 } cips3d_generator_plan;
 
 typedef struct cips3d_forward_io {

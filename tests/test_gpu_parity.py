@@ -744,3 +744,41 @@ def test_generator_rays_forward_equals_fused_forward():
     assert maxdiff(img(mask)[:, 0:1], full["mask"]) < 2e-6 and maxdiff(sdf.view(B, S, S, N, 1), full["sdf"]) < 2e-6
     rgb = G.decoder(features=img(feats).contiguous(), styles=s_d, noise=nb)
     assert maxdiff(rgb, full["rgb"]) < 1e-4
+
+
+def test_modconv1x1_torgb_fold_vs_oracle():
+    """GEMM with the following ToRGB folded into its epilogue + the fixed-order reduction == StyledConv then ToRGB."""
+    import ctypes as C
+    from cips_3dplusplus_amd import _lib
+    dec = _dec_mod()
+    torch.manual_seed(31)
+    B, cin, cout, hw = 2, 64, 128, 16
+    sc = dec.StyledConv(cin, cout, 1, 32)
+    sc.noise.weight.data.fill_(0.25)
+    sc.activate.bias.data = torch.randn(cout) * 0.2
+    tr = dec.ToRGB(cout, 32, upsample=False)
+    tr.bias.data = torch.randn(1, 3, 1, 1)
+    sd = {**{"c." + k: v.clone() for k, v in sc.state_dict().items()}, **{"t." + k: v.clone() for k, v in tr.state_dict().items()}}
+    x, st, st2 = torch.randn(B, cin, hw, hw), torch.randn(B, 32), torch.randn(B, 32)
+    nz, skip = torch.randn(1, 1, hw, hw), torch.randn(B, 3, hw, hw)
+    y_ref = O.styled_conv(sd, "c", x, st, nz)
+    rgb_ref = O.to_rgb(sd, "t", y_ref, st2, skip, upsample=False)
+    sc, tr = sc.to(DEV), tr.to(DEV)
+    wm = sc.conv.modulated_weight(cu(st), packed=True)
+    wrgb = tr.conv.modulated_weight(cu(st2), packed=False)
+    lib = _lib.load()
+    out = torch.empty(B, cout, hw, hw, device=DEV)
+    part = torch.empty(16, B, 3, hw, hw, device=DEV)
+    nblk = C.c_int(0)
+    xg, nzg = cu(x), cu(nz)
+    _lib.check(lib.cips3d_modconv1x1_torgb(xg.data_ptr(), wm.data_ptr(), out.data_ptr(), B, cin, cout, hw * hw, 1, nzg.data_ptr(), 0,
+                                           sc.noise.weight.data_ptr(), sc.activate.bias.data_ptr(), wrgb.data_ptr(),
+                                           part.data_ptr(), C.byref(nblk), hip.stream_ptr()), "cips3d_modconv1x1_torgb")
+    assert nblk.value == 1                      # Cout = 128 -> one 128-row block
+    rgb = torch.empty(B, 3, hw, hw, device=DEV)
+    biases = (C.c_void_p * 1)(tr.bias.data_ptr())
+    skg = cu(skip)
+    _lib.check(lib.cips3d_torgb_reduce(part.data_ptr(), nblk.value, biases, 1, skg.data_ptr(), rgb.data_ptr(), B, hw * hw,
+                                       hip.stream_ptr()), "cips3d_torgb_reduce")
+    assert maxdiff(out.cpu(), y_ref) < 3e-5 * max(1.0, float(y_ref.abs().max()))
+    assert maxdiff(rgb.cpu(), rgb_ref) < 5e-5 * max(1.0, float(rgb_ref.abs().max()))
