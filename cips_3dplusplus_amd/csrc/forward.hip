@@ -140,10 +140,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const int64_t hw = (int64_t)L.H * L.W;
         const bool fold = T && T->kind == 2 && li + 1 != P.n_dec_layers - 1 && T->Cin == L.Cout && hw % 4 == 0 && P.rgb_part &&
                           fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
-                          (fold_slots == 0 || (fold_H == L.H && fold_W == L.W)) && !gemm_flag;
+                          (fold_slots == 0 || (fold_H == L.H && fold_W == L.W));
         if (fold) {
           int nblk = 0;
-          TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias, T->wm,
+          TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias, T->wm,
                                       P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, stream));
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;
