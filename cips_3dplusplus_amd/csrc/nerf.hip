@@ -511,6 +511,55 @@ __global__ void __launch_bounds__(256) nerf_finish_kernel(const float* __restric
   }
 }
 
+// the same, four consecutive rays per thread (16-byte loads / stores); R % 4 == 0
+__global__ void __launch_bounds__(256) nerf_finish4_kernel(const float* __restrict__ part, int C, int B, int R, int H,
+                                                           float* __restrict__ features, float* __restrict__ thumb,
+                                                           float* __restrict__ xyz, float* __restrict__ mask) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const int CH = H + 8, R4 = R / 4;
+  const int64_t total = (int64_t)B * (H + 7) * R4;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ray = (int)(i % R4) * 4;
+  const int ch = (int)((i / R4) % (H + 7));
+  const int b = (int)(i / ((int64_t)R4 * (H + 7)));
+  v4 Tp = {1.f, 1.f, 1.f, 1.f}, acc = {0.f, 0.f, 0.f, 0.f};
+  for (int c = 0; c < C; ++c) {
+    const float* pc = part + ((int64_t)(c * B + b) * CH) * R + ray;
+    const v4 v = *reinterpret_cast<const v4*>(pc + (int64_t)ch * R);
+    const v4 t = *reinterpret_cast<const v4*>(pc + (int64_t)(H + 7) * R);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { acc[e] = fmaf(Tp[e], v[e], acc[e]); Tp[e] *= t[e]; }
+  }
+  if (ch < H) {
+    *reinterpret_cast<v4*>(features + ((int64_t)b * H + ch) * R + ray) = acc;
+  } else if (ch < H + 3) {
+    v4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = -1.f + 2.f * acc[e];
+    *reinterpret_cast<v4*>(thumb + ((int64_t)b * 3 + (ch - H)) * R + ray) = o;
+  } else if (ch < H + 6) {
+    *reinterpret_cast<v4*>(xyz + ((int64_t)b * 3 + (ch - H - 3)) * R + ray) = acc;
+  } else {
+    *reinterpret_cast<v4*>(mask + ((int64_t)b * 2 + 0) * R + ray) = acc;
+    v4 Tq = {1.f, 1.f, 1.f, 1.f}, ax = {0.f, 0.f, 0.f, 0.f}, ay = ax, az = ax;
+    for (int c = 0; c < C; ++c) {
+      const float* pc = part + ((int64_t)(c * B + b) * CH) * R + ray;
+      const v4 x4 = *reinterpret_cast<const v4*>(pc + (int64_t)(H + 3) * R), y4 = *reinterpret_cast<const v4*>(pc + (int64_t)(H + 4) * R),
+               z4 = *reinterpret_cast<const v4*>(pc + (int64_t)(H + 5) * R), t = *reinterpret_cast<const v4*>(pc + (int64_t)(H + 7) * R);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ax[e] = fmaf(Tq[e], x4[e], ax[e]); ay[e] = fmaf(Tq[e], y4[e], ay[e]); az[e] = fmaf(Tq[e], z4[e], az[e]);
+        Tq[e] *= t[e];
+      }
+    }
+    v4 d;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = -sqrtf((ax[e] * ax[e] + ay[e] * ay[e]) + az[e] * az[e]);
+    *reinterpret_cast<v4*>(mask + ((int64_t)b * 2 + 1) * R + ray) = d;
+  }
+}
+
 template <int NT, int TPS, bool XG>
 int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
@@ -612,7 +661,14 @@ extern "C" int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, i
   const int R = n_rays;
   const int64_t total = (int64_t)B * (hidden + 7) * R;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(nerf_finish_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, st, part,
-                     n_chunks, B, R, hidden, features, thumb_rgb, xyz, mask);
+  const bool vec = (R % 4 == 0) && (((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(features) |
+                                      reinterpret_cast<uintptr_t>(thumb_rgb) | reinterpret_cast<uintptr_t>(xyz) |
+                                      reinterpret_cast<uintptr_t>(mask)) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL(nerf_finish4_kernel, dim3((unsigned)ceil_div<int64_t>(total / 4, 256)), dim3(256), 0, st, part, n_chunks,
+                       B, R, hidden, features, thumb_rgb, xyz, mask);
+  else
+    hipLaunchKernelGGL(nerf_finish_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, st, part,
+                       n_chunks, B, R, hidden, features, thumb_rgb, xyz, mask);
   return cips3d_launch_status();
 }
