@@ -1001,6 +1001,9 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
       case 5: return launch_gemm<2, 2, 4, 32, 3>(a, st);    // 64 x 256, 8 waves
       case 6: return launch_gemm<1, 8, 1, 32, 4>(a, st);    // 128 x 64, 8 waves
       case 7: return launch_gemm<1, 2, 2, 32, 4>(a, st);    // 32 x 128, 4 waves
+      case 8: return launch_gemm<2, 4, 1, 32, 2>(a, st);    // 128 x 64, 8 waves, 8 accumulator chains per wave
+      case 9: return launch_gemm<2, 4, 1, 32, 3>(a, st);
+      case 10: return launch_gemm<2, 2, 2, 32, 2>(a, st);   // 64 x 128, 4 waves, 8 chains
     }
   }
   if (Cout >= 256 && Cout % 64 == 0) return launch_gemm<1, 4, 2, 32, 2>(a, st);   // 64 x 128 tiles, 8 waves

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for c in 1 2 3 4 5 6 7 8; do
+for c in 0 1 2 3 4 5 6 7 8 9 10; do
   CIPS3D_GEMM_CFG=$c rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/gemm_cfg$c -- python3 tools/run_kernel.py gemm64 --iters 30 > /dev/null 2>&1
   python3 - <<PY
 import csv,glob
