@@ -53,8 +53,8 @@ __global__ void camera_kernel(const float* __restrict__ loc, const float* __rest
 extern "C" int cips3d_camera_params(const float* locations, const float* fov_deg, float fov_deg_scalar,
                                     const float* up, float dist_radius, int img_size, int B, float* extrinsics,
                                     float* focal, float* near_, float* far_, void* stream) {
+  if (B == 0) return 0;                          // empty batch (the tensors may have no storage)
   if (!locations || !extrinsics || !focal || !near_ || !far_ || B < 0 || img_size <= 0) return CIPS3D_E_BADARG;
-  if (B == 0) return 0;
   hipLaunchKernelGGL(camera_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, as_stream(stream), locations, fov_deg,
                      fov_deg_scalar, up, dist_radius, img_size, B, extrinsics, focal, near_, far_);
   return cips3d_launch_status();

@@ -123,6 +123,7 @@ extern "C" int cips3d_upfirdn2d(const float* input, const float* kernel, float* 
                                 int in_h, int in_w, int minor, int kernel_h, int kernel_w, int up_x,
                                 int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0,
                                 int pad_y1, void* stream) {
+  if (major == 0) return 0;                       // empty batch: nothing to do (the tensors may have no storage)
   if (!input || !kernel || !out) return CIPS3D_E_BADARG;
   if (major < 0 || in_h <= 0 || in_w <= 0 || minor <= 0 || kernel_h <= 0 || kernel_w <= 0 ||
       up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)

@@ -782,3 +782,20 @@ def test_modconv1x1_torgb_fold_vs_oracle():
                                        hip.stream_ptr()), "cips3d_torgb_reduce")
     assert maxdiff(out.cpu(), y_ref) < 3e-5 * max(1.0, float(y_ref.abs().max()))
     assert maxdiff(rgb.cpu(), rgb_ref) < 5e-5 * max(1.0, float(rgb_ref.abs().max()))
+
+
+def test_empty_and_degenerate_inputs():
+    """Edge cases at the op boundary: empty batches are legal and launch nothing; single-sample rays; 1x1 images."""
+    k = torch.tensor([[1., 3., 3., 1.]]).t() @ torch.tensor([[1., 3., 3., 1.]]) / 64
+    y = op.fused_leaky_relu(torch.empty(0, 8, 4, 4, device=DEV), torch.zeros(8, device=DEV))
+    assert y.shape == (0, 8, 4, 4)
+    y = op.upfirdn2d(torch.empty(0, 3, 8, 8, device=DEV), cu(k), up=2, pad=(2, 1))
+    assert y.shape == (0, 3, 16, 16)
+    x = torch.randn(2, 3, 1, 1)
+    y = op.upfirdn2d(cu(x), cu(k), up=2, pad=(2, 1))
+    assert maxdiff(y.cpu(), O.upfirdn2d(x, k, 2, 1, (2, 1))) < 1e-6
+    assert hip.rgb_to_uint8(torch.empty(0, 3, 4, 4, device=DEV)).shape == (0, 3, 4, 4)
+    u8 = hip.rgb_to_uint8(torch.tensor([[-2.0, -1.0, 0.0, 0.5, 1.0, 3.0, float("-inf"), 1e-9]], device=DEV))
+    assert u8.cpu().tolist() == [[0, 0, 128, 191, 255, 255, 0, 128]]          # clamp, round half to even on 127.5
+    e, f, n, fa = hip.camera_params(torch.empty(0, 2, device=DEV), 64)
+    assert e.shape == (0, 3, 4) and f.shape == (0, 1, 1)
