@@ -656,7 +656,8 @@ def test_bf16_decoder_generator(golden):
 
 @pytest.mark.parametrize("hidden,D,S,N,B,static,perturb,trunc", [
     (64, 2, 8, 5, 3, False, True, 1.0), (128, 3, 12, 7, 1, True, False, 0.7), (32, 1, 16, 1, 2, False, False, 1.0),
-    (64, 4, 20, 9, 2, True, True, 0.5), (32, 2, 4, 24, 5, False, True, 1.0)])
+    (64, 4, 20, 9, 2, True, True, 0.5), (32, 2, 4, 24, 5, False, True, 1.0), (32, 2, 5, 3, 2, False, False, 1.0),
+    (32, 2, 7, 4, 1, True, True, 0.8)])
 def test_generator_shape_sweep_vs_oracle(hidden, D, S, N, B, static, perturb, trunc):
     """Widths / depths / ray-grid sizes / sample counts / batch sizes off the released recipe: whole generator vs oracle."""
     cfg = configs.tiny_G_cfg(hidden, D, 1)
