@@ -41,7 +41,8 @@ class NerfParams(C.Structure):
                 ("B", C.c_int32), ("img_size", C.c_int32), ("n_samples", C.c_int32), ("hidden", C.c_int32),
                 ("depth", C.c_int32), ("static_viewdirs", C.c_int32), ("n_chunks", C.c_int32), ("n_rays", C.c_int32),
                 ("part", C.c_void_p), ("sdf", C.c_void_p),
-                ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p)]
+                ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
+                ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -67,6 +68,7 @@ _SIGS = {
     "cips3d_nerf_suggest_chunks": (c_int, [c_int, c_int, c_int]),
     "cips3d_nerf_part_floats": (c_i64, [c_int, c_int, c_int, c_int]),
     "cips3d_nerf_render": (c_int, [C.POINTER(NerfParams), C.c_void_p]),
+    "cips3d_nerf_fuses_finish": (c_int, [C.POINTER(NerfParams)]),
     "cips3d_nerf_finish": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_nerf_finish_rays": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_modulate_weights": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int, c_f32, c_int,

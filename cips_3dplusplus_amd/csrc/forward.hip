@@ -80,9 +80,13 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   np.cam_poses = IO.cam_poses; np.focals = IO.focals; np.near_ = IO.near_; np.far_ = IO.far_;
   np.perturb_u = IO.perturb_u; np.sdf = IO.sdf;
   if (IO.ev_nerf_start) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_start), as_stream(stream));
+  // the chunk partials are combined inside the render kernel when the shape allows it, else by cips3d_nerf_finish
+  np.o_features = P.features; np.o_thumb = IO.thumb; np.o_xyz = IO.xyz; np.o_mask = IO.mask;
+  const bool fused_finish = cips3d_nerf_fuses_finish(&np) != 0;
   TRY(cips3d_nerf_render(&np, stream));
   if (IO.ev_nerf_stop) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_stop), as_stream(stream));
-  TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, P.features, IO.thumb, IO.xyz, IO.mask, stream));
+  if (!fused_finish)
+    TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, P.features, IO.thumb, IO.xyz, IO.mask, stream));
 
   // ---- decoder (model_v3.py:592-637)
   const float* x = P.features;

@@ -35,6 +35,8 @@
 //
 // Roofline: MFMA-bound. flops/point = 2*3*H + (D-1)*2*H^2 + 2*(H+3)*H + 2*H*4; HBM traffic is the
 // partials only (n_chunks * (H+8) * 4 B per ray).
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifdef CIPS3D_STAMPS
@@ -69,7 +71,14 @@ struct NerfArgs {
   int groups;          // ray groups of 16 per view
   int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
   int chunk;           // samples per chunk (uniform trip count)
+  int fuse_finish;     // the workgroup's eight chunk waves combine their partials in LDS and write the final maps
 };
+
+// LDS floats of the render kernel: slab ring (or the 8 x 16 x H partial exchange of the fused finish, whichever is
+// larger) + per-view tables (which double as the 8 x 8 x 16 scalar exchange once the last sample is done)
+__host__ __device__ constexpr int nerf_ring_floats(int H, int TPS, bool fuse) {
+  return (fuse && WAVES * RAYS * H > 2 * 16 * H * TPS) ? WAVES * RAYS * H : 2 * 16 * H * TPS;
+}
 
 // ------------------------------------------------------------------------------------------------
 // weight packing.  o-tile t = 16 output units; k-step s = 4 input units, one per lane quarter.
@@ -258,7 +267,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int D = P.depth;
   const int L = D + 1;
   float* ringmem = lds;                      // 2 * SLAB
-  float* s_film = ringmem + 2 * SLAB;        // L * 2 * H
+  float* s_film = ringmem + (a.fuse_finish ? nerf_ring_floats(H, TPS, true) : 2 * SLAB);   // L * 2 * H
   float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed
   float* s_wd = s_w0 + 3 * H;                // [3][H]  view-direction columns of the view layer
   float* s_ws = s_wd + 3 * H;                // [H]     sigma head
@@ -453,6 +462,72 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
 
   STAMP(5);   // last compositing tail
+  if (a.fuse_finish) {
+    // ---- the eight waves of this workgroup are the eight chunks of ONE ray group (n_chunks == WAVES): exchange the
+    // partials through LDS (the ring and the tables are dead) and combine them in sample order,
+    //   S = sum_c (prod_{c' < c} T_c') S_c,
+    // with the arithmetic of nerf_finish_kernel.  xf[c][ray][ch] (16-byte lane writes), xs[c][k][ray] for the 8 scalars.
+    float* xf = ringmem;
+    float* xs = s_film;
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // no LDS-DMA of this wave still in flight
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();                         // every wave is done with the ring and the tables
+    {
+      float* d = xf + ((int64_t)(wave * RAYS + pl)) * H + 4 * qd;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        *reinterpret_cast<f32x4*>(d + t * 16) = f32x4{FA[t * 4], FA[t * 4 + 1], FA[t * 4 + 2], FA[t * 4 + 3]};
+      float* e = xs + wave * 8 * RAYS + pl;
+      if (qd == 0) { e[0 * RAYS] = cr; e[1 * RAYS] = cg; }
+      else if (qd == 1) { e[2 * RAYS] = cb; e[3 * RAYS] = ax; }
+      else if (qd == 2) { e[4 * RAYS] = ay; e[5 * RAYS] = az; }
+      else { e[6 * RAYS] = wlast; e[7 * RAYS] = T; }
+    }
+    __syncthreads();
+    const int rr = tid & 15;                 // ray of the group
+    const int gray = g * RAYS + rr;
+    if (gray < R) {
+      float Tp[WAVES];
+      Tp[0] = 1.f;
+#pragma unroll
+      for (int cc = 1; cc < WAVES; ++cc) Tp[cc] = Tp[cc - 1] * xs[(cc - 1) * 8 * RAYS + 7 * RAYS + rr];
+      // features: thread (ray rr, channel quad cq) for cq = tid >> 4 + 32 j
+      for (int cq = tid >> 4; cq < H / 4; cq += WAVES * 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int cc = 0; cc < WAVES; ++cc) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xf + ((int64_t)(cc * RAYS + rr)) * H + 4 * cq);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = fmaf(Tp[cc], v[e], acc[e]);
+        }
+        float* o = P.o_features + ((int64_t)b * H + 4 * cq) * R + gray;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[(int64_t)e * R] = acc[e];
+      }
+      const int k = tid >> 4;                // scalar channel 0..6 for the first 7 x 16 threads
+      if (k < 7) {
+        float acc = 0.f;
+#pragma unroll
+        for (int cc = 0; cc < WAVES; ++cc) acc = fmaf(Tp[cc], xs[cc * 8 * RAYS + k * RAYS + rr], acc);
+        if (k < 3) {
+          P.o_thumb[((int64_t)b * 3 + k) * R + gray] = -1.f + 2.f * acc;
+        } else if (k < 6) {
+          P.o_xyz[((int64_t)b * 3 + (k - 3)) * R + gray] = acc;
+        } else {
+          P.o_mask[((int64_t)b * 2 + 0) * R + gray] = acc;
+          float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+          for (int cc = 0; cc < WAVES; ++cc) {
+            sx = fmaf(Tp[cc], xs[cc * 8 * RAYS + 3 * RAYS + rr], sx);
+            sy = fmaf(Tp[cc], xs[cc * 8 * RAYS + 4 * RAYS + rr], sy);
+            sz = fmaf(Tp[cc], xs[cc * 8 * RAYS + 5 * RAYS + rr], sz);
+          }
+          P.o_mask[((int64_t)b * 2 + 1) * R + gray] = -sqrtf((sx * sx + sy * sy) + sz * sz);
+        }
+      }
+    }
+    return;
+  }
   // ---- write the chunk partial: part[c][b][ch][ray]
   if (ray_ok) {
     float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray;
@@ -564,7 +639,7 @@ template <int NT, int TPS, bool XG>
 int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
-  const size_t lds_bytes = sizeof(float) * (2 * 16 * H * TPS + (size_t)(P.depth + 1) * 2 * H + 10 * H);
+  const size_t lds_bytes = sizeof(float) * (nerf_ring_floats(H, TPS, a.fuse_finish != 0) + (size_t)(P.depth + 1) * 2 * H + 10 * H);
   if (lds_bytes > 160 * 1024) return CIPS3D_E_UNSUPP;
   static bool attr_set = false;
   if (!attr_set) {
@@ -614,11 +689,27 @@ extern "C" int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int 
   return (int64_t)n_chunks * B * (hidden + 8) * img_size * img_size;
 }
 
+// fused finish: needs the 8 chunk waves of a ray group in one workgroup, the tables large enough for the scalar exchange
+// and the partial exchange + tables within the 160 KB of LDS
+extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
+  if (!p || !p->o_features || !p->o_thumb || !p->o_xyz || !p->o_mask) return 0;
+  static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
+  if (off) return 0;
+  const int H = p->hidden, L = p->depth + 1;
+  if (p->n_chunks != WAVES || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
+  const int tables = L * 2 * H + 10 * H;
+  if (tables < WAVES * 8 * RAYS) return 0;
+  return sizeof(float) * ((size_t)WAVES * RAYS * H + tables) <= 160 * 1024;
+}
+
 extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if (!p) return CIPS3D_E_BADARG;
   const cips3d_nerf_params& P = *p;
+  if ((P.o_features || P.o_thumb || P.o_xyz || P.o_mask) && !(P.o_features && P.o_thumb && P.o_xyz && P.o_mask))
+    return CIPS3D_E_BADARG;
+  const int fuse = cips3d_nerf_fuses_finish(p);
   if (!P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
-      !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || !P.sigmoid_beta || !P.part)
+      !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || !P.sigmoid_beta || (!P.part && !fuse))
     return CIPS3D_E_BADARG;
   if (P.x_pts ? (!P.x_rays_d || !P.x_viewdirs || !P.x_z_vals || P.n_rays <= 0) : (!P.cam_poses || !P.focals || P.n_rays != 0))
     return CIPS3D_E_BADARG;
@@ -631,6 +722,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   a.groups = ceil_div(P.n_rays > 0 ? P.n_rays : P.img_size * P.img_size, RAYS);
   a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
   a.chunk = ceil_div(P.n_samples, P.n_chunks);
+  a.fuse_finish = fuse;
   hipStream_t st = as_stream(stream);
   switch (P.hidden) {
     case 32: return launch_render<2, 2>(a, st);

@@ -128,14 +128,13 @@ def nerf_suggest_chunks(B, img_size, n_samples):
     return int(_lib.load().cips3d_nerf_suggest_chunks(B, img_size, n_samples))
 
 
-def nerf_render(**kw):
-    """Fill cips3d_nerf_params from keyword tensors / ints and launch the fused renderer."""
-    lib = _lib.load()
+def _nerf_params(kw):
     p = _lib.NerfParams()
     ptr_fields = ("near_", "far_", "w_first", "packed", "w_view", "film", "layer_bias",
-                  "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta", "part")
+                  "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta")
     for f in ptr_fields:
         setattr(p, f, dev_ptr(kw[f], f))
+    p.part = dev_ptr(kw.get("part"), "part", True)
     for f in ("cam_poses", "focals"):
         setattr(p, f, dev_ptr(kw.get(f), f, kw.get("x_pts") is not None))
     p.perturb_u = dev_ptr(kw.get("perturb_u"), "perturb_u", True)
@@ -145,10 +144,48 @@ def nerf_render(**kw):
     p.n_rays = int(kw.get("n_rays", 0))
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))
+    return p
+
+
+def nerf_render(**kw):
+    """Fill cips3d_nerf_params from keyword tensors / ints and launch the fused renderer (chunk partials -> `part`)."""
+    lib = _lib.load()
+    if kw.get("part") is None:
+        raise RuntimeError("part is required")
+    p = _nerf_params(kw)
     ev = _timed("nerf_render")
     check(lib.cips3d_nerf_render(C.byref(p), stream_ptr()), "cips3d_nerf_render")
     if ev:
         ev[1].record()
+
+
+def nerf_render_maps(**kw):
+    """Renderer + ordered combination of the chunk partials -> (features, thumb, xyz, mask), [B,C,S,S] (or [B,C,n_rays,1] in
+    explicit-geometry mode).  The render kernel combines the partials itself when cips3d_nerf_fuses_finish says so; else
+    they go through `part` and cips3d_nerf_finish."""
+    lib = _lib.load()
+    p = _nerf_params(kw)
+    B, H, S, n_rays = p.B, p.hidden, p.img_size, p.n_rays
+    dev = kw["near_"].device
+    shp = (n_rays, 1) if n_rays > 0 else (S, S)
+    features = torch.empty(B, H, *shp, device=dev)
+    thumb, xyz = torch.empty(B, 3, *shp, device=dev), torch.empty(B, 3, *shp, device=dev)
+    mask = torch.empty(B, 2, *shp, device=dev)
+    p.o_features, p.o_thumb, p.o_xyz, p.o_mask = dev_ptr(features), dev_ptr(thumb), dev_ptr(xyz), dev_ptr(mask)
+    fused = bool(lib.cips3d_nerf_fuses_finish(C.byref(p)))
+    part = None
+    if not fused:
+        R = n_rays if n_rays > 0 else S * S
+        part = torch.empty(p.n_chunks, B, H + 8, R, device=dev)
+        p.part = dev_ptr(part)
+    ev = _timed("nerf_render")
+    check(lib.cips3d_nerf_render(C.byref(p), stream_ptr()), "cips3d_nerf_render")
+    if ev:
+        ev[1].record()
+    if not fused:
+        check(lib.cips3d_nerf_finish_rays(p.part, p.n_chunks, B, n_rays if n_rays > 0 else S * S, H, dev_ptr(features),
+                                          dev_ptr(thumb), dev_ptr(xyz), dev_ptr(mask), stream_ptr()), "cips3d_nerf_finish_rays")
+    return features, thumb, xyz, mask
 
 
 def rays_in_world(cam_poses, focals, img_size, static_viewdirs=False):

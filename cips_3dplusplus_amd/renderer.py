@@ -169,17 +169,15 @@ class VolumeFeatureRenderer(nn.Module):
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)
         R = img_size * img_size
-        part = torch.empty(n_chunks, B, H + 8, R, device=dev)
         sdf = torch.empty(B, R, N_samples, device=dev) if return_sdf else None
-        hip.nerf_render(cam_poses=cam_poses.float().contiguous(), focals=focals.float().reshape(B).contiguous(),
+        features, thumb, xyz, mask = hip.nerf_render_maps(cam_poses=cam_poses.float().contiguous(), focals=focals.float().reshape(B).contiguous(),
                         near_=near.float().reshape(B).contiguous(), far_=far.float().reshape(B).contiguous(),
                         perturb_u=None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous(),
                         w_first=net.pts_linears[0].weight, packed=packed, w_view=net.views_linears.weight, film=film,
                         layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=img_size, n_samples=N_samples, hidden=H, depth=D,
-                        static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, part=part, sdf=sdf)
-        features, thumb, xyz, mask = hip.nerf_finish(part, n_chunks, B, img_size, H)
+                        static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf)
         if sdf is not None:
             sdf = sdf.view(B, img_size, img_size, N_samples, 1)
         return thumb, features, sdf, mask, xyz
@@ -215,14 +213,12 @@ class VolumeFeatureRenderer(nn.Module):
         styles_buf.copy_(styles)
         tab.run(B)
         n_chunks = max(1, min(N, hip.nerf_suggest_chunks(B, max(1, int(R ** 0.5)), N)))
-        part = torch.empty(n_chunks, B, H + 8, R, device=dev)
         sdf = torch.empty(B, R, N, device=dev)
-        hip.nerf_render(near_=near.float().reshape(B).contiguous(), far_=far.float().reshape(B).contiguous(),
+        features, thumb, xyz, mask = hip.nerf_render_maps(near_=near.float().reshape(B).contiguous(), far_=far.float().reshape(B).contiguous(),
                         w_first=net.pts_linears[0].weight, packed=packed, w_view=net.views_linears.weight, film=film,
                         layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
-                        B=B, img_size=1, n_samples=N, hidden=H, depth=D, static_viewdirs=0, n_chunks=n_chunks, part=part,
+                        B=B, img_size=1, n_samples=N, hidden=H, depth=D, static_viewdirs=0, n_chunks=n_chunks,
                         sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R)
-        features, thumb, xyz, mask = hip.nerf_finish(part, n_chunks, B, 1, H, n_rays=R)
         to_rays = lambda t: t.view(B, t.shape[1], R).transpose(1, 2).reshape(*lead, t.shape[1]).contiguous()
         return to_rays(thumb), to_rays(features), sdf.view(*lead, N, 1), to_rays(mask), to_rays(xyz), None

@@ -155,7 +155,16 @@ typedef struct cips3d_nerf_params {
   const float* x_rays_d;    /* [B, R, 3] */
   const float* x_viewdirs;  /* [B, R, 3] (already normalised) */
   const float* x_z_vals;    /* [B, R, n_samples] */
+  /* optional: final maps written by the render kernel itself (all four or none).  When cips3d_nerf_fuses_finish() says
+   * yes for this shape, the eight chunk waves of a ray group meet in LDS, combine their partials in sample order (the
+   * arithmetic of cips3d_nerf_finish, bit for bit) and write features [B,H,R], thumb_rgb [B,3,R], xyz [B,3,R],
+   * mask [B,2,R]; `part` is then not touched and cips3d_nerf_finish must not be called.  Otherwise the pointers are
+   * ignored and `part` + cips3d_nerf_finish is the way. */
+  float* o_features; float* o_thumb; float* o_xyz; float* o_mask;
 } cips3d_nerf_params;
+
+/* 1 when cips3d_nerf_render(p) will write p->o_* itself (o_* set, n_chunks == 8, LDS large enough), else 0 */
+int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p);
 
 /* Chunk count the render kernel wants for (B, n_samples): enough workgroups to fill the chip. */
 int cips3d_nerf_suggest_chunks(int B, int img_size, int n_samples);

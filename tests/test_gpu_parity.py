@@ -185,6 +185,37 @@ def test_nerf_render_hidden256(D, N, img, B, chunks):
                       chunks=chunks, tol=2e-4)
 
 
+@pytest.mark.parametrize("hidden,D,img,N,B", [(256, 2, 10, 24, 1), (256, 8, 8, 9, 2), (64, 2, 9, 16, 2)])
+def test_nerf_in_kernel_chunk_combination_is_bit_identical(hidden, D, img, N, B, monkeypatch):
+    """With eight chunks the render kernel combines the partials itself (cips3d_nerf_fuses_finish); the result must equal
+    the `part` + cips3d_nerf_finish route bit for bit -- ragged ray groups (img^2 % 16 != 0), N not a multiple of 8."""
+    cfg = configs.ffhq_G_cfg(256, D) if hidden == 256 else configs.tiny_G_cfg(hidden, D)
+    G = pkg.build_generator(cfg, DEV, seed=5)
+    g = torch.Generator().manual_seed(1)
+    styles = cu(torch.randn(B, D + 1, cfg["mapping_renderer_cfg"]["style_dim"], generator=g))
+    cam = [cu(t) for t in O.camera_params((torch.rand(B, 2, generator=g) - 0.5) * 0.8, img, 6, 0.12)[:4]]
+    u = cu(torch.rand(B, img, img, 1, generator=g))
+    seen = {}
+    real = hip.nerf_render_maps
+
+    def spy(**kw):
+        seen.update(kw)
+        return real(**kw)
+
+    monkeypatch.setattr(hip, "nerf_render_maps", spy)
+    thumb, feat, _, mask, xyz = G.renderer.render(*cam, styles, img, N, perturb_u=u, n_chunks=8)
+    p = hip._nerf_params(seen)
+    out = [torch.empty_like(t) for t in (feat, thumb, xyz, mask)]
+    p.o_features, p.o_thumb, p.o_xyz, p.o_mask = (t.data_ptr() for t in out)
+    from cips_3dplusplus_amd import _lib
+    import ctypes
+    assert _lib.load().cips3d_nerf_fuses_finish(ctypes.byref(p)) == 1
+    part = torch.empty(8, B, hidden + 8, img * img, device=DEV)
+    hip.nerf_render(**{**seen, "part": part})
+    f2, t2, x2, m2 = hip.nerf_finish(part, 8, B, img, hidden)
+    assert torch.equal(feat, f2) and torch.equal(thumb, t2) and torch.equal(xyz, x2) and torch.equal(mask, m2)
+
+
 def test_nerf_chunk_count_does_not_change_result():
     cfg = configs.ffhq_G_cfg(256, 2)
     G = pkg.build_generator(cfg, DEV, seed=2)
