@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--n-samples", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="A/B: no HIP events around the dominant kernel (roofline = null)")
     ap.add_argument("--deterministic", action="store_true", help="perturb off + fixed noise buffers (demo semantics)")
     ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32)")
@@ -142,14 +143,21 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    # HIP events around the dominant kernel, recorded inside cips3d_generator_forward on the stream it launches on.  An
+    # event record between kernels drains the queue (~6 us each, measured), so every `stride`-th step is instrumented, with
+    # the event handles created here, before the timed region.
+    stride = 8 if a.steps >= 64 else 1
+    hip.KERNEL_EVENTS_STRIDE = stride
+    hip.prepare_event_pairs(a.steps // stride + 2)
     barrier()
-    hip.KERNEL_EVENTS["nerf_render"] = []
+    if not a.no_kernel_events:
+        hip.KERNEL_EVENTS["nerf_render"] = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    events = hip.KERNEL_EVENTS.pop("nerf_render")
+    events = hip.KERNEL_EVENTS.pop("nerf_render", [])
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -158,7 +166,7 @@ def main():
     if rank == 0:
         views = a.steps * B * world
         value = views / elapsed
-        kern_ms = sum(s.elapsed_time(t) for s, t in events) / max(1, len(events))
+        kern_ms = sum(s.elapsed_time(t) for s, t in events) / max(1, len(events)) if events else float("nan")
         H = cfg["renderer_cfg"]["hidden_dim"]
         flops = B * 64 * 64 * a.n_samples * nerf_flops_per_point(H, a.depth)
         achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -185,7 +193,8 @@ def main():
             "roofline": {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
                          "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": kern_ms, "flop_per_launch": flops},
+                         "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": len(events),
+                         "timed_every_nth_step": stride},
         }
         if world == 1 and not a.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, {**nerf_cfg, "perturb": True}, B)

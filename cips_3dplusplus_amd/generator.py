@@ -190,10 +190,9 @@ class Generator(nn.Module):
                 mean_r = self.style_render_mean.reshape(-1).contiguous()
                 mean_d = self.style_decoder_mean.reshape(-1).contiguous()
         events = None
-        lst = hip.KERNEL_EVENTS.get("nerf_render")
+        lst = hip.want_events("nerf_render")
         if lst is not None:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record(); ev[1].record()          # materialise the hipEvent_t handles
+            ev = hip.event_pair()
             lst.append(ev)
             events = (ev[0].cuda_event, ev[1].cuda_event)
         rgb, thumb, xyz, mask, sdf = plan.run(

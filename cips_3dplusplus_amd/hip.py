@@ -16,13 +16,44 @@ MOD_PACKED = 2
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 KERNEL_EVENTS = {}
+# An event record between two kernels drains the queue (~6 us bubble on MI355X), so a bench that times every launch slows
+# the step it measures by 2-3 %: collect on every n-th call only, with event handles created ahead of the timed region.
+KERNEL_EVENTS_STRIDE = 1
+_EVENT_POOL = []
+_event_calls = {}
 
 
-def _timed(name):
+def prepare_event_pairs(n):
+    """Create n (start, stop) event pairs with live hipEvent_t handles now (a handle only exists after a first record)."""
+    for _ in range(n):
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(); ev[1].record()
+        _EVENT_POOL.append(ev)
+
+
+def want_events(name):
+    """The list to append this call's event pair to, or None (not collecting / not this call's turn)."""
     lst = KERNEL_EVENTS.get(name)
     if lst is None:
         return None
+    k = _event_calls.get(name, 0)
+    _event_calls[name] = k + 1
+    return lst if k % max(1, KERNEL_EVENTS_STRIDE) == 0 else None
+
+
+def event_pair():
+    if _EVENT_POOL:
+        return _EVENT_POOL.pop()
     ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    ev[0].record(); ev[1].record()              # materialise the hipEvent_t handles
+    return ev
+
+
+def _timed(name):
+    lst = want_events(name)
+    if lst is None:
+        return None
+    ev = event_pair()
     lst.append(ev)
     ev[0].record()
     return ev
