@@ -481,11 +481,11 @@ def test_volume_integration_vs_oracle(n, N, C):
     assert out[1] is None and maxdiff(out[0].cpu(), ref[0]) < 2e-5
 
 
-@pytest.mark.parametrize("hidden,D,R,N", [(32, 2, 50, 5), (256, 2, 64, 6), (32, 3, 129, 8)])
+@pytest.mark.parametrize("hidden,D,R,N", [(32, 2, 50, 5), (256, 2, 64, 6), (32, 3, 129, 8), (256, 2, 100, 8), (64, 2, 37, 16)])
 def test_renderer_explicit_points_entry_vs_oracle(hidden, D, R, N):
     """VolumeFeatureRenderer.forward(pts, rays_d, viewdirs, z_vals, near, far, styles): the reference entry with
     caller-made geometry (arbitrary ray count, rays that come from no camera)."""
-    cfg = configs.tiny_G_cfg(32, D, 1) if hidden == 32 else configs.ffhq_G_cfg(256, D)
+    cfg = configs.tiny_G_cfg(hidden, D, 1) if hidden < 256 else configs.ffhq_G_cfg(256, D)
     G = pkg.build_generator(cfg, DEV, seed=2)
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
     g = torch.Generator().manual_seed(R)
