@@ -24,6 +24,8 @@ struct cips3d_linear_args {
   const float* trunc_mean; float trunc_psi; int out_repeat; int64_t out_repeat_stride;
 };
 int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream);
+int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_desc* table_dev, int n_desc, int total_rows,
+                            void* stream);
 
 // floor division for possibly negative numerators (b > 0)
 __host__ __device__ static inline int floor_div_i(int a, int b) {

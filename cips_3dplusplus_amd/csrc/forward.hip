@@ -30,8 +30,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const bool trunc = IO.mean_r && IO.mean_d && IO.trunc_psi < 1.f;
 
   // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot.  The two chains
-  // are independent: their i-th layers share a launch (8 dependent ~4.5 us launches -> 5).
+  // are independent: their i-th layers share a launch (8 dependent ~4.5 us launches -> 5), and the FiLM heads of the
+  // (shorter) renderer chain ride on the decoder chain's next layer.
   cips3d_linear_args ar[CIPS3D_MAX_MAP_LAYERS], ad[CIPS3D_MAX_MAP_LAYERS];
+  bool film_done = false;
   const int nr = IO.z_r ? P.n_map_r : 0, nd = IO.z_d ? P.n_map_d : 0;
   {
     const float* x = IO.z_r;
@@ -61,6 +63,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
     for (int i = 0; i < (nr > nd ? nr : nd); ++i) {
       if (i < nr && i < nd) {
         TRY(cips3d_linear_pair(ar[i], ad[i], stream));
+      } else if (i == nr && nr > 0 && P.film_n > 0) {
+        // the renderer's W+ is complete: its FiLM heads share the launch of the decoder chain's next layer
+        TRY(cips3d_linear_and_table(ad[i], P.film_table, P.film_n, P.film_rows, stream));
+        film_done = true;
       } else {
         const cips3d_linear_args& a = i < nr ? ar[i] : ad[i];
         TRY(cips3d_linear(a.x, a.x_stride, a.W, a.bias, a.out, a.out_stride, a.B, a.in_dim, a.out_dim, a.w_scale, a.b_scale,
@@ -71,7 +77,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   }
 
   // ---- style heads: FiLM gamma/beta of every SIREN layer; every decoder modulation; modulated weights
-  TRY(cips3d_linear_table(P.film_table, P.film_n, P.film_rows, B, stream));
+  if (!film_done) TRY(cips3d_linear_table(P.film_table, P.film_n, P.film_rows, B, stream));
   TRY(cips3d_linear_table(P.mod_table, P.mod_n, P.mod_rows, B, stream));
   TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, stream));
 

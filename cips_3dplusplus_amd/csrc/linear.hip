@@ -96,10 +96,25 @@ __device__ __forceinline__ void linear_rows(const cips3d_linear_args& a, int row
   }
 }
 
+__device__ __forceinline__ void table_rows(const cips3d_linear_desc* __restrict__ table, int n_desc, int total_rows, int B,
+                                           int grow);
+
 __global__ void __launch_bounds__(256) linear_table_kernel(const cips3d_linear_desc* __restrict__ table,
                                                            int n_desc, int total_rows, int B) {
+  table_rows(table, n_desc, total_rows, B, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// one mapping layer and an independent table of heads in one launch: blocks [0, blocks_a) run the layer
+__global__ void __launch_bounds__(256) linear_and_table_kernel(cips3d_linear_args a, int blocks_a,
+                                                               const cips3d_linear_desc* __restrict__ table, int n_desc,
+                                                               int total_rows, int B) {
+  if ((int)blockIdx.x < blocks_a) linear_rows(a, blockIdx.x * 4 + (threadIdx.x >> 6));
+  else table_rows(table, n_desc, total_rows, B, (blockIdx.x - blocks_a) * 4 + (threadIdx.x >> 6));
+}
+
+__device__ __forceinline__ void table_rows(const cips3d_linear_desc* __restrict__ table, int n_desc, int total_rows, int B,
+                                           int grow) {
   const int lane = threadIdx.x & 63;
-  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (grow >= total_rows) return;
   // binary search for the descriptor owning this row (row_begin is an exclusive prefix sum)
   int lo = 0, hi = n_desc - 1;
@@ -165,6 +180,15 @@ extern "C" int cips3d_linear(const float* x, int64_t x_stride, const float* W, c
 int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream) {
   const int ba = ceil_div(a.out_dim, 4), bb = ceil_div(b.out_dim, 4);
   hipLaunchKernelGGL(linear_pair_kernel, dim3(ba + bb), dim3(256), 0, as_stream(stream), a, b, ba);
+  return cips3d_launch_status();
+}
+
+// library-internal (forward.hip): a layer and a table that do not depend on each other, one launch
+int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_desc* table_dev, int n_desc, int total_rows,
+                            void* stream) {
+  const int ba = ceil_div(a.out_dim, 4);
+  hipLaunchKernelGGL(linear_and_table_kernel, dim3(ba + ceil_div(total_rows, 4)), dim3(256), 0, as_stream(stream), a, ba,
+                     table_dev, n_desc, total_rows, a.B);
   return cips3d_launch_status();
 }
 
