@@ -87,6 +87,10 @@ _SIGS = {
     "cips3d_fused_up_conv": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int,
                                      C.c_void_p]),
+    "cips3d_fused_up_conv_chains": (c_int, [c_int]),
+    "cips3d_fused_up_conv_next": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
+                                          c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int,
+                                          c_int, C.c_void_p]),
     "cips3d_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -74,7 +74,10 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
     if (demod) v *= d;
     if (packed) {
       const int i = e;  // ksq == 1
-      const int ot = o >> 4, kq = i >> 4, j = (i >> 2) & 3, q = i & 3;
+      const int ot = o >> 4, kq = i >> 4;
+      // standard: k-step j of the 16-byte piece, lane quarter q = i & 3.  chained (packed == 2): the roles swap, lane quarter
+      // (i >> 2) & 3 and k-step i & 3 -- the order of the MFMA D layout (4 consecutive channels per lane)
+      const int j = packed == 2 ? (i & 3) : ((i >> 2) & 3), q = packed == 2 ? ((i >> 2) & 3) : (i & 3);
       wm[(((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = v;
     } else {
       wm[((int64_t)b * Cout + o) * len + e] = v;
@@ -115,7 +118,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags >> 1) & 1, lane);
+               d.flags & 1, (d.flags & 2) ? ((d.flags & 4) ? 2 : 1) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,11 +682,13 @@ struct FusedArgs {
   const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
   int bf16;
+  // optional (NEXT instantiation): the next stage's low-resolution GEMM y_next = wm_next (C/2 x C, chained pack) out2
+  const float* wm_next; float* y_next;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
@@ -868,6 +873,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * 1.41421356237309515f;
+      if (NEXT) {   // keep the activated value where the accumulator was: it is the next GEMM's B operand
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[i][c][r] = v[c];
+      }
       if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((int64_t)b * C + obase + r) * HWo + (int64_t)oy * OW + ox) = v;
       if (a.wm_rgb) {
 #pragma unroll
@@ -879,24 +888,97 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
     }
   }
-  if (!a.wm_rgb) return;
-  // ---- ToRGB: reduce over the 4 lane quarters, then over the WGM wave rows through LDS
+  // ---- NEXT: the next stage's low-resolution GEMM y_next = Wn out2 from the registers.  acc[i][c][r] is channel
+  // 16 (wm_i WM + i) + 4 q + r of pixel c: with Wn in the chained pack that IS the B operand of k-step r of k-group
+  // (wm_i WM + i).  Each wave row covers its own WM k-groups (split K); rows 1.. park their partial in the (now free) B
+  // stages and row 0 adds them in order and stores.
+  constexpr int OTN = NEXT ? C / 32 : 1;           // o-tiles of the C/2 output channels
+  f32x4 accn[OTN][4];
+  if (NEXT) {
+    static_assert(!NEXT || (WGM - 1) * WGN * OTN * 4 * 64 * 4 <= NBUF * BK * BN * 4, "split-K partials must fit the B stages");
+    const float* an = a.wm_next + (int64_t)b * (C / 2) * C;      // packed [ot'][kq][256]
+    f32x4 afn[OTN][WM];
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch)
+    for (int t = 0; t < OTN; ++t)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = prgb[ch][c];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      prgb[ch][c] = v;
+      for (int i = 0; i < WM; ++i)
+        afn[t][i] = *reinterpret_cast<const f32x4*>(an + ((int64_t)t * (C / 16) + wm_i * WM + i) * 256 + lane * 4);
+#pragma unroll
+    for (int t = 0; t < OTN; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accn[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      if (BF16) {
+        s16x4 bh[4], ah[OTN];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bh[c] = pack_bf16(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3]);
+#pragma unroll
+        for (int t = 0; t < OTN; ++t) ah[t] = pack_bf16(afn[t][i][0], afn[t][i][1], afn[t][i][2], afn[t][i][3]);
+#pragma unroll
+        for (int t = 0; t < OTN; ++t)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) accn[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[t], bh[c], accn[t][c], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int t = 0; t < OTN; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              accn[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afn[t][i][r], acc[i][c][r], accn[t][c], 0, 0, 0);
+      }
     }
-  if (q == 0) {
+    if (wm_i > 0) {
+      float* sp = sB + ((int64_t)((wm_i - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4;
+#pragma unroll
+      for (int t = 0; t < OTN; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(sp + (t * 4 + c) * 256) = accn[t][c];
+    }
+  }
+  if (!a.wm_rgb && !NEXT) return;
+  // ---- ToRGB: reduce over the 4 lane quarters, then over the WGM wave rows through LDS
+  if (a.wm_rgb) {
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-      *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) =
-          f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = prgb[ch][c];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        prgb[ch][c] = v;
+      }
+    if (q == 0) {
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) =
+            f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+    }
   }
   __syncthreads();
+  if (NEXT && wm_i == 0) {
+#pragma unroll
+    for (int m = 1; m < WGM; ++m) {
+      const float* sp = sB + ((int64_t)((m - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4;
+#pragma unroll
+      for (int t = 0; t < OTN; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const f32x4 pv4 = *reinterpret_cast<const f32x4*>(sp + (t * 4 + c) * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) accn[t][c][r] += pv4[r];
+        }
+    }
+    float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (int64_t)oy * OW + ox;
+#pragma unroll
+    for (int t = 0; t < OTN; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(yn + (int64_t)(t * 16 + 4 * q + r) * HWo) =
+            f32x4{accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]};
+  }
+  if (!a.wm_rgb) return;
   if (rgb_lane) {                     // quarter q finishes colour channel q
     const int ch = q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -924,12 +1006,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   }
 }
 
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -940,7 +1022,7 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? 1 : 0;
+  const int packed = (demodulate & 2) ? ((demodulate & 4) ? 2 : 1) : 0;
   if (packed && (ksq != 1 || Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
   const int64_t rows = (int64_t)B * Cout;
   hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)ceil_div<int64_t>(rows, 4)), dim3(256), 0, as_stream(stream), W,
@@ -1046,14 +1128,29 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
                                     int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
                                     const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
                                     float* rgb, int B, int C, int H, int W, void* stream) {
+  return cips3d_fused_up_conv_next(y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2,
+                                   bias2, out2, wm_rgb, bias_rgb, skip, skip_up, rgb, nullptr, nullptr, B, C, H, W, stream);
+}
+
+extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64; }
+
+extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
+                                         const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
+                                         int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
+                                         const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
+                                         float* rgb, const float* wm_next, float* y_next, int B, int C, int H, int W,
+                                         void* stream) {
   if (!y_lo || !fir || !bias1 || !wm2 || !bias2 || B < 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
-  if (!out2 && !wm_rgb) return CIPS3D_E_BADARG;
+  if ((wm_next == nullptr) != (y_next == nullptr)) return CIPS3D_E_BADARG;
+  if (wm_next && !cips3d_fused_up_conv_chains(C)) return CIPS3D_E_UNSUPP;
+  if (!out2 && !wm_rgb && !wm_next) return CIPS3D_E_BADARG;
   if (wm_rgb && (!bias_rgb || !rgb)) return CIPS3D_E_BADARG;
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
-              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0};
+              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
   hipStream_t st = as_stream(stream);
+  if (wm_next) return launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st);   // C == 64 (cips3d_fused_up_conv_chains)
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2

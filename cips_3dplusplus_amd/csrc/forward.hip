@@ -98,6 +98,9 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const float* x = P.features;
   const float* skip = nullptr;
   int act_i = 0, skip_i = 0;
+  float* ylo_cur = P.y_lo;                       // low-resolution GEMM result of the stage being run
+  float* ylo_alt = P.y_lo2;                      // ... of the next stage, when the current stage's kernel computes it
+  bool ylo_ready = false;                        // ylo_cur was already filled by the previous stage's kernel
   // ToRGB folding: a non-up-sampling ToRGB that follows a StyledConv is computed from that conv's registers (partial sums
   // per row block, cips3d_modconv1x1_torgb); the slots of consecutive such layers are folded by ONE cips3d_torgb_reduce
   // when their sum is first needed (the skip chain at an unchanged resolution is a plain sum).
@@ -132,12 +135,23 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const bool stage_last = li + 2 == P.n_dec_layers - 1;
         const float* nz2 = L2.noise_index >= 0 ? IO.noise[L2.noise_index] : nullptr;
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
-        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
-                              nullptr, stream));
-        float* out2 = stage_last ? nullptr : P.act[act_i];
+        if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
+        if (!ylo_ready)
+          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
+                                nullptr, stream));
+        // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
+        // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
+        const cips3d_dec_layer* LN = li + 3 < P.n_dec_layers ? &P.layers[li + 3] : nullptr;
+        const bool chain = LN && LN->kind == 1 && (LN->flags & 1) && LN->Cin == L.Cout && LN->Cout * 2 == L.Cout &&
+                           LN->H == 2 * L.H && LN->W == 2 * L.W && ylo_alt && cips3d_fused_up_conv_chains(L.Cout);
+        if (LN && LN->kind == 1 && (LN->flags & 1) && !chain) return CIPS3D_E_BADARG;
+        float* out2 = (stage_last || chain) ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
-        TRY(cips3d_fused_up_conv(P.y_lo, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                 L3.wm, L3.bias, skip, 1 | gemm_flag, rgb, B, L.Cout, L.H, L.W, stream));
+        TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
+                                      L3.wm, L3.bias, skip, 1 | gemm_flag, rgb, chain ? LN->wm : nullptr,
+                                      chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stream));
+        ylo_ready = chain;
+        if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }
         x = out2;
         act_i ^= 1;
         skip = rgb;
@@ -165,6 +179,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         }
         TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias, stream));
       } else {
+        if (L.flags & 1) return CIPS3D_E_BADARG;   // chained packs only exist for stages that take the fused route above
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
                               nullptr, stream));
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));

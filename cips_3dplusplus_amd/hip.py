@@ -12,6 +12,7 @@ from ._lib import dev_ptr, stream_ptr, check
 
 MOD_DEMODULATE = 1
 MOD_PACKED = 2
+MOD_CHAINED = 4       # with MOD_PACKED: k-steps in the MFMA D-layout order (cips3d_fused_up_conv_next)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -382,25 +383,34 @@ def modconv_kxk(x, wm, Cout, k, transpose2=False):
     return out
 
 
+def fused_up_conv_chains(C_):
+    return bool(_lib.load().cips3d_fused_up_conv_chains(C_))
+
+
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
-                  skip=None, skip_up=True, want_out2=True, bf16=False):
-    """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv)."""
+                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None):
+    """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv).
+    wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
     dev = y_lo.device
     out2 = torch.empty(B, Cc, 2 * H, 2 * W, device=dev) if want_out2 else None
     rgb = torch.empty(B, 3, 2 * H, 2 * W, device=dev) if wm_rgb is not None else None
+    y_next = torch.empty(B, Cc // 2, 2 * H, 2 * W, device=dev) if wm_next is not None else None
 
     def bs(nz):
         return 4 * H * W if (nz is not None and nz.shape[0] == B and B > 1) else 0
 
-    check(lib.cips3d_fused_up_conv(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
-                                   dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
-                                   dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
-                                   dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
-                                   dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
-                                   int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0),
-                                   dev_ptr(rgb, "rgb", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv")
+    check(lib.cips3d_fused_up_conv_next(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
+                                        dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
+                                        dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
+                                        dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
+                                        dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
+                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0),
+                                        dev_ptr(rgb, "rgb", True), dev_ptr(wm_next, "wm_next", True),
+                                        dev_ptr(y_next, "y_next", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv_next")
+    if wm_next is not None:
+        return out2, rgb, y_next
     return out2, rgb
 
 

@@ -3,6 +3,7 @@ parameters + a persistent workspace) once per (batch, img_size, N_samples, stati
 the small per-call io struct.  One ctypes call then enqueues the whole forward.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -15,8 +16,8 @@ MAX_DEC = 40
 
 class DecLayer(C.Structure):
     _fields_ = [("kind", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
-                ("noise_index", C.c_int32), ("wm", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
-                ("fir", C.c_void_p)]
+                ("noise_index", C.c_int32), ("flags", C.c_int32), ("pad_", C.c_int32), ("wm", C.c_void_p),
+                ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p)]
 
 
 class GeneratorPlan(C.Structure):
@@ -32,7 +33,8 @@ class GeneratorPlan(C.Structure):
                 ("wm_table", C.c_void_p), ("wm_n", C.c_int32), ("wm_rows", C.c_int32),
                 ("nerf", _lib.NerfParams), ("features", C.c_void_p),
                 ("layers", DecLayer * MAX_DEC),
-                ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("skip", C.c_void_p * 2), ("rgb_part", C.c_void_p),
+                ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("y_lo2", C.c_void_p), ("skip", C.c_void_p * 2),
+                ("rgb_part", C.c_void_p),
                 ("rgb_part_slots", C.c_int64)]
 
 
@@ -44,6 +46,11 @@ class ForwardIO(C.Structure):
                 ("noise", C.c_void_p * MAX_DEC), ("noise_bstride", C.c_int64 * MAX_DEC),
                 ("rgb", C.c_void_p), ("thumb", C.c_void_p), ("xyz", C.c_void_p), ("mask", C.c_void_p),
                 ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p)]
+
+
+# A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
+# stage launches its own (A/B knob)
+CHAIN_STAGES = os.environ.get("CIPS3D_CHAIN_STAGES", "1") != "0"
 
 
 class PlanUnsupported(RuntimeError):
@@ -142,6 +149,21 @@ class ForwardPlan:
             layer_info.append(info)
         self.out_res = res
         self.noise_sizes = [li["Hout"] for li in layer_info if li["kind"] in (0, 1)]
+        # An up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] of equal widths runs as low-res GEMM + one fused kernel
+        # (forward.hip).  When the NEXT stage is one too and the fused kernel has the chained form for this width, that kernel
+        # also computes the next stage's low-res GEMM from its registers: the next up-conv's weights are then packed in the
+        # chained order and its own GEMM launch disappears.
+        def fused_stage(i):
+            if i + 2 >= len(layer_info):
+                return False
+            a, b_, c = layer_info[i], layer_info[i + 1], layer_info[i + 2]
+            return (a["kind"] == 1 and b_["kind"] == 0 and c["kind"] == 3 and b_["Cin"] == a["Cout"] and b_["Cout"] == a["Cout"]
+                    and c["Cin"] == a["Cout"] and bool(lib.cips3d_fused_up_conv_supported(a["Cout"], a["H"], a["W"])))
+        for i in range(len(layer_info) - 3):
+            a, nx = layer_info[i], layer_info[i + 3]
+            if (CHAIN_STAGES and fused_stage(i) and fused_stage(i + 3) and lib.cips3d_fused_up_conv_chains(a["Cout"])
+                    and nx["Cin"] == a["Cout"] and nx["Cout"] * 2 == a["Cout"] and nx["H"] == 2 * a["H"]):
+                nx["chained"] = True
         wm_buf = torch.empty(sum(wm_sizes), device=dev)
         wm_tab = (_lib.ModulateDesc * len(seq))()
         rows, woff = 0, 0
@@ -153,13 +175,15 @@ class ForwardPlan:
             d.out = wm_buf.data_ptr() + 4 * woff
             d.s_stride = total
             d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
-            d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0)
+            d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0) | (
+                hip.MOD_CHAINED if info.get("chained") else 0)
             d.scale = conv.scale
             d.row_begin = rows
             rows += conv.out_channel
             L = p.layers[idx]
             L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
                                                               info["W"], info["noise_index"])
+            L.flags = 1 if info.get("chained") else 0
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)
@@ -190,10 +214,11 @@ class ForwardPlan:
 
         # ---- decoder workspace
         act = torch.empty(2, max_act, device=dev)
-        y_lo = torch.empty(max_lo, device=dev)
+        y_lo = torch.empty(2 if any(li.get("chained") for li in layer_info) else 1, max_lo, device=dev)
         skip = torch.empty(2, max_skip, device=dev)
         p.act[0], p.act[1] = act[0].data_ptr(), act[1].data_ptr()
-        p.y_lo = y_lo.data_ptr()
+        p.y_lo = y_lo[0].data_ptr()
+        p.y_lo2 = y_lo[1].data_ptr() if y_lo.shape[0] > 1 else None
         p.skip[0], p.skip[1] = skip[0].data_ptr(), skip[1].data_ptr()
         # ToRGB layers at the input resolution fold into the epilogue of the conv that feeds them (forward.hip): one slot
         # of [B,3,S,S] per row block per layer

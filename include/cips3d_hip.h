@@ -192,6 +192,10 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  *   wm[b][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
 #define CIPS3D_MOD_DEMODULATE 1
 #define CIPS3D_MOD_PACKED     2
+/* with CIPS3D_MOD_PACKED: the A-fragment order whose k-steps follow the MFMA *D* layout, so that a GEMM result still in
+ * registers is the B operand of the next GEMM (cips3d_fused_up_conv_next):
+ *   wm[b][o/16][i/16][(((i>>2)&3)<<4 | (o&15))*4 + (i&3)]. */
+#define CIPS3D_MOD_CHAINED    4
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
@@ -271,6 +275,17 @@ int cips3d_torgb(const float* x, const float* wm, const float* bias, const float
  * y_lo [B,C,H,W]; wm2 in the PACKED order of cips3d_modulate_weights, wm_rgb plain [B,3,C]; skip [B,3,H,W] when
  * skip_up else [B,3,2H,2W] (or NULL).  C in {32,64,128,256}, W % 32 == 0, H % 2 == 0. */
 int cips3d_fused_up_conv_supported(int C, int H, int W);
+/* The stage above plus the low-resolution GEMM of the NEXT up-sampling stage (its `StyledConv(up)` 1x1 conv, C -> C/2,
+ * which reads out2): y_next[b] = wm_next[b] (C/2 x C) out2[b], taken from the registers that hold out2, so out2 need not be
+ * stored (pass NULL) and the next stage starts at its own cips3d_fused_up_conv with y_lo = y_next.  wm_next in the
+ * CIPS3D_MOD_PACKED | CIPS3D_MOD_CHAINED order, y_next [B,C/2,2H,2W].  wm_next == y_next == NULL: plain cips3d_fused_up_conv.
+ * cips3d_fused_up_conv_chains(C): 1 for the widths that have the chained form. */
+int cips3d_fused_up_conv_chains(int C);
+int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
+                              const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
+                              int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
+                              const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up, float* rgb,
+                              const float* wm_next, float* y_next, int B, int C, int H, int W, void* stream);
 int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
                          const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
                          int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
@@ -298,6 +313,9 @@ typedef struct cips3d_dec_layer {
   int32_t kind;            /* 0 StyledConv, 1 StyledConv with 2x up-sampling, 2 ToRGB, 3 ToRGB + up-sampled skip */
   int32_t Cin, Cout, H, W; /* H, W = INPUT resolution of the layer (ToRGB: its own resolution) */
   int32_t noise_index;     /* index into cips3d_forward_io.noise (StyledConv) or -1 */
+  int32_t flags;           /* bit 0 (kind 1 only): wm is in the CIPS3D_MOD_CHAINED order and this conv's low-resolution GEMM is
+                              computed by the previous stage's kernel (cips3d_fused_up_conv_next) */
+  int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */
   const float* noise_w;    /* NoiseInjection.weight [1] (StyledConv) */
@@ -326,6 +344,7 @@ typedef struct cips3d_generator_plan {
   cips3d_dec_layer layers[CIPS3D_MAX_DEC_LAYERS];
   float* act[2];                 /* activation ping-pong, each >= B * max(C*H*W) floats */
   float* y_lo;                   /* low-resolution GEMM result feeding the FIR up-sampler */
+  float* y_lo2;                  /* second one (a chained stage writes the next stage's while reading its own) or NULL */
   float* skip[2];                /* RGB skip ping-pong, each >= B*3*Hout*Wout floats */
   float* rgb_part;               /* ToRGB partial-sum slots, each [B,3,H0*W0] at the input resolution (or NULL: no folding) */
   int64_t rgb_part_slots;        /* capacity in slots */

@@ -421,6 +421,45 @@ def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
     assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_stage_also_computes_next_low_res_gemm(bf16):
+    """cips3d_fused_up_conv_next: y_next = W_next out2 taken from the registers that hold out2 (split K over the wave rows)
+    against the separate cips3d_modconv1x1 of the stored out2; out2 / rgb unchanged by the extra work."""
+    torch.manual_seed(7)
+    C, H, B, S = 64, 32, 2, 64
+    assert hip.fused_up_conv_chains(C)
+    y_lo = torch.randn(B, C, H, H, device=DEV)
+    fir = cu(torch.tensor([1.0, 3.0, 3.0, 1.0]).outer(torch.tensor([1.0, 3.0, 3.0, 1.0])) / 16.0)
+    n1, n2 = torch.randn(1, 1, 2 * H, 2 * H, device=DEV), torch.randn(B, 1, 2 * H, 2 * H, device=DEV)
+    nw1, nw2 = torch.full((1,), 0.3, device=DEV), torch.full((1,), -0.2, device=DEV)
+    b1, b2 = torch.randn(C, device=DEV) * 0.2, torch.randn(C, device=DEV) * 0.2
+    W2, Wn, Wr = torch.randn(C, C, device=DEV), torch.randn(C // 2, C, device=DEV), torch.randn(3, C, device=DEV)
+    s2, sn, sr = (torch.randn(B, C, device=DEV) * 0.3 + 1 for _ in range(3))
+    def _mod_flags(W, s, flags):
+        from cips_3dplusplus_amd import _lib
+        out = torch.empty(B * W.shape[0] * C, device=DEV)
+        _lib.check(_lib.load().cips3d_modulate_weights(W.data_ptr(), s.data_ptr(), C, out.data_ptr(), B, W.shape[0], C, 1,
+                                                       1.0 / math.sqrt(C), flags, torch.cuda.current_stream().cuda_stream), "mod")
+        return out
+
+    wm2 = _mod_flags(W2, s2, hip.MOD_DEMODULATE | hip.MOD_PACKED)
+    wmn_std = _mod_flags(Wn, sn, hip.MOD_DEMODULATE | hip.MOD_PACKED)
+    wmn_chn = _mod_flags(Wn, sn, hip.MOD_DEMODULATE | hip.MOD_PACKED | hip.MOD_CHAINED)
+    wmr = _mod_flags(Wr, sr, 0)
+    brgb = torch.randn(3, device=DEV) * 0.1
+    skip = torch.randn(B, 3, H, H, device=DEV)
+    out2, rgb = hip.fused_up_conv(y_lo, fir, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, skip_up=True, bf16=bf16)
+    ref = hip.modconv1x1(out2, wmn_std, C // 2, epilogue=0, bf16=bf16)
+    o2, rgb2, y_next = hip.fused_up_conv(y_lo, fir, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, skip_up=True, bf16=bf16,
+                                         wm_next=wmn_chn)
+    assert torch.equal(o2, out2) and torch.equal(rgb2, rgb)
+    assert maxdiff(y_next, ref) < 2e-6 * float(ref.abs().max())
+    # activations not stored at all
+    _, rgb3, y3 = hip.fused_up_conv(y_lo, fir, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, skip_up=True, bf16=bf16,
+                                    wm_next=wmn_chn, want_out2=False)
+    assert torch.equal(rgb3, rgb) and torch.equal(y3, y_next)
+
+
 def test_rgb_to_uint8():
     x = torch.randn(2, 3, 37, 41) * 0.8
     x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -3.0, 3.0])
