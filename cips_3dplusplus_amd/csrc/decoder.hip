@@ -1132,7 +1132,7 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
                                    bias2, out2, wm_rgb, bias_rgb, skip, skip_up, rgb, nullptr, nullptr, B, C, H, W, stream);
 }
 
-extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64; }
+extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64 || C == 128; }
 
 extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
                                          const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
@@ -1150,7 +1150,8 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
   hipStream_t st = as_stream(stream);
-  if (wm_next) return launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st);   // C == 64 (cips3d_fused_up_conv_chains)
+  if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
+    return C == 64 ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st) : launch_fused<128, 4, 2, 4, 1, 32, 2, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2
