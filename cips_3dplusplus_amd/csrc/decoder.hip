@@ -1088,7 +1088,16 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
       case 10: return launch_gemm<2, 2, 2, 32, 2>(a, st);   // 64 x 128, 4 waves, 8 chains
     }
   }
-  if (Cout >= 256 && Cout % 64 == 0) return launch_gemm<1, 4, 2, 32, 2>(a, st);   // 64 x 128 tiles, 8 waves
+  if (Cout >= 256 && Cout % 64 == 0) {
+    // 64 x 128 tiles.  A grid that covers at most half of the 256 CUs (the 512 -> 256 low-res GEMM at 64^2: 128 tiles)
+    // runs on smaller tiles instead; not for the ToRGB fold, whose slot count follows gemm_block_rows()
+    static const int small_cfg = getenv("CIPS3D_GEMM_SMALL") ? atoi(getenv("CIPS3D_GEMM_SMALL")) : 1;
+    if (!rgb_part && small_cfg && (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) <= 128) {
+      if (small_cfg == 1) return launch_gemm<1, 2, 2, 32, 4>(a, st);    // 32 x 128, 4 waves
+      if (small_cfg == 2) return launch_gemm<1, 4, 1, 32, 4>(a, st);    // 64 x 64, 4 waves
+    }
+    return launch_gemm<1, 4, 2, 32, 2>(a, st);   // 8 waves
+  }
   if (Cout == 128) return launch_gemm<1, 8, 1, 32, 4>(a, st);                     // all 128 rows: x read once
   if (Cout == 64) return launch_gemm<1, 4, 2, 32, 4>(a, st);                      // 64 x 128
   return launch_gemm<1, 2, 2, 32, 4>(a, st);                                      // 32 x 128 (any Cout % 32 == 0)
