@@ -1163,7 +1163,9 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
   hipStream_t st = as_stream(stream);
   if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
-    return C == 64 ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st) : launch_fused<128, 4, 2, 4, 1, 32, 2, true>(a, st);
+    // C = 128: 2 rows x 64 with four waves (512 workgroups) beats the unchained kernel's 4 x 64 / eight waves by 3 us once
+    // the chained GEMM is in (sweep on one box, whole-view time)
+    return C == 64 ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st) : launch_fused<128, 4, 2, 2, 1, 32, 2, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2
