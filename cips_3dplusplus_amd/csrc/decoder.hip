@@ -893,9 +893,59 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // (wm_i WM + i).  Each wave row covers its own WM k-groups (split K); rows 1.. park their partial in the (now free) B
   // stages and row 0 adds them in order and stores.
   constexpr int OTN = NEXT ? C / 32 : 1;           // o-tiles of the C/2 output channels
+  // Wide stage (C = 256: eight wave rows over the same 64 pixels, eight output tiles): split K would need a 224 KB
+  // exchange of partials.  Instead the ACTIVATIONS are exchanged: in two rounds half of the wave rows drop their 32
+  // channels into the dead B stages (32 KB, lane-linear: the lane that produced a k-step's fragment is the lane that
+  // needs it), and every wave accumulates ITS output tile over the full K.
+  constexpr bool XCHG = NEXT && WGN == 1 && OTN == WGM && WGM % 2 == 0;
+  if (XCHG) {
+    static_assert(!XCHG || (WGM / 2) * WM * 4 * 256 <= NBUF * BK * BN, "half of the activations must fit the B stages");
+    constexpr int GR = (WGM / 2) * WM;             // k-groups (16 channels) per round
+    const float* an = a.wm_next + (int64_t)b * (C / 2) * C + ((int64_t)wm_i * (C / 16)) * 256 + lane * 4;
+    f32x4 accx[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      f32x4 af[GR];
+#pragma unroll
+      for (int gl = 0; gl < GR; ++gl) af[gl] = *reinterpret_cast<const f32x4*>(an + (int64_t)(rd * GR + gl) * 256);
+      if (wm_i / (WGM / 2) == rd) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x4*>(sB + (((wm_i % (WGM / 2)) * WM + i) * 4 + r) * 256 + lane * 4) =
+                f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      }
+      __syncthreads();
+#pragma unroll
+      for (int gl = 0; gl < GR; ++gl) {
+        f32x4 bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = *reinterpret_cast<const f32x4*>(sB + (gl * 4 + r) * 256 + lane * 4);
+        if (BF16) {
+          const s16x4 ah = pack_bf16(af[gl][0], af[gl][1], af[gl][2], af[gl][3]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            accx[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pack_bf16(bv[0][c], bv[1][c], bv[2][c], bv[3][c]), accx[c], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accx[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gl][r], bv[r][c], accx[c], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+    }
+    float* yn = a.y_next + ((int64_t)b * (C / 2) + wm_i * 16 + 4 * q) * HWo + (int64_t)oy * OW + ox;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(yn + (int64_t)r * HWo) = f32x4{accx[0][r], accx[1][r], accx[2][r], accx[3][r]};
+  }
   f32x4 accn[OTN][4];
-  if (NEXT) {
-    static_assert(!NEXT || (WGM - 1) * WGN * OTN * 4 * 64 * 4 <= NBUF * BK * BN * 4, "split-K partials must fit the B stages");
+  if (NEXT && !XCHG) {
+    static_assert(!NEXT || XCHG || (WGM - 1) * WGN * OTN * 4 * 64 * 4 <= NBUF * BK * BN * 4, "split-K partials must fit the B stages");
     const float* an = a.wm_next + (int64_t)b * (C / 2) * C;      // packed [ot'][kq][256]
     f32x4 afn[OTN][WM];
 #pragma unroll
@@ -957,7 +1007,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     }
   }
   __syncthreads();
-  if (NEXT && wm_i == 0) {
+  if (NEXT && !XCHG && wm_i == 0) {
 #pragma unroll
     for (int m = 1; m < WGM; ++m) {
       const float* sp = sB + ((int64_t)((m - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4;
@@ -1144,7 +1194,7 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
                                    bias2, out2, wm_rgb, bias_rgb, skip, skip_up, rgb, nullptr, nullptr, B, C, H, W, stream);
 }
 
-extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64 || C == 128; }
+extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64 || C == 128 || C == 256; }
 
 extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
                                          const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
@@ -1165,7 +1215,9 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
     // C = 128: 2 rows x 64 with four waves (512 workgroups) beats the unchained kernel's 4 x 64 / eight waves by 3 us once
     // the chained GEMM is in (sweep on one box, whole-view time)
-    return C == 64 ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st) : launch_fused<128, 4, 2, 2, 1, 32, 2, true>(a, st);
+    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st)
+           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true>(a, st)
+                      : launch_fused<256, 2, 8, 1, 2, 64, 2, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2

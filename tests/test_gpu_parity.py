@@ -421,7 +421,7 @@ def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
     assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
 
 
-@pytest.mark.parametrize("C,bf16", [(64, False), (64, True), (128, False), (128, True)])
+@pytest.mark.parametrize("C,bf16", [(64, False), (64, True), (128, False), (128, True), (256, False), (256, True)])
 def test_fused_stage_also_computes_next_low_res_gemm(C, bf16):
     """cips3d_fused_up_conv_next: y_next = W_next out2 taken from the registers that hold out2 (split K over the wave rows)
     against the separate cips3d_modconv1x1 of the stored out2; out2 / rgb unchanged by the extra work."""
