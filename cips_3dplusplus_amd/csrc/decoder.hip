@@ -688,7 +688,7 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false, bool XPREF = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
@@ -897,25 +897,32 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // exchange of partials.  Instead the ACTIVATIONS are exchanged: in two rounds half of the wave rows drop their 32
   // channels into the dead B stages (32 KB, lane-linear: the lane that produced a k-step's fragment is the lane that
   // needs it), and every wave accumulates ITS output tile over the full K.
-  constexpr bool XCHG = NEXT && WGN == 1 && OTN == WGM && WGM % 2 == 0;
+  constexpr bool XCHG = NEXT && XPREF && OTN % WGM == 0 && WGM % 2 == 0;
   if (XCHG) {
-    static_assert(!XCHG || (WGM / 2) * WM * 4 * 256 <= NBUF * BK * BN, "half of the activations must fit the B stages");
     constexpr int GR = (WGM / 2) * WM;             // k-groups (16 channels) per round
-    const float* an = a.wm_next + (int64_t)b * (C / 2) * C + ((int64_t)wm_i * (C / 16)) * 256 + lane * 4;
-    f32x4 accx[4];
+    constexpr int TPW = XCHG ? OTN / WGM : 1;      // output tiles per wave
+    static_assert(!XCHG || WGN * GR * 4 * 256 <= NBUF * BK * BN, "half of the activations must fit the B stages");
+    const float* an = a.wm_next + (int64_t)b * (C / 2) * C + lane * 4;
+    float* sx = sB + wn_i * GR * 4 * 256 + lane * 4;            // this pixel set's exchange area
+    f32x4 accx[TPW][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) accx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) accx[tp][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
-      f32x4 af[GR];
+      f32x4 af[TPW][GR];
 #pragma unroll
-      for (int gl = 0; gl < GR; ++gl) af[gl] = *reinterpret_cast<const f32x4*>(an + (int64_t)(rd * GR + gl) * 256);
+      for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+        for (int gl = 0; gl < GR; ++gl)
+          af[tp][gl] = *reinterpret_cast<const f32x4*>(an + ((int64_t)(wm_i * TPW + tp) * (C / 16) + rd * GR + gl) * 256);
       if (wm_i / (WGM / 2) == rd) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            *reinterpret_cast<f32x4*>(sB + (((wm_i % (WGM / 2)) * WM + i) * 4 + r) * 256 + lane * 4) =
+            *reinterpret_cast<f32x4*>(sx + (((wm_i % (WGM / 2)) * WM + i) * 4 + r) * 256) =
                 f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       }
       __syncthreads();
@@ -923,25 +930,36 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       for (int gl = 0; gl < GR; ++gl) {
         f32x4 bv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[r] = *reinterpret_cast<const f32x4*>(sB + (gl * 4 + r) * 256 + lane * 4);
+        for (int r = 0; r < 4; ++r) bv[r] = *reinterpret_cast<const f32x4*>(sx + (gl * 4 + r) * 256);
         if (BF16) {
-          const s16x4 ah = pack_bf16(af[gl][0], af[gl][1], af[gl][2], af[gl][3]);
+          s16x4 bh[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
-            accx[c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, pack_bf16(bv[0][c], bv[1][c], bv[2][c], bv[3][c]), accx[c], 0, 0, 0);
+          for (int c = 0; c < 4; ++c) bh[c] = pack_bf16(bv[0][c], bv[1][c], bv[2][c], bv[3][c]);
+#pragma unroll
+          for (int tp = 0; tp < TPW; ++tp) {
+            const s16x4 ah = pack_bf16(af[tp][gl][0], af[tp][gl][1], af[tp][gl][2], af[tp][gl][3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) accx[tp][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[c], accx[tp][c], 0, 0, 0);
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) accx[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[gl][r], bv[r][c], accx[c], 0, 0, 0);
+            for (int tp = 0; tp < TPW; ++tp)
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                accx[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tp][gl][r], bv[r][c], accx[tp][c], 0, 0, 0);
         }
       }
       __syncthreads();
     }
-    float* yn = a.y_next + ((int64_t)b * (C / 2) + wm_i * 16 + 4 * q) * HWo + (int64_t)oy * OW + ox;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(yn + (int64_t)r * HWo) = f32x4{accx[0][r], accx[1][r], accx[2][r], accx[3][r]};
+    for (int tp = 0; tp < TPW; ++tp) {
+      float* yn = a.y_next + ((int64_t)b * (C / 2) + (wm_i * TPW + tp) * 16 + 4 * q) * HWo + (int64_t)oy * OW + ox;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<f32x4*>(yn + (int64_t)r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
+    }
   }
   f32x4 accn[OTN][4];
   if (NEXT && !XCHG) {
@@ -1056,12 +1074,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   }
 }
 
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false, bool XPREF = false>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT, XPREF>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT, XPREF>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -1215,9 +1233,12 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
     // C = 128: 2 rows x 64 with four waves (512 workgroups) beats the unchained kernel's 4 x 64 / eight waves by 3 us once
     // the chained GEMM is in (sweep on one box, whole-view time)
-    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true>(a, st)
-           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true>(a, st)
-                      : launch_fused<256, 2, 8, 1, 2, 64, 2, true>(a, st);
+    // how the stage's activations reach the chained GEMM: exchanged through LDS, every wave owning output tiles over the
+    // full K (C = 256: the only form that fits; C = 64: -2.7 us per view against split K), or split K over the wave rows
+    // with the partials added through LDS (C = 128: a tie, kept)
+    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true, true>(a, st)
+           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false>(a, st)
+                      : launch_fused<256, 2, 8, 1, 2, 64, 2, true, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2
