@@ -688,7 +688,8 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false, bool XPREF = false>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false, bool XPREF = false,
+          bool LATE_OPS = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
@@ -727,16 +728,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
     for (int i = 0; i < WM; ++i)
       afr_next[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + kq) * 256 + lane * 4);
+  // LATE (single-stage kernels, C = BK): the epilogue's operands are requested after the MFMAs instead of up front -- 24
+  // registers that buy a sixth resident wave per SIMD
+  constexpr bool LATE = LATE_OPS;
   f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
-  if (a.noise2 && a.nw2) {
-    nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
-    const float nw = a.nw2[0];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) nz2[c] *= nw;
-  }
   f32x4 bias4[WM];
+  auto load_epilogue_ops = [&]() {
+    if (a.noise2 && a.nw2) {
+      nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
+      const float nw = a.nw2[0];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) bias4[i] = *reinterpret_cast<const f32x4*>(a.bias2 + (wm_i * WM + i) * 16 + 4 * q);
+      for (int c = 0; c < 4; ++c) nz2[c] *= nw;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) bias4[i] = *reinterpret_cast<const f32x4*>(a.bias2 + (wm_i * WM + i) * 16 + 4 * q);
+  };
+  if (!LATE) load_epilogue_ops();
 
   float kf[16];   // flipped taps
 #pragma unroll
@@ -746,13 +753,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   float skp[3][4];
   f32x4 skv = {0.f, 0.f, 0.f, 0.f};
   float rgb_bias = 0.f;
-  if (rgb_lane) {
-    rgb_bias = a.bias_rgb[q];
-    if (a.skip) {
-      if (a.skip_up) up2_load(a.skip + ((int64_t)b * 3 + q) * HWlo, H, W, oy >> 1, ox >> 2, skp);
-      else skv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + q) * HWo + (int64_t)oy * OW + ox);
+  auto load_skip_ops = [&]() {
+    if (rgb_lane) {
+      rgb_bias = a.bias_rgb[q];
+      if (a.skip) {
+        if (a.skip_up) up2_load(a.skip + ((int64_t)b * 3 + q) * HWlo, H, W, oy >> 1, ox >> 2, skp);
+        else skv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + q) * HWo + (int64_t)oy * OW + ox);
+      }
     }
-  }
+  };
+  if (!LATE) load_skip_ops();
 
   // FIR patches of one K stage: loaded early (before the MFMAs that precede their use), filtered late
   float pv[BPT][3][4];
@@ -860,6 +870,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   }
 
   // ---- epilogue of conv2: this lane holds channels o = (wm_i*WM+i)*16 + 4q + r at pixels (oy, ox .. ox+3)
+  if (LATE) { load_epilogue_ops(); load_skip_ops(); }
   float prgb[3][4];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
@@ -1074,12 +1085,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   }
 }
 
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false, bool XPREF = false>
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false, bool XPREF = false, bool LATE = false>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT, XPREF>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT, XPREF>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -1236,12 +1247,16 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
     // how the stage's activations reach the chained GEMM: exchanged through LDS, every wave owning output tiles over the
     // full K (C = 256: the only form that fits; C = 64: -2.7 us per view against split K), or split K over the wave rows
     // with the partials added through LDS (C = 128: a tie, kept)
-    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true, true>(a, st)
-           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false>(a, st)
+    // (last template flag: epilogue operands requested after the MFMAs -- at C = 64 / 128 that removes the spills of the
+    // chained form, -2 us / neutral; at C = 256 it measured +1 us and stays off)
+    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true, true, true>(a, st)
+           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false, true>(a, st)
                       : launch_fused<256, 2, 8, 1, 2, 64, 2, true, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
-    case 32: return launch_fused<32, 1, 2, 2, 1, 32, 4>(a, st);      // 2 rows x 64, 4 waves            52 us @1024^2
+    // C = 32 (one K stage): with the epilogue's operands (noise2, bias2, skip patch) requested after the MFMAs instead of up
+    // front the kernel needs 71 instead of 93 registers: seven instead of five resident waves per SIMD, -6 us at 1024^2
+    case 32: return launch_fused<32, 1, 2, 2, 1, 32, 6, false, false, true>(a, st);   // 2 rows x 64, 4 waves     46 us @1024^2
     case 64: return launch_fused<64, 2, 2, 2, 1, 16, 4>(a, st);      // 2 rows x 64, 4 waves, BK 16     42 us @512^2
     case 128: return launch_fused<128, 4, 2, 4, 1, 32, 2>(a, st);    // 4 rows x 64                     33 us @256^2
     case 256: return launch_fused<256, 2, 8, 1, 2, 64, 2>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
