@@ -41,7 +41,11 @@ def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=25.0):
     G = pkg.Generator(**cfg)
     sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
     del G
-    cores = torch.get_num_threads()
+    # the per-op torch CPU path stops scaling early: on the GPU box's 64-core / 128-thread host one 1024^2 view takes 4.0 s
+    # with 128 threads, 2.5 s with 64, 1.9 s with 32, 1.7 s with 16, 1.9 s with 8 -- time it where it is fastest
+    all_threads = torch.get_num_threads()
+    cores = min(all_threads, 16)
+    torch.set_num_threads(cores)
     g = torch.Generator().manual_seed(12345)
     zs = [torch.randn(batch, 256, generator=g), torch.randn(batch, 256, generator=g)]
     cam = O.camera_params(torch.zeros(batch, 2), 64, 6, 0.12)
@@ -56,10 +60,12 @@ def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=25.0):
             times.append(time.perf_counter() - t0)
             if it >= 1 and time.perf_counter() - t_all > seconds_budget:
                 break
+    torch.set_num_threads(all_threads)
     timed = times[1:] if len(times) > 1 else times   # first call is the warm-up
     per_view = sum(timed) / len(timed) / batch
     return {"value": 1.0 / per_view, "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"{len(timed)} forward(s) of the same workload after 1 warm-up ({per_view * 1e3:.0f} ms/view)"}
+            "sample": f"{len(timed)} forward(s) of the same workload after 1 warm-up ({per_view * 1e3:.0f} ms/view; "
+                      f"{cores} of {all_threads} host threads: more are slower)"}
 
 
 def main():
