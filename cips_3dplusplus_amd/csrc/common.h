@@ -41,6 +41,16 @@ __device__ static inline float wave_sum(float v) {
 
 __device__ static inline float lrelu02(float v) { return v > 0.f ? v : v * 0.2f; }
 
+// Index of the table entry owning global row `grow` (row_begin = exclusive prefix sums, ascending): every lane fetches one
+// entry's row_begin and a ballot counts the entries that start at or before the row -- one load round trip instead of the
+// log2(n) dependent ones of a binary search.  n <= 64 (wave-uniform `grow`).
+template <typename Desc>
+__device__ static inline int owner_desc(const Desc* __restrict__ table, int n_desc, int grow, int lane) {
+  const int rb = lane < n_desc ? table[lane].row_begin : 0x7fffffff;
+  const unsigned long long m = __ballot(rb <= grow);
+  return __popcll(m) - 1;
+}
+
 // sin(x) for the FiLM-SIREN activations.  Arguments reach tens of radians (gamma ~ 30), so the
 // reduction must be exact: two-constant Cody-Waite with FMA (k*PI_HI is absorbed by the fused
 // multiply-add, PI_LO restores the bits PI_HI lacks), then an odd degree-11 polynomial on

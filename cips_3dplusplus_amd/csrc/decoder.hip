@@ -111,10 +111,16 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (grow >= total_rows) return;
   const int b = blockIdx.y;
-  int lo = 0, hi = n_desc - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].row_begin <= grow) lo = mid; else hi = mid - 1;
+  int lo;
+  if (n_desc <= 64) {
+    lo = owner_desc(table, n_desc, grow, lane);
+  } else {
+    lo = 0;
+    int hi = n_desc - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].row_begin <= grow) lo = mid; else hi = mid - 1;
+    }
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,

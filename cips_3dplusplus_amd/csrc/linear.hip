@@ -116,11 +116,17 @@ __device__ __forceinline__ void table_rows(const cips3d_linear_desc* __restrict_
                                            int grow) {
   const int lane = threadIdx.x & 63;
   if (grow >= total_rows) return;
-  // binary search for the descriptor owning this row (row_begin is an exclusive prefix sum)
-  int lo = 0, hi = n_desc - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (table[mid].row_begin <= grow) lo = mid; else hi = mid - 1;
+  // the descriptor owning this row (row_begin is an exclusive prefix sum)
+  int lo;
+  if (n_desc <= 64) {
+    lo = owner_desc(table, n_desc, grow, lane);
+  } else {
+    lo = 0;
+    int hi = n_desc - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (table[mid].row_begin <= grow) lo = mid; else hi = mid - 1;
+    }
   }
   const cips3d_linear_desc d = table[lo];
   const int row = grow - d.row_begin;
