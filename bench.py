@@ -134,14 +134,14 @@ def main():
             # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
             # step i overlaps the rendering of step i+1.
             if pending[0] is not None:
-                pending[0].wait()
+                pending[0].wait(assemble=False)       # the gathered blocks stay on rank 0; no per-step concatenation copy
             pending[0] = gather_views_async(hip.rgb_to_uint8(rgb), B * world)
         return rgb
 
     def barrier():
         if world > 1:
             if pending[0] is not None:
-                pending[0].wait()
+                pending[0].wait(assemble=False)
                 pending[0] = None
             torch.cuda.synchronize()
             torch.distributed.barrier()

@@ -45,11 +45,13 @@ class PendingGather:
     def __init__(self, work, outs, counts, keep):
         self.work, self.outs, self.counts, self.keep = work, outs, counts, keep
 
-    def wait(self):
+    def wait(self, assemble=True):
+        """assemble=False: only order the current stream after the collective (dst keeps the per-rank blocks in `outs`);
+        a steady-state loop that does not look at every frame skips the concatenation copy."""
         if self.work is not None:
             self.work.wait()
             self.work = None
-        if self.outs is None:
+        if self.outs is None or not assemble:
             return None
         return torch.cat([o[: hi - lo] for o, (lo, hi) in zip(self.outs, self.counts)], 0)
 
