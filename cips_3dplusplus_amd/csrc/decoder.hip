@@ -395,6 +395,17 @@ __device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, i
 
 // 3 x 4 input patch (rows iy-1..iy+1, columns 2*qx-1..2*qx+2, zero outside the image) of the 2 x 4 output block
 // at rows 2*iy, 2*iy+1, columns 4*qx .. 4*qx+3
+// (interior variant: the whole patch is inside the image, no predication)
+__device__ __forceinline__ void up2_load_interior(const float* __restrict__ src, int W, int iy, int qx, float (&v)[3][4]) {
+  const float* row = src + (int64_t)(iy - 1) * W + 2 * qx;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const float2 mid = *reinterpret_cast<const float2*>(row);
+    v[r][0] = row[-1]; v[r][1] = mid.x; v[r][2] = mid.y; v[r][3] = row[2];
+    row += W;
+  }
+}
+
 __device__ __forceinline__ void up2_load(const float* __restrict__ src, int H, int W, int iy, int qx, float (&v)[3][4]) {
   const int c = 2 * qx;
 #pragma unroll
@@ -770,7 +781,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   };
   if (!LATE) load_skip_ops();
 
-  // FIR patches of one K stage: loaded early (before the MFMAs that precede their use), filtered late
+  // FIR patches of one K stage: loaded early (before the MFMAs that precede their use), filtered late.  Tiles whose
+  // low-resolution window (rows oy0/2-1 .. oy0/2+TH/2, columns ox0/2-1 .. ox0/2+TW/2) lies inside the image take loads
+  // without edge predication (workgroup-uniform branch; 87 % of the tiles at 1024^2).
+  const bool interior = oy0 / 2 >= 1 && oy0 / 2 + TH / 2 < H && ox0 / 2 >= 1 && ox0 / 2 + TW / 2 < W;
   float pv[BPT][3][4];
   auto patch_load = [&](int st) {
 #pragma unroll
@@ -778,7 +792,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
-      up2_load(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      if (interior) up2_load_interior(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      else up2_load(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
     }
   };
   auto patch_store = [&](int st, float* dst) {
