@@ -39,7 +39,9 @@ __device__ static inline float wave_sum(float v) {
   return v;
 }
 
-__device__ static inline float lrelu02(float v) { return v > 0.f ? v : v * 0.2f; }
+// leaky ReLU, slope 0.2: max(v, 0.2 v) is the select (v > 0 ? v : 0.2 v) for every finite v and both zeros, in two
+// instructions (v_mul, v_max) instead of three (v_mul, v_cmp, v_cndmask)
+__device__ static inline float lrelu02(float v) { return fmaxf(v, v * 0.2f); }
 
 // Index of the table entry owning global row `grow` (row_begin = exclusive prefix sums, ascending): every lane fetches one
 // entry's row_begin and a ballot counts the entries that start at or before the row -- one load round trip instead of the
