@@ -397,7 +397,7 @@ __device__ __forceinline__ float up2_tap(const float* __restrict__ src, int H, i
 // at rows 2*iy, 2*iy+1, columns 4*qx .. 4*qx+3
 // (interior variant: the whole patch is inside the image, no predication)
 __device__ __forceinline__ void up2_load_interior(const float* __restrict__ src, int W, int iy, int qx, float (&v)[3][4]) {
-  const float* row = src + (int64_t)(iy - 1) * W + 2 * qx;
+  const float* row = src + ((iy - 1) * W + 2 * qx);
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
     const float2 mid = *reinterpret_cast<const float2*>(row);
@@ -412,7 +412,7 @@ __device__ __forceinline__ void up2_load(const float* __restrict__ src, int H, i
   for (int r = 0; r < 3; ++r) {
     const int y = iy - 1 + r;
     const bool yok = (y >= 0) && (y < H);
-    const float* row = src + (int64_t)(yok ? y : 0) * W;
+    const float* row = src + (yok ? y : 0) * W;
     float2 mid = make_float2(0.f, 0.f);           // middle pair is 8-byte aligned (c even, W even)
     if (yok) mid = *reinterpret_cast<const float2*>(row + c);
     v[r][1] = mid.x; v[r][2] = mid.y;
@@ -734,7 +734,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W;
   const int tiles_x = OW / TW;
   const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
-  const int64_t HWlo = (int64_t)H * W, HWo = (int64_t)OH * OW;
+  // Per-lane index arithmetic stays in 32 bits (a 64 x 64-bit multiply is three quarter-rate VALU instructions): 64-bit
+  // products only in the workgroup-uniform per-sample bases (the host refuses C * 4HW >= 2^31)
+  const int HWlo = H * W, HWo = OH * OW;
   const int oy = oy0 + wn_i * RW + lrow, ox = ox0 + lx4 * 4;
 
   // Everything that does not depend on a barrier is requested first: conv2's first A fragments, its noise / bias.
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   for (int kq = 0; kq < KQ; ++kq)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
-      afr_next[kq][i] = *reinterpret_cast<const f32x4*>(ab + ((int64_t)(wm_i * WM + i) * (C / 16) + kq) * 256 + lane * 4);
+      afr_next[kq][i] = *reinterpret_cast<const f32x4*>(ab + (((wm_i * WM + i) * (C / 16) + kq) * 256 + lane * 4));
   // LATE (single-stage kernels, C = BK): the epilogue's operands are requested after the MFMAs instead of up front -- 24
   // registers that buy a sixth resident wave per SIMD
   constexpr bool LATE = LATE_OPS;
@@ -752,7 +754,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   f32x4 bias4[WM];
   auto load_epilogue_ops = [&]() {
     if (a.noise2 && a.nw2) {
-      nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (int64_t)oy * OW + ox);
+      nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (oy * OW + ox));
       const float nw = a.nw2[0];
 #pragma unroll
       for (int c = 0; c < 4; ++c) nz2[c] *= nw;
@@ -774,8 +776,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     if (rgb_lane) {
       rgb_bias = a.bias_rgb[q];
       if (a.skip) {
-        if (a.skip_up) up2_load(a.skip + ((int64_t)b * 3 + q) * HWlo, H, W, oy >> 1, ox >> 2, skp);
-        else skv = *reinterpret_cast<const f32x4*>(a.skip + ((int64_t)b * 3 + q) * HWo + (int64_t)oy * OW + ox);
+        if (a.skip_up) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
+        else skv = *reinterpret_cast<const f32x4*>(a.skip + (int64_t)b * 3 * HWo + (q * HWo + oy * OW + ox));
       }
     }
   };
@@ -792,8 +794,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
-      if (interior) up2_load_interior(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
-      else up2_load(a.y_lo + ((int64_t)b * C + st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      if (interior) up2_load_interior(a.y_lo + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      else up2_load(a.y_lo + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
     }
   };
   auto patch_store = [&](int st, float* dst) {
@@ -822,7 +824,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     const int r = tid / (TW / 4), x4 = tid % (TW / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (a.noise1 && a.nw1) {
-      v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + (int64_t)(oy0 + r) * OW + ox0 + x4 * 4);
+      v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + ((oy0 + r) * OW + ox0 + x4 * 4));
       const float nw = a.nw1[0];
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] *= nw;
@@ -855,7 +857,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
         for (int i = 0; i < WM; ++i)
           afr_next[kq][i] = *reinterpret_cast<const f32x4*>(
-              ab + ((int64_t)(wm_i * WM + i) * (C / 16) + (st + 1) * KQ + kq) * 256 + lane * 4);
+              ab + (((wm_i * WM + i) * (C / 16) + (st + 1) * KQ + kq) * 256 + lane * 4));
       patch_load(st + 1);
     }
 #pragma unroll
@@ -909,7 +911,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][c][r] = v[c];
       }
-      if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + ((int64_t)b * C + obase + r) * HWo + (int64_t)oy * OW + ox) = v;
+      if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + (int64_t)b * C * HWo + ((obase + r) * HWo + oy * OW + ox)) = v;
       if (a.wm_rgb) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -948,7 +950,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
         for (int gl = 0; gl < GR; ++gl)
-          af[tp][gl] = *reinterpret_cast<const f32x4*>(an + ((int64_t)(wm_i * TPW + tp) * (C / 16) + rd * GR + gl) * 256);
+          af[tp][gl] = *reinterpret_cast<const f32x4*>(an + ((wm_i * TPW + tp) * (C / 16) + rd * GR + gl) * 256);
       if (wm_i / (WGM / 2) == rd) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -987,10 +989,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     }
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
-      float* yn = a.y_next + ((int64_t)b * (C / 2) + (wm_i * TPW + tp) * 16 + 4 * q) * HWo + (int64_t)oy * OW + ox;
+      float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (((wm_i * TPW + tp) * 16 + 4 * q) * HWo + oy * OW + ox);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(yn + (int64_t)r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
+        *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
     }
   }
   f32x4 accn[OTN][4];
@@ -1002,7 +1004,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
       for (int i = 0; i < WM; ++i)
-        afn[t][i] = *reinterpret_cast<const f32x4*>(an + ((int64_t)t * (C / 16) + wm_i * WM + i) * 256 + lane * 4);
+        afn[t][i] = *reinterpret_cast<const f32x4*>(an + ((t * (C / 16) + wm_i * WM + i) * 256 + lane * 4));
 #pragma unroll
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
@@ -1030,7 +1032,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
     }
     if (wm_i > 0) {
-      float* sp = sB + ((int64_t)((wm_i - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4;
+      float* sp = sB + ((((wm_i - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4);
 #pragma unroll
       for (int t = 0; t < OTN; ++t)
 #pragma unroll
@@ -1060,7 +1062,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   if (NEXT && !XCHG && wm_i == 0) {
 #pragma unroll
     for (int m = 1; m < WGM; ++m) {
-      const float* sp = sB + ((int64_t)((m - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4;
+      const float* sp = sB + ((((m - 1) * WGN + wn_i) * OTN * 4) * 256 + lane * 4);
 #pragma unroll
       for (int t = 0; t < OTN; ++t)
 #pragma unroll
@@ -1070,12 +1072,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           for (int r = 0; r < 4; ++r) accn[t][c][r] += pv4[r];
         }
     }
-    float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (int64_t)oy * OW + ox;
+    float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (oy * OW + ox);
 #pragma unroll
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(yn + (int64_t)(t * 16 + 4 * q + r) * HWo) =
+        *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) =
             f32x4{accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]};
   }
   if (!a.wm_rgb) return;
@@ -1102,7 +1104,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int c = 0; c < 4; ++c) v[c] += skv[c];
       }
     }
-    *reinterpret_cast<f32x4*>(a.rgb + ((int64_t)b * 3 + ch) * HWo + (int64_t)oy * OW + ox) = v;
+    *reinterpret_cast<f32x4*>(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox)) = v;
   }
 }
 
@@ -1258,6 +1260,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (!out2 && !wm_rgb && !wm_next) return CIPS3D_E_BADARG;
   if (wm_rgb && (!bias_rgb || !rgb)) return CIPS3D_E_BADARG;
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
+  if ((int64_t)C * 4 * H * W >= (int64_t)1 << 31) return CIPS3D_E_UNSUPP;   // 32-bit intra-sample offsets in the kernel
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
