@@ -178,8 +178,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * BM;
-  const int64_t n0 = (int64_t)blockIdx.x * BN;
-  const int64_t HW = a.HW;
+  // per-lane index arithmetic in 32 bits (the host refuses max(Cin, Cout) * HW >= 2^31); 64-bit products only in the
+  // workgroup-uniform sample bases
+  const int n0 = blockIdx.x * BN;
+  const int HW = (int)a.HW;
   const int K = a.Cin;
   const int nstage = K / BK;
   const float* xb = a.x + (int64_t)b * K * HW;
@@ -194,16 +196,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       const int piece = j * NW + wave;
       if (piece < A_PIECES) {
         const int ot_l = piece / KQ, kq_l = piece % KQ;
-        const float* src = ab + ((int64_t)((m0 >> 4) + ot_l) * (K >> 4) + (k0 >> 4) + kq_l) * 256 + lane * 4;
+        const float* src = ab + ((((m0 >> 4) + ot_l) * (K >> 4) + (k0 >> 4) + kq_l) * 256 + lane * 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
       } else {
         const int pb = piece - A_PIECES;
         const int f = pb * 256 + lane * 4;
         const int row = f / BN, col = f % BN;
-        int64_t n = n0 + col;
+        int n = n0 + col;
         if (n > HW - 4) n = HW - 4;                       // clamp: those columns are never stored
-        const float* src = xb + (int64_t)(k0 + row) * HW + n;
+        const float* src = xb + ((k0 + row) * HW + n);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
       }
@@ -212,7 +214,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 
   const int q = lane >> 4, jn = lane & 15;
   // epilogue operands first (registers, ordinary loads, consumed only after the main loop)
-  const int64_t ncol = n0 + wn_i * 64 + jn * 4;            // this lane's 4 consecutive pixels
+  const int ncol = n0 + wn_i * 64 + jn * 4;                // this lane's 4 consecutive pixels
   f32x4 nz4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 bias4[WM];
   if (a.epilogue == 1) {
@@ -313,9 +315,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c]) + bias4[i][r]) * 1.41421356237309515f;
       }
-      if (col_ok) *reinterpret_cast<f32x4*>(ob + (int64_t)(obase + r) * HW) = v;
+      if (col_ok) *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
       if (a.rgb_part) {
-        const float* w = a.rgb_w + (int64_t)b * 3 * a.Cout + obase + r;
+        const float* w = a.rgb_w + (int64_t)b * 3 * a.Cout + (obase + r);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           const float wc = w[ch * a.Cout];
@@ -354,7 +356,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] += t[c];
     }
-    *reinterpret_cast<f32x4*>(a.rgb_part + (((int64_t)blockIdx.y * a.B + b) * 3 + q) * HW + ncol) = v;
+    *reinterpret_cast<f32x4*>(a.rgb_part + ((int64_t)blockIdx.y * a.B + b) * 3 * HW + (q * HW + ncol)) = v;
   }
 }
 
@@ -1142,7 +1144,9 @@ extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int 
 }
 
 extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
-  return (Cin % 32 == 0) && (Cout % 32 == 0) && (HW % 4 == 0) && HW >= 4;
+  // (the kernel keeps intra-sample offsets in 32 bits)
+  return (Cin % 32 == 0) && (Cout % 32 == 0) && (HW % 4 == 0) && HW >= 4 &&
+         (int64_t)(Cin > Cout ? Cin : Cout) * HW + 256 < ((int64_t)1 << 31);
 }
 
 extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
