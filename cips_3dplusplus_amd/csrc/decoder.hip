@@ -217,18 +217,26 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   const int ncol = n0 + wn_i * 64 + jn * 4;                // this lane's 4 consecutive pixels
   f32x4 nz4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 bias4[WM];
-  if (a.epilogue == 1) {
-    if (a.noise && a.noise_w && ncol < HW) {
-      nz4 = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)b * a.noise_bstride + ncol);
-      const float nw = a.noise_w[0];
+  float nw = 0.f;
+  // With a 2-slot ring the first wait of the loop is vmcnt(0) anyway, so the operand loads go out right AFTER the first
+  // stage's DMA (one exposed round trip less per launch).  Deeper rings count their waits in DMA pieces only: there the
+  // operands are retired before the prologue.
+  constexpr bool OPS_AFTER_PROLOGUE = NS == 2;
+  auto load_ops = [&]() {
+    if (a.epilogue == 1) {
+      if (a.noise && a.noise_w && ncol < HW) {
+        nz4 = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)b * a.noise_bstride + ncol);
+        nw = a.noise_w[0];
+      }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) nz4[c] *= nw;
+      for (int i = 0; i < WM; ++i)
+        bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
     }
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-      bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
+  };
+  if (!OPS_AFTER_PROLOGUE) {
+    load_ops();
     // retire them now so that the counted waits below see DMA pieces only
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.epilogue == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   f32x4 acc[WM][4];
@@ -241,6 +249,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < nstage) stage_load(s0);
+  if (OPS_AFTER_PROLOGUE) load_ops();
 
   for (int st = 0; st < nstage; ++st) {
     // stage st must have landed; stages st+1 .. st+NS-2 (as far as they exist) stay in flight
@@ -313,7 +322,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       if (a.epilogue == 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c]) + bias4[i][r]) * 1.41421356237309515f;
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
       }
       if (col_ok) *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
       if (a.rgb_part) {
