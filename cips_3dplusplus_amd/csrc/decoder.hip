@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   const int ncol = n0 + wn_i * 64 + jn * 4;                // this lane's 4 consecutive pixels
   f32x4 nz4 = {0.f, 0.f, 0.f, 0.f};
   f32x4 bias4[WM];
+  f32x4 wrgb[WM][3];
   float nw = 0.f;
   // With a 2-slot ring the first wait of the loop is vmcnt(0) anyway, so the operand loads go out right AFTER the first
   // stage's DMA (one exposed round trip less per launch).  Deeper rings count their waits in DMA pieces only: there the
@@ -231,6 +232,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
       for (int i = 0; i < WM; ++i)
         bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    }
+    if (a.rgb_part) {        // the folded ToRGB's weights of this lane's rows (an epilogue-time load would be an exposed round trip)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          wrgb[i][ch] = *reinterpret_cast<const f32x4*>(a.rgb_w + (int64_t)b * 3 * a.Cout + ch * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q);
     }
   };
   if (!OPS_AFTER_PROLOGUE) {
@@ -326,10 +334,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       }
       if (col_ok) *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
       if (a.rgb_part) {
-        const float* w = a.rgb_w + (int64_t)b * 3 * a.Cout + (obase + r);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-          const float wc = w[ch * a.Cout];
+          const float wc = wrgb[i][ch][r];
 #pragma unroll
           for (int c = 0; c < 4; ++c) prgb[ch][c] = fmaf(wc, v[c], prgb[ch][c]);
         }
