@@ -344,11 +344,14 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
   const float u = (P.perturb_u && !explicit_geom) ? P.perturb_u[bray] : 0.f;
   const float* xz = explicit_geom ? P.x_z_vals + bray * P.n_samples : nullptr;
-  const float span = farv - nearv;
+  // Wave-uniform floats that come out of the VALU live in VGPRs and, under this kernel's register pressure, get spilled
+  // to scratch and reloaded one dependent round trip at a time at every sample start: pin them in SGPRs.
+  auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  const float span = uniform(farv - nearv);
   const int N = P.n_samples;
   // torch.linspace(0, 1 - 1/N, N): symmetric evaluation around the midpoint
-  const float t_end = (float)(1.0 - 1.0 / (double)N);
-  const float t_step = N > 1 ? t_end / (float)(N - 1) : 0.f;
+  const float t_end = uniform((float)(1.0 - 1.0 / (double)N));
+  const float t_step = uniform(N > 1 ? t_end / (float)(N - 1) : 0.f);
   auto zbase = [&](int k) -> float {  // un-perturbed depth of sample k; k == N gives `far`
     if (k >= N) return farv;
     const float t = (k < N / 2) ? t_step * (float)k : t_end - t_step * (float)(N - 1 - k);
