@@ -72,6 +72,8 @@ struct NerfArgs {
   int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
   int chunk;           // samples per chunk (uniform trip count)
   int fuse_finish;     // the workgroup's eight chunk waves combine their partials in LDS and write the final maps
+  float t_end, t_step; // torch.linspace(0, 1 - 1/N, N): last value and step, computed on the host (kernel arguments are
+                       // re-readable scalars; computed in the kernel they ended up as spilled VGPR copies)
 };
 
 // LDS floats of the render kernel: slab ring (or the 8 x 16 x H partial exchange of the fused finish, whichever is
@@ -350,8 +352,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const float span = uniform(farv - nearv);
   const int N = P.n_samples;
   // torch.linspace(0, 1 - 1/N, N): symmetric evaluation around the midpoint
-  const float t_end = uniform((float)(1.0 - 1.0 / (double)N));
-  const float t_step = uniform(N > 1 ? t_end / (float)(N - 1) : 0.f);
+  const float t_end = a.t_end, t_step = a.t_step;
   auto zbase = [&](int k) -> float {  // un-perturbed depth of sample k; k == N gives `far`
     if (k >= N) return farv;
     const float t = (k < N / 2) ? t_step * (float)k : t_end - t_step * (float)(N - 1 - k);
@@ -388,6 +389,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     const int sg = s_begin + si;
     const bool live = ray_ok && sg < N;
     const int sk = sg < N ? sg : N - 1;
+    // the ray's spilled constants that the set-up needs come back in ONE batch of reloads (touching them together here)
+    // instead of one dependent round trip each where they are first used
+    if (!explicit_geom) asm volatile("" ::"v"(u), "v"(dx), "v"(dy), "v"(dz));
     const float z = zsample(sk);
     float ptx, pty, ptz;
     if (explicit_geom) {
@@ -726,6 +730,8 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
   a.chunk = ceil_div(P.n_samples, P.n_chunks);
   a.fuse_finish = fuse;
+  a.t_end = (float)(1.0 - 1.0 / (double)P.n_samples);
+  a.t_step = P.n_samples > 1 ? a.t_end / (float)(P.n_samples - 1) : 0.f;
   hipStream_t st = as_stream(stream);
   switch (P.hidden) {
     case 32: return launch_render<2, 2>(a, st);
