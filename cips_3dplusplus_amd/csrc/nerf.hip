@@ -173,6 +173,10 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
     // The TPS o-tiles of the slab are independent accumulator chains, interleaved so that one wave alone
     // covers the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
     f32x4 acc[TPS];
+    // (opaque per step: as loop invariants the packed-math operand pairs {vx,vx}, {vy,vy}, {vz,vz} were hoisted out of the
+    // sample loop, spilled, and reloaded -- twelve registers, one exposed scratch round trip -- in front of every step)
+    float vxo = vx, vyo = vy, vzo = vz;
+    if (VIEW) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
       const int o4 = o_base + tt * 16;
@@ -181,7 +185,7 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
         const f32x4 wy = *reinterpret_cast<const f32x4*>(s_wd + H + o4);
         const f32x4 wz = *reinterpret_cast<const f32x4*>(s_wd + 2 * H + o4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[tt][i] = fmaf(wz[i], vz, fmaf(wy[i], vy, wx[i] * vx));
+        for (int i = 0; i < 4; ++i) acc[tt][i] = fmaf(wz[i], vzo, fmaf(wy[i], vyo, wx[i] * vxo));
       } else {
         acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
