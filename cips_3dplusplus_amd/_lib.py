@@ -62,6 +62,8 @@ _SIGS = {
                               c_int, c_f32, c_f32, c_f32, c_f32p, c_f32, c_int, c_i64, C.c_void_p]),
     "cips3d_pixel_norm": (c_int, [c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     "cips3d_linear_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_linear_table_bwd": (c_int, [C.c_void_p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, c_f32p,
+                                        c_f32p, C.c_void_p]),
     "cips3d_camera_params": (c_int, [c_f32p, c_f32p, c_f32, c_f32p, c_f32, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_void_p]),
     "cips3d_nerf_pack_weights": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),

@@ -6,6 +6,8 @@ and sums fan-out gradients; the reference relies on the same engine (`loss.backw
 Used by `Generator.forward` when gradients are enabled and something that reaches the output requires them
 (flip inversion: camera angles, W+ styles, decoder parameters, noise buffers — projector_v10.py:985-1009).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -14,6 +16,10 @@ from . import hip, op
 
 def _c(t):
     return t.contiguous() if t is not None else None
+
+
+# the decoder's 26 style modulations go through one table launch (and a two-launch table backward); 0 = one op per layer
+STYLE_TABLE = os.environ.get("CIPS3D_STYLE_TABLE", "1") != "0"
 
 
 class LinearFn(Function):
@@ -129,12 +135,80 @@ class ToRGBFn(Function):
         return dx, dwm, db.view(1, 3, 1, 1) if db is not None else None, (drgb if ctx.has_skip else None)
 
 
+class StyleTableFn(Function):
+    """Every ModulatedConv2d.modulation of the decoder (26 EqualLinears style -> Cin, models/model_v3.py:254,268) in one
+    launch forward (cips3d_linear_table) and two backward (cips3d_linear_table_bwd) instead of 26 + 78 launches of ~5-14 us.
+    Outputs: one contiguous [B, Cin_l] tensor per layer (blocks of one buffer)."""
+
+    @staticmethod
+    def _table(dec, B, device):
+        key = (B, dec.conv1.conv.modulation.weight.data_ptr())
+        ent = getattr(dec, "_grad_style_table", None)
+        if ent is None or ent[0] != key:
+            seq = dec._mod_layers()
+            sizes = [m.conv.in_channel for m, _ in seq]
+            styles_buf = torch.empty(B, dec.n_latent, dec.style_dim, device=device)
+            s_buf = torch.empty(B * sum(sizes), device=device)
+            tab = hip.LinearTable(device)
+            offs, off = [], 0
+            for (m, li), cin in zip(seq, sizes):
+                mod = m.conv.modulation
+                tab.add(mod.weight, mod.bias, styles_buf, dec.n_latent * dec.style_dim, s_buf, cin, w_scale=mod.scale,
+                        b_scale=mod.lr_mul, x_offset=li * dec.style_dim, out_offset=off)
+                offs.append(off)
+                off += B * cin
+            ent = (key, styles_buf, s_buf, tab, offs, sizes)
+            dec._grad_style_table = ent
+        return ent[1:]
+
+    @staticmethod
+    def forward(ctx, dec, styles, *params):
+        B = styles.shape[0]
+        styles_buf, s_buf, tab, offs, sizes = StyleTableFn._table(dec, B, styles.device)
+        styles_buf.copy_(styles)
+        tab.run(B)
+        out = s_buf.clone()
+        ctx.dec, ctx.B = dec, B
+        ctx.save_for_backward(styles.detach().float().contiguous())
+        return tuple(out[o:o + B * c].view(B, c) for o, c in zip(offs, sizes))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dec, B = ctx.dec, ctx.B
+        (styles,) = ctx.saved_tensors
+        styles_buf, s_buf, tab, offs, sizes = StyleTableFn._table(dec, B, styles.device)
+        styles_buf.copy_(styles)                    # the staging buffer may have been reused since the forward
+        dy = torch.cat([(g if g is not None else torch.zeros(B, c, device=styles.device)).reshape(-1).float()
+                        for g, c in zip(grads, sizes)])
+        need_p = any(ctx.needs_input_grad[2:])
+        dstyles = torch.zeros_like(styles_buf) if ctx.needs_input_grad[1] else None
+        dW, woffs, db = tab.backward(B, s_buf, dy, styles_buf, dstyles, need_dW=need_p, need_db=need_p)
+        outs = [None, dstyles]
+        row = 0
+        for i, (d, wo) in enumerate(zip(tab._descs, woffs)):
+            nW, nb = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            outs.append(dW[wo:wo + d.out_dim * d.in_dim].view(d.out_dim, d.in_dim) if (nW and dW is not None) else None)
+            outs.append(db[row:row + d.out_dim] if (nb and db is not None) else None)
+            row += d.out_dim
+        return tuple(outs)
+
+
+def decoder_styles(dec, styles):
+    """s_l of every decoder layer, in `dec._mod_layers()` order."""
+    params = []
+    for m, _ in dec._mod_layers():
+        params += [m.conv.modulation.weight, m.conv.modulation.bias]
+    return StyleTableFn.apply(dec, styles, *params)
+
+
 # ------------------------------------------------------------------------------------------ decoder, differentiable walk
-def styled_conv(sc, x, style, noise):
-    """StyledConv (models/model_v3.py:444-454) as a chain of differentiable HIP ops."""
+def styled_conv(sc, x, style, noise, s=None):
+    """StyledConv (models/model_v3.py:444-454) as a chain of differentiable HIP ops.  `s`: the layer's modulation when it
+    was computed by the table (decoder_styles)."""
     conv = sc.conv
     mod = conv.modulation
-    s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
+    if s is None:
+        s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
     wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate)
     y = Conv1x1Fn.apply(x, wm)
     if conv.upsample:
@@ -144,10 +218,11 @@ def styled_conv(sc, x, style, noise):
     return NoiseBiasActFn.apply(y, noise, sc.noise.weight, sc.activate.bias)
 
 
-def to_rgb(tr, x, style, skip):
+def to_rgb(tr, x, style, skip, s=None):
     conv = tr.conv
     mod = conv.modulation
-    s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
+    if s is None:
+        s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
     wm = ModulateFn.apply(conv.weight, s, conv.scale, False)
     if skip is not None and tr.upsample:
         skip = tr.upsample(skip)            # op.upfirdn2d, differentiable
@@ -160,13 +235,17 @@ def decoder_forward(dec, features, styles, noise=None):
         raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
     if noise is None:
         noise = [None] * dec.num_layers
-    out = styled_conv(dec.conv1, features, styles[:, 0], noise[0])
-    skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None)
+    # all 26 style modulations from one table launch (forward and backward); S maps module -> its s
+    seq = dec._mod_layers()
+    S = {id(m): sl for (m, _), sl in zip(seq, decoder_styles(dec, styles))} if (STYLE_TABLE and dec.style_dim % 4 == 0) else {}
+    out = styled_conv(dec.conv1, features, styles[:, 0], noise[0], S.get(id(dec.conv1)))
+    skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None, S.get(id(dec.to_rgb1)))
     i = 1
     for st in range(len(dec.to_rgbs)):
-        out = styled_conv(dec.convs[2 * st], out, styles[:, i], noise[2 * st + 1])
-        out = styled_conv(dec.convs[2 * st + 1], out, styles[:, i + 1], noise[2 * st + 2])
-        skip = to_rgb(dec.to_rgbs[st], out, styles[:, i + 2], skip)
+        c0, c1, tr = dec.convs[2 * st], dec.convs[2 * st + 1], dec.to_rgbs[st]
+        out = styled_conv(c0, out, styles[:, i], noise[2 * st + 1], S.get(id(c0)))
+        out = styled_conv(c1, out, styles[:, i + 1], noise[2 * st + 2], S.get(id(c1)))
+        skip = to_rgb(tr, out, styles[:, i + 2], skip, S.get(id(tr)))
         i += 2
     return skip
 

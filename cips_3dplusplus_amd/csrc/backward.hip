@@ -314,6 +314,70 @@ __global__ void __launch_bounds__(256) torgb_bwd_kernel(const float* __restrict_
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// backward of a table of linear heads (cips3d_linear_table_bwd)
+// rows kernel: one wave per output row of the table: dW[row][:] = w_scale out_scale sum_b dy[b][row] x[b][:], db[row]
+// ------------------------------------------------------------------------------------------------
+struct TableBwd {
+  const cips3d_linear_desc* table; int n_desc, total_rows, in_dim, B;
+  const float* out_base; const float* dy_base; const float* x_base; float* dx_base;
+  const int64_t* w_off; float* dW; float* db;
+};
+
+__global__ void __launch_bounds__(256) table_bwd_rows_kernel(TableBwd a) {
+  const int lane = threadIdx.x & 63;
+  const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grow >= a.total_rows) return;
+  const int di = owner_desc(a.table, a.n_desc, grow, lane);
+  const cips3d_linear_desc d = a.table[di];
+  const int row = grow - d.row_begin;
+  const float* dy = a.dy_base + (d.out - a.out_base) + row;
+  const float* x = a.x_base + (d.x - a.x_base);
+  float bsum = 0.f;
+  for (int b = 0; b < a.B; ++b) bsum += dy[(int64_t)b * d.out_stride];
+  if (a.db && lane == 0) a.db[grow] = bsum * (d.b_scale * d.out_scale);
+  if (!a.dW) return;
+  float* dw = a.dW + a.w_off[di] + (int64_t)row * d.in_dim;
+  const float sc = d.w_scale * d.out_scale;
+  for (int k = lane * 4; k < d.in_dim; k += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < a.B; ++b) {
+      const float g = dy[(int64_t)b * d.out_stride];
+      const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)b * d.x_stride + k);
+      acc.x = fmaf(g, xv.x, acc.x); acc.y = fmaf(g, xv.y, acc.y); acc.z = fmaf(g, xv.z, acc.z); acc.w = fmaf(g, xv.w, acc.w);
+    }
+    *reinterpret_cast<float4*>(dw + k) = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+  }
+}
+
+// columns kernel: block = (head, 64-column block, row group): dx[b][col] += w_scale out_scale sum_{rows of the group} dy[b][row] W[row][col]
+constexpr int TB_RG = 4;     // row groups per (head, column block)
+__global__ void __launch_bounds__(256) table_bwd_cols_kernel(TableBwd a) {
+  __shared__ float s_acc[4][64];
+  const int cblocks = (a.in_dim + 63) / 64;
+  const int di = blockIdx.x / (cblocks * TB_RG);
+  const int rem = blockIdx.x % (cblocks * TB_RG);
+  const int cb = rem / TB_RG, rg = rem % TB_RG;
+  const cips3d_linear_desc d = a.table[di];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int col = cb * 64 + tx;
+  const bool col_ok = col < d.in_dim;
+  const float* dy = a.dy_base + (d.out - a.out_base);
+  float* dx = a.dx_base + (d.x - a.x_base);
+  const float sc = d.w_scale * d.out_scale;
+  for (int b = 0; b < a.B; ++b) {
+    float acc = 0.f;
+    if (col_ok)
+      for (int r = rg * 4 + ty; r < d.out_dim; r += 4 * TB_RG)
+        acc = fmaf(dy[(int64_t)b * d.out_stride + r], d.W[(int64_t)r * d.in_dim + col], acc);
+    s_acc[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col_ok) atomicAdd(dx + (int64_t)b * d.x_stride + col, ((s_acc[0][tx] + s_acc[1][tx]) + (s_acc[2][tx] + s_acc[3][tx])) * sc);
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int cips3d_linear_bwd(const float* x, int64_t x_stride, const float* W, const float* out, int64_t out_stride,
@@ -418,5 +482,20 @@ extern "C" int cips3d_torgb_bwd(const float* drgb, const float* x, const float* 
   if (dbias) { e = hipMemsetAsync(dbias, 0, sizeof(float) * 3, st); if (e != hipSuccess) return (int)e; }
   hipLaunchKernelGGL(torgb_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st,
                      drgb, x, wm, dx, dwm, dbias, C, HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_linear_table_bwd(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int in_dim, int B,
+                                       const float* out_base, const float* dy_base, const float* x_base, float* dx_base,
+                                       const int64_t* w_offsets_dev, float* dW, float* db, void* stream) {
+  if (!table_dev || n_desc <= 0 || n_desc > 64 || total_rows <= 0 || in_dim <= 0 || B < 0 || !out_base || !dy_base || !x_base ||
+      (dW && !w_offsets_dev))
+    return CIPS3D_E_BADARG;
+  if (in_dim % 4 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  TableBwd a{table_dev, n_desc, total_rows, in_dim, B, out_base, dy_base, x_base, dx_base, w_offsets_dev, dW, db};
+  hipStream_t st = as_stream(stream);
+  if (dW || db) hipLaunchKernelGGL(table_bwd_rows_kernel, dim3((unsigned)ceil_div(total_rows, 4)), dim3(256), 0, st, a);
+  if (dx_base) hipLaunchKernelGGL(table_bwd_cols_kernel, dim3((unsigned)(n_desc * ((in_dim + 63) / 64) * TB_RG)), dim3(256), 0, st, a);
   return cips3d_launch_status();
 }

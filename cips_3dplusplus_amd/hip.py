@@ -122,6 +122,26 @@ class LinearTable:
         check(_lib.load().cips3d_linear_table(self._dev.data_ptr(), len(self._descs), self._rows, B, stream_ptr()),
               "cips3d_linear_table")
 
+    def backward(self, B, out_base, dy_base, x_base, dx_base=None, need_dW=True, need_db=True):
+        """Gradients of every head (cips3d_linear_table_bwd).  dy_base / dx_base mirror the forward's out / x buffers
+        (dx_base is accumulated into: zero it first).  Returns (dW_flat, w_offsets (python list), db_flat)."""
+        if self._dev is None:
+            self._upload()
+        in_dim = self._descs[0].in_dim
+        offs, off = [], 0
+        for d in self._descs:
+            offs.append(off)
+            off += d.out_dim * d.in_dim
+        if getattr(self, "_woff_dev", None) is None or self._woff_dev.numel() != len(offs):
+            self._woff_dev = torch.tensor(offs, dtype=torch.int64).to(self.device)
+        dW = torch.empty(off, device=self.device) if need_dW else None
+        db = torch.empty(self._rows, device=self.device) if need_db else None
+        check(_lib.load().cips3d_linear_table_bwd(self._dev.data_ptr(), len(self._descs), self._rows, in_dim, B,
+                                                  dev_ptr(out_base, "out"), dev_ptr(dy_base, "dy"), dev_ptr(x_base, "x"),
+                                                  dev_ptr(dx_base, "dx", True), self._woff_dev.data_ptr(), dev_ptr(dW, "dW", True),
+                                                  dev_ptr(db, "db", True), stream_ptr()), "cips3d_linear_table_bwd")
+        return dW, offs, db
+
 
 def camera_params(locations, img_size, fov_ang=6.0, dist_radius=0.12, up=None):
     """locations [B,2] -> extrinsics [B,3,4], focal/near/far [B,1,1] (reference return shapes)."""

@@ -106,6 +106,18 @@ typedef struct cips3d_linear_desc {
 int cips3d_linear_table(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int B,
                         void* stream);
 
+/* Backward of cips3d_linear_table (heads without activation: y = (w_scale W x + b_scale bias) out_scale + out_shift), all
+ * heads in two launches.  The table is the forward's; tensors of the backward sit at the same offsets as the forward's:
+ *   dy at dy_base + (desc.out - out_base)   [row b at + b * desc.out_stride]
+ *   dx at dx_base + (desc.x - x_base)       [row b at + b * desc.x_stride]; ACCUMULATED with atomics (heads share inputs):
+ *                                            the caller zeroes dx; NULL = not wanted
+ *   dW flat, head i at dW + w_offsets[i] ([out_dim, in_dim]; w_offsets = device array of int64 element offsets); NULL = not wanted
+ *   db flat [total_rows] (rows of heads without bias receive their value all the same); NULL = not wanted
+ * Every head must have the same in_dim (% 4 == 0). */
+int cips3d_linear_table_bwd(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int in_dim, int B,
+                            const float* out_base, const float* dy_base, const float* x_base, float* dx_base,
+                            const int64_t* w_offsets_dev, float* dW, float* db, void* stream);
+
 /* ------------------------------------------------------------------ camera */
 
 /* locations [B,2] = (azim, elev); fov_deg [B] or NULL (then fov_deg_scalar); up [B,3] or NULL

@@ -48,6 +48,47 @@ def test_linear_bwd():
         close(xg.grad, xr.grad, what="dx"); close(Wg.grad, Wr.grad, what="dW"); close(bg.grad, br.grad, what="db")
 
 
+@pytest.mark.parametrize("in_dim,B", [(512, 2), (36, 3), (256, 1)])
+def test_linear_table_bwd(in_dim, B):
+    """cips3d_linear_table_bwd: heads of different heights over shared input slots, against torch autograd."""
+    g = torch.Generator().manual_seed(in_dim)
+    n_slots, outs, slots = 4, (48, 3, 130, 64, 7), (0, 1, 1, 3, 0)          # two heads share slot 1, two share slot 0
+    x = torch.randn(B, n_slots, in_dim, generator=g)
+    Ws = [torch.randn(o, in_dim, generator=g) for o in outs]
+    bs = [torch.randn(o, generator=g) for o in outs]
+    dys = [torch.randn(B, o, generator=g) for o in outs]
+    ws, bsc, osc, osh = 0.21, 0.5, 3.0, 1.5
+    xr = leaf(x)
+    Wr, br = [leaf(W) for W in Ws], [leaf(b) for b in bs]
+    tot = sum(((xr[:, s] @ (W * ws).t() + b * bsc) * osc + osh) .mul(dy).sum() for W, b, s, dy in zip(Wr, br, slots, dys))
+    tot.backward()
+    xd = cu(x)
+    out = torch.empty(B * sum(outs), device=DEV)
+    tab = hip.LinearTable(DEV)
+    keep, off = [], 0
+    for W, b, s_, o in zip(Ws, bs, slots, outs):
+        Wd, bd = cu(W), cu(b)
+        keep += [Wd, bd]
+        tab.add(Wd, bd, xd, n_slots * in_dim, out, o, w_scale=ws, b_scale=bsc, out_scale=osc, out_shift=osh,
+                x_offset=s_ * in_dim, out_offset=off)
+        off += B * o
+    tab.run(B)
+    off = 0
+    for W, b, s_, o in zip(Ws, bs, slots, outs):
+        ref = (x[:, s_] @ (W * ws).t() + b * bsc) * osc + osh
+        close(out[off:off + B * o].view(B, o), ref, 1e-5, "forward")
+        off += B * o
+    dy = torch.cat([cu(d).reshape(-1) for d in dys])
+    dx = torch.zeros_like(xd)
+    dW, woffs, db = tab.backward(B, out, dy, xd, dx)
+    close(dx, xr.grad, what="dx")
+    row = 0
+    for i, o in enumerate(outs):
+        close(dW[woffs[i]:woffs[i] + o * in_dim].view(o, in_dim), Wr[i].grad, what=f"dW{i}")
+        close(db[row:row + o], br[i].grad, what=f"db{i}")
+        row += o
+
+
 @pytest.mark.parametrize("cin,cout,hw,up,B,per_sample_noise", [
     (32, 32, 16, False, 2, False), (64, 32, 16, True, 1, False), (128, 64, 8, True, 2, True), (96, 160, 6, False, 2, False),
     (256, 512, 12, False, 1, False)])
