@@ -267,10 +267,48 @@ class CameraFn(Function):
         return hip.camera_params_bwd(locations, dextr, up).to(locations.dtype), None, None, None, None
 
 
+class FilmTableFn(Function):
+    """gamma / beta of every FiLM layer in one launch (the renderer's own table, cips3d_linear_table) with the table backward."""
+
+    @staticmethod
+    def forward(ctx, renderer, styles, *params):
+        B = styles.shape[0]
+        styles_buf, film, tab = renderer._film_table(B, styles.device)
+        styles_buf.copy_(styles)
+        tab.run(B)
+        ctx.renderer, ctx.B = renderer, B
+        ctx.save_for_backward(styles.detach().float().contiguous())
+        return film.clone()
+
+    @staticmethod
+    def backward(ctx, dfilm):
+        renderer, B = ctx.renderer, ctx.B
+        (styles,) = ctx.saved_tensors
+        styles_buf, film, tab = renderer._film_table(B, styles.device)
+        styles_buf.copy_(styles)
+        need_p = any(ctx.needs_input_grad[2:])
+        dstyles = torch.zeros_like(styles_buf) if ctx.needs_input_grad[1] else None
+        dW, woffs, db = tab.backward(B, film, _c(dfilm.float()), styles_buf, dstyles, need_dW=need_p, need_db=need_p)
+        outs = [None, dstyles]
+        row = 0
+        for i, (d, wo) in enumerate(zip(tab._descs, woffs)):
+            nW, nb = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            outs.append(dW[wo:wo + d.out_dim * d.in_dim].view(d.out_dim, d.in_dim) if (nW and dW is not None) else None)
+            outs.append(db[row:row + d.out_dim] if (nb and db is not None) else None)
+            row += d.out_dim
+        return tuple(outs)
+
+
 def film_table(renderer, styles):
     """gamma / beta of every FiLM layer from the W+ styles (B, D+1, style_dim) -> [B, D+1, 2, H]
     (cips3d/volume_renderer.py:66-67 through LinearLayer :15-35)."""
     net = renderer.network
+    if STYLE_TABLE and renderer.style_dim % 4 == 0:
+        params = []
+        for layer in list(net.pts_linears) + [net.views_linears]:
+            for head in (layer.gamma, layer.beta):
+                params += [head.weight, head.bias]
+        return FilmTableFn.apply(renderer, styles, *params)
     rows = []
     for l, layer in enumerate(list(net.pts_linears) + [net.views_linears]):
         st = styles[:, l]
