@@ -53,15 +53,18 @@ class ModulateFn(Function):
     """ModulatedConv2d weight modulation (k = 1): W [1,Cout,Cin,1,1], s [B,Cin] -> wm [B,Cout,Cin]."""
 
     @staticmethod
-    def forward(ctx, W, s, scale, demodulate):
+    def forward(ctx, W, s, scale, demodulate, pre=None):
+        """pre: this layer's wm when every layer was modulated by one table launch (modulate_all); the node then only
+        records the dependency."""
         _, Cout, Cin, kh, kw = W.shape
         if kh * kw != 1:
             raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
         s = _c(s)
-        wm = hip.modulate_weights(W, s, s.shape[1], s.shape[0], Cout, Cin, 1, scale, demodulate, packed=False)
+        if pre is None:
+            pre = hip.modulate_weights(W, s, s.shape[1], s.shape[0], Cout, Cin, 1, scale, demodulate, packed=False)
         ctx.save_for_backward(W, s)
         ctx.cfg = (Cout, Cin, scale, demodulate)
-        return wm.view(s.shape[0], Cout, Cin)
+        return pre.view(s.shape[0], Cout, Cin)
 
     @staticmethod
     def backward(ctx, dwm):
@@ -69,18 +72,18 @@ class ModulateFn(Function):
         Cout, Cin, scale, demodulate = ctx.cfg
         dW, ds = hip.modulate_bwd(dwm.contiguous().clone(), W, s, Cout, Cin, 1, scale, demodulate,
                                   need_dW=ctx.needs_input_grad[0])
-        return dW, ds, None, None
+        return dW, ds, None, None, None
 
 
 class Conv1x1Fn(Function):
     """Per-sample GEMM y[b] = wm[b] x[b] (x [B,Cin,H,W]); backward = the same GEMM on wm^T + the pixel-contraction GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wm):
+    def forward(ctx, x, wm, packed=None):
         x = _c(x)
         wm = _c(wm)
         Cout = wm.shape[1]
-        y = hip.modconv1x1(x, hip.pack_weights(wm), Cout, epilogue=0)
+        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm), Cout, epilogue=0)
         ctx.save_for_backward(x, wm)
         return y
 
@@ -93,7 +96,7 @@ class Conv1x1Fn(Function):
             dx = hip.modconv1x1(dy, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0)
         if ctx.needs_input_grad[1]:
             dwm = hip.gemm_wgrad(dy, x)
-        return dx, dwm
+        return dx, dwm, None
 
 
 class NoiseBiasActFn(Function):
@@ -193,6 +196,59 @@ class StyleTableFn(Function):
         return tuple(outs)
 
 
+@torch.no_grad()
+def modulate_all(dec, s_list):
+    """Modulated weights of every decoder layer from its s (values only; the autograd dependency is recorded per layer by
+    ModulateFn(pre=...)): ONE cips3d_modulate_table launch writes the plain [B,Cout,Cin] form of all 26 layers and the
+    MFMA-packed form of the 17 StyledConvs, instead of 26 modulate + 17 pack launches.
+    Returns {id(module): (wm_plain, wm_packed or None)}."""
+    from . import _lib
+    from .decoder import StyledConv
+    seq = dec._mod_layers()
+    B, dev = s_list[0].shape[0], s_list[0].device
+    key = (B, dec.conv1.conv.modulation.weight.data_ptr())
+    ent = getattr(dec, "_grad_mod_table", None)
+    if ent is None or ent[0] != key:
+        sizes = [m.conv.in_channel for m, _ in seq]
+        s_stage = torch.empty(B * sum(sizes), device=dev)
+        plain_n = [B * m.conv.out_channel * m.conv.in_channel for m, _ in seq]
+        packs = [isinstance(m, StyledConv) and hip.modconv1x1_supported(m.conv.in_channel, m.conv.out_channel, 4096) for m, _ in seq]
+        plain = torch.empty(sum(plain_n), device=dev)
+        packed = torch.empty(sum(n for n, p in zip(plain_n, packs) if p), device=dev)
+        descs, rows, so, po, ko = [], 0, 0, 0, 0
+        layout = []
+        for (m, _), cin, n, pk in zip(seq, sizes, plain_n, packs):
+            conv = m.conv
+            for want_packed in ((False, True) if pk else (False,)):
+                d = _lib.ModulateDesc()
+                d.W = conv.weight.data_ptr()
+                d.s = s_stage.data_ptr() + 4 * so
+                d.out = (packed.data_ptr() + 4 * ko) if want_packed else (plain.data_ptr() + 4 * po)
+                d.s_stride = cin
+                d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
+                d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if want_packed else 0)
+                d.scale = conv.scale
+                d.row_begin = rows
+                rows += conv.out_channel
+                descs.append(d)
+            layout.append((po, n, ko if pk else None))
+            so += B * cin
+            po += n
+            ko += n if pk else 0
+        arr = (_lib.ModulateDesc * len(descs))(*descs)
+        tab_dev = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to(dev)
+        ent = (key, s_stage, plain, packed, tab_dev, len(descs), rows, layout)
+        dec._grad_mod_table = ent
+    _, s_stage, plain, packed, tab_dev, n_desc, rows, layout = ent
+    torch.cat([t.reshape(-1) for t in s_list], out=s_stage)
+    _lib.check(_lib.load().cips3d_modulate_table(tab_dev.data_ptr(), n_desc, rows, B, _lib.stream_ptr()), "cips3d_modulate_table")
+    plain_now = plain.clone()            # saved by Conv1x1Fn / ToRGBFn for their backward: must outlive the next forward
+    out = {}
+    for (m, _), (po, n, ko) in zip(seq, layout):
+        out[id(m)] = (plain_now[po:po + n], packed[ko:ko + n] if ko is not None else None)
+    return out
+
+
 def decoder_styles(dec, styles):
     """s_l of every decoder layer, in `dec._mod_layers()` order."""
     params = []
@@ -202,15 +258,15 @@ def decoder_styles(dec, styles):
 
 
 # ------------------------------------------------------------------------------------------ decoder, differentiable walk
-def styled_conv(sc, x, style, noise, s=None):
+def styled_conv(sc, x, style, noise, s=None, pre=None):
     """StyledConv (models/model_v3.py:444-454) as a chain of differentiable HIP ops.  `s`: the layer's modulation when it
-    was computed by the table (decoder_styles)."""
+    was computed by the table (decoder_styles); `pre`: (wm, packed wm) from modulate_all."""
     conv = sc.conv
     mod = conv.modulation
     if s is None:
         s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
-    wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate)
-    y = Conv1x1Fn.apply(x, wm)
+    wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate, pre[0] if pre else None)
+    y = Conv1x1Fn.apply(x, wm, pre[1] if (pre and x.shape[2] * x.shape[3] % 4 == 0) else None)
     if conv.upsample:
         y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
     if noise is None:
@@ -218,12 +274,12 @@ def styled_conv(sc, x, style, noise, s=None):
     return NoiseBiasActFn.apply(y, noise, sc.noise.weight, sc.activate.bias)
 
 
-def to_rgb(tr, x, style, skip, s=None):
+def to_rgb(tr, x, style, skip, s=None, pre=None):
     conv = tr.conv
     mod = conv.modulation
     if s is None:
         s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
-    wm = ModulateFn.apply(conv.weight, s, conv.scale, False)
+    wm = ModulateFn.apply(conv.weight, s, conv.scale, False, pre[0] if pre else None)
     if skip is not None and tr.upsample:
         skip = tr.upsample(skip)            # op.upfirdn2d, differentiable
     return ToRGBFn.apply(x, wm, tr.bias, skip)
@@ -237,15 +293,20 @@ def decoder_forward(dec, features, styles, noise=None):
         noise = [None] * dec.num_layers
     # all 26 style modulations from one table launch (forward and backward); S maps module -> its s
     seq = dec._mod_layers()
-    S = {id(m): sl for (m, _), sl in zip(seq, decoder_styles(dec, styles))} if (STYLE_TABLE and dec.style_dim % 4 == 0) else {}
-    out = styled_conv(dec.conv1, features, styles[:, 0], noise[0], S.get(id(dec.conv1)))
-    skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None, S.get(id(dec.to_rgb1)))
+    S, M = {}, {}
+    if STYLE_TABLE and dec.style_dim % 4 == 0:
+        s_list = decoder_styles(dec, styles)
+        S = {id(m): sl for (m, _), sl in zip(seq, s_list)}
+        if all(m.conv.in_channel % 32 == 0 and m.conv.out_channel % 32 == 0 for m, _ in seq if hasattr(m, "noise")):
+            M = modulate_all(dec, s_list)
+    out = styled_conv(dec.conv1, features, styles[:, 0], noise[0], S.get(id(dec.conv1)), M.get(id(dec.conv1)))
+    skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None, S.get(id(dec.to_rgb1)), M.get(id(dec.to_rgb1)))
     i = 1
     for st in range(len(dec.to_rgbs)):
         c0, c1, tr = dec.convs[2 * st], dec.convs[2 * st + 1], dec.to_rgbs[st]
-        out = styled_conv(c0, out, styles[:, i], noise[2 * st + 1], S.get(id(c0)))
-        out = styled_conv(c1, out, styles[:, i + 1], noise[2 * st + 2], S.get(id(c1)))
-        skip = to_rgb(tr, out, styles[:, i + 2], skip, S.get(id(tr)))
+        out = styled_conv(c0, out, styles[:, i], noise[2 * st + 1], S.get(id(c0)), M.get(id(c0)))
+        out = styled_conv(c1, out, styles[:, i + 1], noise[2 * st + 2], S.get(id(c1)), M.get(id(c1)))
+        skip = to_rgb(tr, out, styles[:, i + 2], skip, S.get(id(tr)), M.get(id(tr)))
         i += 2
     return skip
 
