@@ -99,6 +99,28 @@ class Conv1x1Fn(Function):
         return dx, dwm, None
 
 
+class Conv1x1ActFn(Function):
+    """StyledConv without up-sampling in one forward launch: GEMM with the noise + bias + leaky-ReLU epilogue
+    (cips3d_modconv1x1, epilogue 1); backward = NoiseBiasActFn's followed by Conv1x1Fn's."""
+
+    @staticmethod
+    def forward(ctx, x, wm, packed, noise, noise_w, bias):
+        x, wm, noise = _c(x), _c(wm), _c(noise)
+        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm), wm.shape[1], epilogue=1, noise=noise,
+                           noise_w=noise_w, bias=bias)
+        ctx.save_for_backward(x, wm, y, noise, noise_w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm, y, noise, noise_w = ctx.saved_tensors
+        n_x, n_wm, _, n_noise, n_nw, n_b = ctx.needs_input_grad
+        dpre, dnoise, dnw, db = hip.noise_bias_act_bwd(_c(dy), y, noise, noise_w, need_dnoise=n_noise, need_dnw=n_nw, need_db=n_b)
+        dx = hip.modconv1x1(dpre, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0) if n_x else None
+        dwm = hip.gemm_wgrad(dpre, x) if n_wm else None
+        return dx, dwm, None, dnoise, dnw, db
+
+
 class NoiseBiasActFn(Function):
     """NoiseInjection + FusedLeakyReLU: y = lrelu(x + nw*noise + bias_c)*sqrt2."""
 
@@ -266,9 +288,13 @@ def styled_conv(sc, x, style, noise, s=None, pre=None):
     if s is None:
         s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
     wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate, pre[0] if pre else None)
-    y = Conv1x1Fn.apply(x, wm, pre[1] if (pre and x.shape[2] * x.shape[3] % 4 == 0) else None)
-    if conv.upsample:
-        y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
+    packed = pre[1] if (pre and x.shape[2] * x.shape[3] % 4 == 0) else None
+    if not conv.upsample:
+        if noise is None:
+            noise = torch.randn(x.shape[0], 1, x.shape[2], x.shape[3], device=x.device)
+        return Conv1x1ActFn.apply(x, wm, packed, noise, sc.noise.weight, sc.activate.bias)
+    y = Conv1x1Fn.apply(x, wm, packed)
+    y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
     if noise is None:
         noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], device=y.device)
     return NoiseBiasActFn.apply(y, noise, sc.noise.weight, sc.activate.bias)
