@@ -460,6 +460,37 @@ def test_fused_stage_also_computes_next_low_res_gemm(C, bf16):
     assert torch.equal(rgb3, rgb) and torch.equal(y3, y_next)
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_chained_stages_equal_unchained_full_size(bf16):
+    """The one-call forward with every up-sampling stage computing the next stage's low-res GEMM (plan.CHAIN_STAGES) against
+    the same forward with one GEMM launch per stage: same arithmetic up to the split-K / exchange summation order."""
+    from cips_3dplusplus_amd import plan as _plan
+    G = pkg.build_generator(configs.ffhq_G_cfg(1024, 2), DEV, seed=4)
+    G.set_decoder_precision("bf16" if bf16 else "fp32")
+    g = torch.Generator(device=DEV).manual_seed(9)
+    B = 2
+    zs = [torch.randn(B, 256, device=DEV, generator=g) for _ in range(2)]
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[0.2, 0.05], [-0.4, -0.1]], device=DEV))
+    nb = G.create_noise_bufs(64, DEV)
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=nb,
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    old = _plan.CHAIN_STAGES
+    try:
+        _plan.CHAIN_STAGES = True
+        G._plans = {}
+        a = G(**kw)["rgb"].clone()
+        assert any(L.flags & 1 for L in list(G._plans.values())[0].plan.layers[: list(G._plans.values())[0].plan.n_dec_layers])
+        _plan.CHAIN_STAGES = False
+        G._plans = {}
+        b = G(**kw)["rgb"].clone()
+        assert not any(L.flags & 1 for L in list(G._plans.values())[0].plan.layers[: list(G._plans.values())[0].plan.n_dec_layers])
+    finally:
+        _plan.CHAIN_STAGES = old
+        G._plans = {}
+    tol = (2e-2 if bf16 else 2e-5) * float(b.abs().max())
+    assert maxdiff(a, b) < tol
+
+
 def test_rgb_to_uint8():
     x = torch.randn(2, 3, 37, 41) * 0.8
     x[0, 0, 0, :4] = torch.tensor([-1.0, 1.0, -3.0, 3.0])
