@@ -1254,7 +1254,9 @@ extern "C" int cips3d_noise_bias_act(const float* x, const float* noise, int64_t
 }
 
 extern "C" int cips3d_fused_up_conv_supported(int C, int H, int W) {
-  return (C == 32 || C == 64 || C == 128 || C == 256) && W % 32 == 0 && H % 2 == 0 && H >= 2;
+  // (the kernel keeps intra-sample offsets in 32 bits: C * 2H * 2W must stay below 2^31)
+  return (C == 32 || C == 64 || C == 128 || C == 256) && W % 32 == 0 && H % 2 == 0 && H >= 2 &&
+         (int64_t)C * 4 * H * W < ((int64_t)1 << 31);
 }
 
 extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
@@ -1280,7 +1282,6 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (!out2 && !wm_rgb && !wm_next) return CIPS3D_E_BADARG;
   if (wm_rgb && (!bias_rgb || !rgb)) return CIPS3D_E_BADARG;
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
-  if ((int64_t)C * 4 * H * W >= (int64_t)1 << 31) return CIPS3D_E_UNSUPP;   // 32-bit intra-sample offsets in the kernel
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
