@@ -7,14 +7,24 @@ One step = one `Generator.forward` over one batch of synthetic views with inputs
 reference's `test__rendering_time` (/root/reference/exp/tests/test_cips3dpp.py:709-748): FFHQ 1024^2
 release recipe (N_layers_renderer=2, 1x1 modulated convs), batch 1, 64x64 rays x 24 samples,
 perturb=True, fresh decoder noise every call, random-init (synthetic) weights, fp32.
-For N > 1 GPUs (launched with torch.distributed.run) every rank renders its own batch per step and the
-images are gathered to rank 0 over RCCL inside the timed region (weak scaling).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (a fresh
+`python -m torch.distributed.run` child, before this process touches the GPU) -- the launch form of the
+reference's own multi-process scripts (exp/tests/test_cips3dpp.py:814-820, scripts/gen_images.py:44-84).
+Every rank renders its own batch per step and the images are gathered to rank 0 over RCCL inside the
+timed region (weak scaling).
+
+The timed region is K steps between (barrier + device synchronise) brackets, max over ranks; it is
+repeated `--repeats` times and the MEDIAN repeat is reported (all repeats are listed).  At N = 1 the other
+BASELINE.json configurations are timed after the headline and reported under "also" in the same line.
 
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -25,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 PUBLISHED_VIEWS_PER_S = 46.93085418313323   # test__rendering_time docstring, unknown CUDA GPU
 MFMA_F32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+EVENT_STRIDE = 8                           # HIP events around the dominant kernel on every 8th step (a record drains the queue)
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_nerf_traffic.json")
 
 
 def nerf_flops_per_point(H, D):
@@ -32,40 +44,223 @@ def nerf_flops_per_point(H, D):
     return 2 * 3 * H + (D - 1) * 2 * H * H + 2 * (H + 3) * H + 2 * H * 1 + 2 * H * 3
 
 
-def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=25.0):
+def make_inputs(rank, B, dev):
+    """Per-rank synthetic inputs of a step (device RNG seeded by rank): latent codes and camera angles."""
+    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
+    zs = [torch.randn(B, 256, device=dev, generator=gen), torch.randn(B, 256, device=dev, generator=gen)]
+    if B == 1:
+        locs = torch.zeros(B, 2, device=dev)      # test__rendering_time: frontal camera
+    else:
+        locs = torch.randn(B, 2, device=dev, generator=gen) * torch.tensor([0.3, 0.15], device=dev)
+    return zs, locs
+
+
+def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=16.0):
     """The oracle (CPU port of the reference path) timed on this host on the same workload."""
     from cips_3dplusplus_amd import weights
     from oracle import path as O
     import cips_3dplusplus_amd as pkg
-    torch.manual_seed(0)
     G = pkg.Generator(**cfg)
     sd = weights.synth_state_dict({k: tuple(v.shape) for k, v in G.state_dict().items()}, seed=0)
     del G
     # the per-op torch CPU path stops scaling early: on the GPU box's 64-core / 128-thread host one 1024^2 view takes 4.0 s
-    # with 128 threads, 2.5 s with 64, 1.9 s with 32, 1.7 s with 16, 1.9 s with 8 -- time it where it is fastest
+    # with 128 threads, 2.5 s with 64, 1.9 s with 32, 1.7 s with 16, 1.9 s with 8 -- time it where it is fastest, and once
+    # with a single thread
     all_threads = torch.get_num_threads()
     cores = min(all_threads, 16)
-    torch.set_num_threads(cores)
-    g = torch.Generator().manual_seed(12345)
-    zs = [torch.randn(batch, 256, generator=g), torch.randn(batch, 256, generator=g)]
+    zs, _, _ = weights.synth_inputs(cfg, batch=batch)
     cam = O.camera_params(torch.zeros(batch, 2), 64, 6, 0.12)
+    g = torch.Generator().manual_seed(12345)
+
+    def one_view():
+        nb = O.create_noise_bufs(cfg, 64, generator=g)
+        u = torch.rand(batch, 64, 64, 1, generator=g)
+        t0 = time.perf_counter()
+        O.generator_forward(sd, cfg, zs, cam[0], cam[1], 64, cam[2], cam[3], nerf_cfg, nb, perturb_u=u)
+        return time.perf_counter() - t0
+
     times = []
     t_all = time.perf_counter()
     with torch.no_grad():
-        for it in range(6):
-            nb = O.create_noise_bufs(cfg, 64, generator=g)
-            u = torch.rand(batch, 64, 64, 1, generator=g)
-            t0 = time.perf_counter()
-            O.generator_forward(sd, cfg, zs, cam[0], cam[1], 64, cam[2], cam[3], nerf_cfg, nb, perturb_u=u)
-            times.append(time.perf_counter() - t0)
-            if it >= 1 and time.perf_counter() - t_all > seconds_budget:
+        torch.set_num_threads(cores)
+        for it in range(3 + 5):                  # 3 warm-ups (SURVEY 8d), then up to 5 timed views inside the budget
+            times.append(one_view())
+            if it >= 3 and time.perf_counter() - t_all > seconds_budget:
                 break
+        warm = min(3, len(times) - 1)
+        timed = times[warm:]
+        torch.set_num_threads(1)
+        t1 = one_view()
     torch.set_num_threads(all_threads)
-    timed = times[1:] if len(times) > 1 else times   # first call is the warm-up
-    per_view = sum(timed) / len(timed) / batch
-    return {"value": 1.0 / per_view, "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"{len(timed)} forward(s) of the same workload after 1 warm-up ({per_view * 1e3:.0f} ms/view; "
-                      f"{cores} of {all_threads} host threads: more are slower)"}
+    per_view = statistics.median(timed) / batch
+    return {"value": 1.0 / per_view, "unit": "views/s", "cores": cores, "host_threads": all_threads, "kind": "port",
+            "value_1_thread": batch / t1,
+            "sample": f"median of {len(timed)} forward(s) of the same workload after {warm} warm-up(s) "
+                      f"({per_view * 1e3:.0f} ms/view with {cores} of {all_threads} host threads: more are slower; "
+                      f"{t1 / batch * 1e3:.0f} ms/view with 1 thread, one view)"}
+
+
+class ForwardWorkload:
+    """One BASELINE configuration of the generator forward: builds the generator + inputs, runs steps."""
+
+    def __init__(self, dev, rank, world, res, depth, n_samples, batch, precision, deterministic):
+        import cips_3dplusplus_amd as pkg
+        from cips_3dplusplus_amd import configs
+        from cips_3dplusplus_amd.camera import Camera
+        self.dev, self.rank, self.world = dev, rank, world
+        self.res, self.depth, self.n_samples, self.B = res, depth, n_samples, batch
+        self.precision, self.deterministic = precision, deterministic
+        self.cfg = configs.ffhq_G_cfg(res, depth)
+        self.nerf_cfg = {"N_samples": n_samples, "perturb": not deterministic, "static_viewdirs": False}
+        self.G = pkg.build_generator(self.cfg, dev, seed=0)
+        self.G.set_decoder_precision(precision)
+        self.zs, locs = make_inputs(rank, batch, dev)
+        self.cam = Camera.generate_camera_params(64, dev, locations=locs, **{k: v for k, v in configs.FFHQ_CAM_CFG.items()
+                                                                             if k in ("fov_ang", "dist_radius")})
+        self.noise_bufs = self.G.create_noise_bufs(64, dev) if deterministic else None
+        if deterministic:                          # every rank must use the same buffers
+            g = torch.Generator(device=dev).manual_seed(777)
+            self.noise_bufs = [torch.randn(b.shape, device=dev, generator=g) for b in self.noise_bufs]
+        self.pending = None
+        self.last_gathered = None
+
+    def name(self):
+        return (f"ffhq_r{self.res}_nerf64x64x{self.n_samples}_D{self.depth}_B{self.B}_{self.precision} "
+                f"(test__rendering_time loop body: perturb={not self.deterministic}, "
+                f"{'fixed' if self.deterministic else 'fresh'} decoder noise, random-init weights)")
+
+    def render(self):
+        e, f, n, fa, _ = self.cam
+        with torch.no_grad():                       # `with torch.set_grad_enabled(False)`, test_cips3dpp.py:724
+            return self.G(zs=self.zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1,
+                          noise_bufs=self.noise_bufs, nerf_cfg=self.nerf_cfg)["rgb"]
+
+    def step(self):
+        from cips_3dplusplus_amd import hip
+        from cips_3dplusplus_amd.multiview import gather_views_async
+        rgb = self.render()
+        if self.world > 1:
+            # the one exchange step of the path: finished images -> rank 0.  uint8 on the device first (what the
+            # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
+            # step i overlaps the rendering of step i+1.
+            if self.pending is not None:
+                self.pending.wait(assemble=False)       # the gathered blocks stay on rank 0; no per-step concatenation copy
+            self.pending = gather_views_async(hip.rgb_to_uint8(rgb), self.B * self.world)
+        return rgb
+
+    def barrier(self):
+        if self.world > 1:
+            if self.pending is not None:
+                self.last_gathered = self.pending.wait(assemble=True) if self.keep_last else self.pending.wait(assemble=False)
+                self.pending = None
+            torch.cuda.synchronize()
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    keep_last = False
+
+    def measure(self, steps, warmup, repeats, kernel_events=True):
+        """`repeats` timed regions of `steps` steps each (barrier + synchronise on both sides, max over ranks)."""
+        from cips_3dplusplus_amd import hip
+        for _ in range(warmup):
+            self.step()
+        hip.KERNEL_EVENTS_STRIDE = EVENT_STRIDE
+        hip.prepare_event_pairs(repeats * (steps // EVENT_STRIDE + 2))
+        events, elapsed = [], []
+        for _ in range(repeats):
+            self.barrier()
+            if kernel_events:
+                hip.KERNEL_EVENTS["nerf_render"] = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.barrier()
+            dt = time.perf_counter() - t0
+            events += hip.KERNEL_EVENTS.pop("nerf_render", [])
+            if self.world > 1:
+                t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dt = float(t)
+            elapsed.append(dt)
+        med = statistics.median(elapsed)
+        kern_ms = sum(s.elapsed_time(t) for s, t in events) / len(events) if events else float("nan")
+        return med, elapsed, kern_ms, len(events)
+
+    def roofline(self, kern_ms, n_events):
+        H = self.cfg["renderer_cfg"]["hidden_dim"]
+        flops = self.B * 64 * 64 * self.n_samples * nerf_flops_per_point(H, self.depth)
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE and WRITE_SIZE
+        # cannot share a pass with timing): the committed summary of that pass is REPLAYED here for the matching
+        # configuration, not measured in this run.
+        traffic, src = None, None
+        tp = os.path.join(ROOT, TRAFFIC_FILE)
+        if self.depth == 2 and self.n_samples == 24 and self.B == 1 and os.path.exists(tp):
+            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
+            src = f"replayed from {TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command)"
+        return {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
+                "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": src,
+                "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
+                "timed_every_nth_step": EVENT_STRIDE}
+
+
+def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24):
+    """BASELINE config 5: CompCars 256^2, D = 6, batch 2 (image + mirrored view): steps/s of the pose phase of the
+    flip-inversion loop (forward + backward + Adam; /root/reference/exp/cips3d/models/projector_v10.py:915-1216)."""
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs, hip
+    from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss
+    G = pkg.build_generator(configs.ffhq_G_cfg(res, depth), dev, seed=0)
+    cam_cfg = {"img_size": 64, "fov_ang": configs.COMPCARS_CAM_CFG["fov_ang"],
+               "dist_radius": configs.COMPCARS_CAM_CFG["dist_radius"]}
+    ncfg = {"N_samples": n_samples, "perturb": False, "static_viewdirs": True}
+    g = torch.Generator(device=dev).manual_seed(1)
+    t_rgb = torch.randn(2, 3, res, res, device=dev, generator=g).clamp(-1, 1)
+    t_thumb = torch.randn(2, 3, 64, 64, device=dev, generator=g).clamp(-1, 1)
+    proj = FlipProjector(G, dev)
+    warmup = max(warmup, 4)                         # first steps: allocator warm-up, plan builds
+    elapsed = []
+    for _ in range(repeats):
+        marks = {}
+
+        def on_step(step, loss, azim, elev):
+            if step == warmup - 1:
+                torch.cuda.synchronize()
+                marks["t0"] = time.perf_counter()
+
+        proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=warmup + steps, N_steps_app=0,
+                           w_avg_samples=2000, on_step=on_step, azim_init=(-1.0, 3.0))
+        torch.cuda.synchronize()
+        elapsed.append(time.perf_counter() - marks["t0"])
+    med = statistics.median(elapsed)
+    H = 256
+    line = {"metric": "flip-inversion steps/s (forward + backward + Adam, batch 2 = image + mirrored view)",
+            "value": steps / med, "unit": "steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "repeats": repeats,
+            "ms_per_step_repeats": [e / steps * 1e3 for e in elapsed], "dtype": "f32",
+            "config": {"workload": f"BASELINE config 5: compcars_r{res}_nerf64x64x{n_samples}_D{depth}_B2 pose phase "
+                                   f"(surrogate loss, random-init weights)"},
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    rl = hip.inversion_roofline(B=2, n_samples=n_samples, hidden=H, depth=depth) if hasattr(hip, "inversion_roofline") else None
+    if rl is not None:
+        line["roofline"] = rl
+    return line
+
+
+def spawn_ranks(a):
+    """`--gpus N` without a launcher: start N fresh ranks (this process has not touched the GPU and never will)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    n_dev = torch.cuda.device_count()               # counting devices does not initialise HIP on this image
+    if n_dev < a.gpus and "CIPS3D_DIST_BACKEND" not in env:
+        # fewer devices than ranks (a 1-GPU box): the ranks share devices round-robin and the exchange runs over gloo, so
+        # that the N > 1 leg is still exercised end to end; RCCL needs one device per rank.  The line says so.
+        env["CIPS3D_DIST_BACKEND"] = "gloo"
+        print(f"bench.py: {n_dev} device(s) for {a.gpus} ranks -> ranks share devices, gather over gloo", file=sys.stderr)
+    port = env.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -73,27 +268,37 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--res", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--n-samples", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (N=64, config 3, config 5)")
     ap.add_argument("--no-kernel-events", action="store_true", help="A/B: no HIP events around the dominant kernel (roofline = null)")
     ap.add_argument("--deterministic", action="store_true", help="perturb off + fixed noise buffers (demo semantics)")
     ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32)")
+    ap.add_argument("--dump-gathered", default=None, help="rank 0 saves the last step's gathered uint8 frames (torch.save)")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
+                         f"(or without a launcher: bench.py starts its own ranks)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # CIPS3D_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks then share
     # devices round-robin); the driver's runs use the default: nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("CIPS3D_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
     if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
+        local_rank %= max(1, n_dev)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -103,107 +308,63 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
             dist.init_process_group(backend=backend)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    import cips_3dplusplus_amd as pkg
-    from cips_3dplusplus_amd import configs, hip
-    from cips_3dplusplus_amd.camera import Camera
-    from cips_3dplusplus_amd.multiview import gather_views_async
-
-    cfg = configs.ffhq_G_cfg(a.res, a.depth)
-    nerf_cfg = {"N_samples": a.n_samples, "perturb": not a.deterministic, "static_viewdirs": False}
-    G = pkg.build_generator(cfg, dev, seed=0)
-    G.set_decoder_precision(a.decoder_precision)
-    B = a.batch
-    gen = torch.Generator(device=dev).manual_seed(12345 + rank)
-    zs = [torch.randn(B, 256, device=dev, generator=gen), torch.randn(B, 256, device=dev, generator=gen)]
-    locs = torch.zeros(B, 2, device=dev) if B == 1 else torch.randn(B, 2, device=dev, generator=gen) * torch.tensor([0.3, 0.15], device=dev)
-    e, f, n, fa, _ = Camera.generate_camera_params(64, dev, locations=locs, **{k: v for k, v in configs.FFHQ_CAM_CFG.items()
-                                                                               if k in ("fov_ang", "dist_radius")})
-    noise_bufs = G.create_noise_bufs(64, dev) if a.deterministic else None
-
-    pending = [None]
-
-    def step():
-        r = G(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1, noise_bufs=noise_bufs,
-              nerf_cfg=nerf_cfg)
-        rgb = r["rgb"]
-        if world > 1:
-            # the one exchange step of the path: finished images -> rank 0.  uint8 on the device first (what the
-            # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
-            # step i overlaps the rendering of step i+1.
-            if pending[0] is not None:
-                pending[0].wait(assemble=False)       # the gathered blocks stay on rank 0; no per-step concatenation copy
-            pending[0] = gather_views_async(hip.rgb_to_uint8(rgb), B * world)
-        return rgb
-
-    def barrier():
-        if world > 1:
-            if pending[0] is not None:
-                pending[0].wait(assemble=False)
-                pending[0] = None
-            torch.cuda.synchronize()
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    # HIP events around the dominant kernel, recorded inside cips3d_generator_forward on the stream it launches on.  An
-    # event record between kernels drains the queue (~6 us each, measured), so every `stride`-th step is instrumented, with
-    # the event handles created here, before the timed region.
-    stride = 8 if a.steps >= 64 else 1
-    hip.KERNEL_EVENTS_STRIDE = stride
-    hip.prepare_event_pairs(a.steps // stride + 2)
-    barrier()
-    if not a.no_kernel_events:
-        hip.KERNEL_EVENTS["nerf_render"] = []
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    events = hip.KERNEL_EVENTS.pop("nerf_render", [])
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
+    wl = ForwardWorkload(dev, rank, world, a.res, a.depth, a.n_samples, a.batch, a.decoder_precision, a.deterministic)
+    wl.keep_last = a.dump_gathered is not None
+    med, elapsed, kern_ms, n_ev = wl.measure(a.steps, a.warmup, a.repeats, kernel_events=not a.no_kernel_events)
+    if a.dump_gathered and rank == 0:
+        frames = wl.last_gathered if world > 1 else None
+        if frames is None:
+            from cips_3dplusplus_amd import hip
+            frames = hip.rgb_to_uint8(wl.render())
+        torch.save(frames.cpu(), a.dump_gathered)
 
     if rank == 0:
-        views = a.steps * B * world
-        value = views / elapsed
-        kern_ms = sum(s.elapsed_time(t) for s, t in events) / max(1, len(events)) if events else float("nan")
-        H = cfg["renderer_cfg"]["hidden_dim"]
-        flops = B * 64 * 64 * a.n_samples * nerf_flops_per_point(H, a.depth)
-        achieved = flops / (kern_ms * 1e-3) / 1e12
+        B = a.batch
+        value = a.steps * B * world / med
         published_cfg = (a.res == 1024 and a.depth == 2 and a.n_samples == 24 and B == 1 and not a.deterministic and
                          a.decoder_precision == "fp32")
-        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE and
-        # WRITE_SIZE cannot share a pass with timing); the committed summary is quoted for the matching config.
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_pmc_nerf_traffic.json")
-        if a.depth == 2 and a.n_samples == 24 and B == 1 and os.path.exists(tp):
-            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
         line = {
             "metric": "rendered views/sec at FFHQ 1024^2 (generator forward: 64x64-ray NeRF + StyleGAN2 decoder)",
             "value": value, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": med / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (value / PUBLISHED_VIEWS_PER_S) if published_cfg else None,
             "dtype": "f32" if a.decoder_precision == "fp32" else "bf16 decoder GEMMs (f32 accumulate), f32 NeRF",
             "data": "synthetic",
-            "config": {"workload": f"ffhq_r{a.res}_nerf64x64x{a.n_samples}_D{a.depth}_B{B}_{a.decoder_precision} "
-                                   f"(test__rendering_time loop body: perturb={not a.deterministic}, "
-                                   f"{'fixed' if a.deterministic else 'fresh'} decoder noise, random-init weights)",
-                       "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
+            "repeats": a.repeats, "ms_per_step_repeats": [e / a.steps * 1e3 for e in elapsed],
+            "config": {"workload": wl.name(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
-            "roofline": {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
-                         "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": len(events),
-                         "timed_every_nth_step": stride},
+            "roofline": wl.roofline(kern_ms, n_ev),
         }
+        if world > 1:
+            line["rccl_ranks"] = torch.distributed.get_world_size()
+            line["dist_backend"] = backend + (" (RCCL)" if backend == "nccl" else " (ranks share devices: not an RCCL measurement)")
+            line["physical_gpus"] = n_dev
+        if world == 1 and not a.no_also and published_cfg:
+            # the other BASELINE.json configurations, same command, same box (each its own timed regions)
+            also = []
+            del wl
+            torch.cuda.empty_cache()
+            for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
+                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder", dict(n_samples=24, batch=4, precision="bf16"))):
+                w2 = ForwardWorkload(dev, 0, 1, 1024, 2, kw["n_samples"], kw["batch"], kw["precision"], False)
+                steps2 = max(10, a.steps // 2)
+                m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
+                also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
+                             "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
+                             "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
+                             "dtype": "f32" if kw["precision"] == "fp32" else "bf16 decoder GEMMs (f32 accumulate), f32 NeRF",
+                             "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2)})
+                del w2
+                torch.cuda.empty_cache()
+            inv = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3))
+            inv["what"] = "BASELINE config 5: one flip-inversion step"
+            also.append(inv)
+            line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, {**nerf_cfg, "perturb": True}, B)
+            from cips_3dplusplus_amd import configs
+            line["cpu_baseline"] = cpu_baseline(configs.ffhq_G_cfg(a.res, a.depth),
+                                                {"N_samples": a.n_samples, "perturb": True, "static_viewdirs": False}, B)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -30,10 +30,12 @@ def __getattr__(name):
 
 def build_generator(G_cfg, device="cuda", state_dict=None, seed=0):
     """`build_model(G_cfg)` of the reference harness (tl2 registry lookup, test_cips3dpp.py:706):
-    construct, load either a checkpoint `state_dict` or deterministic synthetic weights, move to device."""
+    construct, load either a checkpoint `state_dict` or deterministic synthetic weights, move to device.  The handle is
+    an inference / inversion model: `eval()` with every parameter frozen (`requires_grad_(False)`); the inversion loop
+    re-enables the decoder's (`G.decoder.requires_grad_(True)`, projector_v10.py:117-123)."""
     from .generator import Generator
     cfg = {k: v for k, v in G_cfg.items() if k not in ("register_modules", "name")}
-    G = Generator(**cfg).eval()
+    G = Generator(**cfg).eval().requires_grad_(False)
     if state_dict is None:
         shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
         state_dict = weights.synth_state_dict(shapes, seed=seed,

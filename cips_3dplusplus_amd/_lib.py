@@ -128,29 +128,45 @@ _SIGS = {
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),
+    "cips3d_sizeof_struct": (c_i64, [c_int]),
 }
 
 EXPORTED = tuple(_SIGS)
+ABI_VERSION = 2            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 
+def _struct_table():
+    """index of cips3d_sizeof_struct -> the ctypes mirror of that struct (plan.py holds the two big ones)."""
+    from . import plan
+    return {0: plan.GeneratorPlan, 1: plan.ForwardIO, 2: NerfParams, 3: LinearDesc, 4: ModulateDesc, 5: plan.DecLayer,
+            6: NerfBwdGeom}
+
+
 def load(build_if_missing=True):
-    """dlopen the HIP library (building it in-tree with hipcc first if it is absent)."""
+    """dlopen the HIP library.  A missing OR stale library (older than any csrc/*.hip, *.h or the public header) is rebuilt
+    in-tree with hipcc first; with `build_if_missing=False` either case raises instead."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    from . import build
+    if not build.up_to_date():
+        state = "stale (older than its sources)" if os.path.exists(LIB_PATH) else "missing"
         if not build_if_missing:
-            raise RuntimeError(f"{LIB_PATH} is missing: run `python -m cips_3dplusplus_amd.build`")
-        from . import build
-        build.build_library()
+            raise RuntimeError(f"{LIB_PATH} is {state}: run `python -m cips_3dplusplus_amd.build`")
+        build.build_library(force=True)
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)   # AttributeError here = ABI mismatch between header and library
         fn.restype = res
         fn.argtypes = args
-    if lib.cips3d_abi_version() != 1:
-        raise RuntimeError("libcips3d_hip.so ABI version mismatch; rebuild with cips_3dplusplus_amd.build")
+    if lib.cips3d_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libcips3d_hip.so has ABI version {lib.cips3d_abi_version()}, this binding expects {ABI_VERSION}; "
+                           "rebuild with cips_3dplusplus_amd.build")
+    for which, st in _struct_table().items():
+        if lib.cips3d_sizeof_struct(which) != C.sizeof(st):
+            raise RuntimeError(f"layout mismatch for {st.__name__}: library {lib.cips3d_sizeof_struct(which)} bytes, "
+                               f"binding {C.sizeof(st)} bytes")
     _lib = lib
     return lib
 

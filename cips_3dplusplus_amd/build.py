@@ -30,14 +30,29 @@ def hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built on this machine")
 
 
-def _deps_mtime():
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+STAMP = LIB + ".srchash"      # content hash of the sources the library was built from (travels with the .so)
+
+
+def source_hash():
+    """sha256 over every csrc/*.hip, csrc/*.h, the public header, the flags and this file: file times do not survive a
+    snapshot copy to the GPU box, contents do."""
+    import hashlib
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files += [os.path.join(os.path.dirname(PKG), "include", "cips3d_hip.h"), os.path.abspath(__file__)]
-    return max(os.path.getmtime(f) for f in files if os.path.exists(f))
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in files:
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
 
 
 def up_to_date():
-    return os.path.exists(LIB) and os.path.getmtime(LIB) >= _deps_mtime()
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == source_hash()
 
 
 def _compile(src, keep_temps):
@@ -67,6 +82,8 @@ def build_library(force=False, keep_temps=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     os.replace(LIB + ".tmp", LIB)
+    with open(STAMP, "w") as fh:
+        fh.write(source_hash() + "\n")
     return LIB
 
 

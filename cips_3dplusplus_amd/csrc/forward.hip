@@ -13,6 +13,18 @@
 
 extern "C" int64_t cips3d_sizeof_plan(void) { return (int64_t)sizeof(cips3d_generator_plan); }
 extern "C" int64_t cips3d_sizeof_io(void) { return (int64_t)sizeof(cips3d_forward_io); }
+extern "C" int64_t cips3d_sizeof_struct(int which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(cips3d_generator_plan);
+    case 1: return (int64_t)sizeof(cips3d_forward_io);
+    case 2: return (int64_t)sizeof(cips3d_nerf_params);
+    case 3: return (int64_t)sizeof(cips3d_linear_desc);
+    case 4: return (int64_t)sizeof(cips3d_modulate_desc);
+    case 5: return (int64_t)sizeof(cips3d_dec_layer);
+    case 6: return (int64_t)sizeof(cips3d_nerf_bwd_geom);
+    default: return -1;
+  }
+}
 
 extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io,
                                         void* stream) {

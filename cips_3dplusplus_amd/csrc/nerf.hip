@@ -37,6 +37,7 @@
 // partials only (n_chunks * (H+8) * 4 B per ray).
 #include <stdlib.h>
 
+#include <atomic>
 #include "common.h"
 
 #ifdef CIPS3D_STAMPS
@@ -652,12 +653,16 @@ int launch_render_x(const NerfArgs& a, hipStream_t st) {
   constexpr int H = NT * 16;
   const size_t lds_bytes = sizeof(float) * (nerf_ring_floats(H, TPS, a.fuse_finish != 0) + (size_t)(P.depth + 1) * 2 * H + 10 * H);
   if (lds_bytes > 160 * 1024) return CIPS3D_E_UNSUPP;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device (a process may render on several GPUs) and the flag is shared by host threads
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev_id = 0;
+  if (hipError_t e = hipGetDevice(&dev_id); e != hipSuccess) return (int)e;
+  const unsigned long long bit = 1ull << (dev_id & 63);
+  if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
   hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);

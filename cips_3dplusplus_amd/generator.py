@@ -209,11 +209,14 @@ class Generator(nn.Module):
                 path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
                 eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
                 N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
-                renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, **kwargs):
-        """model_v3.py:875-1042.  Inference runs the fused path without an autograd graph.  When gradients are enabled
-        and an INPUT tensor (cam_poses, style_render, style_decoder, a noise buffer) requires them -- the inversion loop,
-        projector_v10.py:211-277 -- the differentiable op chain of `autograd.py` is used instead; parameters with
-        requires_grad then receive gradients as well (decoder only: the renderer's weights are constants there)."""
+                renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, differentiable=None, **kwargs):
+        """model_v3.py:875-1042.  Inference runs the fused path without an autograd graph.  The differentiable op chain of
+        `autograd.py` (the inversion loop, projector_v10.py:211-277) is used when `differentiable=True`, or -- with the
+        default `differentiable=None` -- when gradients are enabled and either an INPUT tensor (cam_poses, style_render,
+        style_decoder, a noise buffer) or a DECODER parameter requires them.  Differentiable leaves: those inputs and the
+        decoder's parameters.  The renderer's and the mapping networks' weights are constants of that path
+        (`optim_render_params: false`, train_cips3d_compcars_v10.yaml:585): if one of them requires grad the call raises
+        instead of silently returning no gradient -- freeze them (`build_generator` does) or call under `torch.no_grad()`."""
         kw = dict(zs=zs, cam_poses=cam_poses, focals=focals, img_size=img_size, near=near, far=far, truncation=truncation,
                   inject_index=inject_index, path_reg=path_reg, style_render=style_render, style_decoder=style_decoder,
                   noise_bufs=noise_bufs, randomize_noise=randomize_noise, eikonal_reg=eikonal_reg, return_sdf=return_sdf,
@@ -221,10 +224,24 @@ class Generator(nn.Module):
                   N_samples_forward=N_samples_forward, nerf_cfg=nerf_cfg, recompute_mean=recompute_mean,
                   project_noise=project_noise, mesh_path=mesh_path, renderer_detach=renderer_detach,
                   sample_idx_h=sample_idx_h, sample_idx_w=sample_idx_w, perturb_u=perturb_u)
-        if torch.is_grad_enabled():
-            ins = [cam_poses, style_render, style_decoder] + list(noise_bufs or [])
-            if any(torch.is_tensor(t) and t.requires_grad for t in ins):
-                return self._forward_grad(**kw)
+        if differentiable is None:
+            differentiable = False
+            if torch.is_grad_enabled():
+                ins = [cam_poses, style_render, style_decoder] + list(noise_bufs or [])
+                differentiable = (any(torch.is_tensor(t) and t.requires_grad for t in ins)
+                                  or any(p.requires_grad for p in self.decoder.parameters()))
+        if differentiable:
+            if not torch.is_grad_enabled():
+                raise RuntimeError("differentiable=True under torch.no_grad()")
+            frozen = [n for mod in ("renderer", "style", "style_decoder")
+                      for n, p in getattr(self, mod).named_parameters(prefix=mod) if p.requires_grad]
+            if frozen:
+                raise NotImplementedError(
+                    f"{len(frozen)} renderer / mapping-network parameters require grad (first: {frozen[0]}): their gradients "
+                    "are not implemented (the released inversion recipes keep them constant); call "
+                    "`G.requires_grad_(False); G.decoder.requires_grad_(True)` as projector_v10.py does, or run under "
+                    "torch.no_grad()")
+            return self._forward_grad(**kw)
         with torch.no_grad():
             return self._forward_infer(**kw, **kwargs)
 

@@ -245,7 +245,8 @@ def rays_in_world(cam_poses, focals, img_size, static_viewdirs=False):
     lib = _lib.load()
     B = cam_poses.shape[0]
     o, d, v = (torch.empty(B, img_size, img_size, 3, device=cam_poses.device) for _ in range(3))
-    check(lib.cips3d_rays_in_world(dev_ptr(cam_poses.float().contiguous(), "c2w"), dev_ptr(focals.float().reshape(B).contiguous(), "focal"),
+    c2w, foc = cam_poses.float().contiguous(), focals.float().reshape(B).contiguous()     # converted copies live until the launch
+    check(lib.cips3d_rays_in_world(dev_ptr(c2w, "c2w"), dev_ptr(foc, "focal"),
                                    img_size, int(bool(static_viewdirs)), B, dev_ptr(o), dev_ptr(d), dev_ptr(v), stream_ptr()),
           "cips3d_rays_in_world")
     return o, d, v
@@ -255,7 +256,8 @@ def z_vals(near, far, B, R, N, perturb_u=None):
     lib = _lib.load()
     z = torch.empty(B, R, N, device=near.device)
     u = None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous()
-    check(lib.cips3d_z_vals(dev_ptr(near.float().reshape(B).contiguous(), "near"), dev_ptr(far.float().reshape(B).contiguous(), "far"),
+    nr, fr = near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous()   # converted copies live until the launch
+    check(lib.cips3d_z_vals(dev_ptr(nr, "near"), dev_ptr(fr, "far"),
                             dev_ptr(u, "u", True), B, R, N, dev_ptr(z), stream_ptr()), "cips3d_z_vals")
     return z
 
@@ -530,7 +532,8 @@ def camera_params_bwd(locations, dextr, up=None):
     loc = locations.detach().float().contiguous()
     up_t = up.detach().float().contiguous() if up is not None else None
     dloc = torch.empty(B, 2, device=loc.device)
-    check(lib.cips3d_camera_params_bwd(dev_ptr(loc, "locations"), dev_ptr(up_t, "up", True), dev_ptr(dextr.contiguous(), "dextr"),
+    dextr = dextr.contiguous()
+    check(lib.cips3d_camera_params_bwd(dev_ptr(loc, "locations"), dev_ptr(up_t, "up", True), dev_ptr(dextr, "dextr"),
                                        B, dev_ptr(dloc), stream_ptr()), "cips3d_camera_params_bwd")
     return dloc
 

@@ -79,6 +79,9 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
     Every rank renders its block in `chunk`-view calls; the entries named in `keys` are gathered to dst."""
     ws = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if ws > 1 else 0
+    if n_views < ws:
+        # decided from (n_views, world size) alone, so EVERY rank raises here: no rank is left waiting in the gather
+        raise ValueError(f"{n_views} view(s) for {ws} ranks: a rank would receive no views; use n_views >= world_size")
     lo, hi = view_slice(n_views, rank, ws)
     parts = {k: [] for k in keys}
     for a in range(lo, hi, chunk):
@@ -92,9 +95,6 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
         else:
             local = None
         if ws > 1:
-            shape_src = local
-            if shape_src is None:
-                raise RuntimeError("a rank received no views; use n_views >= world_size")
             result[k] = gather_views(local, n_views, dst=dst, group=group)
         else:
             result[k] = local

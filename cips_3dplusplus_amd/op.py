@@ -26,8 +26,10 @@ def bias_act_raw(x, bias, ref, act, grad, alpha, scale):
     for d in x.shape[2:]:
         step_b *= d
     size_b = bias.numel() if bias is not None and bias.numel() else 0
-    b_ptr = _lib.dev_ptr(bias.contiguous(), "bias") if size_b else None
-    r_ptr = _lib.dev_ptr(ref.contiguous(), "refer") if ref is not None and ref.numel() else None
+    bias_c = bias.contiguous() if size_b else None                      # contiguous copies live until the launch
+    ref_c = ref.contiguous() if ref is not None and ref.numel() else None
+    b_ptr = _lib.dev_ptr(bias_c, "bias", allow_none=True)
+    r_ptr = _lib.dev_ptr(ref_c, "refer", allow_none=True)
     _lib.check(lib.cips3d_fused_bias_act(_lib.dev_ptr(x, "input"), b_ptr, r_ptr, _lib.dev_ptr(out), x.numel(), step_b,
                                          max(size_b, 1), act, grad, float(alpha), float(scale), _lib.stream_ptr()),
                "cips3d_fused_bias_act")

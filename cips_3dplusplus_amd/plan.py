@@ -278,9 +278,11 @@ class ForwardPlan:
         else:
             if len(noise_bufs) != len(self.noise_sizes):
                 raise RuntimeError(f"expected {len(self.noise_sizes)} noise buffers, got {len(noise_bufs)}")
+            keep = []                 # fresh per-layer draws must outlive the enqueue below (only raw pointers go into io)
             for i, (nb, s) in enumerate(zip(noise_bufs, self.noise_sizes)):
                 if nb is None:
                     nb = torch.randn(B, 1, s, s, device=dev)
+                    keep.append(nb)
                 if tuple(nb.shape[-2:]) != (s, s) or nb.shape[0] not in (1, B):
                     raise RuntimeError(f"noise buffer {i} has shape {tuple(nb.shape)}, expected (1|{B},1,{s},{s})")
                 io.noise[i] = dev_ptr(nb, f"noise_bufs[{i}]")

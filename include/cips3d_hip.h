@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 1
+#define CIPS3D_ABI_VERSION 2   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -386,6 +386,10 @@ int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_for
 /* sizeof() of the two structs as the library sees them (layout check for foreign-language bindings) */
 int64_t cips3d_sizeof_plan(void);
 int64_t cips3d_sizeof_io(void);
+/* sizeof() of every struct that crosses the boundary (a binding checks its own layout against these at load time):
+ * which = 0 cips3d_generator_plan, 1 cips3d_forward_io, 2 cips3d_nerf_params, 3 cips3d_linear_desc,
+ * 4 cips3d_modulate_desc, 5 cips3d_dec_layer, 6 cips3d_nerf_bwd_geom; -1 for an unknown index */
+int64_t cips3d_sizeof_struct(int which);
 
 /* ------------------------------------------------------------------ stand-alone renderer steps
  * The fused kernel does these in registers; as separate entry points they give every method of the reference's `Render`

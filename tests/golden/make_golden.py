@@ -264,13 +264,9 @@ STRIDE = 37
 
 
 def full_inputs(cfg, seed=12345):
-    """Inputs shared by make_golden and the GPU parity test (reproducible from seeds)."""
-    g = torch.Generator().manual_seed(seed)
-    zs = [torch.randn(1, 256, generator=g), torch.randn(1, 256, generator=g)]
+    """Inputs shared by make_golden and the GPU parity test: closed form (weights.synth_inputs), no RNG."""
+    zs, nb, means = weights.synth_inputs(cfg, batch=1, seed=seed)
     locs = torch.tensor([[0.31, -0.08]])
-    from oracle import path as _o
-    nb = _o.create_noise_bufs(cfg, 64, generator=g)
-    means = (torch.randn(1, 256, generator=g) * 0.2, torch.randn(1, 512, generator=g) * 0.2)
     return zs, locs, nb, means
 
 
@@ -288,7 +284,7 @@ def g_full():
                                                      fov_ang=6, dist_radius=0.12)
         ncfg = dict(N_samples=N, perturb=False, static_viewdirs=static)
         r = _run_ref(G, zs, cam, 64, ncfg, nb, truncation=trunc, means=means)
-        out[f"{tag}.sd_checksum"] = np.float64(weights.state_dict_checksum(sd))
+        out[f"{tag}.sd_checksum"] = np.uint64(weights.state_dict_checksum(sd))
         out[f"{tag}.nkeys"] = np.int64(len(shapes))
         out[f"{tag}.rgb_s"] = r["rgb"].flatten()[::STRIDE]
         out[f"{tag}.rgb_absmax"] = r["rgb"].abs().max()
@@ -348,6 +344,55 @@ def g_backward():
     save("backward", **out)
 
 
+# ---------------------------------------------------------------- 9c. BASELINE config 5 at its stated size
+CONFIG5_STRIDE = 53
+
+
+def g_config5():
+    """One flip-inversion step of the reference at the size BASELINE config 5 states: CompCars camera (fov 15, radius 0.3),
+    256^2 output, D = 6 NeRF layers, 64x64 rays x 24 samples, static view directions, batch 2 (image + mirrored view),
+    forward + backward of the surrogate loss (models/projector_v10.py:211-277 call pattern).  Stores the loss, strided
+    outputs and strided gradients of every leaf the loop optimises."""
+    res, D, N = 256, 6, 24
+    out = {"_src": "models/projector_v10.py:211-277 + models/model_v3.py:875-1042 under autograd; CompCars 256^2, D=6, B=2",
+           "stride": np.int64(CONFIG5_STRIDE)}
+    cfg = configs.ffhq_G_cfg(resolution=res, N_layers_renderer=D)
+    G = ref.Generator(**cfg).eval()
+    shapes = {k: tuple(v.shape) for k, v in G.state_dict().items()}
+    sd = weights.synth_state_dict(shapes, seed=2)
+    G.load_state_dict(sd, strict=True)
+    out["sd_checksum"] = np.uint64(weights.state_dict_checksum(sd))
+    G.requires_grad_(False)
+    G.decoder.requires_grad_(True)
+    locs, w_r, w_d, nb, t_rgb, t_thumb = weights.synth_inversion_inputs(cfg, res)
+    assert w_d.shape[1] == G.decoder.n_latent
+    locs.requires_grad_(True); w_r.requires_grad_(True); w_d.requires_grad_(True)
+    nb = [b.requires_grad_(True) for b in nb]
+    ncfg = dict(N_samples=N, perturb=False, static_viewdirs=True)
+    cam_cfg = configs.COMPCARS_CAM_CFG
+    with torch.enable_grad():
+        cam = ref_nerf.Camera.generate_camera_params(img_size=64, device="cpu", locations=locs, fov_ang=cam_cfg["fov_ang"],
+                                                     dist_radius=cam_cfg["dist_radius"])
+        r = G(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=cam[0], focals=cam[1], img_size=64,
+              near=cam[2], far=cam[3], noise_bufs=nb, nerf_cfg=ncfg, renderer_detach=False, return_xyz=True)
+        loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
+        loss.backward()
+    st = CONFIG5_STRIDE
+    out.update(loss=loss.detach(), rgb_s=r["rgb"].detach().flatten()[::st], rgb_absmax=r["rgb"].detach().abs().max(),
+               thumb=r["thumb_rgb"].detach(), xyz=r["xyz"].detach(), mask=r["mask"].detach(), depth=r["depth"].detach())
+    out.update({"g.locs": locs.grad, "g.w_r": w_r.grad, "g.w_d": w_d.grad})
+    for i, b in enumerate(nb):
+        out[f"g.noise{i}_s"] = b.grad.flatten()[::st]
+        out[f"g.noise{i}_absmax"] = b.grad.abs().max()
+    for name, p in G.decoder.named_parameters():
+        if p.grad is not None:
+            out[f"g.dec.{name}_s"] = p.grad.flatten()[::st]
+            out[f"g.dec.{name}_absmax"] = p.grad.abs().max()
+    print("config5 loss", float(loss), "|dlocs|", locs.grad.abs().max().item(), "|dw_r|", w_r.grad.abs().max().item(),
+          "|dw_d|", w_d.grad.abs().max().item())
+    save("config5", **out)
+
+
 # ---------------------------------------------------------------- 10. on-disk formats (SURVEY 8f row 3)
 def g_ckpt_tiny():
     """A checkpoint directory and an inversion file as the reference's writers lay them out, holding the
@@ -391,6 +436,7 @@ if __name__ == "__main__":
                 tiny_generator=g_tiny_generator, ckpt_tiny=g_ckpt_tiny, backward=g_backward)
     if a.full:
         jobs["full_size"] = g_full
+        jobs["config5"] = g_config5
     for name, fn in jobs.items():
         if a.only is None or a.only == name:
             fn()

@@ -1,0 +1,68 @@
+"""bench.py's N > 1 leg: `--gpus N` starts N ranks itself (the launch form of the reference's multi-process scripts,
+/root/reference/exp/tests/test_cips3dpp.py:814-820, scripts/gen_images.py:44-84).  CPU tests cover the launcher and
+its loud failures; the GPU test runs the bench step with 2 ranks on the box's device(s) and checks the frames gathered on
+rank 0 against two single-rank renders."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_flag_must_match_world_size():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "3"], env=_env(WORLD_SIZE="1", RANK="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="covered by the GPU test below")
+def test_gpus_flag_spawns_ranks_that_fail_loudly_without_a_gpu():
+    """No GPU here: the launcher must still start 2 ranks, each of which refuses to run (no CPU fallback)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=_env(),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert r.stderr.count("bench.py needs a GPU") >= 1, r.stderr[-2000:]     # the launcher may stop rank 1 before it prints
+    assert "for 2 ranks" in r.stderr
+    assert '"n_gpus"' not in r.stdout
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_step_gathers_the_single_rank_frames(tmp_path):
+    dump = str(tmp_path / "frames.pt")
+    env = _env()
+    if torch.cuda.device_count() < 2:
+        env["CIPS3D_DIST_BACKEND"] = "gloo"           # one device: the two ranks share it, the exchange runs over gloo
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2",
+                        "--deterministic", "--no-cpu-baseline", "--dump-gathered", dump], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parallelism"] == "views x2" and line["value"] > 0
+    assert len(line["ms_per_step_repeats"]) == 2
+    frames = torch.load(dump)
+    assert frames.shape == (2, 3, 1024, 1024) and frames.dtype == torch.uint8
+    sys.path.insert(0, ROOT)
+    import bench
+    from cips_3dplusplus_amd import hip
+    dev = torch.device("cuda", 0)
+    for rank in range(2):
+        wl = bench.ForwardWorkload(dev, rank, 1, 1024, 2, 24, 1, "fp32", True)
+        with torch.no_grad():
+            exp = hip.rgb_to_uint8(wl.render()).cpu()
+        assert torch.equal(frames[rank:rank + 1], exp), f"rank {rank}'s gathered frame differs from its single-rank render"
+        del wl
+    assert not torch.equal(frames[0], frames[1])

@@ -267,14 +267,32 @@ def test_generator_backward_golden(golden, tag, D, static):
     assert all(p.grad is None for p in G.renderer.parameters())
 
 
-def test_inference_path_unchanged_without_input_grads():
-    """Parameters require grad by default; the fused no-graph path must still be the one that runs for plain inference."""
+def test_path_selection_by_grad_requirements():
+    """Plain inference (frozen handle, or torch.no_grad()) runs the fused no-graph path; decoder parameters that require
+    grad select the differentiable path even when no input does; renderer parameters that require grad raise."""
     from cips_3dplusplus_amd.camera import Camera
     G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=1)
+    assert not any(p.requires_grad for p in G.parameters())
     e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
     zs = [torch.randn(1, 32, device=DEV), torch.randn(1, 32, device=DEV)]
-    r = G(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, nerf_cfg=dict(N_samples=6, perturb=False))
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=8, near=n, far=fa, nerf_cfg=dict(N_samples=6, perturb=False),
+              noise_bufs=G.create_noise_bufs(8, DEV))
+    r = G(**kw)
     assert not r["rgb"].requires_grad
+    G.decoder.requires_grad_(True)                      # flip steps / optim_cam=False: only decoder parameters are leaves
+    with torch.no_grad():
+        r0 = G(**kw)
+    assert not r0["rgb"].requires_grad
+    r1 = G(**kw)
+    assert r1["rgb"].requires_grad
+    close(r1["rgb"], r["rgb"], 1e-5, "rgb on the two paths")
+    r1["rgb"].square().mean().backward()
+    assert G.decoder.conv1.conv.weight.grad is not None and float(G.decoder.conv1.conv.weight.grad.abs().max()) > 0
+    G.renderer.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="renderer"):
+        G(**kw)
+    with torch.no_grad():
+        G(**kw)                                          # inference is unaffected
 
 
 def test_flip_inversion_loop_reduces_loss():

@@ -60,6 +60,35 @@ def _worker(rank, world, port, n_views, chunk, q):
     dist.destroy_process_group()
 
 
+def _worker_too_few(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cips_3dplusplus_amd.multiview import render_views_sharded
+    try:
+        render_views_sharded(lambda a, b: {"rgb": torch.zeros(b - a, 1)}, world - 1)
+        q.put((rank, False))
+    except ValueError:
+        q.put((rank, True))
+    dist.barrier()                     # every rank raised: nobody is stuck in a gather
+    dist.destroy_process_group()
+
+
+def test_fewer_views_than_ranks_raises_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_too_few, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
 @pytest.mark.parametrize("world,n_views,chunk", [(2, 8, 1), (2, 7, 2), (3, 8, 3)])
 def test_sharded_render_and_gather(world, n_views, chunk):
     ctx = mp.get_context("spawn")

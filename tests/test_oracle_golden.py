@@ -188,3 +188,30 @@ def test_oracle_autograd_matches_reference_gradients(golden, tag, D, static):
             close(sd["decoder." + k[len(f"{tag}.g.dec."):]].grad, fx[k], k)
             n += 1
     assert n > 30
+
+
+def test_oracle_config5_at_stated_size(golden):
+    """BASELINE config 5 at its stated size (CompCars camera, 256^2, D = 6, batch 2, forward + backward of the surrogate
+    loss): the oracle under autograd against the imported reference (tests/golden/config5.npz) -- outputs, loss and the
+    gradients of the leaves the inversion loop optimises.  This pins what tests/test_gpu_reference_fixtures.py leans on."""
+    fx = golden("config5")
+    res, D, N = 256, 6, 24
+    cfg = configs.ffhq_G_cfg(res, D)
+    import cips_3dplusplus_amd as pkg
+    shapes = {k: tuple(v.shape) for k, v in pkg.Generator(**cfg).state_dict().items()}
+    sd = weights.synth_state_dict(shapes, seed=2)
+    assert weights.state_dict_checksum(sd) == fx["sd_checksum"]
+    locs, w_r, w_d, nb, t_rgb, t_thumb = weights.synth_inversion_inputs(cfg, res)
+    locs.requires_grad_(True); w_r.requires_grad_(True); w_d.requires_grad_(True)
+    cam = O.camera_params(locs, 64, configs.COMPCARS_CAM_CFG["fov_ang"], configs.COMPCARS_CAM_CFG["dist_radius"])
+    r = O.generator_forward(sd, cfg, [None, None], cam[0], cam[1], 64, cam[2], cam[3],
+                            dict(N_samples=N, perturb=False, static_viewdirs=True), nb, style_render=w_r, style_decoder=w_d,
+                            return_xyz=True)
+    st = int(fx["stride"])
+    assert maxdiff(r["rgb"].detach().flatten()[::st], fx["rgb_s"]) < 2e-4
+    assert maxdiff(r["thumb_rgb"].detach(), fx["thumb"]) < 2e-6 and maxdiff(r["xyz"].detach(), fx["xyz"]) < 2e-6
+    loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx["loss"])) < 1e-5 * float(fx["loss"])
+    for a, k in ((locs.grad, "g.locs"), (w_r.grad, "g.w_r"), (w_d.grad, "g.w_d")):
+        assert float((a - fx[k]).abs().max()) <= 2e-4 * float(fx[k].abs().max()) + 1e-8, k
