@@ -50,7 +50,7 @@ def load_generator(ckpt_dir, device="cuda", model="G_ema", strict=True):
     Returns (generator on `device`, the loaded command config)."""
     from .generator import Generator
     cfg = load_config_command(os.path.join(ckpt_dir, "config_command.yaml"))
-    G = Generator(**generator_ctor_cfg(cfg["G_cfg"])).eval()
+    G = Generator(**generator_ctor_cfg(cfg["G_cfg"])).eval().requires_grad_(False)     # an inference / inversion handle, as build_generator
     sd = _torch_load(os.path.join(ckpt_dir, f"{model}.pth"))
     missing, unexpected = G.load_state_dict(sd, strict=strict)
     if not strict and (missing or unexpected):

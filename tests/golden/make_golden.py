@@ -364,32 +364,44 @@ def g_config5():
     out["sd_checksum"] = np.uint64(weights.state_dict_checksum(sd))
     G.requires_grad_(False)
     G.decoder.requires_grad_(True)
-    locs, w_r, w_d, nb, t_rgb, t_thumb = weights.synth_inversion_inputs(cfg, res)
-    assert w_d.shape[1] == G.decoder.n_latent
-    locs.requires_grad_(True); w_r.requires_grad_(True); w_d.requires_grad_(True)
-    nb = [b.requires_grad_(True) for b in nb]
     ncfg = dict(N_samples=N, perturb=False, static_viewdirs=True)
     cam_cfg = configs.COMPCARS_CAM_CFG
-    with torch.enable_grad():
-        cam = ref_nerf.Camera.generate_camera_params(img_size=64, device="cpu", locations=locs, fov_ang=cam_cfg["fov_ang"],
-                                                     dist_radius=cam_cfg["dist_radius"])
-        r = G(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=cam[0], focals=cam[1], img_size=64,
-              near=cam[2], far=cam[3], noise_bufs=nb, nerf_cfg=ncfg, renderer_detach=False, return_xyz=True)
-        loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
-        loss.backward()
+
+    def one_step(G, dt):
+        locs, w_r, w_d, nb, t_rgb, t_thumb = (weights.synth_inversion_inputs(cfg, res))
+        w_r, w_d, t_rgb, t_thumb = (t.to(dt) for t in (w_r, w_d, t_rgb, t_thumb))     # the camera construction is fp32-only
+        nb = [b.to(dt).requires_grad_(True) for b in nb]
+        locs.requires_grad_(True); w_r.requires_grad_(True); w_d.requires_grad_(True)
+        for p in G.parameters():
+            p.grad = None
+        with torch.enable_grad():
+            cam = ref_nerf.Camera.generate_camera_params(img_size=64, device="cpu", locations=locs, fov_ang=cam_cfg["fov_ang"],
+                                                         dist_radius=cam_cfg["dist_radius"])
+            cam = [c.to(dt) for c in cam[:4]]
+            r = G(zs=[None, None], style_render=w_r, style_decoder=w_d, cam_poses=cam[0], focals=cam[1], img_size=64,
+                  near=cam[2], far=cam[3], noise_bufs=nb, nerf_cfg=ncfg, renderer_detach=False, return_xyz=True)
+            loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
+            loss.backward()
+        grads = {"locs": locs.grad, "w_r": w_r.grad, "w_d": w_d.grad}
+        grads.update({f"noise{i}": b.grad for i, b in enumerate(nb)})
+        grads.update({f"dec.{name}": p.grad for name, p in G.decoder.named_parameters() if p.grad is not None})
+        return loss.detach(), {k: v.detach() for k, v in r.items() if v is not None}, grads
+
+    loss, r, g32 = one_step(G, torch.float32)
+    assert g32["w_d"].shape[1] == G.decoder.n_latent
+    _, r64, g64 = one_step(G.double(), torch.float64)       # the reference's own fp32 noise floor, per gradient
     st = CONFIG5_STRIDE
-    out.update(loss=loss.detach(), rgb_s=r["rgb"].detach().flatten()[::st], rgb_absmax=r["rgb"].detach().abs().max(),
-               thumb=r["thumb_rgb"].detach(), xyz=r["xyz"].detach(), mask=r["mask"].detach(), depth=r["depth"].detach())
-    out.update({"g.locs": locs.grad, "g.w_r": w_r.grad, "g.w_d": w_d.grad})
-    for i, b in enumerate(nb):
-        out[f"g.noise{i}_s"] = b.grad.flatten()[::st]
-        out[f"g.noise{i}_absmax"] = b.grad.abs().max()
-    for name, p in G.decoder.named_parameters():
-        if p.grad is not None:
-            out[f"g.dec.{name}_s"] = p.grad.flatten()[::st]
-            out[f"g.dec.{name}_absmax"] = p.grad.abs().max()
-    print("config5 loss", float(loss), "|dlocs|", locs.grad.abs().max().item(), "|dw_r|", w_r.grad.abs().max().item(),
-          "|dw_d|", w_d.grad.abs().max().item())
+    out.update(loss=loss, rgb_s=r["rgb"].flatten()[::st], rgb_absmax=r["rgb"].abs().max(), thumb=r["thumb_rgb"], xyz=r["xyz"],
+               mask=r["mask"], depth=r["depth"], noise_floor_rgb=(r64["rgb"].float() - r["rgb"]).abs().max())
+    worst = 0.0
+    for k, g in g32.items():
+        small = k in ("locs", "w_r", "w_d")
+        out[f"g.{k}" if small else f"g.{k}_s"] = g if small else g.flatten()[::st]
+        out[f"g.{k}_absmax"] = g.abs().max()
+        out[f"g.{k}_floor"] = (g64[k].float() - g).abs().max()
+        worst = max(worst, float(out[f"g.{k}_floor"]) / (float(out[f"g.{k}_absmax"]) + 1e-30))
+    print("config5 loss", float(loss), "|dlocs|", g32["locs"].abs().max().item(), "|dw_r|", g32["w_r"].abs().max().item(),
+          "|dw_d|", g32["w_d"].abs().max().item(), "worst fp32 noise floor / absmax over all gradients", worst)
     save("config5", **out)
 
 

@@ -285,7 +285,7 @@ def test_path_selection_by_grad_requirements():
     assert not r0["rgb"].requires_grad
     r1 = G(**kw)
     assert r1["rgb"].requires_grad
-    close(r1["rgb"], r["rgb"], 1e-5, "rgb on the two paths")
+    close(r1["rgb"], r["rgb"].cpu(), 1e-5, "rgb on the two paths")
     r1["rgb"].square().mean().backward()
     assert G.decoder.conv1.conv.weight.grad is not None and float(G.decoder.conv1.conv.weight.grad.abs().max()) > 0
     G.renderer.requires_grad_(True)
