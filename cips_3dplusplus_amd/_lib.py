@@ -97,6 +97,9 @@ _SIGS = {
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
+    "cips3d_modconv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "cips3d_modconv3x3": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_int, c_f32p,
+                                  c_i64, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_rays_in_world": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_z_vals": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
     "cips3d_ray_points": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, C.c_void_p]),
@@ -132,7 +135,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 2            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 3            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -45,6 +45,8 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
 //   plain : wm[b][o][i*ksq + t]
 //   packed (ksq == 1, Cout % 16 == 0, Cin % 16 == 0): A-fragment order of v_mfma_f32_16x16x4_f32
 //           wmp[b][ot][kq][lane][j] = wm[b][ot*16 + (lane&15)][16*kq + 4*j + (lane>>4)]
+//   packed, ksq == 9 (the 3x3 implicit GEMM, conv3x3.hip): the same fragment order per tap, tap-major:
+//           wmp[b][t'][ot][kq][lane][j], t' = t, or 8 - t with CIPS3D_MOD_FLIP (the transposed conv of the up-sampling branch)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb,
                                              float* __restrict__ wm, int b, int o, int Cout, int Cin, int ksq,
@@ -73,12 +75,14 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
   auto put = [&](int e, float v) {
     if (demod) v *= d;
     if (packed) {
-      const int i = e;  // ksq == 1
+      const int i = ksq == 1 ? e : e / ksq;
+      const int tap = ksq == 1 ? 0 : ((packed & 8) ? ksq - 1 - e % ksq : e % ksq);
       const int ot = o >> 4, kq = i >> 4;
       // standard: k-step j of the 16-byte piece, lane quarter q = i & 3.  chained (packed == 2): the roles swap, lane quarter
       // (i >> 2) & 3 and k-step i & 3 -- the order of the MFMA D layout (4 consecutive channels per lane)
-      const int j = packed == 2 ? (i & 3) : ((i >> 2) & 3), q = packed == 2 ? ((i >> 2) & 3) : (i & 3);
-      wm[(((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = v;
+      const bool chained = (packed & 7) == 2;
+      const int j = chained ? (i & 3) : ((i >> 2) & 3), q = chained ? ((i >> 2) & 3) : (i & 3);
+      wm[((((int64_t)b * ksq + tap) * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = v;
     } else {
       wm[((int64_t)b * Cout + o) * len + e] = v;
     }
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? ((d.flags & 4) ? 2 : 1) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 8)) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1142,8 +1146,9 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? ((demodulate & 4) ? 2 : 1) : 0;
-  if (packed && (ksq != 1 || Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
+  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 8)) : 0;   // bit 3: flipped taps
+  if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
+  if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;
   const int64_t rows = (int64_t)B * Cout;
   hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)ceil_div<int64_t>(rows, 4)), dim3(256), 0, as_stream(stream), W,
                      s, s_stride, wm, B, Cout, Cin, ksq, scale, demodulate & 1, packed);

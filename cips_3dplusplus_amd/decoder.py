@@ -9,7 +9,9 @@ Same class names, constructor arguments, parameter / buffer names and shapes as 
                             (== conv_transpose2d(stride 2) + Blur)
     StyledConv              the same with noise + bias + leaky-ReLU fused in the GEMM / FIR epilogue
     ToRGB                   3-channel modulated GEMV + bias + (FIR-upsampled) skip in one kernel
-    k=3 / odd channel counts  direct k x k kernel + standalone FIR / epilogue kernels (generality path)
+    ModulatedConv2d (k=3)   LDS-tiled implicit GEMM on MFMA (csrc/conv3x3.hip); the up-sampling variant applies the FIR to the
+                            input tile in LDS; noise + bias + leaky-ReLU in its epilogue for StyledConv
+    odd channel counts      direct k x k kernel + standalone FIR / epilogue kernels (generality path)
 """
 import math
 
@@ -138,11 +140,15 @@ class ModulatedConv2d(nn.Module):
     def fast(self, HW):
         return self.kernel_size == 1 and hip.modconv1x1_supported(self.in_channel, self.out_channel, HW)
 
-    def modulated_weight(self, style, packed):
+    def tiled3x3(self, H, W):
+        """The 3x3 MFMA kernel tiles this layer at input size H x W."""
+        return self.kernel_size == 3 and hip.modconv3x3_supported(self.in_channel, self.out_channel, H, W, self.upsample)
+
+    def modulated_weight(self, style, packed, flip=False):
         """style (B, style_dim) -> wm (packed MFMA order or plain [B,Cout,Cin,k,k])."""
         s = self.modulation(style.contiguous())
         return hip.modulate_weights(self.weight, s, s.shape[1], s.shape[0], self.out_channel, self.in_channel,
-                                    self.kernel_size ** 2, self.scale, self.demodulate, packed)
+                                    self.kernel_size ** 2, self.scale, self.demodulate, packed, flip=flip)
 
     def forward(self, input, style):
         B, Cin, H, W = input.shape
@@ -153,6 +159,9 @@ class ModulatedConv2d(nn.Module):
             if self.upsample:
                 y = op.upfirdn2d(y, self.blur.kernel, up=2, pad=(2, 1))
             return y
+        if self.tiled3x3(H, W):
+            wm = self.modulated_weight(style, packed=True, flip=self.upsample)
+            return hip.modconv3x3(x, wm, self.out_channel, up=self.upsample, fir=self.blur.kernel if self.upsample else None)
         wm = self.modulated_weight(style, packed=False)
         y = hip.modconv_kxk(x, wm, self.out_channel, self.kernel_size, transpose2=self.upsample)
         if self.upsample:
@@ -201,6 +210,11 @@ class StyledConv(nn.Module):
                 return hip.up2_fir_act(y_lo, conv.blur.kernel, noise, nw, self.activate.bias)
             return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias,
                                   bf16=self.bf16)
+        if conv.tiled3x3(H, W):
+            if wm is None:
+                wm = conv.modulated_weight(style, packed=True, flip=conv.upsample)
+            return hip.modconv3x3(x, wm, conv.out_channel, up=conv.upsample, fir=conv.blur.kernel if conv.upsample else None,
+                                  epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias)
         y = conv(x, style)
         return hip.noise_bias_act(y, noise, nw, self.activate.bias)
 
@@ -330,11 +344,12 @@ class Decoder(nn.Module):
         def wm_of(idx, H, W):
             m = seq[idx][0]
             conv = m.conv
-            packed = isinstance(m, StyledConv) and conv.fast(H * W)
+            packed = isinstance(m, StyledConv) and (conv.fast(H * W) or conv.tiled3x3(H, W))
             if isinstance(m, StyledConv) and not packed:
                 return None
             return hip.modulate_weights(conv.weight, s_buf, total, B, conv.out_channel, conv.in_channel,
-                                        conv.kernel_size ** 2, conv.scale, conv.demodulate, packed, s_offset=offs[idx])
+                                        conv.kernel_size ** 2, conv.scale, conv.demodulate, packed, s_offset=offs[idx],
+                                        flip=packed and conv.kernel_size == 3 and conv.upsample)
 
         H, W = features.shape[2], features.shape[3]
         out = self.conv1(features, styles[:, 0], noise=noise[0], wm=wm_of(0, H, W))

@@ -13,6 +13,7 @@ from ._lib import dev_ptr, stream_ptr, check
 MOD_DEMODULATE = 1
 MOD_PACKED = 2
 MOD_CHAINED = 4       # with MOD_PACKED: k-steps in the MFMA D-layout order (cips3d_fused_up_conv_next)
+MOD_FLIP = 8          # with MOD_PACKED and ksq = 9: taps stored 180 degrees rotated (up-sampling branch of cips3d_modconv3x3)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -327,11 +328,11 @@ def nerf_finish(part, n_chunks, B, img_size, hidden, n_rays=None):
     return features, thumb, xyz, mask
 
 
-def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None):
+def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None, flip=False):
     lib = _lib.load()
     if out is None:
         out = torch.empty(B * Cout * Cin * ksq, device=W.device, dtype=torch.float32)
-    flags = (MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0)
+    flags = (MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0) | (MOD_FLIP if flip else 0)
     check(lib.cips3d_modulate_weights(dev_ptr(W, "W"), dev_ptr(s, "s") + 4 * s_offset, s_stride, dev_ptr(out), B, Cout, Cin,
                                       ksq, float(scale), flags, stream_ptr()), "cips3d_modulate_weights")
     return out
@@ -402,6 +403,29 @@ def modconv_kxk(x, wm, Cout, k, transpose2=False):
     out = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
     check(lib.cips3d_modconv_kxk(dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(out), B, Cin, Cout, H, W, k,
                                  int(bool(transpose2)), stream_ptr()), "cips3d_modconv_kxk")
+    return out
+
+
+def modconv3x3_supported(Cin, Cout, H, W, up):
+    return bool(_lib.load().cips3d_modconv3x3_supported(Cin, Cout, H, W, int(bool(up))))
+
+
+def modconv3x3(x, wm_packed, Cout, up=False, fir=None, epilogue=0, noise=None, noise_w=None, bias=None):
+    """3x3 modulated conv on the LDS-tiled MFMA kernel (csrc/conv3x3.hip).  x [B,Cin,H,W]; wm_packed from
+    modulate_weights(..., ksq=9, packed=True, flip=up); up: conv_transpose2d(stride 2) + Blur(fir) fused -> [B,Cout,2H,2W]."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    OH, OW = (2 * H, 2 * W) if up else (H, W)
+    out = torch.empty(B, Cout, OH, OW, device=x.device, dtype=torch.float32)
+    nb = 0
+    if noise is not None:
+        if noise.shape[0] not in (1, B) or tuple(noise.shape[-2:]) != (OH, OW):
+            raise RuntimeError(f"noise must be (1|{B},1,{OH},{OW}), got {tuple(noise.shape)}")
+        nb = OH * OW if (noise.shape[0] == B and B > 1) else 0
+    check(lib.cips3d_modconv3x3(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H, W, int(bool(up)),
+                                dev_ptr(fir, "fir", True), int(epilogue), dev_ptr(noise, "noise", True), nb,
+                                dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True), stream_ptr()),
+          "cips3d_modconv3x3")
     return out
 
 

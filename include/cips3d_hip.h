@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 2   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 3   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -208,6 +208,9 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  * registers is the B operand of the next GEMM (cips3d_fused_up_conv_next):
  *   wm[b][o/16][i/16][(((i>>2)&3)<<4 | (o&15))*4 + (i&3)]. */
 #define CIPS3D_MOD_CHAINED    4
+/* with CIPS3D_MOD_PACKED and ksq == 9: tap t is stored in slot 8 - t (the 180-degree rotated kernel the up-sampling branch
+ * of cips3d_modconv3x3 correlates with).  Packed ksq == 9 layout: wm[b][tap][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
+#define CIPS3D_MOD_FLIP       8
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
@@ -308,6 +311,19 @@ int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise
  * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
 int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
                        int H, int W, int k, int transpose2, void* stream);
+
+/* 3x3 ModulatedConv2d (models/model_v3.py:264-314, decoder_cfg.kernel_size = 3) as an LDS-tiled implicit GEMM on MFMA.
+ *   up = 0: out [B,Cout,H,W] = conv2d(x, wm, padding 1)                                           (:296-311)
+ *   up = 1: out [B,Cout,2H,2W] = Blur(conv_transpose2d(x, wm, stride 2)), fir = the Blur's 4x4 taps (:280-291); the FIR is
+ *           applied to the input tile in LDS (the two convolutions commute), nothing full-size is materialised
+ * wm: cips3d_modulate_weights(..., ksq = 9, CIPS3D_MOD_PACKED [| CIPS3D_MOD_FLIP for up = 1]).
+ * epilogue = 1 fuses NoiseInjection + bias + leaky ReLU * sqrt(2) as in cips3d_modconv1x1 (noise at the OUTPUT size).
+ * cips3d_modconv3x3_supported: Cin % 16 == 0, Cout % 16 == 0, output width % 4 == 0 (plain: W % 4 == 0); other shapes use
+ * cips3d_modconv_kxk. */
+int cips3d_modconv3x3_supported(int Cin, int Cout, int H, int W, int up);
+int cips3d_modconv3x3(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int H, int W, int up,
+                      const float* fir, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
+                      const float* bias, void* stream);
 
 /* ------------------------------------------------------------------ whole forward, one call */
 

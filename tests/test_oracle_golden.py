@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/path.py) to golden vectors produced by the reference
 (tests/golden/make_golden.py).  CPU only; runs everywhere."""
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -215,3 +217,27 @@ def test_oracle_config5_at_stated_size(golden):
     assert abs(float(loss.detach()) - float(fx["loss"])) < 1e-5 * float(fx["loss"])
     for a, k in ((locs.grad, "g.locs"), (w_r.grad, "g.w_r"), (w_d.grad, "g.w_d")):
         assert float((a - fx[k]).abs().max()) <= 2e-4 * float(fx[k].abs().max()) + 1e-8, k
+
+
+def test_k3_upsample_identity(golden):
+    """The identity csrc/conv3x3.hip builds its up-sampling branch on: conv_transpose2d(x, w, stride 2) followed by
+    Blur(4x4 taps x 4, pad (1, 1)) (models/model_v3.py:280-291) == a valid 3x3 correlation with the 180-degree rotated
+    taps of  Z = upfirdn2d(x, taps, up=2, pad=(3, 2))  applied per INPUT channel.  Checked on the reference's own
+    k = 3 up-sampling fixtures (tests/golden/modconv.npz: mc_k3_up1_d1 / _d0)."""
+    import torch.nn.functional as F
+    fx = golden("modconv")
+    for tag in ("k3_up1_d1", "k3_up1_d0"):
+        sd = fx.sub(f"mc_{tag}.sd.")
+        x, style, y_ref = fx[f"mc_{tag}.x"], fx[f"mc_{tag}.style"], fx[f"mc_{tag}.y"]
+        B, Cin, H, W = x.shape
+        weight = sd["weight"]
+        Cout = weight.shape[1]
+        s = O._equal_linear(sd, "modulation", style).view(B, 1, Cin, 1, 1)
+        w = (1 / math.sqrt(Cin * 9)) * weight * s
+        if tag.endswith("d1"):
+            w = w * torch.rsqrt(w.pow(2).sum([2, 3, 4]) + 1e-8).view(B, Cout, 1, 1, 1)
+        z = O.upfirdn2d(x, sd["blur.kernel"], up=2, pad=(3, 2))
+        assert z.shape[-2:] == (2 * H + 2, 2 * W + 2)
+        y = F.conv2d(z.reshape(1, B * Cin, 2 * H + 2, 2 * W + 2), torch.flip(w, [3, 4]).reshape(B * Cout, Cin, 3, 3), groups=B)
+        y = y.view(B, Cout, 2 * H, 2 * W)
+        assert y.shape == y_ref.shape and maxdiff(y, y_ref) < 2e-5 * max(1.0, float(y_ref.abs().max()))
