@@ -33,6 +33,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DTYPE_NAMES = {"fp32": "f32",
+               "bf16": "bf16 decoder GEMM operands (f32 accumulate, f32 storage), f32 NeRF",
+               "bf16_storage": "bf16 decoder GEMM operands + bf16 storage of the up-sampling stages' activations "
+                               "(f32 accumulate), f32 NeRF"}
 PUBLISHED_VIEWS_PER_S = 46.93085418313323   # test__rendering_time docstring, unknown CUDA GPU
 MFMA_F32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 EVENT_STRIDE = 8                           # HIP events around the dominant kernel on every 8th step (a record drains the queue)
@@ -277,8 +281,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (N=64, config 3, config 5)")
     ap.add_argument("--no-kernel-events", action="store_true", help="A/B: no HIP events around the dominant kernel (roofline = null)")
     ap.add_argument("--deterministic", action="store_true", help="perturb off + fixed noise buffers (demo semantics)")
-    ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "bf16"],
-                    help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32)")
+    ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "bf16", "bf16_storage"],
+                    help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32); "
+                         "bf16_storage = additionally the up-sampling stages' pre-FIR activations live in HBM as bf16")
     ap.add_argument("--dump-gathered", default=None, help="rank 0 saves the last step's gathered uint8 frames (torch.save)")
     a = ap.parse_args()
 
@@ -329,7 +334,7 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": med / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (value / PUBLISHED_VIEWS_PER_S) if published_cfg else None,
-            "dtype": "f32" if a.decoder_precision == "fp32" else "bf16 decoder GEMMs (f32 accumulate), f32 NeRF",
+            "dtype": DTYPE_NAMES[a.decoder_precision],
             "data": "synthetic",
             "repeats": a.repeats, "ms_per_step_repeats": [e / a.steps * 1e3 for e in elapsed],
             "config": {"workload": wl.name(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
@@ -346,14 +351,15 @@ def main():
             del wl
             torch.cuda.empty_cache()
             for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
-                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder", dict(n_samples=24, batch=4, precision="bf16"))):
+                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder (operands + up-sampling stage storage)",
+                             dict(n_samples=24, batch=4, precision="bf16_storage"))):
                 w2 = ForwardWorkload(dev, 0, 1, 1024, 2, kw["n_samples"], kw["batch"], kw["precision"], False)
                 steps2 = max(10, a.steps // 2)
                 m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
                 also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
                              "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
                              "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
-                             "dtype": "f32" if kw["precision"] == "fp32" else "bf16 decoder GEMMs (f32 accumulate), f32 NeRF",
+                             "dtype": DTYPE_NAMES[kw["precision"]],
                              "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2)})
                 del w2
                 torch.cuda.empty_cache()

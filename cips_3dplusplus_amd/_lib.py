@@ -135,7 +135,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 3            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 4            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 
@@ -180,16 +180,16 @@ def check(code, what):
         raise RuntimeError(f"{what} failed ({code}): {msg}")
 
 
-def dev_ptr(t, name="tensor", allow_none=False):
-    """Device pointer of a contiguous fp32 HIP tensor; loud failure for anything else."""
+def dev_ptr(t, name="tensor", allow_none=False, dtype=torch.float32):
+    """Device pointer of a contiguous HIP tensor of `dtype` (fp32 unless stated); loud failure for anything else."""
     if t is None:
         if allow_none:
             return None
         raise RuntimeError(f"{name} is required")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA tensor (the cips3d HIP path has no CPU fallback)")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     return t.data_ptr()

@@ -15,6 +15,8 @@
 // writes its output once with >= 128-byte row segments.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -144,6 +146,7 @@ struct GemmArgs {
   int B, Cin, Cout; int64_t HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
   int bf16;
+  int out_bf16;             // the output is stored as bf16 (CIPS3D_Y_BF16: the low-resolution GEMM of an up-sampling stage)
   // optional: the ToRGB that follows this conv, folded into the epilogue.  Every workgroup writes the partial sums of its
   // BM output rows, rgb_part[blockIdx.y][b][3][HW]; cips3d_torgb_reduce adds the row blocks (and layers) in a fixed order.
   const float* rgb_w;       // plain [B][3][Cout] modulated ToRGB weights (no demodulation)
@@ -336,7 +339,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
       }
-      if (col_ok) *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
+      if (col_ok) {
+        if (a.out_bf16)
+          *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.Cout * HW + ncol + (obase + r) * HW) =
+              pack_bf16(v[0], v[1], v[2], v[3]);
+        else
+          *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
+      }
       if (a.rgb_part) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -425,6 +434,35 @@ __device__ __forceinline__ void up2_load_interior(const float* __restrict__ src,
     const float2 mid = *reinterpret_cast<const float2*>(row);
     v[r][0] = row[-1]; v[r][1] = mid.x; v[r][2] = mid.y; v[r][3] = row[2];
     row += W;
+  }
+}
+
+// the same patches from a bf16 array (CIPS3D_Y_BF16: the low-resolution GEMM result stored as bf16): a bf16 is the upper
+// half of the fp32 with the same value, the middle pair is one aligned 32-bit load
+typedef unsigned short bf16_t;
+__device__ __forceinline__ float bf16_f32(unsigned bits) { return __uint_as_float(bits << 16); }
+__device__ __forceinline__ void up2_load_interior(const bf16_t* __restrict__ src, int W, int iy, int qx, float (&v)[3][4]) {
+  const bf16_t* row = src + ((iy - 1) * W + 2 * qx);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const unsigned mid = *reinterpret_cast<const unsigned*>(row);
+    v[r][0] = bf16_f32(row[-1]); v[r][1] = bf16_f32(mid & 0xffffu); v[r][2] = __uint_as_float(mid & 0xffff0000u);
+    v[r][3] = bf16_f32(row[2]);
+    row += W;
+  }
+}
+__device__ __forceinline__ void up2_load(const bf16_t* __restrict__ src, int H, int W, int iy, int qx, float (&v)[3][4]) {
+  const int c = 2 * qx;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int y = iy - 1 + r;
+    const bool yok = (y >= 0) && (y < H);
+    const bf16_t* row = src + (yok ? y : 0) * W;
+    unsigned mid = 0u;
+    if (yok) mid = *reinterpret_cast<const unsigned*>(row + c);
+    v[r][1] = bf16_f32(mid & 0xffffu); v[r][2] = __uint_as_float(mid & 0xffff0000u);
+    v[r][0] = (yok && c - 1 >= 0) ? bf16_f32(row[c - 1]) : 0.f;
+    v[r][3] = (yok && c + 2 < W) ? bf16_f32(row[c + 2]) : 0.f;
   }
 }
 
@@ -720,16 +758,19 @@ struct FusedArgs {
   const float* wm2; const float* noise2; int64_t nbs2; const float* nw2; const float* bias2; float* out2;
   const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
-  int bf16;
+  int bf16;      // 0: exact fp32; 1: bf16 GEMM operands (CIPS3D_GEMM_BF16); 2: additionally y_lo / y_next are bf16 arrays (CIPS3D_Y_BF16)
   // optional (NEXT instantiation): the next stage's low-resolution GEMM y_next = wm_next (C/2 x C, chained pack) out2
   const float* wm_next; float* y_next;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
-template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool BF16, bool NEXT = false, bool XPREF = false,
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, int PREC, bool NEXT = false, bool XPREF = false,
           bool LATE_OPS = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
+  constexpr bool BF16 = PREC >= 1;               // bf16 MFMA operands, fp32 accumulate
+  constexpr bool YB = PREC == 2;                 // y_lo (in) and y_next (out) stored as bf16
+  typedef typename std::conditional<YB, bf16_t, float>::type ylo_t;
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
   constexpr int NT = 64 * WGM * WGN;
@@ -816,8 +857,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
-      if (interior) up2_load_interior(a.y_lo + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
-      else up2_load(a.y_lo + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      const ylo_t* src = reinterpret_cast<const ylo_t*>(a.y_lo) + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo;
+      if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      else up2_load(src, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
     }
   };
   auto patch_store = [&](int st, float* dst) {
@@ -1011,10 +1053,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     }
 #pragma unroll
     for (int tp = 0; tp < TPW; ++tp) {
-      float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (((wm_i * TPW + tp) * 16 + 4 * q) * HWo + oy * OW + ox);
+      ylo_t* yn = reinterpret_cast<ylo_t*>(a.y_next) + (int64_t)b * (C / 2) * HWo + (((wm_i * TPW + tp) * 16 + 4 * q) * HWo + oy * OW + ox);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + r * HWo) = pack_bf16(accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]);
+        else *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
+      }
     }
   }
   f32x4 accn[OTN][4];
@@ -1094,13 +1138,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           for (int r = 0; r < 4; ++r) accn[t][c][r] += pv4[r];
         }
     }
-    float* yn = a.y_next + (int64_t)b * (C / 2) * HWo + (oy * OW + ox);
+    ylo_t* yn = reinterpret_cast<ylo_t*>(a.y_next) + (int64_t)b * (C / 2) * HWo + (oy * OW + ox);
 #pragma unroll
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) =
-            f32x4{accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]};
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (YB)
+          *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]);
+        else
+          *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = f32x4{accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]};
+      }
   }
   if (!a.wm_rgb) return;
   if (rgb_lane) {                     // quarter q finishes colour channel q
@@ -1134,8 +1181,9 @@ template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT =
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, true, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, false, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16 == 2) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 2, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 1, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 0, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -1193,12 +1241,14 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
   if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / gemm_block_rows(Cout) : 0;
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : 0;
-  epilogue &= ~CIPS3D_GEMM_BF16;
+  const int out_bf16 = (epilogue & CIPS3D_Y_BF16) ? 1 : 0;
+  epilogue &= ~(CIPS3D_GEMM_BF16 | CIPS3D_Y_BF16);
   if (epilogue != 0 && epilogue != 1) return CIPS3D_E_BADARG;
+  if (out_bf16 && (epilogue != 0 || rgb_part)) return CIPS3D_E_BADARG;     // bf16 storage is for the pre-FIR GEMM result only
   if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
-  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, rgb_w, rgb_part};
+  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, out_bf16, rgb_w, rgb_part};
   hipStream_t st = as_stream(stream);
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
   if (dbg_cfg && !rgb_part && Cout % 128 == 0) {      // (the ToRGB fold needs the default tiling: gemm_block_rows)
@@ -1289,7 +1339,9 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
-              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W, (skip_up & CIPS3D_GEMM_BF16) ? 1 : 0, wm_next, y_next};
+              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W,
+              (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next, y_next};
+  if ((skip_up & CIPS3D_Y_BF16) && !(skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;   // bf16 storage implies bf16 operands
   hipStream_t st = as_stream(stream);
   if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
     // C = 128: 2 rows x 64 with four waves (512 workgroups) beats the unchained kernel's 4 x 64 / eight waves by 3 us once

@@ -39,6 +39,8 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const int B = P.B;
   const int D = P.nerf.depth;
   const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
+  // decoder_bf16 == 2: the low-resolution GEMM results of the fused up-sampling stages (y_lo / y_next) live in HBM as bf16
+  const int ybf_flag = P.decoder_bf16 == 2 ? CIPS3D_Y_BF16 : 0;
   const bool trunc = IO.mean_r && IO.mean_d && IO.trunc_psi < 1.f;
 
   // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot.  The two chains
@@ -149,8 +151,8 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
         if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
         if (!ylo_ready)
-          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
-                                nullptr, stream));
+          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag | ybf_flag, nullptr, 0,
+                                nullptr, nullptr, stream));
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
         const cips3d_dec_layer* LN = li + 3 < P.n_dec_layers ? &P.layers[li + 3] : nullptr;
@@ -160,7 +162,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         float* out2 = (stage_last || chain) ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                      L3.wm, L3.bias, skip, 1 | gemm_flag, rgb, chain ? LN->wm : nullptr,
+                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag, rgb, chain ? LN->wm : nullptr,
                                       chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stream));
         ylo_ready = chain;
         if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }

@@ -256,6 +256,7 @@ class Decoder(nn.Module):
         self.create_synthesis()
         self._tables = {}
         self.bf16 = False
+        self.bf16_storage = False
 
     def create_synthesis(self):
         self.log_in_size = int(math.log(self.size_start, 2))
@@ -281,11 +282,14 @@ class Decoder(nn.Module):
         self.n_latent = (self.log_size - self.log_in_size) * 2 + 2
 
     def set_precision(self, precision):
-        """"fp32" (default, exact) or "bf16": every StyledConv GEMM rounds its operands to bf16 and accumulates in fp32
-        (BASELINE config 3).  Storage, ToRGB, FIR and the epilogues stay fp32."""
-        if precision not in ("fp32", "bf16"):
+        """"fp32" (default, exact); "bf16": every StyledConv GEMM rounds its operands to bf16 and accumulates in fp32
+        (BASELINE config 3), storage / ToRGB / FIR / epilogues stay fp32; "bf16_storage": additionally the low-resolution
+        GEMM result of every fused up-sampling stage (the only activation those stages move through HBM) is stored as bf16
+        (one-call forward only; the per-op path keeps it in fp32)."""
+        if precision not in ("fp32", "bf16", "bf16_storage"):
             raise ValueError(precision)
-        self.bf16 = precision == "bf16"
+        self.bf16 = precision != "fp32"
+        self.bf16_storage = precision == "bf16_storage"
         for m in [self.conv1] + list(self.convs):
             m.bf16 = self.bf16
         return self

@@ -343,20 +343,23 @@ def modconv1x1_supported(Cin, Cout, HW):
 
 
 GEMM_BF16 = 0x100      # CIPS3D_GEMM_BF16: bf16 compute mode of the decoder GEMMs (BASELINE config 3)
+Y_BF16 = 0x200         # CIPS3D_Y_BF16: the pre-FIR low-resolution GEMM result of an up-sampling stage is stored as bf16
 
 
-def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False):
+def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False, out_bf16=False):
+    """out_bf16 (epilogue 0 only): the result is stored as a torch.bfloat16 tensor (CIPS3D_Y_BF16)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
+    odt = torch.bfloat16 if out_bf16 else torch.float32
     if out is None:
-        out = torch.empty(B, Cout, H, W, device=x.device, dtype=torch.float32)
+        out = torch.empty(B, Cout, H, W, device=x.device, dtype=odt)
     nb = 0
     if noise is not None and noise.shape[0] == B and B > 1:
         nb = H * W
     if noise is not None and noise.shape[0] not in (1, B):
         raise RuntimeError("noise batch must be 1 or B")
-    check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H * W,
-                                epilogue | (GEMM_BF16 if bf16 else 0),
+    check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out, "out", dtype=odt), B, Cin, Cout, H * W,
+                                epilogue | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if out_bf16 else 0),
                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
                                 stream_ptr()), "cips3d_modconv1x1")
     return out
@@ -436,25 +439,29 @@ def fused_up_conv_chains(C_):
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
                   skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None):
     """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv).
-    wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next."""
+    wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next.
+    A torch.bfloat16 `y_lo` selects the bf16-storage form (CIPS3D_Y_BF16, needs bf16=True): y_next is then bf16 as well."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
     dev = y_lo.device
+    ydt = y_lo.dtype
+    if ydt == torch.bfloat16 and not bf16:
+        raise RuntimeError("a bf16 y_lo needs the bf16 GEMM mode (bf16=True)")
     out2 = torch.empty(B, Cc, 2 * H, 2 * W, device=dev) if want_out2 else None
     rgb = torch.empty(B, 3, 2 * H, 2 * W, device=dev) if wm_rgb is not None else None
-    y_next = torch.empty(B, Cc // 2, 2 * H, 2 * W, device=dev) if wm_next is not None else None
+    y_next = torch.empty(B, Cc // 2, 2 * H, 2 * W, device=dev, dtype=ydt) if wm_next is not None else None
 
     def bs(nz):
         return 4 * H * W if (nz is not None and nz.shape[0] == B and B > 1) else 0
 
-    check(lib.cips3d_fused_up_conv_next(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
+    check(lib.cips3d_fused_up_conv_next(dev_ptr(y_lo, "y_lo", dtype=ydt), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
                                         dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
                                         dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
                                         dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
                                         dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
-                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0),
+                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if ydt == torch.bfloat16 else 0),
                                         dev_ptr(rgb, "rgb", True), dev_ptr(wm_next, "wm_next", True),
-                                        dev_ptr(y_next, "y_next", True), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv_next")
+                                        dev_ptr(y_next, "y_next", True, dtype=ydt), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv_next")
     if wm_next is not None:
         return out2, rgb, y_next
     return out2, rgb

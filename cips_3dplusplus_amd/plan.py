@@ -77,7 +77,7 @@ class ForwardPlan:
         p.B, p.z_dim = B, G.z_dim
         p.style_dim_r, p.style_dim_d = ren.style_dim, dec.style_dim
         p.n_latent = dec.n_latent
-        p.decoder_bf16 = int(bool(getattr(dec, "bf16", False)))
+        p.decoder_bf16 = (2 if getattr(dec, "bf16_storage", False) else 1) if getattr(dec, "bf16", False) else 0
 
         # ---- mapping networks
         map_r = list(G.style)
@@ -248,7 +248,7 @@ class ForwardPlan:
         and with a change of the NeRF weights the packed copy was made from."""
         ren = G.renderer
         return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key(),
-                bool(getattr(G.decoder, "bf16", False)))
+                bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)))
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
             events=None):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 3   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 4   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -215,6 +215,11 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
 #define CIPS3D_GEMM_BF16      0x100
+/* bf16 STORAGE of the low-resolution GEMM result of an up-sampling stage (the tensor the 2x FIR reads): OR-ed into `epilogue`
+ * of cips3d_modconv1x1 (epilogue 0 only) `out` is written as bf16 [B,Cout,HW]; OR-ed into `skip_up` of cips3d_fused_up_conv[_next]
+ * (together with CIPS3D_GEMM_BF16) `y_lo` is read and `y_next` is written as bf16.  FIR, epilogues and accumulation stay
+ * fp32.  Halves the activation bytes the >= 128^2 stages move through HBM (BASELINE config 3). */
+#define CIPS3D_Y_BF16         0x200
 int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
                             int B, int Cout, int Cin, int ksq, float scale, int flags,
                             void* stream);
@@ -357,7 +362,8 @@ typedef struct cips3d_generator_plan {
   const float* map_d_w[CIPS3D_MAX_MAP_LAYERS]; const float* map_d_b[CIPS3D_MAX_MAP_LAYERS];
   int32_t map_d_in[CIPS3D_MAX_MAP_LAYERS];
   float map_d_lr_mul;
-  int32_t decoder_bf16;          /* != 0: every decoder GEMM runs in the bf16 compute mode (CIPS3D_GEMM_BF16) */
+  int32_t decoder_bf16;          /* != 0: every decoder GEMM runs in the bf16 compute mode (CIPS3D_GEMM_BF16); 2: the fused
+                                    up-sampling stages also keep y_lo / y_next as bf16 (CIPS3D_Y_BF16) */
   float* lat[4];                 /* ping-pong [B, max(style_dim_r, style_dim_d, z_dim)]: [0,1] renderer chain, [2,3] decoder chain */
   float* styles_r;               /* [B, D+1, style_dim_r] */
   float* styles_d;               /* [B, n_latent, style_dim_d] */

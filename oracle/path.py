@@ -251,7 +251,7 @@ def _bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False, bf16_gemm=False):
+def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False, bf16_gemm=False, bf16_store=False):
     """models/model_v3.py:218-314 (plain and up-sampling branches).  bf16_gemm (not in the reference): both GEMM operands
     are rounded to bf16, accumulation stays fp32 -- the restatement the bf16 decoder mode is checked against."""
     B, Cin, H, W = x.shape
@@ -267,15 +267,18 @@ def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False, bf16
         wt = w.transpose(1, 2).reshape(B * Cin, Cout, k, k)
         y = F.conv_transpose2d(x.reshape(1, B * Cin, H, W), wt, padding=0, stride=2, groups=B)
         y = y.view(B, Cout, y.shape[2], y.shape[3])
+        if bf16_store:   # (not in the reference) the pre-FIR result kept as bf16: for k = 1 the transposed conv's output is
+            y = _bf16_round(y)     # the low-resolution GEMM result on the even lattice and zeros elsewhere
         p = (4 - 2) - (k - 1)
         return upfirdn2d(y, sd[prefix + ".blur.kernel"], pad=((p + 1) // 2 + 1, p // 2 + 1))
     y = F.conv2d(x.reshape(1, B * Cin, H, W), w.view(B * Cout, Cin, k, k), padding=k // 2, groups=B)
     return y.view(B, Cout, y.shape[2], y.shape[3])
 
 
-def styled_conv(sd, prefix, x, style, noise, upsample=False, bf16_gemm=False):
+def styled_conv(sd, prefix, x, style, noise, upsample=False, bf16_gemm=False, bf16_store=False):
     """models/model_v3.py:418-454 with NoiseInjection :327-341 (explicit noise only)."""
-    y = modulated_conv2d(sd, prefix + ".conv", x, style, demodulate=True, upsample=upsample, bf16_gemm=bf16_gemm)
+    y = modulated_conv2d(sd, prefix + ".conv", x, style, demodulate=True, upsample=upsample, bf16_gemm=bf16_gemm,
+                         bf16_store=bf16_store)
     y = y + sd[prefix + ".noise.weight"] * noise
     return fused_leaky_relu(y, sd[prefix + ".activate.bias"])
 
@@ -315,7 +318,7 @@ def create_noise_bufs(cfg, start_size, generator=None, dtype=torch.float32):
     return [torch.randn(1, 1, s, s, generator=generator, dtype=dtype) for s in sizes]
 
 
-def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder", bf16_gemm=False):
+def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder", bf16_gemm=False, bf16_store=False):
     """models/model_v3.py:592-637."""
     lay = decoder_layout(cfg)
     out = styled_conv(sd, prefix + ".conv1", features, styles[:, 0], noise[0], bf16_gemm=bf16_gemm)
@@ -323,7 +326,7 @@ def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder", bf16_gem
     i = 1
     for s, st in enumerate(lay["stages"]):
         out = styled_conv(sd, f"{prefix}.convs.{2 * s}", out, styles[:, i], noise[2 * s + 1],
-                          upsample=st["up"], bf16_gemm=bf16_gemm)
+                          upsample=st["up"], bf16_gemm=bf16_gemm, bf16_store=bf16_store and st["up"])
         out = styled_conv(sd, f"{prefix}.convs.{2 * s + 1}", out, styles[:, i + 1], noise[2 * s + 2], bf16_gemm=bf16_gemm)
         skip = to_rgb(sd, f"{prefix}.to_rgbs.{s}", out, styles[:, i + 2], skip, upsample=st["up"])
         i += 2
@@ -336,7 +339,8 @@ def generator_forward(sd, cfg, zs, cam_poses, focals, img_size, near, far, nerf_
                       style_render_mean=None, style_decoder_mean=None, perturb_u=None,
                       return_sdf=False, return_xyz=False, bf16_decoder=False):
     """models/model_v3.py:875-1042 for the inference configuration (explicit noise_bufs,
-    injected perturbation/means).  Returns the ret_maps dict."""
+    injected perturbation/means).  Returns the ret_maps dict.  bf16_decoder (not in the reference): True = the StyledConv
+    GEMM operands rounded to bf16; "storage" = additionally the pre-FIR result of every up-sampling conv rounded to bf16."""
     D = cfg["renderer_cfg"]["N_layers_renderer"]
     if style_render is None or style_decoder is None:
         style_render = mapping_renderer(sd, cfg, zs[0], truncation, style_render_mean)
@@ -353,7 +357,8 @@ def generator_forward(sd, cfg, zs, cam_poses, focals, img_size, near, far, nerf_
         z.reshape(B, R, N), near, far, style_render, D)
     to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S).contiguous()
     features = to_img(feat)
-    rgb = decoder_forward(sd, cfg, features, style_decoder, noise_bufs, bf16_gemm=bf16_decoder)
+    rgb = decoder_forward(sd, cfg, features, style_decoder, noise_bufs, bf16_gemm=bool(bf16_decoder),
+                          bf16_store=bf16_decoder == "storage")
     mask_img = to_img(mask)
     return {
         "rgb": rgb, "thumb_rgb": to_img(thumb), "style_decoder": None, "eikonal_term": None,
