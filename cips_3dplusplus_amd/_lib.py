@@ -67,6 +67,7 @@ _SIGS = {
     "cips3d_camera_params": (c_int, [c_f32p, c_f32p, c_f32, c_f32p, c_f32, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_void_p]),
     "cips3d_nerf_pack_weights": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    "cips3d_nerf_packed_floats": (c_i64, [c_int, c_int]),
     "cips3d_nerf_suggest_chunks": (c_int, [c_int, c_int, c_int]),
     "cips3d_nerf_part_floats": (c_i64, [c_int, c_int, c_int, c_int]),
     "cips3d_nerf_render": (c_int, [C.POINTER(NerfParams), C.c_void_p]),
@@ -135,7 +136,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 4            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 5            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -11,10 +11,11 @@
 // evaluates the whole MLP for its 16 points:
 //
 //   layer 0 (3 -> H)          VALU, written straight into MFMA "D layout"
-//   layers 1..D-1 (H -> H)    Y^T[o][p] = sum_k W[o][k] X^T[k][p] on fp32 MFMA: A = W tile (from LDS),
+//   layers 1..D-1 (H -> H)    Y^T[o][p] = sum_k W[o][k] X^T[k][p] on the matrix cores: A = W tile (from LDS),
 //                             B = X^T, D = Y^T.  D has the point on the lane and 4 consecutive hidden
-//                             units in its 4 accumulator registers, which is exactly the B-operand
-//                             layout of the next layer -> no LDS round trip, no shuffles for activations.
+//                             units in its 4 accumulator registers, which (two tiles at a time) is exactly the
+//                             B-operand layout of the next layer -> no LDS round trip, no shuffles for activations.
+//                             Arithmetic: fp32-equivalent SPLIT-fp16 products (see "Split-fp16 MFMA" below).
 //   view layer (H+3 -> H)     3 view-direction terms pre-loaded into the accumulator, then MFMA; the
 //                             finished tile is folded straight into the feature accumulators
 //   sigma / rgb heads         per-lane dot over its registers + two cross-quarter adds
@@ -22,8 +23,17 @@
 //                             lane owns a ray), partial sums kept in registers
 //
 // Register budget per lane (H = 256): X 64 + Y 64 + feature accumulators 64 + scalars => < 256, so two
-// waves share a SIMD: one wave's sine epilogue (VALU) runs under the other's MFMAs, and the 40-cycle
-// dependent-accumulator latency of the 16x16x4 form is covered by the partner wave.
+// waves share a SIMD: one wave's sine epilogue (VALU) runs under the other's MFMAs.
+//
+// Split-fp16 MFMA.  The fp32 matrix instruction (v_mfma_f32_16x16x4_f32) runs at 1/16 of the fp16 rate.  Every operand
+// is therefore held as an unevaluated sum of two fp16 numbers, x = x_hi + x_lo (x_hi = fp16(x), x_lo = fp16(x - x_hi):
+// 22 significant bits, the same 4 bytes per value as an fp32), weights pre-scaled per layer by a power of two into
+// fp16's normal range, and a product w x is accumulated IN FP32 as the three exact fp16 x fp16 products
+// w_hi x_hi + w_hi x_lo + w_lo x_hi on v_mfma_f32_16x16x32_f16: 3 instructions of 16 cycles per 16x16x32 block instead
+// of 8 of 32 cycles.  The dropped term and the operand representation error are both ~2^-22 relative per PRODUCT, below
+// the rounding error fp32 accumulation itself makes on the SUM: against an fp64 run the outputs sit exactly where the
+// plain-fp32 path sits (tools/split_probe.py).  The power-of-two scale is undone for free in the FiLM
+// multiplier (gamma * 2^-s).
 //
 // Weights: every CU streams the same (D * H*H) packed floats from L2 through a 2-slot LDS ring, one
 // slab = TPS o-tiles (16*TPS rows x H) per step, fetched with global_load_lds (LDS-DMA) while the
@@ -33,8 +43,9 @@
 // Chunk partials (T, sum w*feat, ...) are combined in sample order by nerf_finish (compositing is
 // associative: S = S_a + T_a * S_b, T = T_a * T_b), which also emits the NCHW feature map.
 //
-// Roofline: MFMA-bound. flops/point = 2*3*H + (D-1)*2*H^2 + 2*(H+3)*H + 2*H*4; HBM traffic is the
-// partials only (n_chunks * (H+8) * 4 B per ray).
+// Roofline: MFMA-bound on paper (flops/point = 2*3*H + (D-1)*2*H^2 + 2*(H+3)*H + 2*H*4, executed as 3 fp16 products per
+// fp32 product); with the split form the sine epilogues (VALU) and the LDS fragment reads are of the same order as the
+// matrix time.  HBM traffic is the partials only (n_chunks * (H+8) * 4 B per ray).
 #include <stdlib.h>
 
 #include <atomic>
@@ -60,9 +71,44 @@ extern "C" int cips3d_debug_read_stamps(unsigned long long* out8) {
 #define STAMP(i)
 #endif
 
+#ifdef CIPS3D_CLOCK
+// Diagnostic build only: candidate sine forms side by side (tools/sin_probe.py compares them with fp64)
+__device__ static inline float sin_hw_reduced(float x) {
+  // exact Cody-Waite reduction by 2 pi (k * 2PI_HI absorbed by the FMA), then the hardware sine on r / (2 pi) in [-0.5, 0.5]
+  const float INV_2PI = 0.159154943091895336f;
+  const float TWO_PI_HI = 6.28318548202514648f;        // float(2 pi)
+  const float TWO_PI_LO = -1.74845553146951715e-7f;    // 2 pi - TWO_PI_HI
+  const float k = rintf(x * INV_2PI);
+  float r = fmaf(k, -TWO_PI_HI, x);
+  r = fmaf(k, -TWO_PI_LO, r);
+  return __builtin_amdgcn_sinf(r * INV_2PI);
+}
+__global__ void sin_probe_kernel(const float* __restrict__ x, float* __restrict__ ya, float* __restrict__ yh, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { ya[i] = sin_accurate(x[i]); yh[i] = sin_hw_reduced(x[i]); }
+}
+extern "C" int cips3d_debug_sin(const float* x, float* ya, float* yh, int n, void* stream) {
+  hipLaunchKernelGGL(sin_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), x, ya, yh, n);
+  return cips3d_launch_status();
+}
+// Diagnostic build only: the shader clock the render kernel actually runs at = d(s_memtime) / d(s_memrealtime) x 100 MHz,
+// one stamp pair around the whole kernel per workgroup (MI355X_MICROARCH.md, DVFS give-back item 6).  The sums go to a
+// buffer nothing else reads.
+__device__ unsigned long long g_nerf_clock[2];
+extern "C" int cips3d_debug_read_clock(unsigned long long* out2) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_nerf_clock), 16);
+  unsigned long long z[2] = {0, 0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_clock), z, 16);
+  return 0;
+}
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));    // one MFMA 16x16x32 operand fragment (8 fp16 = 4 VGPRs)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 constexpr int RAYS = 16;    // rays per wave task
 constexpr int WAVES = 8;    // waves (tasks) per workgroup
@@ -84,32 +130,75 @@ __host__ __device__ constexpr int nerf_ring_floats(int H, int TPS, bool fuse) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing.  o-tile t = 16 output units; k-step s = 4 input units, one per lane quarter.
-//   packed[l][t][q4][lane][j] = W_l[t*16 + (lane&15)][ (s>>2)*16 + 4*(lane>>4) + (s&3) ],  s = 4*q4 + j
-// (s indexes the B-operand register of the previous layer's D layout: tile s>>2, register s&3.)
+// weight packing (split-fp16).  o-tile t = 16 output units; k-block m = 32 input units = one v_mfma_f32_16x16x32_f16.
+//   packed[l][t][m][plane][lane][j] (fp16) = plane(hi|lo) of 2^s_l * W_l[t*16 + (lane&15)][32 m + 16 (j>>2) + 4 (lane>>4) + (j&3)]
+// The k order inside a block follows the D layout of the previous layer's accumulators: lane quarter q holds units
+// 4q..4q+3 of each 16-unit tile, so the 8 fragment elements of quarter q are units 4q+r of tile 2m (j = r) and of tile
+// 2m+1 (j = 4 + r).  One tile = (H/32) blocks x 2 planes x 1 KiB = 16*H*4 bytes, the size of the fp32 tile it replaces.
+// The per-layer scales (2^s_l, 2^-s_l) follow the matrices: packed[D*H*H + 2 l], [.. + 1].
 // ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr int64_t nerf_packed_floats(int H, int D) { return (int64_t)D * H * H + 2 * 64; }
+
+// one workgroup per layer: s = power of two with max |2^s W| in [512, 1024) (1 for an all-zero matrix)
+__global__ void __launch_bounds__(256) nerf_scale_kernel(const float* __restrict__ w_hidden, const float* __restrict__ w_view,
+                                                         float* __restrict__ packed, int H, int D) {
+  __shared__ float s_max[4];
+  const int l = blockIdx.x;
+  float m = 0.f;
+  if (l < D - 1) {
+    const float* w = w_hidden + (int64_t)l * H * H;
+    for (int i = threadIdx.x; i < H * H; i += 256) m = fmaxf(m, fabsf(w[i]));
+  } else {
+    for (int i = threadIdx.x; i < H * H; i += 256) m = fmaxf(m, fabsf(w_view[(int64_t)(i / H) * (H + 3) + (i % H)]));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    int e = 0;
+    if (m > 0.f && m < 3.0e38f) {
+      frexpf(m, &e);                 // m = f * 2^e, f in [0.5, 1)
+      e = 10 - e;                    // 2^e' * m in [512, 1024)
+      if (e > 100) e = 100;
+      if (e < -100) e = -100;
+    }
+    float* sc = packed + (int64_t)D * H * H + 2 * l;
+    sc[0] = ldexpf(1.f, e);
+    sc[1] = ldexpf(1.f, -e);
+  }
+}
+
 __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict__ w_hidden,
                                                         const float* __restrict__ w_view,
                                                         float* __restrict__ packed, int H, int D) {
   const int64_t per_layer = (int64_t)H * H;
-  const int64_t total = per_layer * D;
+  const int64_t total = per_layer * D;             // one thread per weight: writes its hi and lo halves
+  _Float16* out = reinterpret_cast<_Float16*>(packed);
+  const float* scales = packed + total;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int l = (int)(i / per_layer);
-    int64_t rem = i - l * per_layer;
-    const int tile_floats = 16 * H;
-    const int t = (int)(rem / tile_floats);
-    rem -= (int64_t)t * tile_floats;
-    const int q4 = (int)(rem / 256);
-    const int lane = (int)((rem % 256) / 4);
-    const int j = (int)(rem % 4);
-    const int s = 4 * q4 + j;
+    int64_t rem = i - l * per_layer;               // index inside the layer in (t, m, lane, j) order
+    const int tile_w = 16 * H;                     // weights per o-tile
+    const int t = (int)(rem / tile_w);
+    rem -= (int64_t)t * tile_w;
+    const int m = (int)(rem / 512);                // 512 weights per k-block (64 lanes x 8)
+    const int lane = (int)((rem % 512) / 8);
+    const int j = (int)(rem % 8);
     const int o = t * 16 + (lane & 15);
-    const int k = (s >> 2) * 16 + 4 * (lane >> 4) + (s & 3);
+    const int k = 32 * m + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
     float v;
     if (l < D - 1) v = w_hidden[(int64_t)l * per_layer + (int64_t)o * H + k];
     else           v = w_view[(int64_t)o * (H + 3) + k];
-    packed[i] = v;
+    v *= scales[2 * l];
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    // fp16 units: layer base 2*per_layer, tile 2*tile_w, block m: [plane][lane][8]
+    _Float16* blk = out + 2 * ((int64_t)l * per_layer + (int64_t)t * tile_w) + (int64_t)m * 1024;
+    blk[lane * 8 + j] = hi;
+    blk[512 + lane * 8 + j] = lo;
   }
 }
 
@@ -142,26 +231,44 @@ struct Ring {
   int per_sample;        // slabs per sample
 };
 
-// One MFMA layer for the wave's 16 points.
-//   VIEW = false: Y = sin(gamma * (W X) + c)
-//   VIEW = true : f = sin(gamma * (W X + Wd v) + c);  FA += w * f;  rgb head partial sums += Wc f
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits in the 4 bytes of an fp32
+__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+// eight fp32 values (units 4q..4q+3 of tile 2m, then of tile 2m+1) -> the hi / lo B fragments of k-block m
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    _Float16 a, b;
+    split2(v[j], a, b);
+    hi[j] = a;
+    lo[j] = b;
+  }
+}
+
+// One MFMA layer for the wave's 16 points (split-fp16 products, fp32 accumulation; see the file header).
+//   VIEW = false: Y = sin(gamma' * (W' X) + c)            gamma' = gamma 2^-s, W' = 2^s W (s_film holds gamma')
+//   VIEW = true : f = sin(gamma' * (W' X + Wd' v) + c);  FA += w * f;  rgb head partial sums += Wc f
+//   last (hidden layers): Y is h_D, the sigma head's partial sum  sdf_acc += Ws . Y  is taken from the epilogue's fp32 values
 // The caller guarantees slab `seq` is resident in slot (seq & 1); every slab step prefetches seq+1
 // while multiplying and ends with wait + barrier.
 template <int NT, int TPS, bool VIEW>
-__device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[NT * 4], float (&FA)[NT * 4],
-                                           float wgt, float (&chead)[3], Ring& ring, const float* film_l,
-                                           const float* s_wd, const float* s_wc, float vx, float vy, float vz,
-                                           int wave, int lane, int q4o) {
+__device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], h8 (&Yh)[NT / 2], h8 (&Yl)[NT / 2],
+                                           float (&FA)[NT * 4], float wgt, float (&chead)[3], float& sdf_acc, bool last,
+                                           Ring& ring, const float* film_l, const float* s_wd, const float* s_wc,
+                                           const float* s_ws, float vx, float vy, float vz, int wave, int lane, int q4o) {
   constexpr int H = NT * 16;
-  constexpr int TILE = 16 * H;          // floats of one o-tile's A fragments
+  constexpr int TILE = 16 * H;          // floats (= 4-byte hi/lo pairs) of one o-tile's A fragments
   constexpr int SLAB = TILE * TPS;
   constexpr int STEPS = NT / TPS;
-  constexpr int R = TPS * 4;            // output registers produced per step
-  // The slab-step loop is a REAL loop: one step's code (TPS*H/4 MFMAs + epilogue) is ~3 KB, the fully
-  // unrolled layer was ~25 KB and the whole kernel ~70 KB, more than the instruction cache can hold across
-  // one sample pass.  Output registers cannot be indexed by the (run-time) step, so the step always writes
-  // the LAST R registers of Y / FA and the array is rotated down by R; after STEPS steps every element is
-  // back in natural order.
+  constexpr int R = TPS * 4;            // output values produced per step
+  constexpr int MB = NT / 2;            // 32-unit k-blocks of the layer input
+  constexpr int BPS = TPS / 2;          // k-blocks of the NEXT layer's input a step completes
+  static_assert(TPS % 2 == 0 && NT % TPS == 0, "a slab step must complete whole 32-unit blocks");
+  // The slab-step loop is a REAL loop (code size: the fully unrolled layer overflowed the instruction cache).  Output
+  // registers cannot be indexed by the (run-time) step, so the step always writes the LAST entries of Yh / Yl / FA and the
+  // arrays are rotated down; after STEPS steps every element is back in natural order.
   const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
 #pragma unroll 1
   for (int sl = 0; sl < STEPS; ++sl) {
@@ -171,17 +278,14 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
     }
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
     const int o_base = sl * (TPS * 16) + q4o;          // this lane's first output unit of the step
-    // The TPS o-tiles of the slab are independent accumulator chains, interleaved so that one wave alone
-    // covers the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
     f32x4 acc[TPS];
-    // (opaque per step: as loop invariants the packed-math operand pairs {vx,vx}, {vy,vy}, {vz,vz} were hoisted out of the
-    // sample loop, spilled, and reloaded -- twelve registers, one exposed scratch round trip -- in front of every step)
+    // (opaque per step: as loop invariants the operand copies of vx, vy, vz were hoisted out of the sample loop and spilled)
     float vxo = vx, vyo = vy, vzo = vz;
     if (VIEW) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
       const int o4 = o_base + tt * 16;
-      if (VIEW) {
+      if (VIEW) {       // view-direction columns (pre-scaled by 2^s at staging) straight into the accumulator
         const f32x4 wx = *reinterpret_cast<const f32x4*>(s_wd + o4);
         const f32x4 wy = *reinterpret_cast<const f32x4*>(s_wd + H + o4);
         const f32x4 wz = *reinterpret_cast<const f32x4*>(s_wd + 2 * H + o4);
@@ -191,23 +295,25 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
         acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    // All TPS tiles' fragments of a k-group are read together and their MFMAs interleaved: TPS independent accumulator
-    // chains.  (Reading them two tiles at a time saves 8 registers / 22 spills but leaves only 2 chains in flight and
-    // gives the gain back: 243 vs 237 us.)
+    // per k-block: hi and lo fragments of the TPS tiles (2 x TPS ds_read_b128, lane-linear image), then the three
+    // products.  A v_mfma_f32_16x16x32_f16 chain issues back to back on one accumulator; the TPS tiles interleave anyway.
 #pragma unroll
-    for (int q4 = 0; q4 < H / 16; ++q4) {
-      f32x4 a4[TPS];
+    for (int m = 0; m < MB; ++m) {
+      h8 ah[TPS], al[TPS];
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt)
-        a4[tt] = *reinterpret_cast<const f32x4*>(slab + tt * TILE + (q4 * 64 + lane) * 4);
+      for (int tt = 0; tt < TPS; ++tt) {
+        ah[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m) * 64 + lane) * 4);
+        al[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m + 1) * 64 + lane) * 4);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tt], Xh[m], acc[tt], 0, 0, 0);
 #pragma unroll
-        for (int tt = 0; tt < TPS; ++tt)
-          acc[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[tt][j], X[4 * q4 + j], acc[tt], 0, 0, 0);
+      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xl[m], acc[tt], 0, 0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xh[m], acc[tt], 0, 0, 0);
     }
     // Epilogue stagger.  Waves w and w + WAVES/2 share a SIMD and meet at every slab barrier; with the barrier
-    // after the FiLM/sine epilogue both would run its ~250 VALU instructions together while the matrix pipe
+    // after the FiLM/sine epilogue both would run its VALU instructions together while the matrix pipe
     // idles.  The upper half of the waves takes the step barrier BEFORE its epilogue instead, which then overlaps
     // the partner wave's next-step MFMAs, and the partner's epilogue overlaps this wave's MFMA tail.  Either
     // position is after this wave's last read of slot (seq&1) and before its next stage_slab into it.
@@ -236,6 +342,11 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) res[tt * 4 + i] = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
+        if (last) {     // h_D: sigma head partial (volume_renderer.py:148) from the fp32 values, before they are split
+          const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sdf_acc = fmaf(ws4[i], res[tt * 4 + i], sdf_acc);
+        }
       }
     }
     // The sink pass would otherwise move the sines below the barrier that follows (undoing the stagger): make
@@ -243,7 +354,7 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
 #pragma unroll
     for (int k = 0; k < R; ++k) asm volatile("" : "+v"(res[k]));
     if (VIEW) asm volatile("" : "+v"(chead[0]), "+v"(chead[1]), "+v"(chead[2]));
-    // rotate: drop the first R registers, append this step's results
+    // rotate: drop the first entries, append this step's results
     if (VIEW) {
 #pragma unroll
       for (int k = 0; k < NT * 4 - R; ++k) FA[k] = FA[k + R];
@@ -251,9 +362,14 @@ __device__ __forceinline__ void mfma_layer(const float (&X)[NT * 4], float (&Y)[
       for (int k = 0; k < R; ++k) FA[NT * 4 - R + k] = res[k];
     } else {
 #pragma unroll
-      for (int k = 0; k < NT * 4 - R; ++k) Y[k] = Y[k + R];
+      for (int k = 0; k < MB - BPS; ++k) { Yh[k] = Yh[k + BPS]; Yl[k] = Yl[k + BPS]; }
 #pragma unroll
-      for (int k = 0; k < R; ++k) Y[NT * 4 - R + k] = res[k];
+      for (int bb = 0; bb < BPS; ++bb) {
+        float v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = res[(2 * bb) * 4 + j];      // tile 2bb (j = 0..3), tile 2bb+1 (j = 4..7)
+        split8(v8, Yh[MB - BPS + bb], Yl[MB - BPS + bb]);
+      }
     }
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
     if (!late_epilogue) {
@@ -285,6 +401,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int lane = tid & 63;
   const int qd = lane >> 4;
   const int pl = lane & 15;
+#ifdef CIPS3D_CLOCK
+  const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- task decode (b is uniform over the workgroup: tasks_per_view is a multiple of WAVES)
   const int64_t task0 = (int64_t)blockIdx.x * WAVES;
@@ -303,17 +422,21 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   {
     // FiLM table: s_film[l][0][o] = gamma, s_film[l][1][o] = gamma * bias_l[o] + beta, so that
     // sin(gamma * (W x + bias) + beta) = sin(gamma * (W x) + c) costs one FMA per unit.
+    // MFMA layers (l >= 1) run on weights pre-scaled by 2^s (packed layer l - 1): their gamma carries 2^-s, the
+    // view-direction columns that are pre-loaded into the view layer's accumulator carry 2^s (both exact).
     const float* film_b = P.film + (int64_t)b * L * 2 * H;
+    const float* scales = P.packed + (int64_t)D * H * H;
     for (int i = tid; i < L * H; i += WAVES * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
-      s_film[(l * 2) * H + o] = gm;
+      s_film[(l * 2) * H + o] = l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm;
       s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]);
     }
+    const float view_scale = scales[2 * (D - 1)];
     for (int i = tid; i < 3 * H; i += WAVES * 64) {
       const int k = i / H, o = i - k * H;
       s_w0[i] = P.w_first[o * 3 + k];
-      s_wd[i] = P.w_view[o * (H + 3) + H + k];
+      s_wd[i] = P.w_view[o * (H + 3) + H + k] * view_scale;
       s_wc[i] = P.w_rgb[i];
     }
     for (int i = tid; i < H; i += WAVES * 64) s_ws[i] = P.w_sigma[i];
@@ -412,40 +535,44 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     asm volatile("" : "+v"(opq));
     const int q4o = 4 * qd + opq;
 
-    float X[NT * 4], Y[NT * 4];
-    // ---- layer 0: 3 -> H on the VALU, in D layout
+    h8 Xh[NT / 2], Xl[NT / 2], Yh[NT / 2], Yl[NT / 2];
+    float sdf = 0.f;            // sigma head partial of this lane's units (taken where h_D is produced in fp32)
+    // ---- layer 0: 3 -> H on the VALU, in D layout, split into the hi / lo B fragments of the first MFMA layer
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int o4 = t * 16 + q4o;
-      const f32x4 wx = *reinterpret_cast<const f32x4*>(s_w0 + o4);
-      const f32x4 wy = *reinterpret_cast<const f32x4*>(s_w0 + H + o4);
-      const f32x4 wz = *reinterpret_cast<const f32x4*>(s_w0 + 2 * H + o4);
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_film + o4);
-      const f32x4 c4 = *reinterpret_cast<const f32x4*>(s_film + H + o4);
+    for (int m = 0; m < NT / 2; ++m) {
+      float v8[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
-        X[t * 4 + i] = sin_accurate(fmaf(g4[i], pre, c4[i]));
+      for (int hf = 0; hf < 2; ++hf) {
+        const int o4 = (2 * m + hf) * 16 + q4o;
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(s_w0 + o4);
+        const f32x4 wy = *reinterpret_cast<const f32x4*>(s_w0 + H + o4);
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(s_w0 + 2 * H + o4);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_film + o4);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(s_film + H + o4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
+          v8[hf * 4 + i] = sin_accurate(fmaf(g4[i], pre, c4[i]));
+        }
+        if (D == 1) {           // no hidden MFMA layer: this is h_D
+          const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sdf = fmaf(ws4[i], v8[hf * 4 + i], sdf);
+        }
       }
+      split8(v8, Xh[m], Xl[m]);
     }
     float chead[3] = {0.f, 0.f, 0.f};
     STAMP(1);   // sample setup + layer 0
     // ---- hidden layers 1 .. D-1
     for (int l = 1; l < D; ++l) {
-      mfma_layer<NT, TPS, false>(X, Y, FA, 0.f, chead, ring, s_film + l * 2 * H, s_wd, s_wc, vx, vy, vz, wave,
-                                 lane, q4o);
+      mfma_layer<NT, TPS, false>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc, s_ws,
+                                 vx, vy, vz, wave, lane, q4o);
 #pragma unroll
-      for (int i = 0; i < NT * 4; ++i) X[i] = Y[i];
+      for (int i = 0; i < NT / 2; ++i) { Xh[i] = Yh[i]; Xl[i] = Yl[i]; }
     }
     STAMP(2);   // hidden layers
-    // ---- sigma head on h_D (volume_renderer.py:148)
-    float sdf = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const f32x4 w4 = *reinterpret_cast<const f32x4*>(s_ws + t * 16 + q4o);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sdf = fmaf(w4[i], X[t * 4 + i], sdf);
-    }
+    // ---- sigma head on h_D (volume_renderer.py:148): the per-lane partial was accumulated where h_D was produced
     sdf += __shfl_xor(sdf, 16, 64);
     sdf += __shfl_xor(sdf, 32, 64);
     sdf += b_sigma;
@@ -459,8 +586,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 
     STAMP(3);   // sigma head + weight
     // ---- view layer -> features, folded into FA; rgb head partial sums
-    mfma_layer<NT, TPS, true>(X, Y, FA, w, chead, ring, s_film + D * 2 * H, s_wd, s_wc, vx, vy, vz, wave, lane,
-                              q4o);
+    float sdf_unused = 0.f;
+    mfma_layer<NT, TPS, true>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
+                              vx, vy, vz, wave, lane, q4o);
     float c0 = chead[0], c1 = chead[1], c2 = chead[2];
     c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
@@ -474,6 +602,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
 
   STAMP(5);   // last compositing tail
+#ifdef CIPS3D_CLOCK
+  if (tid == 0) {
+    atomicAdd(&g_nerf_clock[0], __builtin_amdgcn_s_memtime() - clk_t0);
+    atomicAdd(&g_nerf_clock[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+  }
+#endif
   if (a.fuse_finish) {
     // ---- the eight waves of this workgroup are the eight chunks of ONE ray group (n_chunks == WAVES): exchange the
     // partials through LDS (the ring and the tables are dead) and combine them in sample order,
@@ -680,10 +814,17 @@ extern "C" int cips3d_nerf_pack_weights(const float* w_hidden, const float* w_vi
                                         int depth, void* stream) {
   if (!w_view || !packed || hidden <= 0 || depth < 1 || (depth > 1 && !w_hidden)) return CIPS3D_E_BADARG;
   if (hidden != 32 && hidden != 64 && hidden != 128 && hidden != 256) return CIPS3D_E_UNSUPP;
+  if (depth > 64) return CIPS3D_E_UNSUPP;
   const int64_t total = (int64_t)hidden * hidden * depth;
+  hipLaunchKernelGGL(nerf_scale_kernel, dim3((unsigned)depth), dim3(256), 0, as_stream(stream), w_hidden, w_view, packed,
+                     hidden, depth);
   hipLaunchKernelGGL(nerf_pack_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0,
                      as_stream(stream), w_hidden, w_view, packed, hidden, depth);
   return cips3d_launch_status();
+}
+
+extern "C" int64_t cips3d_nerf_packed_floats(int hidden, int depth) {
+  return hidden > 0 && depth > 0 ? nerf_packed_floats(hidden, depth) : 0;
 }
 
 extern "C" int cips3d_nerf_suggest_chunks(int B, int img_size, int n_samples) {

@@ -171,7 +171,7 @@ def camera_params(locations, img_size, fov_ang=6.0, dist_radius=0.12, up=None):
 
 def nerf_pack_weights(w_hidden, w_view, hidden, depth):
     lib = _lib.load()
-    packed = torch.empty(depth * hidden * hidden, device=w_view.device, dtype=torch.float32)
+    packed = torch.empty(int(lib.cips3d_nerf_packed_floats(hidden, depth)), device=w_view.device, dtype=torch.float32)
     check(lib.cips3d_nerf_pack_weights(dev_ptr(w_hidden, "w_hidden", True), dev_ptr(w_view, "w_view"), dev_ptr(packed),
                                        hidden, depth, stream_ptr()), "cips3d_nerf_pack_weights")
     return packed

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 4   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 5   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -129,12 +129,17 @@ int cips3d_camera_params(const float* locations, const float* fov_deg, float fov
 /* ------------------------------------------------------------------ NeRF renderer */
 
 /* Re-pack the FiLM-SIREN weight matrices into the MFMA operand order the render kernel streams
- * (once per weight update).  hidden = H (multiple of 32, <= 256), depth = D >= 1.
+ * (once per weight update).  hidden = H (32, 64, 128 or 256), depth = D >= 1.
  *   w_hidden : D-1 matrices [H,H] (pts_linears.1..D-1.weight), concatenated
  *   w_view   : [H, H+3] (views_linears.weight)
- * packed     : D * H*H floats  (hidden layers 1..D-1, then the H x H part of the view layer). */
+ * packed     : cips3d_nerf_packed_floats(H, D) floats: per layer (hidden layers 1..D-1, then the H x H part of the view
+ *              layer) the matrix scaled by a power of two 2^s into fp16's normal range and split into fp16 hi + lo halves
+ *              (w 2^s = hi + lo, 22 significant bits) in v_mfma_f32_16x16x32_f16 A-fragment order, 4 bytes per weight;
+ *              then (2^s, 2^-s) per layer.  The render kernel accumulates the three exact fp16 products
+ *              w_hi x_hi + w_hi x_lo + w_lo x_hi in fp32 (fp32-equivalent results at 16/3 of the fp32 MFMA rate). */
 int cips3d_nerf_pack_weights(const float* w_hidden, const float* w_view, float* packed,
                              int hidden, int depth, void* stream);
+int64_t cips3d_nerf_packed_floats(int hidden, int depth);
 
 typedef struct cips3d_nerf_params {
   /* geometry, per view */

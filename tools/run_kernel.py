@@ -67,3 +67,21 @@ if a.what == "nerf":
         tot = sum(buf[:6])
         for nme, v in zip(names, buf[:6]):
             print(f"  {nme:14s} {v / nwg:10.0f} cycles/wg  {100.0 * v / tot:5.1f}%")
+
+if a.what in ("nerf", "forward"):
+    import ctypes
+    from cips_3dplusplus_amd import _lib as L
+    raw = ctypes.CDLL(L.LIB_PATH)
+    if hasattr(raw, "cips3d_debug_read_clock"):          # -DCIPS3D_CLOCK build: shader clock inside the render kernel
+        t_end = time.perf_counter() + 2.5
+        while time.perf_counter() < t_end:               # >= 2 s of back-to-back launches first
+            for _ in range(50):
+                fn()
+            torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * 2)()
+        raw.cips3d_debug_read_clock(buf)                 # zero the sums
+        for _ in range(300):
+            fn()
+        raw.cips3d_debug_read_clock(buf)
+        print(f"  in-kernel shader clock of nerf_render_kernel ({a.what} loop): {buf[0] / buf[1] * 100:.0f} MHz "
+              f"(sum over workgroups: {buf[0]} shader cycles / {buf[1]} ticks of the 100 MHz reference)")
