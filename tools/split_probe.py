@@ -1,6 +1,12 @@
-"""CPU experiment behind the split-fp16 MFMA arithmetic of csrc/nerf.hip: the oracle generator with every FiLM-SIREN GEMM\nevaluated as w_hi x_hi + w_hi x_lo + w_lo x_hi (fp16 halves of power-of-two-scaled weights / activations, fp32 sums) against\nplain fp32 and against an fp64 run: the split form sits exactly where fp32 sits relative to fp64.\n\n    python tools/split_probe.py        (CPU, ~1 min)\n"""
+"""CPU experiment behind the split-fp16 MFMA arithmetic of csrc/nerf.hip: the oracle generator with every FiLM-SIREN GEMM
+evaluated as w_hi x_hi + w_hi x_lo + w_lo x_hi (fp16 halves of power-of-two-scaled weights / activations, fp32 sums) against
+plain fp32 and against an fp64 run: the split form sits exactly where fp32 sits relative to fp64.
+
+    python tools/split_probe.py        (CPU, ~1 min)
+"""
 import sys, math, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch.nn.functional as F
 from oracle import path as O
 import cips_3dplusplus_amd as pkg
