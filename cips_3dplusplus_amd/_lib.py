@@ -136,7 +136,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 5            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 6            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -24,6 +24,25 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// Split-fp16 GEMM mode (CIPS3D_GEMM_SPLIT): fp32-equivalent products at the fp16 matrix rate.  Every operand is the
+// unevaluated sum of two fp16 numbers, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits in the 4 bytes
+// of an fp32); a product is accumulated in fp32 as the three exact fp16 x fp16 products w_lo x_hi + w_hi x_lo + w_hi x_hi
+// on v_mfma_f32_16x16x32_f16 (3 x 16 cycles per 16x16x32 block against 8 x 32 cycles of v_mfma_f32_16x16x4_f32).  The
+// dropped term and the representation error are ~2^-22 relative per product, below the rounding fp32 accumulation makes
+// on the sum (tools/split_probe.py).  Modulated weights (|wm| <= 1 after demodulation) are pre-scaled by
+// kSplitScale = 2^8 into fp16's normal range and split by the modulate kernel; activations are split in registers after
+// the LDS read; the epilogue undoes the scale exactly.
+constexpr float kSplitScale = 256.f, kSplitInv = 1.f / 256.f;
+__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const _Float16 a = (_Float16)v[j];
+    hi[j] = a;
+    lo[j] = (_Float16)(v[j] - (float)a);
+  }
+}
 
 // bf16 compute mode of the GEMMs (BASELINE config 3: decoder in bf16 with fp32 accumulate).  Storage and data movement
 // stay fp32 and identical; only the fragments are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) in registers and fed to
@@ -47,6 +66,9 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
 //   plain : wm[b][o][i*ksq + t]
 //   packed (ksq == 1, Cout % 16 == 0, Cin % 16 == 0): A-fragment order of v_mfma_f32_16x16x4_f32
 //           wmp[b][ot][kq][lane][j] = wm[b][ot*16 + (lane&15)][16*kq + 4*j + (lane>>4)]
+//   packed + split (ksq == 1, Cin % 32 == 0; CIPS3D_MOD_SPLIT): A fragments of v_mfma_f32_16x16x32_f16, hi and lo fp16 halves of
+//           2^8 wm:  wms[b][ot][kb][plane][lane][j] (fp16) = plane(2^8 wm[b][ot*16 + (lane&15)][32 kb + 4 j + (lane>>4)]) -- one
+//           o-tile x 32-channel block = 2 x 1 KiB = the bytes of the two fp32 k-groups it replaces (same LDS-DMA pieces)
 //   packed, ksq == 9 (the 3x3 implicit GEMM, conv3x3.hip): the same fragment order per tap, tap-major:
 //           wmp[b][t'][ot][kq][lane][j], t' = t, or 8 - t with CIPS3D_MOD_FLIP (the transposed conv of the up-sampling branch)
 // ------------------------------------------------------------------------------------------------
@@ -76,7 +98,16 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
   const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
   auto put = [&](int e, float v) {
     if (demod) v *= d;
-    if (packed) {
+    if (packed & 16) {            // split-fp16 fragments (ksq == 1)
+      const int i = e;
+      const int ot = o >> 4, kb = i >> 5, j = (i >> 2) & 7, q = i & 3;
+      const float sv = v * kSplitScale;
+      const _Float16 hi = (_Float16)sv;
+      const _Float16 lo = (_Float16)(sv - (float)hi);
+      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
+      blk[((q << 4) | (o & 15)) * 8 + j] = hi;
+      blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
+    } else if (packed) {
       const int i = ksq == 1 ? e : e / ksq;
       const int tap = ksq == 1 ? 0 : ((packed & 8) ? ksq - 1 - e % ksq : e % ksq);
       const int ot = o >> 4, kq = i >> 4;
@@ -130,7 +161,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 8)) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 24)) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -145,7 +176,7 @@ struct GemmArgs {
   const float* x; const float* wmp; float* out;
   int B, Cin, Cout; int64_t HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
-  int bf16;
+  int bf16;                 // GEMM mode: 0 exact fp32, 1 bf16 operands, 2 split-fp16 (pre-split weights)
   int out_bf16;             // the output is stored as bf16 (CIPS3D_Y_BF16: the low-resolution GEMM of an up-sampling stage)
   // optional: the ToRGB that follows this conv, folded into the epilogue.  Every workgroup writes the partial sums of its
   // BM output rows, rgb_part[blockIdx.y][b][3][HW]; cips3d_torgb_reduce adds the row blocks (and layers) in a fixed order.
@@ -157,8 +188,11 @@ struct GemmArgs {
 // (gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; expcnt / lgkmcnt fields left at "no wait")
 __device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
-template <int WM, int WGM, int WGN, int BK, int NS, bool BF16 = false>
+// MODE: 0 exact fp32 MFMA, 1 bf16 operands (CIPS3D_GEMM_BF16), 2 split-fp16 (CIPS3D_GEMM_SPLIT; A pre-split by the modulate kernel)
+template <int WM, int WGM, int WGN, int BK, int NS, int MODE = 0>
 __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) {
+  constexpr bool BF16 = MODE == 1;
+  constexpr bool SPLIT = MODE == 2;
   constexpr int NW = WGM * WGN;               // waves per workgroup: 8 = two per SIMD, so one wave's DMA issue,
                                               // waits and fragment reads run under the partner's MFMAs
   constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
@@ -280,6 +314,41 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
     // Issue every fragment read of the stage first (12 x ds_read_b128 for BK = 32, WM = 2), then run the MFMAs
     // back to back behind counted lgkmcnt waits: with one wave per SIMD a read-then-wait per MFMA group
     // leaves the matrix pipe idle for an LDS round trip every 16 MFMAs (measured 64 % busy).
+    if constexpr (SPLIT) {
+      // 32-channel blocks: hi / lo A fragments (pre-split, two 1-KiB pieces per o-tile and block) and eight B rows
+      // (channel 32 kb + 4 j + q = fragment element j of lane quarter q), split into hi / lo fragments in registers.
+      constexpr int KB = BK / 32;
+      static_assert(BK % 32 == 0, "split mode pairs the 16-channel groups");
+      h8 ah[KB][WM], al[KB][WM];
+      f32x4 b8[KB][8];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          ah[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb) * 256 + lane * 4);
+          al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b8[kb][j] = *reinterpret_cast<const f32x4*>(sB + (kb * 32 + j * 4 + q) * BN);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = b8[kb][j][c];
+          h8 bh, bl;
+          split8(v8, bh, bl);
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb][i], bh, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl, acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh, acc[i][c], 0, 0, 0);
+          }
+        }
+    } else {
     f32x4 afr[KQ][WM], bfr[KQ][4];
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) {
@@ -316,6 +385,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
           for (int c = 0; c < 4; ++c)
             acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], bfr[kq][j4][c], acc[i][c], 0, 0, 0);
     }
+    }
     // all LDS reads of this stage retired before the slot can be refilled after the next barrier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -335,6 +405,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] *= kSplitInv;           // exact: the weights carried 2^8
+      }
       if (a.epilogue == 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
@@ -393,8 +467,9 @@ template <int WM, int WGM, int WGN, int BK, int NS>
 int launch_gemm(const GemmArgs& a, hipStream_t st) {
   constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
   dim3 grid((unsigned)ceil_div<int64_t>(a.HW, BN), (unsigned)(a.Cout / BM), (unsigned)a.B);
-  if (a.bf16) hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, false>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16 == 2) hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, 2>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else if (a.bf16) hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, 1>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, 0>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
 }
 
@@ -1194,8 +1269,9 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 8)) : 0;   // bit 3: flipped taps
+  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 24)) : 0;   // bit 3: flipped taps, bit 4: split-fp16
   if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
+  if ((packed & 16) && (ksq != 1 || (packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
   if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;
   const int64_t rows = (int64_t)B * Cout;
   hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)ceil_div<int64_t>(rows, 4)), dim3(256), 0, as_stream(stream), W,
@@ -1240,9 +1316,10 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
   if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
   if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / gemm_block_rows(Cout) : 0;
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
-  const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : 0;
+  if ((epilogue & CIPS3D_GEMM_BF16) && (epilogue & CIPS3D_GEMM_SPLIT)) return CIPS3D_E_BADARG;
+  const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : (epilogue & CIPS3D_GEMM_SPLIT) ? 2 : 0;
   const int out_bf16 = (epilogue & CIPS3D_Y_BF16) ? 1 : 0;
-  epilogue &= ~(CIPS3D_GEMM_BF16 | CIPS3D_Y_BF16);
+  epilogue &= ~(CIPS3D_GEMM_BF16 | CIPS3D_Y_BF16 | CIPS3D_GEMM_SPLIT);
   if (epilogue != 0 && epilogue != 1) return CIPS3D_E_BADARG;
   if (out_bf16 && (epilogue != 0 || rgb_part)) return CIPS3D_E_BADARG;     // bf16 storage is for the pre-FIR GEMM result only
   if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;

@@ -151,8 +151,9 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
         if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
         if (!ylo_ready)
-          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag | ybf_flag, nullptr, 0,
-                                nullptr, nullptr, stream));
+          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
+                                0 | gemm_flag | ybf_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
+                                stream));
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
         const cips3d_dec_layer* LN = li + 3 < P.n_dec_layers ? &P.layers[li + 3] : nullptr;
@@ -179,9 +180,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const bool fold = T && T->kind == 2 && li + 1 != P.n_dec_layers - 1 && T->Cin == L.Cout && hw % 4 == 0 && P.rgb_part &&
                           fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
                           (fold_slots == 0 || (fold_H == L.H && fold_W == L.W));
+        const int split_flag = (L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0;
         if (fold) {
           int nblk = 0;
-          TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias, T->wm,
+          TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, T->wm,
                                       P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, stream));
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;
@@ -191,11 +193,11 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           ++li;                                  // the ToRGB layer is done (its sum is pending in the slots)
           continue;
         }
-        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag, nz, nbs, L.noise_w, L.bias, stream));
+        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, stream));
       } else {
         if (L.flags & 1) return CIPS3D_E_BADARG;   // chained packs only exist for stages that take the fused route above
-        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0 | gemm_flag, nullptr, 0, nullptr,
-                              nullptr, stream));
+        TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
+                              0 | gemm_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr, stream));
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));
       }
       x = out;

@@ -144,11 +144,11 @@ class ModulatedConv2d(nn.Module):
         """The 3x3 MFMA kernel tiles this layer at input size H x W."""
         return self.kernel_size == 3 and hip.modconv3x3_supported(self.in_channel, self.out_channel, H, W, self.upsample)
 
-    def modulated_weight(self, style, packed, flip=False):
-        """style (B, style_dim) -> wm (packed MFMA order or plain [B,Cout,Cin,k,k])."""
+    def modulated_weight(self, style, packed, flip=False, split=False):
+        """style (B, style_dim) -> wm (packed MFMA order [split: fp16 hi + lo fragments] or plain [B,Cout,Cin,k,k])."""
         s = self.modulation(style.contiguous())
         return hip.modulate_weights(self.weight, s, s.shape[1], s.shape[0], self.out_channel, self.in_channel,
-                                    self.kernel_size ** 2, self.scale, self.demodulate, packed, flip=flip)
+                                    self.kernel_size ** 2, self.scale, self.demodulate, packed, flip=flip, split=split)
 
     def forward(self, input, style):
         B, Cin, H, W = input.shape
@@ -192,6 +192,7 @@ class StyledConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, out_channel, 1, 1))     # present in checkpoints, unused in forward
         self.activate = op.FusedLeakyReLU(out_channel)
         self.bf16 = False        # bf16 compute mode of the GEMM (Decoder.set_precision)
+        self.split = True        # fp32-equivalent split-fp16 products in the stand-alone GEMM (the default "fp32" precision)
 
     def forward(self, input, style, noise=None, transform=None, mesh_path=None, wm=None):
         B, Cin, H, W = input.shape
@@ -203,13 +204,14 @@ class StyledConv(nn.Module):
         noise = noise.contiguous()
         nw = self.noise.weight          # device scalar, read by the kernels
         if conv.fast(H * W):
+            split = self.split and not self.bf16
             if wm is None:
-                wm = conv.modulated_weight(style, packed=True)
+                wm = conv.modulated_weight(style, packed=True, split=split)
             if conv.upsample:
-                y_lo = hip.modconv1x1(x, wm, conv.out_channel, epilogue=0, bf16=self.bf16)
+                y_lo = hip.modconv1x1(x, wm, conv.out_channel, epilogue=0, bf16=self.bf16, split=split)
                 return hip.up2_fir_act(y_lo, conv.blur.kernel, noise, nw, self.activate.bias)
             return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias,
-                                  bf16=self.bf16)
+                                  bf16=self.bf16, split=split)
         if conv.tiled3x3(H, W):
             if wm is None:
                 wm = conv.modulated_weight(style, packed=True, flip=conv.upsample)
@@ -257,6 +259,7 @@ class Decoder(nn.Module):
         self._tables = {}
         self.bf16 = False
         self.bf16_storage = False
+        self.split = True         # "fp32" precision = split-fp16 stand-alone GEMMs (set_precision)
 
     def create_synthesis(self):
         self.log_in_size = int(math.log(self.size_start, 2))
@@ -282,16 +285,21 @@ class Decoder(nn.Module):
         self.n_latent = (self.log_size - self.log_in_size) * 2 + 2
 
     def set_precision(self, precision):
-        """"fp32" (default, exact); "bf16": every StyledConv GEMM rounds its operands to bf16 and accumulates in fp32
+        """"fp32" (default): fp32-equivalent results; the stand-alone GEMMs run split-fp16 products (x = hi + lo in fp16,
+        three exact products accumulated in fp32: ~1e-6 relative to the fp32 MFMA, several times faster), the fused
+        up-sampling stages the fp32 MFMA; "fp32_exact": the fp32 MFMA everywhere (bit-exact k-ordered fmaf chains);
+        "bf16": every StyledConv GEMM rounds its operands to bf16 and accumulates in fp32
         (BASELINE config 3), storage / ToRGB / FIR / epilogues stay fp32; "bf16_storage": additionally the low-resolution
         GEMM result of every fused up-sampling stage (the only activation those stages move through HBM) is stored as bf16
         (one-call forward only; the per-op path keeps it in fp32)."""
-        if precision not in ("fp32", "bf16", "bf16_storage"):
+        if precision not in ("fp32", "fp32_exact", "bf16", "bf16_storage"):
             raise ValueError(precision)
-        self.bf16 = precision != "fp32"
+        self.bf16 = precision in ("bf16", "bf16_storage")
         self.bf16_storage = precision == "bf16_storage"
+        self.split = precision == "fp32"
         for m in [self.conv1] + list(self.convs):
             m.bf16 = self.bf16
+            m.split = self.split
         return self
 
     def create_noise_bufs(self, start_size, device):
@@ -353,7 +361,8 @@ class Decoder(nn.Module):
                 return None
             return hip.modulate_weights(conv.weight, s_buf, total, B, conv.out_channel, conv.in_channel,
                                         conv.kernel_size ** 2, conv.scale, conv.demodulate, packed, s_offset=offs[idx],
-                                        flip=packed and conv.kernel_size == 3 and conv.upsample)
+                                        flip=packed and conv.kernel_size == 3 and conv.upsample,
+                                        split=packed and conv.kernel_size == 1 and m.split and not m.bf16)
 
         H, W = features.shape[2], features.shape[3]
         out = self.conv1(features, styles[:, 0], noise=noise[0], wm=wm_of(0, H, W))

@@ -140,7 +140,8 @@ class Generator(nn.Module):
                                   "(model_v3.py:1449-1470, volume_renderer.py: mlp_init_pass): out of scope")
 
     def set_decoder_precision(self, precision):
-        """"fp32" (default: exact fp32 MFMA, the reference's precision), "bf16" (BASELINE config 3: the decoder's GEMM
+        """"fp32" (default: fp32-equivalent; the stand-alone decoder GEMMs use split-fp16 products, see Decoder.set_precision),
+        "fp32_exact" (the fp32 MFMA everywhere in the decoder), "bf16" (BASELINE config 3: the decoder's GEMM
         operands are rounded to bf16 in registers, fp32 accumulate; the NeRF renderer stays fp32 because gamma ~ 30
         re-amplifies input error in every SIREN layer) or "bf16_storage" (bf16 + the pre-FIR activations of the fused
         up-sampling stages stored as bf16: half the activation bytes of the >= 128^2 stages)."""

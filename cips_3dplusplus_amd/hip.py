@@ -14,6 +14,7 @@ MOD_DEMODULATE = 1
 MOD_PACKED = 2
 MOD_CHAINED = 4       # with MOD_PACKED: k-steps in the MFMA D-layout order (cips3d_fused_up_conv_next)
 MOD_FLIP = 8          # with MOD_PACKED and ksq = 9: taps stored 180 degrees rotated (up-sampling branch of cips3d_modconv3x3)
+MOD_SPLIT = 16        # with MOD_PACKED and ksq = 1: fp16 hi + lo fragments of 2^8 wm for the split-fp16 GEMM mode (GEMM_SPLIT)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -328,11 +329,13 @@ def nerf_finish(part, n_chunks, B, img_size, hidden, n_rays=None):
     return features, thumb, xyz, mask
 
 
-def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None, flip=False):
+def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None, flip=False,
+                     split=False):
     lib = _lib.load()
     if out is None:
         out = torch.empty(B * Cout * Cin * ksq, device=W.device, dtype=torch.float32)
-    flags = (MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0) | (MOD_FLIP if flip else 0)
+    flags = ((MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0) | (MOD_FLIP if flip else 0) |
+             (MOD_SPLIT if split else 0))
     check(lib.cips3d_modulate_weights(dev_ptr(W, "W"), dev_ptr(s, "s") + 4 * s_offset, s_stride, dev_ptr(out), B, Cout, Cin,
                                       ksq, float(scale), flags, stream_ptr()), "cips3d_modulate_weights")
     return out
@@ -344,10 +347,13 @@ def modconv1x1_supported(Cin, Cout, HW):
 
 GEMM_BF16 = 0x100      # CIPS3D_GEMM_BF16: bf16 compute mode of the decoder GEMMs (BASELINE config 3)
 Y_BF16 = 0x200         # CIPS3D_Y_BF16: the pre-FIR low-resolution GEMM result of an up-sampling stage is stored as bf16
+GEMM_SPLIT = 0x400     # CIPS3D_GEMM_SPLIT: fp32-equivalent split-fp16 products (weights packed with MOD_SPLIT)
 
 
-def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False, out_bf16=False):
-    """out_bf16 (epilogue 0 only): the result is stored as a torch.bfloat16 tensor (CIPS3D_Y_BF16)."""
+def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False, out_bf16=False,
+               split=False):
+    """out_bf16 (epilogue 0 only): the result is stored as a torch.bfloat16 tensor (CIPS3D_Y_BF16).
+    split: fp32-equivalent split-fp16 products; wm_packed must come from modulate_weights(..., packed=True, split=True)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     odt = torch.bfloat16 if out_bf16 else torch.float32
@@ -359,7 +365,7 @@ def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=No
     if noise is not None and noise.shape[0] not in (1, B):
         raise RuntimeError("noise batch must be 1 or B")
     check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out, "out", dtype=odt), B, Cin, Cout, H * W,
-                                epilogue | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if out_bf16 else 0),
+                                epilogue | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if out_bf16 else 0) | (GEMM_SPLIT if split else 0),
                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
                                 stream_ptr()), "cips3d_modconv1x1")
     return out

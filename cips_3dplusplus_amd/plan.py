@@ -164,6 +164,15 @@ class ForwardPlan:
             if (CHAIN_STAGES and fused_stage(i) and fused_stage(i + 3) and lib.cips3d_fused_up_conv_chains(a["Cout"])
                     and nx["Cin"] == a["Cout"] and nx["Cout"] * 2 == a["Cout"] and nx["H"] == 2 * a["H"]):
                 nx["chained"] = True
+        # Which packed layers the stand-alone GEMM consumes (everything but conv2 of a fused stage and chained up-convs): in the
+        # default "fp32" precision those are packed as split-fp16 fragments and run in CIPS3D_GEMM_SPLIT mode.
+        use_split = bool(getattr(dec, "split", False)) and not getattr(dec, "bf16", False)
+        for i, li in enumerate(layer_info):
+            if not (use_split and li["packed"]):
+                continue
+            conv2_of_fused = li["kind"] == 0 and i >= 1 and fused_stage(i - 1)
+            chained = bool(li.get("chained"))
+            li["split"] = not conv2_of_fused and not chained
         wm_buf = torch.empty(sum(wm_sizes), device=dev)
         wm_tab = (_lib.ModulateDesc * len(seq))()
         rows, woff = 0, 0
@@ -176,14 +185,14 @@ class ForwardPlan:
             d.s_stride = total
             d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
             d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0) | (
-                hip.MOD_CHAINED if info.get("chained") else 0)
+                hip.MOD_CHAINED if info.get("chained") else 0) | (hip.MOD_SPLIT if info.get("split") else 0)
             d.scale = conv.scale
             d.row_begin = rows
             rows += conv.out_channel
             L = p.layers[idx]
             L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
                                                               info["W"], info["noise_index"])
-            L.flags = 1 if info.get("chained") else 0
+            L.flags = (1 if info.get("chained") else 0) | (2 if info.get("split") else 0)
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)
@@ -248,7 +257,8 @@ class ForwardPlan:
         and with a change of the NeRF weights the packed copy was made from."""
         ren = G.renderer
         return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key(),
-                bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)))
+                bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)),
+                bool(getattr(G.decoder, "split", False)))
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
             events=None):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 5   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 6   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -216,10 +216,19 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
 /* with CIPS3D_MOD_PACKED and ksq == 9: tap t is stored in slot 8 - t (the 180-degree rotated kernel the up-sampling branch
  * of cips3d_modconv3x3 correlates with).  Packed ksq == 9 layout: wm[b][tap][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
 #define CIPS3D_MOD_FLIP       8
+/* with CIPS3D_MOD_PACKED and ksq == 1 (Cin % 32 == 0): split-fp16 A fragments for CIPS3D_GEMM_SPLIT -- 2^8 wm as fp16 hi + lo
+ * halves in v_mfma_f32_16x16x32_f16 order, wm[b][o/16][i/32][plane][((i&3)<<4 | (o&15))][(i>>2)&7] (fp16), 4 bytes per weight */
+#define CIPS3D_MOD_SPLIT      16
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
 #define CIPS3D_GEMM_BF16      0x100
+/* OR-ed into `epilogue` of cips3d_modconv1x1[_torgb]: fp32-EQUIVALENT split-fp16 mode.  `wm` must come from
+ * cips3d_modulate_weights(..., CIPS3D_MOD_PACKED | CIPS3D_MOD_SPLIT); activations are split x = fp16(x) + fp16(x - fp16(x)) in
+ * registers and each product is accumulated in fp32 as three exact fp16 products (w_lo x_hi + w_hi x_lo + w_hi x_hi) on
+ * v_mfma_f32_16x16x32_f16: results agree with the fp32 MFMA path to ~1e-6 relative (below fp32's own accumulation
+ * rounding) at a fraction of its matrix time.  Storage and epilogues are unchanged fp32. */
+#define CIPS3D_GEMM_SPLIT     0x400
 /* bf16 STORAGE of the low-resolution GEMM result of an up-sampling stage (the tensor the 2x FIR reads): OR-ed into `epilogue`
  * of cips3d_modconv1x1 (epilogue 0 only) `out` is written as bf16 [B,Cout,HW]; OR-ed into `skip_up` of cips3d_fused_up_conv[_next]
  * (together with CIPS3D_GEMM_BF16) `y_lo` is read and `y_next` is written as bf16.  FIR, epilogues and accumulation stay
@@ -352,7 +361,8 @@ typedef struct cips3d_dec_layer {
   int32_t Cin, Cout, H, W; /* H, W = INPUT resolution of the layer (ToRGB: its own resolution) */
   int32_t noise_index;     /* index into cips3d_forward_io.noise (StyledConv) or -1 */
   int32_t flags;           /* bit 0 (kind 1 only): wm is in the CIPS3D_MOD_CHAINED order and this conv's low-resolution GEMM is
-                              computed by the previous stage's kernel (cips3d_fused_up_conv_next) */
+                              computed by the previous stage's kernel (cips3d_fused_up_conv_next);
+                              bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */
