@@ -42,7 +42,8 @@ class NerfParams(C.Structure):
                 ("depth", C.c_int32), ("static_viewdirs", C.c_int32), ("n_chunks", C.c_int32), ("n_rays", C.c_int32),
                 ("part", C.c_void_p), ("sdf", C.c_void_p),
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
-                ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p)]
+                ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
+                ("features_planes", C.c_int32), ("pad_", C.c_int32)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -98,6 +99,11 @@ _SIGS = {
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
+    "cips3d_planes_supported": (c_int, [c_int, c_int, c_i64]),
+    "cips3d_to_planes": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_from_planes": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_modconv1x1_planes": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64,
+                                         c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "cips3d_modconv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cips3d_modconv3x3": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_int, c_f32p,
                                   c_i64, c_f32p, c_f32p, C.c_void_p]),
@@ -136,7 +142,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 6            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 8            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -1,0 +1,338 @@
+// The run of 1x1 StyledConvs at the NeRF resolution (conv1 + convs.0-7 of the release decoder: nine 512-channel GEMMs at
+// 64^2, models/model_v3.py:602-632) on SPLIT-fp16 activations that STAY split between layers.
+//
+// Split-fp16 arithmetic (decoder.hip, nerf.hip): x = hi + lo with hi = fp16(x), lo = fp16(x - hi) -- 22 significant bits in
+// the 4 bytes of an fp32 -- and a product is three exact fp16 products accumulated in fp32 on v_mfma_f32_16x16x32_f16.
+// cips3d_modconv1x1 in CIPS3D_GEMM_SPLIT mode splits the fp32 activations in registers after every LDS read (3 VALU per
+// value, repeated by every wave row): VALU-bound at ~15.5 us per layer.  Here the PRODUCER's epilogue splits each output
+// once and stores the two halves in the consumer's MFMA fragment order ("planes"), so the main loop of the next layer is
+// ds_read_b128 + MFMA only.
+//
+//   planes layout   P[b][C/8][plane hi|lo][HW][8] (fp16): 16 bytes = the 8 channels 8 cb .. 8 cb + 7 of one pixel, i.e. exactly
+//                   one lane's B fragment of a 32-channel MFMA block (lane quarter q <-> channel block 4 kb + q); same bytes
+//                   as the fp32 tensor it replaces.  Rows (cb, plane) are pixel-contiguous: LDS-DMA pieces of 64 pixels.
+//   weights         cips3d_modulate_weights(CIPS3D_MOD_PACKED | CIPS3D_MOD_SPLIT): natural k order (lane quarter q, element j
+//                   <-> channel 32 kb + 8 q + j), 2^8-scaled, hi / lo halves.
+//   epilogue        x 2^-8 (exact), NoiseInjection + bias + leaky ReLU, optional folded ToRGB partial sums (as
+//                   cips3d_modconv1x1_torgb), then either planes again (the next layer of the run) or fp32 / bf16 NCHW (the
+//                   low-resolution GEMM that feeds the first fused up-sampling stage).
+//
+// Bound: L2 -> LDS bytes (64 x 128 tiles: 384 KB per workgroup and layer) + the launch skeleton; the matrix time is ~1/5 of
+// the fp32 MFMA's.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kSplitInv = 1.f / 256.f;       // the modulate kernel scaled the weights by 2^8
+
+__device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+struct ChainArgs {
+  const _Float16* x;        // planes [B][Cin/8][2][HW][8]
+  const float* wmp;         // split-packed weights
+  void* out;                // planes (out_fmt 1), fp32 NCHW (0) or bf16 NCHW (2)
+  int out_fmt;
+  int B, Cin, Cout; int HW;
+  int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
+  const float* rgb_w; float* rgb_part;
+};
+
+template <int WM, int WGM, int WGN, int BK, int NS>
+__global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a) {
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
+  constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;     // floats (4-byte hi/lo pairs)
+  constexpr int A_PIECES = A_STAGE / 256, B_PIECES = B_STAGE / 256, PIECES = A_PIECES + B_PIECES;
+  constexpr int PW = PIECES / NW;
+  constexpr int KQ = BK / 16, KB = BK / 32;
+  static_assert(PIECES % NW == 0 && BK % 32 == 0, "tile shape");
+  __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm_i = wave / WGN, wn_i = wave % WGN;
+  const int q = lane >> 4, col = lane & 15;
+  const int b = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int HW = a.HW, K = a.Cin;
+  const int nstage = K / BK;
+  const _Float16* xb = a.x + (int64_t)b * K * HW * 2;            // (Cin/8) * 2 planes * HW * 8 halves
+  const float* ab = a.wmp + (int64_t)b * a.Cout * K;
+
+  auto stage_load = [&](int st) {
+    float* dstA = lds + (st % NS) * STAGE;
+    float* dstB = dstA + A_STAGE;
+    const int k0 = st * BK;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int piece = j * NW + wave;
+      if (piece < A_PIECES) {
+        const int ot_l = piece / KQ, kq_l = piece % KQ;
+        const float* src = ab + ((((m0 >> 4) + ot_l) * (K >> 4) + (k0 >> 4) + kq_l) * 256 + lane * 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
+      } else {
+        const int pb = piece - A_PIECES;
+        const int row = pb / (BN / 64), chunk = pb % (BN / 64);     // row = (channel block of the stage) * 2 + plane
+        int n = n0 + chunk * 64 + lane;
+        if (n > HW - 1) n = HW - 1;                                  // clamp: those columns are never stored
+        const _Float16* src = xb + (((int64_t)((k0 >> 3) * 2 + row) * HW + n) * 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
+      }
+    }
+  };
+
+  // this lane's four pixels: 16 c + col of the wave's 64-pixel strip (c = MFMA column tile)
+  const int nl = wn_i * 64 + col;
+  int npx[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) npx[c] = n0 + nl + 16 * c;
+
+  float nz[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4[WM];
+  f32x4 wrgb[WM][3];
+  float nw = 0.f;
+  auto load_ops = [&]() {
+    if (a.epilogue == 1) {
+      if (a.noise && a.noise_w) {
+        nw = a.noise_w[0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (npx[c] < HW) nz[c] = a.noise[(int64_t)b * a.noise_bstride + npx[c]];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    }
+    if (a.rgb_part) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          wrgb[i][ch] = *reinterpret_cast<const f32x4*>(a.rgb_w + (int64_t)b * 3 * a.Cout + ch * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    }
+  };
+  f32x4 acc[WM][4];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  static_assert(NS == 2, "the operand loads ride behind the first stage's DMA: the loop's first wait must be vmcnt(0)");
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nstage) stage_load(s0);
+  load_ops();                       // epilogue operands: retired by the first stage's vmcnt(0), consumed after the loop
+
+  for (int st = 0; st < nstage; ++st) {
+    int younger = nstage - 1 - st;
+    if (younger > NS - 2) younger = NS - 2;
+    if (younger >= 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PW));
+    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    __builtin_amdgcn_s_barrier();
+    if (st + NS - 1 < nstage) stage_load(st + NS - 1);
+    const float* sA = lds + (st % NS) * STAGE;
+    const float* sB = sA + A_STAGE;
+    h8 ah[KB][WM], al[KB][WM], bh[KB][4], bl[KB][4];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+        ah[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb) * 256 + lane * 4);
+        al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {      // row (4 kb + q) * 2 + plane, pixel nl + 16 c: [row][BN px][4 floats]
+        bh[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 0) * BN + nl + 16 * c) * 4);
+        bl[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 1) * BN + nl + 16 * c) * 4);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl[kb][c], acc[i][c], 0, 0, 0);
+          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
+  float prgb[3][4];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int obase = m0 + (wm_i * WM + i) * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][c][r] * kSplitInv;
+        if (a.epilogue == 1) v[r] = lrelu02((v[r] + nz[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
+      }
+      if (a.rgb_part) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) prgb[ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[ch][c]);
+      }
+      if (npx[c] < HW) {
+        if (a.out_fmt == 1) {
+          // planes: channels obase + 4 q + r live in channel block (obase >> 3) + (q >> 1), elements 4 (q & 1) + r
+          h4 hi, lo;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const _Float16 h = (_Float16)v[r];
+            hi[r] = h;
+            lo[r] = (_Float16)(v[r] - (float)h);
+          }
+          _Float16* dst = reinterpret_cast<_Float16*>(a.out) +
+                          ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
+          *reinterpret_cast<h4*>(dst) = hi;
+          *reinterpret_cast<h4*>(dst + (int64_t)HW * 8) = lo;
+        } else if (a.out_fmt == 2) {
+          unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const bf16x2_t p = __builtin_convertvector(f32x2_t{v[r], v[r + 1]}, bf16x2_t);
+            const unsigned bits = __builtin_bit_cast(unsigned, p);
+            dst[(int64_t)r * HW] = (unsigned short)(bits & 0xffffu);
+            dst[(int64_t)(r + 1) * HW] = (unsigned short)(bits >> 16);
+          }
+        } else {
+          float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dst[(int64_t)r * HW] = v[r];
+        }
+      }
+    }
+  }
+  if (!a.rgb_part) return;
+  // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
+  // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = prgb[ch][c];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      prgb[ch][c] = v;
+    }
+  __syncthreads();
+  float* s_red = lds;                                   // [WGM][3][BN]
+  if (q == 0) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_red[(wm_i * 3 + ch) * BN + nl + 16 * c] = prgb[ch][c];
+  }
+  __syncthreads();
+  if (wm_i == 0 && q < 3) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (npx[c] >= HW) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < WGM; ++m) v += s_red[(m * 3 + q) * BN + nl + 16 * c];
+      a.rgb_part[((int64_t)blockIdx.y * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c])] = v;
+    }
+  }
+}
+
+// fp32 [B][C][HW] -> planes [B][C/8][2][HW][8]; one thread per (channel block, pixel)
+__global__ void __launch_bounds__(256) to_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ p, int B, int C,
+                                                        int HW) {
+  const int64_t total = (int64_t)B * (C / 8) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % HW);
+    const int64_t bc = i / HW;               // b * (C/8) + cb
+    h8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = x[(bc * 8 + e) * HW + n];
+      const _Float16 h = (_Float16)v;
+      hi[e] = h;
+      lo[e] = (_Float16)(v - (float)h);
+    }
+    *reinterpret_cast<h8*>(p + ((bc * 2) * HW + n) * 8) = hi;
+    *reinterpret_cast<h8*>(p + ((bc * 2 + 1) * HW + n) * 8) = lo;
+  }
+}
+
+__global__ void __launch_bounds__(256) from_planes_kernel(const _Float16* __restrict__ p, float* __restrict__ x, int B, int C,
+                                                          int HW) {
+  const int64_t total = (int64_t)B * (C / 8) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % HW);
+    const int64_t bc = i / HW;
+    const h8 hi = *reinterpret_cast<const h8*>(p + ((bc * 2) * HW + n) * 8);
+    const h8 lo = *reinterpret_cast<const h8*>(p + ((bc * 2 + 1) * HW + n) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[(bc * 8 + e) * HW + n] = (float)hi[e] + (float)lo[e];
+  }
+}
+
+}  // namespace
+
+extern "C" int cips3d_planes_supported(int Cin, int Cout, int64_t HW) {
+  return Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 && HW >= 16 &&
+         (int64_t)(Cin > Cout ? Cin : Cout) * HW * 2 + 1024 < ((int64_t)1 << 31);
+}
+
+extern "C" int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, void* stream) {
+  if (!x || !planes || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (C % 8 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                     reinterpret_cast<_Float16*>(planes), B, C, (int)HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, void* stream) {
+  if (!x || !planes || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (C % 8 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const _Float16*>(planes), x, B, C, (int)HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, int out_format, int B, int Cin,
+                                        int Cout, int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
+                                        const float* noise_w, const float* bias, const float* rgb_w, float* rgb_part,
+                                        int* n_row_blocks, void* stream) {
+  if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
+  if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / 64 : 0;
+  if (!x_planes || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (out_format < 0 || out_format > 2 || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && !bias)) return CIPS3D_E_BADARG;
+  if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  ChainArgs a{reinterpret_cast<const _Float16*>(x_planes), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
+              noise_bstride, noise_w, bias, rgb_w, rgb_part};
+  // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
+  dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
+  hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), a);
+  return cips3d_launch_status();
+}

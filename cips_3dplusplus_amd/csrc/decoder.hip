@@ -67,7 +67,7 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
 //   packed (ksq == 1, Cout % 16 == 0, Cin % 16 == 0): A-fragment order of v_mfma_f32_16x16x4_f32
 //           wmp[b][ot][kq][lane][j] = wm[b][ot*16 + (lane&15)][16*kq + 4*j + (lane>>4)]
 //   packed + split (ksq == 1, Cin % 32 == 0; CIPS3D_MOD_SPLIT): A fragments of v_mfma_f32_16x16x32_f16, hi and lo fp16 halves of
-//           2^8 wm:  wms[b][ot][kb][plane][lane][j] (fp16) = plane(2^8 wm[b][ot*16 + (lane&15)][32 kb + 4 j + (lane>>4)]) -- one
+//           2^8 wm:  wms[b][ot][kb][plane][lane][j] (fp16) = plane(2^8 wm[b][ot*16 + (lane&15)][32 kb + 8 (lane>>4) + j]) -- one
 //           o-tile x 32-channel block = 2 x 1 KiB = the bytes of the two fp32 k-groups it replaces (same LDS-DMA pieces)
 //   packed, ksq == 9 (the 3x3 implicit GEMM, conv3x3.hip): the same fragment order per tap, tap-major:
 //           wmp[b][t'][ot][kq][lane][j], t' = t, or 8 - t with CIPS3D_MOD_FLIP (the transposed conv of the up-sampling branch)
@@ -100,7 +100,7 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
     if (demod) v *= d;
     if (packed & 16) {            // split-fp16 fragments (ksq == 1)
       const int i = e;
-      const int ot = o >> 4, kb = i >> 5, j = (i >> 2) & 7, q = i & 3;
+      const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;      // natural k order: k = 8 q + j
       const float sv = v * kSplitScale;
       const _Float16 hi = (_Float16)sv;
       const _Float16 lo = (_Float16)(sv - (float)hi);
@@ -316,7 +316,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
     // leaves the matrix pipe idle for an LDS round trip every 16 MFMAs (measured 64 % busy).
     if constexpr (SPLIT) {
       // 32-channel blocks: hi / lo A fragments (pre-split, two 1-KiB pieces per o-tile and block) and eight B rows
-      // (channel 32 kb + 4 j + q = fragment element j of lane quarter q), split into hi / lo fragments in registers.
+      // (channel 32 kb + 8 q + j = fragment element j of lane quarter q), split into hi / lo fragments in registers.
       constexpr int KB = BK / 32;
       static_assert(BK % 32 == 0, "split mode pairs the 16-channel groups");
       h8 ah[KB][WM], al[KB][WM];
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
           al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) b8[kb][j] = *reinterpret_cast<const f32x4*>(sB + (kb * 32 + j * 4 + q) * BN);
+        for (int j = 0; j < 8; ++j) b8[kb][j] = *reinterpret_cast<const f32x4*>(sB + (kb * 32 + 8 * q + j) * BN);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

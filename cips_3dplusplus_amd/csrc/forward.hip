@@ -103,10 +103,17 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   // the chunk partials are combined inside the render kernel when the shape allows it, else by cips3d_nerf_finish
   np.o_features = P.features; np.o_thumb = IO.thumb; np.o_xyz = IO.xyz; np.o_mask = IO.mask;
   const bool fused_finish = cips3d_nerf_fuses_finish(&np) != 0;
+  // the first decoder layer reads split-fp16 planes (flags bit 2): the render kernel's fused finish writes them directly,
+  // the stand-alone finish writes fp32 into the spare activation buffer and a conversion pass follows
+  const bool feat_planes = (P.layers[0].flags & 4) != 0;
+  np.features_planes = (feat_planes && fused_finish) ? 1 : 0;
   TRY(cips3d_nerf_render(&np, stream));
   if (IO.ev_nerf_stop) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_stop), as_stream(stream));
-  if (!fused_finish)
-    TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, P.features, IO.thumb, IO.xyz, IO.mask, stream));
+  if (!fused_finish) {
+    float* feat32 = feat_planes ? P.act[1] : P.features;
+    TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, feat32, IO.thumb, IO.xyz, IO.mask, stream));
+    if (feat_planes) TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, (int64_t)np.img_size * np.img_size, stream));
+  }
 
   // ---- decoder (model_v3.py:592-637)
   const float* x = P.features;
@@ -150,10 +157,15 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const float* nz2 = L2.noise_index >= 0 ? IO.noise[L2.noise_index] : nullptr;
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
         if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
-        if (!ylo_ready)
-          TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
-                                0 | gemm_flag | ybf_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
-                                stream));
+        if (!ylo_ready) {
+          if (L.flags & 4)       // the run's last activation arrives as planes
+            TRY(cips3d_modconv1x1_planes(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
+                                         nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+          else
+            TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
+                                  0 | gemm_flag | ybf_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
+                                  stream));
+        }
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
         const cips3d_dec_layer* LN = li + 3 < P.n_dec_layers ? &P.layers[li + 3] : nullptr;
@@ -172,6 +184,31 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         skip = rgb;
         skip_i ^= 1;
         li += 2;
+        continue;
+      }
+      if (L.kind == 0 && (L.flags & 4)) {
+        // a layer of the split-fp16 run (csrc/chain.hip): planes in; planes out (flags bit 3) with the ToRGB that follows
+        // folded from the registers -- nothing else may read this activation
+        const cips3d_dec_layer* T = li + 1 < P.n_dec_layers ? &P.layers[li + 1] : nullptr;
+        const int64_t hw = (int64_t)L.H * L.W;
+        const bool has_rgb = T && T->kind == 2;
+        const bool fold = has_rgb && li + 1 != P.n_dec_layers - 1 && T->Cin == L.Cout && P.rgb_part &&
+                          fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
+                          (fold_slots == 0 || (fold_H == L.H && fold_W == L.W));
+        const int fmt = (L.flags & 8) ? 1 : 0;          // planes for the next layer of the run, or fp32 when the run ends here
+        if (!(L.flags & 2) || (fmt == 1 && has_rgb && !fold)) return CIPS3D_E_BADARG;   // the plan promised otherwise
+        int nblk = 0;
+        TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
+                                     fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
+                                     stream));
+        if (fold) {
+          fold_slots += nblk;
+          fold_bias[fold_nb++] = T->bias;
+          fold_H = L.H; fold_W = L.W;
+          ++li;
+        }
+        x = out;
+        act_i ^= 1;
         continue;
       }
       if (L.kind == 0) {
@@ -196,6 +233,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, stream));
       } else {
         if (L.flags & 1) return CIPS3D_E_BADARG;   // chained packs only exist for stages that take the fused route above
+        if (L.flags & 4) return CIPS3D_E_BADARG;   // planes reach an up-conv only on the fused route (the plan guarantees it)
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
                               0 | gemm_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr, stream));
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));

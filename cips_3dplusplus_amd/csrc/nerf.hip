@@ -646,9 +646,26 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = fmaf(Tp[cc], v[e], acc[e]);
         }
-        float* o = P.o_features + ((int64_t)b * H + 4 * cq) * R + gray;
+        if (P.features_planes) {
+          // split-fp16 planes [b][H/8][hi|lo][R][8]: channels 4 cq .. 4 cq + 3 = elements 4 (cq & 1) .. of channel block cq >> 1
+          typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+          h4 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[(int64_t)e * R] = acc[e];
+          for (int e = 0; e < 4; ++e) {
+            _Float16 a_, b_;
+            split2(acc[e], a_, b_);
+            hi[e] = a_;
+            lo[e] = b_;
+          }
+          _Float16* o = reinterpret_cast<_Float16*>(P.o_features) +
+                        ((((int64_t)b * (H / 8) + (cq >> 1)) * 2) * R + gray) * 8 + 4 * (cq & 1);
+          *reinterpret_cast<h4*>(o) = hi;
+          *reinterpret_cast<h4*>(o + (int64_t)R * 8) = lo;
+        } else {
+          float* o = P.o_features + ((int64_t)b * H + 4 * cq) * R + gray;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[(int64_t)e * R] = acc[e];
+        }
       }
       const int k = tid >> 4;                // scalar channel 0..6 for the first 7 x 16 threads
       if (k < 7) {

@@ -415,6 +415,48 @@ def modconv_kxk(x, wm, Cout, k, transpose2=False):
     return out
 
 
+def planes_supported(Cin, Cout, HW):
+    return bool(_lib.load().cips3d_planes_supported(Cin, Cout, HW))
+
+
+def to_planes(x):
+    """fp32 [B,C,H,W] -> split-fp16 planes (torch.float16 tensor [B, C/8, 2, H*W, 8]: hi plane, lo plane; x = hi + lo)."""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    p = torch.empty(B, Cc // 8, 2, H * W, 8, device=x.device, dtype=torch.float16)
+    check(lib.cips3d_to_planes(dev_ptr(x, "x"), p.data_ptr(), B, Cc, H * W, stream_ptr()), "cips3d_to_planes")
+    return p
+
+
+def from_planes(p, H, W):
+    lib = _lib.load()
+    B, C8 = p.shape[0], p.shape[1]
+    x = torch.empty(B, C8 * 8, H, W, device=p.device, dtype=torch.float32)
+    check(lib.cips3d_from_planes(dev_ptr(p, "planes", dtype=torch.float16), dev_ptr(x), B, C8 * 8, H * W, stream_ptr()),
+          "cips3d_from_planes")
+    return x
+
+
+def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, noise=None, noise_w=None, bias=None,
+                      rgb_w=None, rgb_part=None):
+    """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call; wm_split from
+    modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW])."""
+    lib = _lib.load()
+    B, Cin = xp.shape[0], xp.shape[1] * 8
+    fmt = {"fp32": 0, "planes": 1, "bf16": 2}[out_format]
+    if fmt == 1:
+        out = torch.empty(B, Cout // 8, 2, HW, 8, device=xp.device, dtype=torch.float16)
+    else:
+        out = torch.empty(B, Cout, HW, device=xp.device, dtype=torch.bfloat16 if fmt == 2 else torch.float32)
+    nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    check(lib.cips3d_modconv1x1_planes(dev_ptr(xp, "x_planes", dtype=torch.float16), dev_ptr(wm_split, "wm"), out.data_ptr(), fmt,
+                                       B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
+                                       dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
+                                       dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), None, stream_ptr()),
+          "cips3d_modconv1x1_planes")
+    return out
+
+
 def modconv3x3_supported(Cin, Cout, H, W, up):
     return bool(_lib.load().cips3d_modconv3x3_supported(Cin, Cout, H, W, int(bool(up))))
 

@@ -51,6 +51,9 @@ class ForwardIO(C.Structure):
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
 # stage launches its own (A/B knob)
 CHAIN_STAGES = os.environ.get("CIPS3D_CHAIN_STAGES", "1") != "0"
+# The run of StyledConvs at the NeRF resolution keeps its activations as split-fp16 planes (csrc/chain.hip); 0 = every layer
+# reads / writes fp32 and splits in registers (A/B knob)
+PLANES_RUN = os.environ.get("CIPS3D_PLANES", "1") != "0"
 
 
 class PlanUnsupported(RuntimeError):
@@ -173,6 +176,33 @@ class ForwardPlan:
             conv2_of_fused = li["kind"] == 0 and i >= 1 and fused_stage(i - 1)
             chained = bool(li.get("chained"))
             li["split"] = not conv2_of_fused and not chained
+        # The run of equal-resolution StyledConvs at the NeRF resolution keeps its activations as split-fp16 planes
+        # (csrc/chain.hip): the render kernel writes the feature map as planes, every layer of the run reads and writes them,
+        # the ToRGBs in between are folded from registers, and the first up-sampling conv's low-resolution GEMM reads them.
+        if use_split and PLANES_RUN:
+            hw = img_size * img_size
+            ok_conv = lambda c: (c is not None and c.get("split") and c["kind"] in (0, 1) and c["H"] == img_size   # noqa: E731
+                                 and bool(lib.cips3d_planes_supported(c["Cin"], c["Cout"], hw)))
+            i, n_fold = 0, 0
+            while i < len(layer_info) and ok_conv(layer_info[i]):
+                li = layer_info[i]
+                if li["kind"] == 1:
+                    if fused_stage(i):
+                        li["planes_in"] = True
+                    break
+                nxt = layer_info[i + 1] if i + 1 < len(layer_info) else None
+                has_rgb = nxt is not None and nxt["kind"] == 2
+                foldable = (has_rgb and i + 1 != len(layer_info) - 1 and nxt["Cin"] == li["Cout"] and hw % 4 == 0 and n_fold < 8)
+                j = i + (2 if has_rgb else 1)
+                nconv = layer_info[j] if j < len(layer_info) else None
+                next_takes = ok_conv(nconv) and (nconv["kind"] == 0 or fused_stage(j))
+                li["planes_in"] = True
+                li["planes_out"] = bool(next_takes and (not has_rgb or foldable))
+                if has_rgb and foldable:
+                    n_fold += 1
+                if not li["planes_out"]:
+                    break
+                i = j
         wm_buf = torch.empty(sum(wm_sizes), device=dev)
         wm_tab = (_lib.ModulateDesc * len(seq))()
         rows, woff = 0, 0
@@ -192,7 +222,8 @@ class ForwardPlan:
             L = p.layers[idx]
             L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
                                                               info["W"], info["noise_index"])
-            L.flags = (1 if info.get("chained") else 0) | (2 if info.get("split") else 0)
+            L.flags = ((1 if info.get("chained") else 0) | (2 if info.get("split") else 0) | (4 if info.get("planes_in") else 0) |
+                       (8 if info.get("planes_out") else 0))
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 6   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 8   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -178,6 +178,10 @@ typedef struct cips3d_nerf_params {
    * mask [B,2,R]; `part` is then not touched and cips3d_nerf_finish must not be called.  Otherwise the pointers are
    * ignored and `part` + cips3d_nerf_finish is the way. */
   float* o_features; float* o_thumb; float* o_xyz; float* o_mask;
+  /* != 0 (fused finish only): o_features receives the feature map as split-fp16 planes [B][H/8][hi|lo][R][8] (fp16), the
+   * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes) */
+  int32_t features_planes;
+  int32_t pad_;
 } cips3d_nerf_params;
 
 /* 1 when cips3d_nerf_render(p) will write p->o_* itself (o_* set, n_chunks == 8, LDS large enough), else 0 */
@@ -217,7 +221,7 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  * of cips3d_modconv3x3 correlates with).  Packed ksq == 9 layout: wm[b][tap][o/16][i/16][((i&3)<<4 | (o&15))*4 + ((i>>2)&3)]. */
 #define CIPS3D_MOD_FLIP       8
 /* with CIPS3D_MOD_PACKED and ksq == 1 (Cin % 32 == 0): split-fp16 A fragments for CIPS3D_GEMM_SPLIT -- 2^8 wm as fp16 hi + lo
- * halves in v_mfma_f32_16x16x32_f16 order, wm[b][o/16][i/32][plane][((i&3)<<4 | (o&15))][(i>>2)&7] (fp16), 4 bytes per weight */
+ * halves in v_mfma_f32_16x16x32_f16 order, wm[b][o/16][i/32][plane][(((i>>3)&3)<<4 | (o&15))][i&7] (fp16), 4 bytes per weight */
 #define CIPS3D_MOD_SPLIT      16
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
@@ -331,6 +335,19 @@ int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise
 int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
                        int H, int W, int k, int transpose2, void* stream);
 
+/* The same 1x1 modulated conv on activations that are STORED split ("planes": x = fp16 hi + fp16 lo, laid out
+ * [B][C/8][plane hi|lo][HW][8] fp16 = the consumer's MFMA B fragments, 4 bytes per value like fp32).  The producer's epilogue
+ * splits every output once, so the main loop is LDS reads + MFMA only (csrc/chain.hip); used for the run of equal-resolution
+ * StyledConvs at the NeRF resolution.  wm: CIPS3D_MOD_PACKED | CIPS3D_MOD_SPLIT.  out_format: 0 fp32 [B,Cout,HW], 1 planes,
+ * 2 bf16 [B,Cout,HW].  epilogue / noise / bias / rgb_w / rgb_part / n_row_blocks as cips3d_modconv1x1_torgb (row blocks of 64).
+ * cips3d_planes_supported: Cin % 64 == 0, Cout % 64 == 0. */
+int cips3d_planes_supported(int Cin, int Cout, int64_t HW);
+int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, void* stream);      /* C % 8 == 0 */
+int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, void* stream);
+int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, int out_format, int B, int Cin, int Cout,
+                             int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
+                             const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
+
 /* 3x3 ModulatedConv2d (models/model_v3.py:264-314, decoder_cfg.kernel_size = 3) as an LDS-tiled implicit GEMM on MFMA.
  *   up = 0: out [B,Cout,H,W] = conv2d(x, wm, padding 1)                                           (:296-311)
  *   up = 1: out [B,Cout,2H,2W] = Blur(conv_transpose2d(x, wm, stride 2)), fir = the Blur's 4x4 taps (:280-291); the FIR is
@@ -362,7 +379,8 @@ typedef struct cips3d_dec_layer {
   int32_t noise_index;     /* index into cips3d_forward_io.noise (StyledConv) or -1 */
   int32_t flags;           /* bit 0 (kind 1 only): wm is in the CIPS3D_MOD_CHAINED order and this conv's low-resolution GEMM is
                               computed by the previous stage's kernel (cips3d_fused_up_conv_next);
-                              bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode */
+                              bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode;
+                              bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes) */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */

@@ -97,3 +97,116 @@ def test_fp32_exact_mode_agrees_with_the_default():
     assert 0 < d < 2e-5 * rng
     G.set_decoder_precision("fp32")
     assert torch.equal(G(**kw)["rgb"], a)
+
+
+def test_planes_roundtrip_and_chain_gemm():
+    """Split-fp16 "planes" storage (csrc/chain.hip): x -> (hi, lo) -> x to 2^-22 relative; a chain of 1x1 modulated convs whose
+    activations stay in planes against the fp32-MFMA kernel layer by layer; fp32 / bf16 exits; folded ToRGB partial sums."""
+    B, C, H = 2, 512, 64
+    HW = H * H
+    x = cu(weights.det_normal("pl.x", (B, C, H, H), 2.0, 1) * (1.0 + 5.0 * weights.det_unit_uniform("pl.m", (B, C, 1, 1), 2)))
+    p = hip.to_planes(x)
+    assert p.shape == (B, C // 8, 2, HW, 8) and p.dtype == torch.float16
+    back = hip.from_planes(p, H, H)
+    # 22 significant bits, and an absolute floor of half an fp16 subnormal step (2^-25) for residuals below fp16's normal range
+    assert bool(((back - x).abs() <= 2.5e-7 * x.abs() + 3.1e-8).all())
+    # planes layout: channel 8 cb + e of pixel n lives at [b, cb, plane, n, e]
+    hi = x.to(torch.float16)
+    assert torch.equal(p[:, :, 0].permute(0, 1, 3, 2).reshape(B, C, HW), hi.reshape(B, C, HW))
+    scale = 1.0 / math.sqrt(C)
+    nw = torch.full((1,), 0.2, device=DEV)
+    cur_p, cur_x = p, x
+    for layer in range(3):
+        Cout = 512 if layer < 2 else 256
+        W = cu(weights.det_normal(f"pl.W{layer}", (1, Cout, C, 1, 1), 1.0, 3))
+        s = cu(1.0 + weights.det_uniform(f"pl.s{layer}", (B, C), 0.4, 4))
+        bias = cu(weights.det_uniform(f"pl.b{layer}", (Cout,), 0.3, 5))
+        nz = cu(weights.det_normal(f"pl.n{layer}", (B if layer == 1 else 1, 1, H, H), 1.0, 6))
+        wm_x = hip.modulate_weights(W, s, C, B, Cout, C, 1, scale, True, True)
+        wm_s = hip.modulate_weights(W, s, C, B, Cout, C, 1, scale, True, True, split=True)
+        if layer < 2:
+            Wr = cu(weights.det_normal(f"pl.Wr{layer}", (1, 3, Cout, 1, 1), 1.0, 7))
+            wr = hip.modulate_weights(Wr, cu(1.0 + weights.det_uniform("pl.sr", (B, Cout), 0.3, 8)), Cout, B, 3, Cout, 1,
+                                      1.0 / math.sqrt(Cout), False, False)
+            part_ref = torch.zeros(Cout // 64, B, 3, HW, device=DEV)
+            lib = _lib.load()
+            ref = torch.empty(B, Cout, H, H, device=DEV)
+            nb = HW if nz.shape[0] == B else 0
+            _lib.check(lib.cips3d_modconv1x1_torgb(cur_x.data_ptr(), wm_x.data_ptr(), ref.data_ptr(), B, C, Cout, HW, 1, nz.data_ptr(),
+                                                   nb, nw.data_ptr(), bias.data_ptr(), wr.data_ptr(), part_ref.data_ptr(), None,
+                                                   torch.cuda.current_stream().cuda_stream), "ref")
+            part = torch.zeros_like(part_ref)
+            out_p = hip.modconv1x1_planes(cur_p, wm_s, Cout, HW, "planes", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr,
+                                          rgb_part=part)
+            got = hip.from_planes(out_p, H, H)
+            rng = float(ref.abs().max())
+            assert maxdiff(got, ref) < 4e-6 * rng, layer
+            assert maxdiff(part, part_ref) < 4e-6 * float(part_ref.abs().max()), layer
+            cur_p, cur_x = out_p, ref
+        else:       # the low-resolution GEMM that leaves the run: fp32 and bf16 exits, no epilogue
+            ref = hip.modconv1x1(cur_x, wm_x, Cout, epilogue=0)
+            o32 = hip.modconv1x1_planes(cur_p, wm_s, Cout, HW, "fp32")
+            o16 = hip.modconv1x1_planes(cur_p, wm_s, Cout, HW, "bf16")
+            rng = float(ref.abs().max())
+            assert maxdiff(o32.view_as(ref), ref) < 4e-6 * rng
+            assert torch.equal(o16, o32.to(torch.bfloat16))
+    assert hip.planes_supported(512, 512, 4096) and not hip.planes_supported(32, 512, 4096)
+
+
+def test_planes_run_in_the_one_call_forward():
+    """The default plan runs conv1 + convs.0-7 and the first low-resolution GEMM on split-fp16 planes (flags bits 2 / 3),
+    fed by the render kernel's planes output; the result agrees with the same plan without planes (fp32 storage, split in
+    registers) to the rounding of the stored activations (2^-22 relative per value)."""
+    from cips_3dplusplus_amd import plan as _plan
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=2)
+    zs, nb, _ = weights.synth_inputs(cfg, seed=6)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[-0.3, 0.1]], device=DEV))
+    kw = dict(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    old = _plan.PLANES_RUN
+    try:
+        _plan.PLANES_RUN = True
+        G._plans = {}
+        a = G(**kw)["rgb"].clone()
+        L = list(G._plans.values())[0].plan.layers
+        kinds = [(L[i].kind, L[i].flags) for i in range(list(G._plans.values())[0].plan.n_dec_layers)]
+        convs64 = [fl for k, fl in kinds if k == 0][:9]
+        assert all(fl & 4 and fl & 8 for fl in convs64), kinds            # planes in and out for the nine 64^2 convs
+        first_up = [fl for k, fl in kinds if k == 1][0]
+        assert first_up & 4 and not first_up & 8
+        _plan.PLANES_RUN = False
+        G._plans = {}
+        b = G(**kw)["rgb"].clone()
+        L = list(G._plans.values())[0].plan.layers
+        assert not any(L[i].flags & 12 for i in range(list(G._plans.values())[0].plan.n_dec_layers))
+    finally:
+        _plan.PLANES_RUN = old
+        G._plans = {}
+    rng = float(b.abs().max())
+    d = maxdiff(a, b)
+    print(f"planes run vs fp32-storage split run, 1024^2: max-abs {d:.2e} on range {rng:.2f}")
+    assert d < 2e-5 * rng
+
+
+def test_planes_run_ends_in_fp32_when_nothing_up_samples():
+    """64^2 output (upsample_list = []): the last ToRGB is the image and cannot be folded, so the run's last conv leaves in
+    fp32; tiny generators (channels the planes kernel does not tile) plan no run at all."""
+    cfg = configs.ffhq_G_cfg(64, 2)
+    G = pkg.build_generator(cfg, DEV, seed=3)
+    zs, nb, _ = weights.synth_inputs(cfg, seed=7)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[0.1, 0.0]], device=DEV))
+    ncfg = dict(N_samples=6, perturb=False, static_viewdirs=False)
+    r = G(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=[cu(b) for b in nb], nerf_cfg=ncfg)
+    plan = list(G._plans.values())[0].plan
+    fl = [plan.layers[i].flags for i in range(plan.n_dec_layers) if plan.layers[i].kind == 0]
+    assert fl[0] & 4 and all(x & 8 for x in fl[:-1]) and fl[-1] & 4 and not fl[-1] & 8
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    cam = O.camera_params(torch.tensor([[0.1, 0.0]]), 64, 6, 0.12)
+    ref = O.generator_forward(sd, cfg, zs, cam[0], cam[1], 64, cam[2], cam[3], ncfg, nb)
+    assert maxdiff(r["rgb"].cpu(), ref["rgb"]) < 1e-3
+    Gt = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=1)
+    et, ft, nt, fat, _ = Camera.generate_camera_params(8, DEV, locations=torch.zeros(1, 2, device=DEV))
+    Gt(zs=[torch.randn(1, 32, device=DEV)] * 2, cam_poses=et, focals=ft, img_size=8, near=nt, far=fat, nerf_cfg=ncfg)
+    pt = list(Gt._plans.values())[0].plan
+    assert not any(pt.layers[i].flags & 12 for i in range(pt.n_dec_layers))
