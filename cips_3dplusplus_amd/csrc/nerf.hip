@@ -269,7 +269,11 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
   // The slab-step loop is a REAL loop (code size: the fully unrolled layer overflowed the instruction cache).  Output
   // registers cannot be indexed by the (run-time) step, so the step always writes the LAST entries of Yh / Yl / FA and the
   // arrays are rotated down; after STEPS steps every element is back in natural order.
+#ifdef CIPS3D_NO_STAGGER
+  const bool late_epilogue = false;
+#else
   const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
+#endif
 #pragma unroll 1
   for (int sl = 0; sl < STEPS; ++sl) {
     if (ring.seq + 1 < ring.seq_end) {
@@ -333,7 +337,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_wc + 2 * H + o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float f = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
+          const float f = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
           res[tt * 4 + i] = fmaf(wgt, f, FA[tt * 4 + i]);     // FA[0..R) currently holds this step's units
           chead[0] = fmaf(w0[i], f, chead[0]);
           chead[1] = fmaf(w1[i], f, chead[1]);
@@ -341,7 +345,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = sin_accurate(fmaf(g4[i], acc[tt][i], c4[i]));
+        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
         if (last) {     // h_D: sigma head partial (volume_renderer.py:148) from the fp32 values, before they are split
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
 #pragma unroll
@@ -552,7 +556,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
-          v8[hf * 4 + i] = sin_accurate(fmaf(g4[i], pre, c4[i]));
+          v8[hf * 4 + i] = cips3d_sin(fmaf(g4[i], pre, c4[i]));
         }
         if (D == 1) {           // no hidden MFMA layer: this is h_D
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
