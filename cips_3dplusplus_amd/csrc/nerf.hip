@@ -266,15 +266,15 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
   constexpr int MB = NT / 2;            // 32-unit k-blocks of the layer input
   constexpr int BPS = TPS / 2;          // k-blocks of the NEXT layer's input a step completes
   static_assert(TPS % 2 == 0 && NT % TPS == 0, "a slab step must complete whole 32-unit blocks");
-  // The slab-step loop is a REAL loop (code size: the fully unrolled layer overflowed the instruction cache).  Output
-  // registers cannot be indexed by the (run-time) step, so the step always writes the LAST entries of Yh / Yl / FA and the
-  // arrays are rotated down; after STEPS steps every element is back in natural order.
+  // The slab steps of a layer are fully unrolled (with 96 fp16 MFMAs per step instead of 256 fp32 ones the whole kernel is
+  // ~40 KB of code): the step index is a constant, results go straight to their final registers (the rolled loop of the
+  // fp32 kernel had to rotate Yh / Yl / FA by 48 moves per step; unrolling measured 107.6 -> 101.0 us).
 #ifdef CIPS3D_NO_STAGGER
   const bool late_epilogue = false;
 #else
   const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
 #endif
-#pragma unroll 1
+#pragma unroll
   for (int sl = 0; sl < STEPS; ++sl) {
     if (ring.seq + 1 < ring.seq_end) {
       const int nxt = (ring.seq + 1) % ring.per_sample;
@@ -338,7 +338,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float f = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
-          res[tt * 4 + i] = fmaf(wgt, f, FA[tt * 4 + i]);     // FA[0..R) currently holds this step's units
+          res[tt * 4 + i] = fmaf(wgt, f, FA[sl * R + tt * 4 + i]);
           chead[0] = fmaf(w0[i], f, chead[0]);
           chead[1] = fmaf(w1[i], f, chead[1]);
           chead[2] = fmaf(w2[i], f, chead[2]);
@@ -358,21 +358,17 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
     for (int k = 0; k < R; ++k) asm volatile("" : "+v"(res[k]));
     if (VIEW) asm volatile("" : "+v"(chead[0]), "+v"(chead[1]), "+v"(chead[2]));
-    // rotate: drop the first entries, append this step's results
+    // fully unrolled steps: the step index is a constant, results go to their final places
     if (VIEW) {
 #pragma unroll
-      for (int k = 0; k < NT * 4 - R; ++k) FA[k] = FA[k + R];
-#pragma unroll
-      for (int k = 0; k < R; ++k) FA[NT * 4 - R + k] = res[k];
+      for (int k = 0; k < R; ++k) FA[sl * R + k] = res[k];
     } else {
-#pragma unroll
-      for (int k = 0; k < MB - BPS; ++k) { Yh[k] = Yh[k + BPS]; Yl[k] = Yl[k + BPS]; }
 #pragma unroll
       for (int bb = 0; bb < BPS; ++bb) {
         float v8[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v8[j] = res[(2 * bb) * 4 + j];      // tile 2bb (j = 0..3), tile 2bb+1 (j = 4..7)
-        split8(v8, Yh[MB - BPS + bb], Yl[MB - BPS + bb]);
+        for (int j = 0; j < 8; ++j) v8[j] = res[(2 * bb) * 4 + j];
+        split8(v8, Yh[sl * BPS + bb], Yl[sl * BPS + bb]);
       }
     }
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
