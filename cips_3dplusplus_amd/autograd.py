@@ -75,6 +75,11 @@ class ModulateFn(Function):
         return dW, ds, None, None, None
 
 
+def _split_ok(k):
+    """Split-fp16 GEMM mode for a forward GEMM (activation operand) whose contraction length is k (hip.SPLIT_BACKWARD: knob)."""
+    return hip.SPLIT_BACKWARD and k % 32 == 0
+
+
 class Conv1x1Fn(Function):
     """Per-sample GEMM y[b] = wm[b] x[b] (x [B,Cin,H,W]); backward = the same GEMM on wm^T + the pixel-contraction GEMM."""
 
@@ -83,7 +88,8 @@ class Conv1x1Fn(Function):
         x = _c(x)
         wm = _c(wm)
         Cout = wm.shape[1]
-        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm), Cout, epilogue=0)
+        sp = _split_ok(wm.shape[2])          # `packed` (from modulate_all) is split-packed under the same condition
+        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), Cout, epilogue=0, split=sp)
         ctx.save_for_backward(x, wm)
         return y
 
@@ -92,7 +98,7 @@ class Conv1x1Fn(Function):
         x, wm = ctx.saved_tensors
         dy = _c(dy)
         dx = dwm = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0]:          # gradient operand: fp32 MFMA (hip.SPLIT_BACKWARD explains)
             dx = hip.modconv1x1(dy, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0)
         if ctx.needs_input_grad[1]:
             dwm = hip.gemm_wgrad(dy, x)
@@ -106,8 +112,9 @@ class Conv1x1ActFn(Function):
     @staticmethod
     def forward(ctx, x, wm, packed, noise, noise_w, bias):
         x, wm, noise = _c(x), _c(wm), _c(noise)
-        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm), wm.shape[1], epilogue=1, noise=noise,
-                           noise_w=noise_w, bias=bias)
+        sp = _split_ok(wm.shape[2])
+        y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), wm.shape[1], epilogue=1,
+                           noise=noise, noise_w=noise_w, bias=bias, split=sp)
         ctx.save_for_backward(x, wm, y, noise, noise_w)
         return y
 
@@ -248,7 +255,8 @@ def modulate_all(dec, s_list):
                 d.out = (packed.data_ptr() + 4 * ko) if want_packed else (plain.data_ptr() + 4 * po)
                 d.s_stride = cin
                 d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
-                d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if want_packed else 0)
+                d.flags = ((hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if want_packed else 0) |
+                           (hip.MOD_SPLIT if (want_packed and _split_ok(conv.in_channel)) else 0))
                 d.scale = conv.scale
                 d.row_begin = rows
                 rows += conv.out_channel

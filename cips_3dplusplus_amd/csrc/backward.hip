@@ -153,8 +153,20 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ wm,
   if (e >= (int64_t)B * M * K) return;
   const int b = (int)(e / ((int64_t)M * K));
   const int r = (int)((e / K) % M), c = (int)(e % K);       // element wm[b][r][c]
-  const int o = transpose ? c : r, i = transpose ? r : c;   // (row, column) of the packed matrix
-  const int OM = transpose ? K : M, OK = transpose ? M : K;
+  const bool tr = transpose & 1;
+  const int o = tr ? c : r, i = tr ? r : c;   // (row, column) of the packed matrix
+  const int OM = tr ? K : M, OK = tr ? M : K;
+  if (transpose & 2) {
+    // split-fp16 fragments for CIPS3D_GEMM_SPLIT (decoder.hip): 2^8 w = fp16 hi + fp16 lo, natural k order
+    const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;
+    const float sv = wm[e] * 256.f;
+    const _Float16 hi = (_Float16)sv;
+    const _Float16 lo = (_Float16)(sv - (float)hi);
+    _Float16* blk = reinterpret_cast<_Float16*>(out) + (((int64_t)b * (OM >> 4) + ot) * (OK >> 5) + kb) * 1024;
+    blk[((q << 4) | (o & 15)) * 8 + j] = hi;
+    blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
+    return;
+  }
   const int ot = o >> 4, kq = i >> 4, j = (i >> 2) & 3, q = i & 3;
   out[(((int64_t)b * (OM >> 4) + ot) * (OK >> 4) + kq) * 256 + ((q << 4) | (o & 15)) * 4 + j] = wm[e];
 }
@@ -421,6 +433,7 @@ extern "C" int cips3d_modulate_bwd(float* dwm, const float* W, const float* s, i
 extern "C" int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int transpose, void* stream) {
   if (!wm || !packed || B < 0 || M <= 0 || K <= 0) return CIPS3D_E_BADARG;
   if (M % 16 || K % 16) return CIPS3D_E_UNSUPP;
+  if ((transpose & 2) && (((transpose & 1) ? M : K) % 32)) return CIPS3D_E_UNSUPP;     // split fragments: 32-wide k blocks
   if (B == 0) return 0;
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * M * K, 256)), dim3(256), 0, as_stream(stream),
                      wm, packed, B, M, K, transpose);

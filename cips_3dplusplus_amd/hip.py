@@ -5,6 +5,8 @@ the current stream are handed to the HIP library.  Nothing here computes on the 
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -553,13 +555,20 @@ def modulate_bwd(dwm, W, s, Cout, Cin, ksq, scale, demodulate, need_dW=True):
     return dW, ds
 
 
-def pack_weights(wm, transpose=False):
-    """wm [B,M,K] -> packed A fragments of wm (or of wm^T)."""
+# The GEMMs of the differentiable path whose B operand is an ACTIVATION (decoder forward, the materialised NeRF recompute) run
+# in the fp32-equivalent split-fp16 mode, as the inference forward's stand-alone GEMMs do; 0 = the fp32 MFMA (A/B knob).  The
+# data-gradient GEMMs keep the fp32 MFMA: their B operand is a gradient tensor whose scale is arbitrary (1e-6 and below), and
+# the fp16 halves of the split have an absolute floor of 2^-25 -- fine for O(1) activations, 5 bits for a 1e-6 gradient.
+SPLIT_BACKWARD = os.environ.get("CIPS3D_SPLIT_BACKWARD", "1") != "0"
+
+
+def pack_weights(wm, transpose=False, split=False):
+    """wm [B,M,K] -> packed A fragments of wm (or of wm^T); split: fp16 hi + lo fragments for modconv1x1(split=True)."""
     lib = _lib.load()
     B, M, K = wm.shape
     out = torch.empty(B * M * K, device=wm.device)
-    check(lib.cips3d_pack_weights(dev_ptr(wm, "wm"), dev_ptr(out), B, M, K, int(bool(transpose)), stream_ptr()),
-          "cips3d_pack_weights")
+    check(lib.cips3d_pack_weights(dev_ptr(wm, "wm"), dev_ptr(out), B, M, K, int(bool(transpose)) | (2 if split else 0),
+                                  stream_ptr()), "cips3d_pack_weights")
     return out
 
 
@@ -653,17 +662,18 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
                                      dev_ptr(pre[0]), dev_ptr(hh[0]), dev_ptr(viewdirs), st), "cips3d_nerf_bwd_points")
     w_view = net.views_linears.weight                      # [H, H+3]
     mats = [net.pts_linears[l].weight.detach() for l in range(1, D)] + [w_view.detach()[:, :H].contiguous()]
+    split = SPLIT_BACKWARD and H % 32 == 0
     packed, packed_t = [], []
     for Wl in mats:                                        # shared over the batch: replicate the (small) matrix
         Wb = Wl.unsqueeze(0).expand(B, H, H).contiguous()
-        packed.append(pack_weights(Wb))
-        packed_t.append(pack_weights(Wb, transpose=True))
+        packed.append(pack_weights(Wb, split=split))            # forward recompute: activations in [-1, 1]
+        packed_t.append(pack_weights(Wb, transpose=True))       # data gradients: fp32 MFMA (see SPLIT_BACKWARD)
 
-    def gemm(x, pk):
-        return modconv1x1(x.view(B, H, P, 1), pk, H, epilogue=0).view(B, H, P)
+    def gemm(x, pk, sp=False):
+        return modconv1x1(x.view(B, H, P, 1), pk, H, epilogue=0, split=sp).view(B, H, P)
 
     for l in range(1, L):
-        acc = gemm(hh[l - 1], packed[l - 1])
+        acc = gemm(hh[l - 1], packed[l - 1], split)
         is_view = l == D
         check(lib.cips3d_nerf_bwd_film(dev_ptr(acc), dev_ptr(hh[l]), layer_bias.data_ptr() + 4 * l * H, film_l(l), fb,
                                        (w_view.data_ptr() + 4 * H) if is_view else None, H + 3,
@@ -710,3 +720,36 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
     check(lib.cips3d_nerf_bwd_camera(gp, dev_ptr(dptsn), dev_ptr(dvd_pt), dev_ptr(ddnorm), dev_ptr(dcam), st),
           "cips3d_nerf_bwd_camera")
     return dfilm, dcam
+
+
+def inversion_roofline(B, n_samples, hidden, depth, img_size=64, iters=20):
+    """Roofline entry of the flip-inversion step's dominant kernel: the hidden x hidden GEMMs over all B * R * N sample points of
+    the materialised NeRF backward (D forward-recompute GEMMs in split-fp16 mode, D data-gradient GEMMs on the fp32 MFMA;
+    together ~1/3 of the step).  Timed stand-alone on the step's shape with HIP events (the loop itself is a tape of ~450
+    launches; its kernel summary is under profiles/)."""
+    dev = "cuda"
+    P = img_size * img_size * n_samples
+    x = torch.randn(B, hidden, P, 1, device=dev)
+    W = (torch.randn(hidden, hidden, device=dev) * 0.006).unsqueeze(0).expand(B, hidden, hidden).contiguous()
+    out = torch.empty(B, hidden, P, 1, device=dev)
+    res = {}
+    for name, sp in (("data_gradient_fp32_mfma", False), ("recompute_split_fp16", True)):
+        pk = pack_weights(W, split=sp)
+        for _ in range(3):
+            modconv1x1(x, pk, hidden, epilogue=0, split=sp, out=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            modconv1x1(x, pk, hidden, epilogue=0, split=sp, out=out)
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / iters
+    flop = 2.0 * hidden * hidden * P * B
+    a = flop / (res["data_gradient_fp32_mfma"] * 1e-3) / 1e12
+    return {"kernel": f"modconv1x1_kernel on [{hidden} x {hidden}] x [{hidden} x {B * P}] (one of the 2 x {depth} point-MLP GEMMs of the "
+                      f"materialised NeRF backward; timed stand-alone on the step's shape)",
+            "bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
+            "avg_launch_ms": res["data_gradient_fp32_mfma"], "flop_per_launch": flop,
+            "split_fp16_form": {"avg_launch_ms": res["recompute_split_fp16"],
+                                "achieved": flop / (res["recompute_split_fp16"] * 1e-3) / 1e12,
+                                "note": "the forward-recompute GEMMs (activation operand) run in this form; algorithmic TFLOP/s"}}

@@ -493,8 +493,9 @@ int cips3d_linear_bwd(const float* x, int64_t x_stride, const float* W, const fl
 int cips3d_modulate_bwd(float* dwm, const float* W, const float* s, int64_t s_stride, int B, int Cout, int Cin, int ksq,
                         float scale, int demodulate, float* dW, float* ds, int64_t ds_stride, void* stream);
 
-/* wm [B,M,K] plain -> the MFMA A-fragment order cips3d_modconv1x1 consumes; transpose != 0 packs wm[b]^T (K x M),
- * which turns cips3d_modconv1x1 into the data-gradient GEMM dx = wm^T dy.  M, K multiples of 16. */
+/* wm [B,M,K] plain -> the MFMA A-fragment order cips3d_modconv1x1 consumes; transpose bit 0 packs wm[b]^T (K x M),
+ * which turns cips3d_modconv1x1 into the data-gradient GEMM dx = wm^T dy.  M, K multiples of 16.  transpose bit 1: split-fp16
+ * fragments (2^8 w = fp16 hi + lo) for the CIPS3D_GEMM_SPLIT mode; the packed matrix's K a multiple of 32, |w| < 255. */
 int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int transpose, void* stream);
 
 /* Weight gradient of the 1x1 convolution: dwm[b][m][k] = sum_p dy[b][m][p] * x[b][k][p]  (dy [B,M,P], x [B,K,P]).
