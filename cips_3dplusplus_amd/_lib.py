@@ -142,7 +142,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 8            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 9            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

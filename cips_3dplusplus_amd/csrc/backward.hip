@@ -160,8 +160,8 @@ __global__ void __launch_bounds__(256) pack_kernel(const float* __restrict__ wm,
     // split-fp16 fragments for CIPS3D_GEMM_SPLIT (decoder.hip): 2^8 w = fp16 hi + fp16 lo, natural k order
     const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;
     const float sv = wm[e] * 256.f;
-    const _Float16 hi = (_Float16)sv;
-    const _Float16 lo = (_Float16)(sv - (float)hi);
+    _Float16 hi, lo;
+    cips3d_split16(sv, hi, lo);
     _Float16* blk = reinterpret_cast<_Float16*>(out) + (((int64_t)b * (OM >> 4) + ot) * (OK >> 5) + kb) * 1024;
     blk[((q << 4) | (o & 15)) * 8 + j] = hi;
     blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;

@@ -197,9 +197,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
           h4 hi, lo;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const _Float16 h = (_Float16)v[r];
-            hi[r] = h;
-            lo[r] = (_Float16)(v[r] - (float)h);
+            _Float16 h_, l_;
+            cips3d_split16(v[r], h_, l_);
+            hi[r] = h_;
+            lo[r] = l_;
           }
           _Float16* dst = reinterpret_cast<_Float16*>(a.out) +
                           ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
@@ -268,9 +269,10 @@ __global__ void __launch_bounds__(256) to_planes_kernel(const float* __restrict_
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float v = x[(bc * 8 + e) * HW + n];
-      const _Float16 h = (_Float16)v;
-      hi[e] = h;
-      lo[e] = (_Float16)(v - (float)h);
+      _Float16 h_, l_;
+      cips3d_split16(v, h_, l_);
+      hi[e] = h_;
+      lo[e] = l_;
     }
     *reinterpret_cast<h8*>(p + ((bc * 2) * HW + n) * 8) = hi;
     *reinterpret_cast<h8*>(p + ((bc * 2 + 1) * HW + n) * 8) = lo;

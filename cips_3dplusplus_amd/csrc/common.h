@@ -94,3 +94,13 @@ __device__ static inline float sin_hw(float x) {
 #else
 #define cips3d_sin sin_hw
 #endif
+
+// Split-fp16: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits; see nerf.hip / decoder.hip / chain.hip).
+// `x` is made opaque first: hipcc otherwise folds a multiplication that produced x into the conversion (v_fma_mixlo_f16:
+// fp16 of the exactly-rounded-once product) while the residual is taken against the fp32-rounded x -- when the two roundings
+// of hi disagree (rare) the halves miss x by a whole fp16 ulp (2^-11 relative; measured 2.5e-4 on the fused stage's output).
+__device__ static inline void cips3d_split16(float x, _Float16& hi, _Float16& lo) {
+  asm volatile("" : "+v"(x));
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}

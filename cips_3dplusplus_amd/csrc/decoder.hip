@@ -26,6 +26,52 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+// ---- split-fp16 inside the fused up-sampling stage (16-channel k-groups, v_mfma_f32_16x16x16_f16): an activation travels
+// through LDS as ONE 32-bit word holding its two halves {fp16 hi (bits 0-15), fp16 lo (bits 16-31)} -- the producer splits
+// it once -- and a lane assembles its 4-element fragments from four such words with two v_perm_b32 each.  Weights come
+// pre-split from the modulate kernel (CIPS3D_MOD_SPLIT16: per o-tile and k-group [lane][hi x4 | lo x4], the 16 bytes of
+// the fp32 fragment they replace), scaled by 2^8.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pack_split(float x) {
+  _Float16 hi, lo;
+  cips3d_split16(x, hi, lo);
+  return __builtin_bit_cast(float, h2{hi, lo});
+}
+// four packed words (fragment elements 0..3) -> the hi fragment and the lo fragment
+__device__ __forceinline__ void unpack_frag(float p0, float p1, float p2, float p3, h4& hi, h4& lo) {
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const unsigned a0 = __float_as_uint(p0), a1 = __float_as_uint(p1), a2 = __float_as_uint(p2), a3 = __float_as_uint(p3);
+  hi = __builtin_bit_cast(h4, u32x2_t{__builtin_amdgcn_perm(a1, a0, 0x05040100u), __builtin_amdgcn_perm(a3, a2, 0x05040100u)});
+  lo = __builtin_bit_cast(h4, u32x2_t{__builtin_amdgcn_perm(a1, a0, 0x07060302u), __builtin_amdgcn_perm(a3, a2, 0x07060302u)});
+}
+// split four fp32 values (fragment elements 0..3) in registers
+__device__ __forceinline__ void split_frag(float v0, float v1, float v2, float v3, h4& hi, h4& lo) {
+  const float v[4] = {v0, v1, v2, v3};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    _Float16 a, b;
+    cips3d_split16(v[e], a, b);
+    hi[e] = a;
+    lo[e] = b;
+  }
+}
+// the three products of one 16x16x16 block: A fragment word = {hi x4 | lo x4}
+__device__ __forceinline__ f32x4 split_mfma16(f32x4 afrag, h4 bh, h4 bl, f32x4 c) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const h4 ah = __builtin_bit_cast(h4, f32x2_t{afrag[0], afrag[1]});
+  const h4 al = __builtin_bit_cast(h4, f32x2_t{afrag[2], afrag[3]});
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, c, 0, 0, 0);
+}
+
+#ifdef CIPS3D_FUSED_NO_MFMA     // timing-only ablation (tools/): what the fused stages would cost with free matrix work
+__device__ __forceinline__ f32x4 fused_mfma(float a, float b, f32x4 c) { c[0] += a * b; return c; }
+#else
+__device__ __forceinline__ f32x4 fused_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
+
 // Split-fp16 GEMM mode (CIPS3D_GEMM_SPLIT): fp32-equivalent products at the fp16 matrix rate.  Every operand is the
 // unevaluated sum of two fp16 numbers, x = hi + lo (hi = fp16(x), lo = fp16(x - hi): 22 significant bits in the 4 bytes
 // of an fp32); a product is accumulated in fp32 as the three exact fp16 x fp16 products w_lo x_hi + w_hi x_lo + w_hi x_hi
@@ -38,9 +84,10 @@ constexpr float kSplitScale = 256.f, kSplitInv = 1.f / 256.f;
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const _Float16 a = (_Float16)v[j];
+    _Float16 a, b;
+    cips3d_split16(v[j], a, b);
     hi[j] = a;
-    lo[j] = (_Float16)(v[j] - (float)a);
+    lo[j] = b;
   }
 }
 
@@ -98,12 +145,24 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
   const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
   auto put = [&](int e, float v) {
     if (demod) v *= d;
-    if (packed & 16) {            // split-fp16 fragments (ksq == 1)
+    if (packed & 32) {            // split-fp16 fragments of the fused stages: 16-channel k-groups, [lane][hi x4 | lo x4]
+      const int i = e;
+      const int ot = o >> 4, kq = i >> 4;
+      const bool chained = (packed & 7) == 2;      // element <-> channel as in the fp32 layouts below
+      const int el = chained ? (i & 3) : ((i >> 2) & 3), q = chained ? ((i >> 2) & 3) : (i & 3);
+      const float sv = v * kSplitScale;
+      _Float16 hi, lo;
+      cips3d_split16(sv, hi, lo);
+      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 512) +
+                      ((q << 4) | (o & 15)) * 8;
+      blk[el] = hi;
+      blk[4 + el] = lo;
+    } else if (packed & 16) {     // split-fp16 fragments (ksq == 1)
       const int i = e;
       const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;      // natural k order: k = 8 q + j
       const float sv = v * kSplitScale;
-      const _Float16 hi = (_Float16)sv;
-      const _Float16 lo = (_Float16)(sv - (float)hi);
+      _Float16 hi, lo;
+      cips3d_split16(sv, hi, lo);
       _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
       blk[((q << 4) | (o & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
@@ -161,7 +220,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 24)) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 56)) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -833,7 +892,8 @@ struct FusedArgs {
   const float* wm2; const float* noise2; int64_t nbs2; const float* nw2; const float* bias2; float* out2;
   const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
   int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
-  int bf16;      // 0: exact fp32; 1: bf16 GEMM operands (CIPS3D_GEMM_BF16); 2: additionally y_lo / y_next are bf16 arrays (CIPS3D_Y_BF16)
+  int bf16;      // 0: exact fp32; 1: bf16 GEMM operands (CIPS3D_GEMM_BF16); 2: additionally y_lo / y_next are bf16 arrays (CIPS3D_Y_BF16);
+                 // 3: fp32-equivalent split-fp16 products (CIPS3D_GEMM_SPLIT; wm2 / wm_next CIPS3D_MOD_SPLIT16-packed)
   // optional (NEXT instantiation): the next stage's low-resolution GEMM y_next = wm_next (C/2 x C, chained pack) out2
   const float* wm_next; float* y_next;
 };
@@ -843,8 +903,9 @@ struct FusedArgs {
 template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, int PREC, bool NEXT = false, bool XPREF = false,
           bool LATE_OPS = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
-  constexpr bool BF16 = PREC >= 1;               // bf16 MFMA operands, fp32 accumulate
+  constexpr bool BF16 = PREC == 1 || PREC == 2;  // bf16 MFMA operands, fp32 accumulate
   constexpr bool YB = PREC == 2;                 // y_lo (in) and y_next (out) stored as bf16
+  constexpr bool SPLIT = PREC == 3;              // fp32-equivalent split-fp16 products (weights CIPS3D_MOD_SPLIT16-packed)
   typedef typename std::conditional<YB, bf16_t, float>::type ylo_t;
   // A wave covers RW image rows x CW columns (64 pixels, 4 consecutive x per lane); the WGN waves of a
   // workgroup are stacked vertically: pixel tile TH x TW.
@@ -952,6 +1013,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * 1.41421356237309515f;
+        if constexpr (SPLIT) {          // split once here; every wave row reads the packed halves
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c]);
+        }
         *reinterpret_cast<f32x4*>(dst + ch * BN + (2 * by + py) * TW + qx * 4) = v;
       }
     }
@@ -1015,6 +1080,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
           for (int c = 0; c < 4; ++c)
             acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[i], bh[c], acc[i][c], 0, 0, 0);
+      } else if constexpr (SPLIT) {
+        f32x4 b4[4];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) b4[j4] = *reinterpret_cast<const f32x4*>(cur + (kq * 16 + j4 * 4 + q) * BN);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          h4 bh, bl;
+          unpack_frag(b4[0][c], b4[1][c], b4[2][c], b4[3][c], bh, bl);
+#pragma unroll
+          for (int i = 0; i < WM; ++i) acc[i][c] = split_mfma16(afr[kq][i], bh, bl, acc[i][c]);
+        }
       } else {
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) {
@@ -1023,7 +1099,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int c = 0; c < 4; ++c)
-            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[kq][i][j4], b4[c], acc[i][c], 0, 0, 0);
+            acc[i][c] = fused_mfma(afr[kq][i][j4], b4[c], acc[i][c]);
       }
       }
     }
@@ -1044,6 +1120,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+      if constexpr (SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] *= kSplitInv;           // exact: conv2's weights carried 2^8
+      }
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * 1.41421356237309515f;
       if (NEXT) {   // keep the activated value where the accumulator was: it is the next GEMM's B operand
@@ -1096,7 +1176,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             *reinterpret_cast<f32x4*>(sx + (((wm_i % (WGM / 2)) * WM + i) * 4 + r) * 256) =
-                f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                SPLIT ? f32x4{pack_split(acc[i][0][r]), pack_split(acc[i][1][r]), pack_split(acc[i][2][r]), pack_split(acc[i][3][r])}
+                      : f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       }
       __syncthreads();
 #pragma unroll
@@ -1114,6 +1195,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
             for (int c = 0; c < 4; ++c) accx[tp][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[c], accx[tp][c], 0, 0, 0);
           }
+        } else if constexpr (SPLIT) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            h4 bh, bl;
+            unpack_frag(bv[0][c], bv[1][c], bv[2][c], bv[3][c], bh, bl);
+#pragma unroll
+            for (int tp = 0; tp < TPW; ++tp) accx[tp][c] = split_mfma16(af[tp][gl], bh, bl, accx[tp][c]);
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
@@ -1121,7 +1210,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
             for (int tp = 0; tp < TPW; ++tp)
 #pragma unroll
               for (int c = 0; c < 4; ++c)
-                accx[tp][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tp][gl][r], bv[r][c], accx[tp][c], 0, 0, 0);
+                accx[tp][c] = fused_mfma(af[tp][gl][r], bv[r][c], accx[tp][c]);
         }
       }
       __syncthreads();
@@ -1131,8 +1220,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       ylo_t* yn = reinterpret_cast<ylo_t*>(a.y_next) + (int64_t)b * (C / 2) * HWo + (((wm_i * TPW + tp) * 16 + 4 * q) * HWo + oy * OW + ox);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        constexpr float ys = SPLIT ? kSplitInv : 1.f;        // the chained weights carried 2^8 as well
         if constexpr (YB) *reinterpret_cast<s16x4*>(yn + r * HWo) = pack_bf16(accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]);
-        else *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]};
+        else *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r] * ys, accx[tp][1][r] * ys, accx[tp][2][r] * ys, accx[tp][3][r] * ys};
       }
     }
   }
@@ -1162,6 +1252,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int t = 0; t < OTN; ++t)
 #pragma unroll
           for (int c = 0; c < 4; ++c) accn[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah[t], bh[c], accn[t][c], 0, 0, 0);
+      } else if constexpr (SPLIT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          h4 bh, bl;
+          split_frag(acc[i][c][0], acc[i][c][1], acc[i][c][2], acc[i][c][3], bh, bl);
+#pragma unroll
+          for (int t = 0; t < OTN; ++t) accn[t][c] = split_mfma16(afn[t][i], bh, bl, accn[t][c]);
+        }
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -1169,7 +1267,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           for (int t = 0; t < OTN; ++t)
 #pragma unroll
             for (int c = 0; c < 4; ++c)
-              accn[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(afn[t][i][r], acc[i][c][r], accn[t][c], 0, 0, 0);
+              accn[t][c] = fused_mfma(afn[t][i][r], acc[i][c][r], accn[t][c]);
       }
     }
     if (wm_i > 0) {
@@ -1218,10 +1316,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        constexpr float ys = SPLIT ? kSplitInv : 1.f;
         if constexpr (YB)
           *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]);
         else
-          *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = f32x4{accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]};
+          *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) =
+              f32x4{accn[t][0][r] * ys, accn[t][1][r] * ys, accn[t][2][r] * ys, accn[t][3][r] * ys};
       }
   }
   if (!a.wm_rgb) return;
@@ -1256,7 +1356,8 @@ template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT =
 int launch_fused(const FusedArgs& a, hipStream_t st) {
   constexpr int TH = RW * WGN, TW = 64 / RW;
   dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16 == 2) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 2, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  if (a.bf16 == 3) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 3, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else if (a.bf16 == 2) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 2, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
   else if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 1, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
   else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 0, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
   return cips3d_launch_status();
@@ -1269,7 +1370,8 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 24)) : 0;   // bit 3: flipped taps, bit 4: split-fp16
+  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 56)) : 0;   // bit 3: flipped taps, bit 4: split-fp16, bit 5: split16
+  if ((packed & 32) && (ksq != 1 || (packed & 24))) return CIPS3D_E_UNSUPP;
   if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
   if ((packed & 16) && (ksq != 1 || (packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
   if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;
@@ -1417,8 +1519,10 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W,
-              (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next, y_next};
+              (skip_up & CIPS3D_GEMM_SPLIT) ? 3 : (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next,
+              y_next};
   if ((skip_up & CIPS3D_Y_BF16) && !(skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;   // bf16 storage implies bf16 operands
+  if ((skip_up & CIPS3D_GEMM_SPLIT) && (skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;
   hipStream_t st = as_stream(stream);
   if (wm_next)                                                            // cips3d_fused_up_conv_chains(C)
     // C = 128: 2 rows x 64 with four waves (512 workgroups) beats the unchained kernel's 4 x 64 / eight waves by 3 us once

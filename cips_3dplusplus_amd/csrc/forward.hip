@@ -174,8 +174,11 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         if (LN && LN->kind == 1 && (LN->flags & 1) && !chain) return CIPS3D_E_BADARG;
         float* out2 = (stage_last || chain) ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
+        // flags bit 4: conv2's (and the chained up-conv's) weights are CIPS3D_MOD_SPLIT16-packed: the stage runs split-fp16
+        const int stage_split = (L2.flags & 16) ? CIPS3D_GEMM_SPLIT : 0;
+        if (chain && ((LN->flags & 16) != (L2.flags & 16))) return CIPS3D_E_BADARG;
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag, rgb, chain ? LN->wm : nullptr,
+                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split, rgb, chain ? LN->wm : nullptr,
                                       chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stream));
         ylo_ready = chain;
         if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }

@@ -193,8 +193,8 @@ __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict_
     if (l < D - 1) v = w_hidden[(int64_t)l * per_layer + (int64_t)o * H + k];
     else           v = w_view[(int64_t)o * (H + 3) + k];
     v *= scales[2 * l];
-    const _Float16 hi = (_Float16)v;
-    const _Float16 lo = (_Float16)(v - (float)hi);
+    _Float16 hi, lo;
+    cips3d_split16(v, hi, lo);
     // fp16 units: layer base 2*per_layer, tile 2*tile_w, block m: [plane][lane][8]
     _Float16* blk = out + 2 * ((int64_t)l * per_layer + (int64_t)t * tile_w) + (int64_t)m * 1024;
     blk[lane * 8 + j] = hi;
@@ -233,8 +233,7 @@ struct Ring {
 
 // x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits in the 4 bytes of an fp32
 __device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)x;
-  lo = (_Float16)(x - (float)hi);
+  cips3d_split16(x, hi, lo);
 }
 // eight fp32 values (units 4q..4q+3 of tile 2m, then of tile 2m+1) -> the hi / lo B fragments of k-block m
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {

@@ -17,6 +17,7 @@ MOD_PACKED = 2
 MOD_CHAINED = 4       # with MOD_PACKED: k-steps in the MFMA D-layout order (cips3d_fused_up_conv_next)
 MOD_FLIP = 8          # with MOD_PACKED and ksq = 9: taps stored 180 degrees rotated (up-sampling branch of cips3d_modconv3x3)
 MOD_SPLIT = 16        # with MOD_PACKED and ksq = 1: fp16 hi + lo fragments of 2^8 wm for the split-fp16 GEMM mode (GEMM_SPLIT)
+MOD_SPLIT16 = 32      # with MOD_PACKED [| MOD_CHAINED]: split-fp16 fragments for the fused up-sampling stage (16-channel k-groups)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -487,10 +488,11 @@ def fused_up_conv_chains(C_):
 
 
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
-                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None):
+                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None, split=False):
     """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv).
     wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next.
-    A torch.bfloat16 `y_lo` selects the bf16-storage form (CIPS3D_Y_BF16, needs bf16=True): y_next is then bf16 as well."""
+    A torch.bfloat16 `y_lo` selects the bf16-storage form (CIPS3D_Y_BF16, needs bf16=True): y_next is then bf16 as well.
+    split: fp32-equivalent split-fp16 products; wm2_packed / wm_next must then be MOD_SPLIT16-packed."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
     dev = y_lo.device
@@ -509,7 +511,8 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
                                         dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
                                         dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
                                         dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
-                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if ydt == torch.bfloat16 else 0),
+                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if ydt == torch.bfloat16 else 0) |
+                                        (GEMM_SPLIT if split else 0),
                                         dev_ptr(rgb, "rgb", True), dev_ptr(wm_next, "wm_next", True),
                                         dev_ptr(y_next, "y_next", True, dtype=ydt), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv_next")
     if wm_next is not None:

@@ -176,6 +176,7 @@ class ForwardPlan:
             conv2_of_fused = li["kind"] == 0 and i >= 1 and fused_stage(i - 1)
             chained = bool(li.get("chained"))
             li["split"] = not conv2_of_fused and not chained
+            li["split16"] = conv2_of_fused or chained           # consumed inside cips3d_fused_up_conv_next
         # The run of equal-resolution StyledConvs at the NeRF resolution keeps its activations as split-fp16 planes
         # (csrc/chain.hip): the render kernel writes the feature map as planes, every layer of the run reads and writes them,
         # the ToRGBs in between are folded from registers, and the first up-sampling conv's low-resolution GEMM reads them.
@@ -215,7 +216,8 @@ class ForwardPlan:
             d.s_stride = total
             d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
             d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0) | (
-                hip.MOD_CHAINED if info.get("chained") else 0) | (hip.MOD_SPLIT if info.get("split") else 0)
+                hip.MOD_CHAINED if info.get("chained") else 0) | (hip.MOD_SPLIT if info.get("split") else 0) | (
+                hip.MOD_SPLIT16 if info.get("split16") else 0)
             d.scale = conv.scale
             d.row_begin = rows
             rows += conv.out_channel
@@ -223,7 +225,7 @@ class ForwardPlan:
             L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
                                                               info["W"], info["noise_index"])
             L.flags = ((1 if info.get("chained") else 0) | (2 if info.get("split") else 0) | (4 if info.get("planes_in") else 0) |
-                       (8 if info.get("planes_out") else 0))
+                       (8 if info.get("planes_out") else 0) | (16 if info.get("split16") else 0))
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 8   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 9   /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -223,6 +223,10 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
 /* with CIPS3D_MOD_PACKED and ksq == 1 (Cin % 32 == 0): split-fp16 A fragments for CIPS3D_GEMM_SPLIT -- 2^8 wm as fp16 hi + lo
  * halves in v_mfma_f32_16x16x32_f16 order, wm[b][o/16][i/32][plane][(((i>>3)&3)<<4 | (o&15))][i&7] (fp16), 4 bytes per weight */
 #define CIPS3D_MOD_SPLIT      16
+/* with CIPS3D_MOD_PACKED [| CIPS3D_MOD_CHAINED] and ksq == 1: split-fp16 fragments for the fused up-sampling stage in
+ * CIPS3D_GEMM_SPLIT mode (16-channel k-groups, v_mfma_f32_16x16x16_f16): the element <-> channel map of the fp32 layout, each
+ * lane's 16 bytes = {fp16 hi x 4 | fp16 lo x 4} of 2^8 wm */
+#define CIPS3D_MOD_SPLIT16    32
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
@@ -380,7 +384,8 @@ typedef struct cips3d_dec_layer {
   int32_t flags;           /* bit 0 (kind 1 only): wm is in the CIPS3D_MOD_CHAINED order and this conv's low-resolution GEMM is
                               computed by the previous stage's kernel (cips3d_fused_up_conv_next);
                               bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode;
-                              bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes) */
+                              bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes);
+                              bit 4: wm is CIPS3D_MOD_SPLIT16-packed (conv2 / chained up-conv of a fused stage run in CIPS3D_GEMM_SPLIT mode) */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */

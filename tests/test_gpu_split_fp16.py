@@ -213,3 +213,44 @@ def test_planes_run_ends_in_fp32_when_nothing_up_samples():
     Gt(zs=[torch.randn(1, 32, device=DEV)] * 2, cam_poses=et, focals=ft, img_size=8, near=nt, far=fat, nerf_cfg=ncfg)
     pt = list(Gt._plans.values())[0].plan
     assert not any(pt.layers[i].flags & 12 for i in range(pt.n_dec_layers))
+
+
+@pytest.mark.parametrize("C,H,B", [(256, 32, 1), (128, 32, 2), (64, 64, 1), (32, 64, 2)])
+def test_fused_stage_split_products_agree_with_fp32(C, H, B):
+    """cips3d_fused_up_conv with CIPS3D_GEMM_SPLIT (weights packed CIPS3D_MOD_SPLIT16; the FIR + noise + bias + leaky-ReLU
+    epilogue of conv1 splits its outputs into fp16 halves before the LDS hand-off) against the fp32-MFMA instantiation of the
+    same kernel on the same inputs: out2, the rgb skip sum and the chained next-stage y agree to ~1e-6 of their range.  (This
+    is the test that caught hipcc folding the sqrt(2) gain into the fp16 conversion of `hi`: 2.5e-4 before cips3d_split16
+    made the value opaque.)"""
+    chains = hip.fused_up_conv_chains(C)
+    lib = _lib.load()
+
+    def mod(W, s, flags):
+        out = torch.empty(B * W.shape[0] * C, device=DEV)
+        _lib.check(lib.cips3d_modulate_weights(W.data_ptr(), s.data_ptr(), C, out.data_ptr(), B, W.shape[0], C, 1,
+                                               1.0 / math.sqrt(C), flags, torch.cuda.current_stream().cuda_stream), "mod")
+        return out
+
+    y = cu(weights.det_normal("f.y", (B, C, H, H), 1.0, C))
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    fir = cu(k1.outer(k1) / 16.0)
+    n1 = cu(weights.det_normal("f.n1", (1, 1, 2 * H, 2 * H), 1.0, 2))
+    n2 = cu(weights.det_normal("f.n2", (1, 1, 2 * H, 2 * H), 1.0, 3))
+    nw1, nw2 = torch.full((1,), 0.3, device=DEV), torch.full((1,), -0.2, device=DEV)
+    b1, b2 = cu(weights.det_uniform("f.b1", (C,), 0.2, 4)), cu(weights.det_uniform("f.b2", (C,), 0.2, 5))
+    W2, Wn, Wr = (cu(weights.det_normal(f"f.{k}", shp, 1.0, 6)) for k, shp in (("W2", (C, C)), ("Wn", (C // 2, C)), ("Wr", (3, C))))
+    s2, sn, sr = (cu(1.0 + weights.det_uniform(f"f.s{k}", (B, C), 0.3, 7)) for k in range(3))
+    wmr = mod(Wr, sr, 0)
+    brgb = cu(weights.det_uniform("f.brgb", (3,), 0.1, 8))
+    skip = cu(weights.det_normal("f.skip", (B, 3, H, H), 1.0, 9))
+    res = {}
+    for split in (False, True):
+        f16 = hip.MOD_SPLIT16 if split else 0
+        wm2 = mod(W2, s2, hip.MOD_DEMODULATE | hip.MOD_PACKED | f16)
+        wmn = mod(Wn, sn, hip.MOD_DEMODULATE | hip.MOD_PACKED | hip.MOD_CHAINED | f16) if chains else None
+        res[split] = hip.fused_up_conv(y, fir, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, skip_up=True, wm_next=wmn,
+                                       split=split)
+    assert len(res[True]) == (3 if chains else 2)
+    for name, a, b in zip(("out2", "rgb", "y_next"), res[False], res[True]):
+        d, rng = float((a - b).abs().max()), float(a.abs().max())
+        assert d < 2e-6 * max(rng, 1.0), (name, d, rng)
