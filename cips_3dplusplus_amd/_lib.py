@@ -52,6 +52,13 @@ class NerfBwdGeom(C.Structure):
                 ("static_viewdirs", C.c_int32)]
 
 
+class NerfBwdFusedParams(C.Structure):
+    _fields_ = [("geom", NerfBwdGeom)] + [(n, C.c_void_p) for n in (
+        "w_first", "packed", "packed_t", "w_view", "film", "layer_bias", "w_sigma", "b_sigma", "w_rgb", "b_rgb",
+        "sigmoid_beta", "d_features", "d_thumb", "stash", "scratch", "dfilm", "dcam")] + [
+        ("hidden", C.c_int32), ("depth", C.c_int32), ("n_chunks", C.c_int32), ("pad_", C.c_int32)]
+
+
 _SIGS = {
     "cips3d_abi_version": (c_int, []),
     "cips3d_strerror": (C.c_char_p, [c_int]),
@@ -135,6 +142,11 @@ _SIGS = {
                                           c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_nerf_bwd_camera": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_camera_params_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "cips3d_nerf_bwd_fused_stash_floats": (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "cips3d_nerf_bwd_fused_scratch_floats": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+    "cips3d_nerf_pack_weights_t": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    "cips3d_nerf_bwd_fused": (c_int, [C.c_void_p, C.c_void_p]),
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),
@@ -142,7 +154,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 9            # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 10           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 
@@ -150,7 +162,7 @@ def _struct_table():
     """index of cips3d_sizeof_struct -> the ctypes mirror of that struct (plan.py holds the two big ones)."""
     from . import plan
     return {0: plan.GeneratorPlan, 1: plan.ForwardIO, 2: NerfParams, 3: LinearDesc, 4: ModulateDesc, 5: plan.DecLayer,
-            6: NerfBwdGeom}
+            6: NerfBwdGeom, 7: NerfBwdFusedParams}
 
 
 def load(build_if_missing=True):

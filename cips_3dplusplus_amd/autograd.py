@@ -415,7 +415,8 @@ def film_table(renderer, styles):
 
 class NerfRenderFn(Function):
     """VolumeFeatureRenderer.render with gradients w.r.t. the camera pose and the FiLM table.  Forward = the fused kernel;
-    backward = the materialised recompute of csrc/nerf_bwd.hip.  The renderer's own weights are treated as constants
+    backward = the fused recompute + backward kernels of csrc/nerf_bwd_fused.hip (the materialised sequence of
+    csrc/nerf_bwd.hip for shapes they do not cover, or with CIPS3D_FUSED_NERF_BACKWARD=0).  The renderer's own weights are treated as constants
     (`optim_render_params: false` in the released inversion recipes, train_cips3d_compcars_v10.yaml:585)."""
 
     @staticmethod
@@ -439,6 +440,12 @@ class NerfRenderFn(Function):
             dfeat = torch.zeros(B, H, img_size, img_size, device=cam_poses.device)
         if dthumb is None:
             dthumb = torch.zeros(B, 3, img_size, img_size, device=cam_poses.device)
-        dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
-                                        layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())
+        if hip.FUSED_NERF_BACKWARD and hip.nerf_backward_fused_supported(H, r.N_layers_renderer, img_size, n_samples):
+            packed, _ = r._derived_buffers()
+            dfilm, dcam = hip.nerf_backward_fused(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u,
+                                                  film, layer_bias, packed, r._packed_transposed(), img_size, n_samples,
+                                                  static, dfeat, dthumb)
+        else:
+            dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
+                                            layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())
         return None, dcam, None, None, None, dfilm, None, None, None, None

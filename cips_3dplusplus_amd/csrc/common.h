@@ -89,6 +89,16 @@ __device__ static inline float sin_hw(float x) {
   r = fmaf(k, -TWO_PI_LO, r);
   return __builtin_amdgcn_sinf(r * INV_2PI);
 }
+// cos(x), same reduction, v_cos_f32 (the FiLM-sine derivative of the fused NeRF backward)
+__device__ static inline float cos_hw(float x) {
+  const float INV_2PI = 0.159154943091895336f;
+  const float TWO_PI_HI = 6.28318548202514648f;
+  const float TWO_PI_LO = -1.74845553146951715e-7f;
+  const float k = rintf(x * INV_2PI);
+  float r = fmaf(k, -TWO_PI_HI, x);
+  r = fmaf(k, -TWO_PI_LO, r);
+  return __builtin_amdgcn_cosf(r * INV_2PI);
+}
 #ifdef CIPS3D_EXACT_SINE
 #define cips3d_sin sin_accurate
 #else

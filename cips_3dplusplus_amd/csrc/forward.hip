@@ -22,6 +22,7 @@ extern "C" int64_t cips3d_sizeof_struct(int which) {
     case 4: return (int64_t)sizeof(cips3d_modulate_desc);
     case 5: return (int64_t)sizeof(cips3d_dec_layer);
     case 6: return (int64_t)sizeof(cips3d_nerf_bwd_geom);
+    case 7: return (int64_t)sizeof(cips3d_nerf_bwd_fused_params);
     default: return -1;
   }
 }

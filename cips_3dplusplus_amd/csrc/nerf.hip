@@ -50,6 +50,7 @@
 
 #include <atomic>
 #include "common.h"
+#include "nerf_mlp.h"
 
 #ifdef CIPS3D_STAMPS
 // Diagnostic build only (never in the shipped library): per-phase cycle sums of wave 0 of every workgroup.
@@ -105,13 +106,6 @@ extern "C" int cips3d_debug_read_clock(unsigned long long* out2) {
 #endif
 
 namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));    // one MFMA 16x16x32 operand fragment (8 fp16 = 4 VGPRs)
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-
-constexpr int RAYS = 16;    // rays per wave task
-constexpr int WAVES = 8;    // waves (tasks) per workgroup
 
 struct NerfArgs {
   cips3d_nerf_params p;
@@ -199,50 +193,6 @@ __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict_
     _Float16* blk = out + 2 * ((int64_t)l * per_layer + (int64_t)t * tile_w) + (int64_t)m * 1024;
     blk[lane * 8 + j] = hi;
     blk[512 + lane * 8 + j] = lo;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-DMA of one weight slab (SLAB floats, linear copy, 1 KiB per wave-instruction)
-// ------------------------------------------------------------------------------------------------
-template <int SLAB>
-__device__ __forceinline__ void stage_slab(const float* __restrict__ gsrc, float* lds_dst, int wave, int lane) {
-  constexpr int PIECES = SLAB * 4 / 1024;
-  constexpr int PER_WAVE = (PIECES + WAVES - 1) / WAVES;
-#pragma unroll
-  for (int j = 0; j < PER_WAVE; ++j) {
-    const int piece = j * WAVES + wave;
-    if (PIECES % WAVES == 0 || piece < PIECES) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
-          (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
-    }
-  }
-}
-
-__device__ __forceinline__ float sigmoidf_acc(float v) { return 1.f / (1.f + expf(-v)); }
-
-// Per-wave streaming state of the weight ring.
-struct Ring {
-  const float* packed;   // global base of the packed stream (one sample's worth, repeated)
-  float* lds;            // 2 slots
-  int seq;               // slabs consumed so far
-  int seq_end;           // total slabs this workgroup will consume
-  int per_sample;        // slabs per sample
-};
-
-// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits in the 4 bytes of an fp32
-__device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
-  cips3d_split16(x, hi, lo);
-}
-// eight fp32 values (units 4q..4q+3 of tile 2m, then of tile 2m+1) -> the hi / lo B fragments of k-block m
-__device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    _Float16 a, b;
-    split2(v[j], a, b);
-    hi[j] = a;
-    lo[j] = b;
   }
 }
 

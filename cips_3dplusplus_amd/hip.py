@@ -725,6 +725,55 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
     return dfilm, dcam
 
 
+def nerf_pack_weights_t(w_hidden, w_view, packed, hidden, depth):
+    """The transposed weight stream of the fused NeRF backward (consumption order, forward scales; cips3d_nerf_pack_weights_t)."""
+    lib = _lib.load()
+    packed_t = torch.empty_like(packed)
+    check(lib.cips3d_nerf_pack_weights_t(dev_ptr(w_hidden, "w_hidden", True), dev_ptr(w_view, "w_view"), dev_ptr(packed),
+                                         dev_ptr(packed_t), hidden, depth, stream_ptr()), "cips3d_nerf_pack_weights_t")
+    return packed_t
+
+
+FUSED_NERF_BACKWARD = os.environ.get("CIPS3D_FUSED_NERF_BACKWARD", "1") != "0"   # A/B knob: 0 = the materialised sequence
+
+
+def nerf_backward_fused_supported(hidden, depth, img_size, n_samples):
+    return bool(_lib.load().cips3d_nerf_bwd_fused_supported(hidden, depth, img_size, n_samples))
+
+
+def nerf_backward_fused(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, film, layer_bias, packed, packed_t, img_size,
+                        n_samples, static_viewdirs, d_features, d_thumb):
+    """The fused NeRF backward (csrc/nerf_bwd_fused.hip): returns (dfilm [B,L,2,H], dcam [B,3,4]); same contract as
+    nerf_backward."""
+    lib = _lib.load()
+    dev = cam_poses.device
+    B, H, D = cam_poses.shape[0], net.W, net.D
+    L, R = D + 1, img_size * img_size
+    p = _lib.NerfBwdFusedParams()
+    keep = [cam_poses.float().contiguous(), focals.float().reshape(B).contiguous(), near.float().reshape(B).contiguous(),
+            far.float().reshape(B).contiguous(),
+            None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous(),
+            film.float().contiguous(), d_features.float().contiguous(), d_thumb.float().contiguous()]
+    g = p.geom
+    g.cam_poses, g.focals, g.near_, g.far_ = (dev_ptr(t) for t in keep[:4])
+    g.perturb_u = dev_ptr(keep[4], "perturb_u", True)
+    g.B, g.img_size, g.n_samples, g.static_viewdirs = B, img_size, n_samples, int(bool(static_viewdirs))
+    n_chunks = nerf_suggest_chunks(B, img_size, n_samples)
+    stash = torch.empty(int(lib.cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, H, D, n_chunks)), device=dev)
+    scratch = torch.empty(int(lib.cips3d_nerf_bwd_fused_scratch_floats(B, img_size, n_samples, H, D)), device=dev)
+    dfilm, dcam = torch.empty(B, L, 2, H, device=dev), torch.empty(B, 3, 4, device=dev)
+    p.w_first, p.packed, p.packed_t = dev_ptr(net.pts_linears[0].weight), dev_ptr(packed), dev_ptr(packed_t)
+    p.w_view, p.film, p.layer_bias = dev_ptr(net.views_linears.weight), dev_ptr(keep[5]), dev_ptr(layer_bias)
+    p.w_sigma, p.b_sigma = dev_ptr(net.sigma_linear.weight), dev_ptr(net.sigma_linear.bias)
+    p.w_rgb, p.b_rgb = dev_ptr(net.rgb_linear.weight), dev_ptr(net.rgb_linear.bias)
+    p.sigmoid_beta = dev_ptr(sigmoid_beta)
+    p.d_features, p.d_thumb = dev_ptr(keep[6]), dev_ptr(keep[7])
+    p.stash, p.scratch, p.dfilm, p.dcam = dev_ptr(stash), dev_ptr(scratch), dev_ptr(dfilm), dev_ptr(dcam)
+    p.hidden, p.depth, p.n_chunks = H, D, n_chunks
+    check(lib.cips3d_nerf_bwd_fused(C.byref(p), stream_ptr()), "cips3d_nerf_bwd_fused")
+    return dfilm, dcam
+
+
 def inversion_roofline(B, n_samples, hidden, depth, img_size=64, iters=20):
     """Roofline entry of the flip-inversion step's dominant kernel: the hidden x hidden GEMMs over all B * R * N sample points of
     the materialised NeRF backward (D forward-recompute GEMMs in split-fp16 mode, D data-gradient GEMMs on the fp32 MFMA;

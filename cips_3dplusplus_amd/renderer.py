@@ -110,6 +110,7 @@ class VolumeFeatureRenderer(nn.Module):
         self.network = SirenGenerator(D=N_layers_renderer, W=hidden_dim, style_dim=style_dim, input_ch=input_dim,
                                       input_ch_views=view_dim, output_features=output_features)
         self._derived = None      # (key, packed, layer_bias)
+        self._packed_t = None
         self._tables = {}         # B -> (styles_buf, film_buf, LinearTable)
 
     # ---- derived, weight-dependent device buffers (re-made when a parameter changes) ------------
@@ -129,7 +130,19 @@ class VolumeFeatureRenderer(nn.Module):
                 packed = hip.nerf_pack_weights(w_hidden, net.views_linears.weight.detach().contiguous(), H, D)
                 layer_bias = torch.stack([l.bias for l in net.pts_linears] + [net.views_linears.bias]).contiguous()
             self._derived = (key, packed, layer_bias)
+            self._packed_t = None
         return self._derived[1], self._derived[2]
+
+    def _packed_transposed(self):
+        """The transposed weight stream of the fused backward, made on first use (inversion only)."""
+        packed, _ = self._derived_buffers()
+        if self._packed_t is None:
+            net = self.network
+            D, H = self.N_layers_renderer, self.hidden_dim
+            with torch.no_grad():
+                w_hidden = torch.stack([l.weight for l in net.pts_linears[1:]]).contiguous() if D > 1 else None
+                self._packed_t = hip.nerf_pack_weights_t(w_hidden, net.views_linears.weight.detach().contiguous(), packed, H, D)
+        return self._packed_t
 
     def _film_table(self, B, device):
         net = self.network

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 9   /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 10  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -448,7 +448,8 @@ int64_t cips3d_sizeof_plan(void);
 int64_t cips3d_sizeof_io(void);
 /* sizeof() of every struct that crosses the boundary (a binding checks its own layout against these at load time):
  * which = 0 cips3d_generator_plan, 1 cips3d_forward_io, 2 cips3d_nerf_params, 3 cips3d_linear_desc,
- * 4 cips3d_modulate_desc, 5 cips3d_dec_layer, 6 cips3d_nerf_bwd_geom; -1 for an unknown index */
+ * 4 cips3d_modulate_desc, 5 cips3d_dec_layer, 6 cips3d_nerf_bwd_geom, 7 cips3d_nerf_bwd_fused_params;
+ * -1 for an unknown index */
 int64_t cips3d_sizeof_struct(int which);
 
 /* ------------------------------------------------------------------ stand-alone renderer steps
@@ -563,6 +564,55 @@ int cips3d_nerf_bwd_film_grad(float* buf, const float* pre, const float* film, i
 /* dptsn [B,3,P], dvd_pt [B,3,P] (d loss / d viewdir per point), ddnorm [B,R] -> dcam [B,3,4] */
 int cips3d_nerf_bwd_camera(const cips3d_nerf_bwd_geom* geom, const float* dptsn, const float* dvd_pt, const float* ddnorm,
                            float* dcam, void* stream);
+/* ---- NeRF half, fused backward (csrc/nerf_bwd_fused.hip): the same gradients as the sequence above -- d loss / d film
+ * [B,L,2,H] and d loss / d cam_poses [B,3,4] from d_features [B,H,R] and d_thumb [B,3,R] -- with the point MLP kept in the
+ * register file in both directions (the reference gets them from autograd through cips3d/volume_renderer.py:39-160 and
+ * cips3d/nerf_utils.py:264-338).  Two MFMA kernels with the task shape of cips3d_nerf_render (16 rays x a chunk of samples
+ * per wave, weights streamed through the LDS ring, split-fp16 products):
+ *   recompute: the forward MLP again, writing per MFMA layer the fp32 accumulators (`stash`, in the wave's own register
+ *              order: 16 * H * 4 bytes per layer and 16-point tile, fully coalesced) and per point sdf, rgb logits and
+ *              <d_features[:, ray], feature>;
+ *   (cips3d_nerf_bwd_composite: volume integration forward + backward per ray, as in the materialised sequence)
+ *   backward : per 16-point tile the layers in reverse -- upstream * cos(arg) from the stash, the d(gamma) / d(beta) sums
+ *              (cross-lane reduce-scatter + LDS accumulation, one global atomic per workgroup and table entry), the data
+ *              gradient W^T d(pre) on the matrix cores with the transposed packed stream (the gradient operand is scaled per
+ *              point by a power of two into fp16's range before it is split, and the result unscaled exactly), the
+ *              view-direction and point gradients on the VALU;
+ *   (cips3d_nerf_bwd_camera: d points / d viewdirs -> d cam_poses)
+ * HBM traffic per point and MFMA layer: one write + one read of H floats (the materialised sequence moves ~10). */
+typedef struct cips3d_nerf_bwd_fused_params {
+  cips3d_nerf_bwd_geom geom;
+  const float* w_first;      /* [H,3] */
+  const float* packed;       /* cips3d_nerf_pack_weights */
+  const float* packed_t;     /* cips3d_nerf_pack_weights_t */
+  const float* w_view;       /* [H,H+3] */
+  const float* film;         /* [B,L,2,H], L = depth + 1 */
+  const float* layer_bias;   /* [L,H] */
+  const float* w_sigma;      /* [H] */
+  const float* b_sigma;      /* [1] */
+  const float* w_rgb;        /* [3,H] */
+  const float* b_rgb;        /* [3] */
+  const float* sigmoid_beta; /* [1] */
+  const float* d_features;   /* [B,H,R] */
+  const float* d_thumb;      /* [B,3,R] */
+  float* stash;              /* cips3d_nerf_bwd_fused_stash_floats() floats */
+  float* scratch;            /* cips3d_nerf_bwd_fused_scratch_floats() floats */
+  float* dfilm;              /* out [B,L,2,H] */
+  float* dcam;               /* out [B,3,4] */
+  int32_t hidden, depth, n_chunks, pad_;
+} cips3d_nerf_bwd_fused_params;
+
+/* 1 when the fused kernels cover the shape (hidden 32/64/128/256, R % 16 == 0, tables within the LDS) */
+int cips3d_nerf_bwd_fused_supported(int hidden, int depth, int img_size, int n_samples);
+int64_t cips3d_nerf_bwd_fused_stash_floats(int B, int img_size, int n_samples, int hidden, int depth, int n_chunks);
+int64_t cips3d_nerf_bwd_fused_scratch_floats(int B, int img_size, int n_samples, int hidden, int depth);
+/* the transposed weight stream of the backward kernel, in its consumption order (view layer first, then hidden layers
+ * depth-1 .. 1), each matrix W_l^T packed like cips3d_nerf_pack_weights packs W_l and with W_l's power-of-two scale (read from
+ * `packed`); packed_t holds cips3d_nerf_packed_floats(hidden, depth) floats */
+int cips3d_nerf_pack_weights_t(const float* w_hidden, const float* w_view, const float* packed, float* packed_t, int hidden,
+                               int depth, void* stream);
+int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* p, void* stream);
+
 /* Backward of cips3d_camera_params w.r.t. locations (azim, elev): dextrinsics [B,3,4] -> dlocations [B,2]
  * (cips3d/nerf_utils.py:344-436,466-564; focal / near / far do not depend on the angles). */
 int cips3d_camera_params_bwd(const float* locations, const float* up, const float* dextrinsics, int B, float* dlocations,
