@@ -53,23 +53,30 @@
 #include "nerf_mlp.h"
 
 #ifdef CIPS3D_STAMPS
+#ifndef CIPS3D_STAMP_WAVE
+#define CIPS3D_STAMP_WAVE 0      // the wave whose phases are summed (0..3 early-epilogue waves, 4..7 late)
+#endif
+#define STAMP_PARAM , unsigned long long& t_prev_
+#define STAMP_ARG , t_prev_
 // Diagnostic build only (never in the shipped library): per-phase cycle sums of wave 0 of every workgroup.
-__device__ unsigned long long g_nerf_stamps[8];
+__device__ unsigned long long g_nerf_stamps[16];
 #define STAMP(i)                                                                         \
   do {                                                                                   \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
-    if (wave == 0 && lane == 0) atomicAdd(&g_nerf_stamps[i], t_ - t_prev_);              \
+    if (wave == CIPS3D_STAMP_WAVE && lane == 0) atomicAdd(&g_nerf_stamps[i], t_ - t_prev_);              \
     t_prev_ = __builtin_amdgcn_s_memtime();                                              \
   } while (0)
-extern "C" int cips3d_debug_read_stamps(unsigned long long* out8) {
+extern "C" int cips3d_debug_read_stamps(unsigned long long* out16) {
   hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_nerf_stamps), 64);
-  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_stamps), z, 64);
+  hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_nerf_stamps), 128);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_stamps), z, 128);
   return 0;
 }
 #else
 #define STAMP(i)
+#define STAMP_PARAM
+#define STAMP_ARG
 #endif
 
 #ifdef CIPS3D_CLOCK
@@ -206,7 +213,7 @@ template <int NT, int TPS, bool VIEW>
 __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], h8 (&Yh)[NT / 2], h8 (&Yl)[NT / 2],
                                            float (&FA)[NT * 4], float wgt, float (&chead)[3], float& sdf_acc, bool last,
                                            Ring& ring, const float* film_l, const float* s_wd, const float* s_wc,
-                                           const float* s_ws, float vx, float vy, float vz, int wave, int lane, int q4o) {
+                                           const float* s_ws, float vx, float vy, float vz, int wave, int lane, int q4o STAMP_PARAM) {
   constexpr int H = NT * 16;
   constexpr int TILE = 16 * H;          // floats (= 4-byte hi/lo pairs) of one o-tile's A fragments
   constexpr int SLAB = TILE * TPS;
@@ -218,6 +225,16 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
   // The slab steps of a layer are fully unrolled (with 96 fp16 MFMAs per step instead of 256 fp32 ones the whole kernel is
   // ~40 KB of code): the step index is a constant, results go straight to their final registers (the rolled loop of the
   // fp32 kernel had to rotate Yh / Yl / FA by 48 moves per step; unrolling measured 107.6 -> 101.0 us).
+  // Epilogue stagger.  Waves w and w + WAVES/2 share a SIMD and meet at every slab barrier; with the barrier after the
+  // FiLM/sine epilogue both would run its VALU instructions together while the matrix pipe idles.  The upper half of the
+  // waves takes the step barrier BEFORE its epilogue instead, which then overlaps the partner wave's next-step MFMAs.  Either
+  // position is after this wave's last read of slot (seq&1) and before its next stage_slab into it.
+  // In-kernel stamps of this scheme (tools/run_kernel.py nerf on a -DCIPS3D_STAMPS build): the two matrix blocks of a SIMD
+  // run together (~2.9k cycles for 192 MFMAs = the pipe is full), then the lower wave's epilogue (~1.3k) with the pipe idle;
+  // a step is ~6.4k cycles.  Tried: a true half-period offset (two barriers per step, the upper half one barrier behind, so
+  // that one wave's matrix block always faces the other's epilogue): correct, but 127 us instead of 97 -- a matrix block
+  // that has the SIMD to itself is bound by its own A-fragment reads (8 x [8 ds_read_b128 -> wait -> 12 MFMAs]; the second
+  // wave is what hides that latency today), and double-buffering the fragments needs 32 registers the kernel does not have.
 #ifdef CIPS3D_NO_STAGGER
   const bool late_epilogue = false;
 #else
@@ -229,6 +246,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
       const int nxt = (ring.seq + 1) % ring.per_sample;
       stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
     }
+    STAMP(8);    // (in-layer stamps: the phase before the first one of a layer is charged to slot 12 / 11 of the previous step)
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
     const int o_base = sl * (TPS * 16) + q4o;          // this lane's first output unit of the step
     f32x4 acc[TPS];
@@ -265,15 +283,12 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xh[m], acc[tt], 0, 0, 0);
     }
-    // Epilogue stagger.  Waves w and w + WAVES/2 share a SIMD and meet at every slab barrier; with the barrier
-    // after the FiLM/sine epilogue both would run its VALU instructions together while the matrix pipe
-    // idles.  The upper half of the waves takes the step barrier BEFORE its epilogue instead, which then overlaps
-    // the partner wave's next-step MFMAs, and the partner's epilogue overlaps this wave's MFMA tail.  Either
-    // position is after this wave's last read of slot (seq&1) and before its next stage_slab into it.
+    STAMP(9);    // matrix block
     if (late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's piece of slab seq+1 has landed
       __syncthreads();
     }
+    STAMP(10);   // late waves: step barrier
     float res[R];
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
@@ -320,11 +335,13 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         split8(v8, Yh[sl * BPS + bb], Yl[sl * BPS + bb]);
       }
     }
+    STAMP(11);   // epilogue
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
     if (!late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
       __syncthreads();
     }
+    STAMP(12);   // early waves: step barrier
     ++ring.seq;
   }
 }
@@ -352,6 +369,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int pl = lane & 15;
 #ifdef CIPS3D_CLOCK
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef CIPS3D_STAMPS
+  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- task decode (b is uniform over the workgroup: tasks_per_view is a multiple of WAVES)
@@ -458,9 +478,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   __syncthreads();
 
   const int s_begin = c * a.chunk;
-#ifdef CIPS3D_STAMPS
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
-#endif
   STAMP(0);   // prologue
   for (int si = 0; si < a.chunk; ++si) {
     const int sg = s_begin + si;
@@ -516,7 +533,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // ---- hidden layers 1 .. D-1
     for (int l = 1; l < D; ++l) {
       mfma_layer<NT, TPS, false>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc, s_ws,
-                                 vx, vy, vz, wave, lane, q4o);
+                                 vx, vy, vz, wave, lane, q4o STAMP_ARG);
 #pragma unroll
       for (int i = 0; i < NT / 2; ++i) { Xh[i] = Yh[i]; Xl[i] = Yl[i]; }
     }
@@ -537,7 +554,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // ---- view layer -> features, folded into FA; rgb head partial sums
     float sdf_unused = 0.f;
     mfma_layer<NT, TPS, true>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
-                              vx, vy, vz, wave, lane, q4o);
+                              vx, vy, vz, wave, lane, q4o STAMP_ARG);
     float c0 = chead[0], c1 = chead[1], c2 = chead[2];
     c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
@@ -638,6 +655,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         }
       }
     }
+    STAMP(6);   // fused finish
     return;
   }
   // ---- write the chunk partial: part[c][b][ch][ray]

@@ -58,15 +58,20 @@ if a.what == "nerf":
     from cips_3dplusplus_amd import _lib as L
     raw = ctypes.CDLL(L.LIB_PATH)
     if hasattr(raw, "cips3d_debug_read_stamps"):
-        buf = (ctypes.c_ulonglong * 8)()
+        buf = (ctypes.c_ulonglong * 16)()
         raw.cips3d_debug_read_stamps(buf)
         fn(); 
         raw.cips3d_debug_read_stamps(buf)
         nwg = 256 * a.batch
-        names = ["prologue", "setup+layer0", "hidden", "sigma+weight", "view", "tail"]
-        tot = sum(buf[:6])
-        for nme, v in zip(names, buf[:6]):
+        names = ["prologue", "setup+layer0", "hidden", "sigma+weight", "view", "tail", "finish"]
+        tot = sum(buf[:7])
+        for nme, v in zip(names, buf[:7]):
             print(f"  {nme:14s} {v / nwg:10.0f} cycles/wg  {100.0 * v / tot:5.1f}%")
+        if sum(buf[8:13]):
+            print("  inside the MFMA layers (per slab step, same wave; the coarse 'hidden'/'view' rows above then only hold what follows the last step):")
+            steps = 24 * nwg          # 3 samples x 2 layers x 4 steps at the default shape
+            for nme, v in zip(["dma issue", "matrix block", "barrier (late waves)", "epilogue", "barrier (early waves)"], buf[8:13]):
+                print(f"    {nme:22s} {v / steps:8.0f} cycles/step")
 
 if a.what in ("nerf", "forward"):
     import ctypes
