@@ -33,7 +33,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DTYPE_NAMES = {"fp32": "f32 (decoder: fp32 MFMA; NeRF point MLP: fp32-equivalent split-fp16 MFMA products, fp32 accumulate)",
+DTYPE_NAMES = {"fp32": "f32 (NeRF point MLP and decoder GEMMs: fp32-equivalent split-fp16 MFMA products -- three exact fp16 products per "
+                       "fp32 product, fp32 accumulate, fp32 storage)",
                "bf16": "bf16 decoder GEMM operands (f32 accumulate, f32 storage), f32 NeRF",
                "bf16_storage": "bf16 decoder GEMM operands + bf16 storage of the up-sampling stages' activations "
                                "(f32 accumulate), f32 NeRF"}
@@ -256,9 +257,7 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
             "config": {"workload": f"BASELINE config 5: compcars_r{res}_nerf64x64x{n_samples}_D{depth}_B2 pose phase "
                                    f"(surrogate loss, random-init weights)"},
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
-    rl = hip.inversion_roofline(B=2, n_samples=n_samples, hidden=H, depth=depth) if hasattr(hip, "inversion_roofline") else None
-    if rl is not None:
-        line["roofline"] = rl
+    line["roofline"] = hip.inversion_roofline(G.renderer, B=2, n_samples=n_samples)
     return line
 
 
@@ -362,7 +361,10 @@ def main():
             del wl
             torch.cuda.empty_cache()
             for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
-                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder (operands + up-sampling stage storage)",
+                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder GEMM operands (fp32 storage: the faster of the two bf16 "
+                             "modes on this build)", dict(n_samples=24, batch=4, precision="bf16")),
+                            ("BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
+                             "(HBM bytes of those stages halved; slower: the stages are VALU-bound)",
                              dict(n_samples=24, batch=4, precision="bf16_storage"))):
                 w2 = ForwardWorkload(dev, 0, 1, 1024, 2, kw["n_samples"], kw["batch"], kw["precision"], False)
                 steps2 = max(10, a.steps // 2)

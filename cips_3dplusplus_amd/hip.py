@@ -774,34 +774,49 @@ def nerf_backward_fused(net, sigmoid_beta, cam_poses, focals, near, far, perturb
     return dfilm, dcam
 
 
-def inversion_roofline(B, n_samples, hidden, depth, img_size=64, iters=20):
-    """Roofline entry of the flip-inversion step's dominant kernel: the hidden x hidden GEMMs over all B * R * N sample points of
-    the materialised NeRF backward (D forward-recompute GEMMs in split-fp16 mode, D data-gradient GEMMs on the fp32 MFMA;
-    together ~1/3 of the step).  Timed stand-alone on the step's shape with HIP events (the loop itself is a tape of ~450
-    launches; its kernel summary is under profiles/)."""
+def inversion_roofline(renderer, B, n_samples, img_size=64, iters=10):
+    """Roofline entry of the flip-inversion step's dominant piece: the fused NeRF backward (csrc/nerf_bwd_fused.hip:
+    nerf_stash_kernel + nerf_bwd_kernel, ~23 % of the step), timed stand-alone on the step's shape with HIP events around
+    cips3d_nerf_bwd_fused (the three per-ray / preparation kernels inside the call are ~4 % of it).  Algorithmic flop = the
+    forward point MLP once more + the data-gradient GEMMs W_l^T d(pre_l); executed as split-fp16 products, so the peak is the
+    fp16 dense MFMA peak / 3 (as for the forward render kernel)."""
+    from . import autograd as AG
+    from .camera import Camera
     dev = "cuda"
-    P = img_size * img_size * n_samples
-    x = torch.randn(B, hidden, P, 1, device=dev)
-    W = (torch.randn(hidden, hidden, device=dev) * 0.006).unsqueeze(0).expand(B, hidden, hidden).contiguous()
-    out = torch.empty(B, hidden, P, 1, device=dev)
-    res = {}
-    for name, sp in (("data_gradient_fp32_mfma", False), ("recompute_split_fp16", True)):
-        pk = pack_weights(W, split=sp)
-        for _ in range(3):
-            modconv1x1(x, pk, hidden, epilogue=0, split=sp, out=out)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            modconv1x1(x, pk, hidden, epilogue=0, split=sp, out=out)
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / iters
-    flop = 2.0 * hidden * hidden * P * B
-    a = flop / (res["data_gradient_fp32_mfma"] * 1e-3) / 1e12
-    return {"kernel": f"modconv1x1_kernel on [{hidden} x {hidden}] x [{hidden} x {B * P}] (one of the 2 x {depth} point-MLP GEMMs of the "
-                      f"materialised NeRF backward; timed stand-alone on the step's shape)",
-            "bound": "mfma", "achieved": a, "peak": 157.3, "unit": "TFLOP/s", "frac": a / 157.3,
-            "avg_launch_ms": res["data_gradient_fp32_mfma"], "flop_per_launch": flop,
-            "split_fp16_form": {"avg_launch_ms": res["recompute_split_fp16"],
-                                "achieved": flop / (res["recompute_split_fp16"] * 1e-3) / 1e12,
-                                "note": "the forward-recompute GEMMs (activation operand) run in this form; algorithmic TFLOP/s"}}
+    net = renderer.network
+    H, D, S = net.W, net.D, img_size
+    locs = torch.tensor([[0.25, 0.1], [-0.25, 0.1]] * ((B + 1) // 2))[:B].to(dev)
+    cam, focal, near, far = Camera.generate_camera_params(locations=locs, img_size=S, device=dev, fov_ang=15,
+                                                          dist_radius=0.3)[:4]
+    from . import weights
+    styles = (0.5 * weights.det_normal("roofline.styles", (B, D + 1, renderer.style_dim), 1.0, 1)).to(dev)
+    film = AG.film_table(renderer, styles).detach()
+    u = weights.det_unit_uniform("roofline.u", (B, S, S, 1), 2).to(dev)
+    dF = (1e-5 * weights.det_normal("roofline.dF", (B, H, S, S), 1.0, 3)).to(dev)
+    dT = (1e-4 * weights.det_normal("roofline.dT", (B, 3, S, S), 1.0, 4)).to(dev)
+    packed, layer_bias = renderer._derived_buffers()
+    packed_t = renderer._packed_transposed()
+    run = lambda: nerf_backward_fused(net, renderer.sigmoid_beta.detach(), cam, focal, near, far, u, film, layer_bias, packed,
+                                      packed_t, S, n_samples, False, dF, dT)
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    P = B * S * S * n_samples
+    fwd = 2.0 * 3 * H + (D - 1) * 2.0 * H * H + 2.0 * (H + 3) * H + 2.0 * H * 4
+    bwd = D * 2.0 * H * H + 2.0 * 6 * H
+    flop = P * (fwd + bwd)
+    a = flop / (ms * 1e-3) / 1e12
+    peak = 2500.0 / 3
+    return {"kernel": "cips3d_nerf_bwd_fused = nerf_stash_kernel (forward recompute, accumulators stashed) + nerf_bwd_kernel "
+                      "(register-resident MFMA backward); timed stand-alone on the step's shape",
+            "bound": "mfma", "achieved": a, "peak": peak, "unit": "TFLOP/s", "frac": a / peak,
+            "peak_definition": "fp16 dense MFMA peak 2500 TFLOP/s / 3 fp16 products per fp32 product",
+            "avg_launch_ms": ms, "flop_per_launch": flop,
+            "stash_bytes_per_launch": 2.0 * 4 * P * D * H,
+            "note": "stash written once and read once: at this time it moves at %.2f TB/s" % (2.0 * 4 * P * D * H / (ms * 1e-3) / 1e12)}
