@@ -43,7 +43,8 @@ class NerfParams(C.Structure):
                 ("part", C.c_void_p), ("sdf", C.c_void_p),
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
-                ("features_planes", C.c_int32), ("pad_", C.c_int32)]
+                ("features_planes", C.c_int32), ("pad_", C.c_int32),
+                ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -56,7 +57,8 @@ class NerfBwdFusedParams(C.Structure):
     _fields_ = [("geom", NerfBwdGeom)] + [(n, C.c_void_p) for n in (
         "w_first", "packed", "packed_t", "w_view", "film", "layer_bias", "w_sigma", "b_sigma", "w_rgb", "b_rgb",
         "sigmoid_beta", "d_features", "d_thumb", "stash", "scratch", "dfilm", "dcam")] + [
-        ("hidden", C.c_int32), ("depth", C.c_int32), ("n_chunks", C.c_int32), ("pad_", C.c_int32)]
+        ("hidden", C.c_int32), ("depth", C.c_int32), ("n_chunks", C.c_int32), ("pad_", C.c_int32),
+        ("fwd_sdf", C.c_void_p), ("fwd_crgb", C.c_void_p)]
 
 
 _SIGS = {
@@ -154,7 +156,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 10           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 11           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -421,9 +421,18 @@ class NerfRenderFn(Function):
 
     @staticmethod
     def forward(ctx, renderer, cam_poses, focals, near, far, film, perturb_u, img_size, n_samples, static_viewdirs):
+        # With the fused backward available the forward keeps what it needs (accumulator stash, per-point sdf / rgb logits):
+        # the backward then does not run the forward again (hip.STASH_IN_FORWARD = 0: it does, and nothing is held meanwhile).
+        fwd = None
+        if hip.FUSED_NERF_BACKWARD and hip.STASH_IN_FORWARD and hip.nerf_backward_fused_supported(
+                renderer.hidden_dim, renderer.N_layers_renderer, img_size, n_samples):
+            fwd = hip.nerf_forward_stash(cam_poses.shape[0], img_size, n_samples, renderer.hidden_dim,
+                                         renderer.N_layers_renderer, cam_poses.device)
         thumb, features, _, mask, xyz = renderer.render(cam_poses.detach(), focals, near, far, None, img_size, n_samples,
-                                                        perturb_u=perturb_u, static_viewdirs=static_viewdirs, film=film)
+                                                        perturb_u=perturb_u, static_viewdirs=static_viewdirs, film=film,
+                                                        stash=fwd)
         ctx.renderer = renderer
+        ctx.fwd = fwd
         ctx.cfg = (img_size, n_samples, static_viewdirs)
         ctx.save_for_backward(cam_poses.detach(), focals, near, far, film.detach(), perturb_u)
         ctx.mark_non_differentiable(mask, xyz)
@@ -444,7 +453,8 @@ class NerfRenderFn(Function):
             packed, _ = r._derived_buffers()
             dfilm, dcam = hip.nerf_backward_fused(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u,
                                                   film, layer_bias, packed, r._packed_transposed(), img_size, n_samples,
-                                                  static, dfeat, dthumb)
+                                                  static, dfeat, dthumb, fwd=ctx.fwd)
+            ctx.fwd = None
         else:
             dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
                                             layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())

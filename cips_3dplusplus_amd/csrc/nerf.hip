@@ -209,11 +209,11 @@ __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict_
 //   last (hidden layers): Y is h_D, the sigma head's partial sum  sdf_acc += Ws . Y  is taken from the epilogue's fp32 values
 // The caller guarantees slab `seq` is resident in slot (seq & 1); every slab step prefetches seq+1
 // while multiplying and ends with wait + barrier.
-template <int NT, int TPS, bool VIEW>
+template <int NT, int TPS, bool VIEW, bool STASH>
 __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], h8 (&Yh)[NT / 2], h8 (&Yl)[NT / 2],
                                            float (&FA)[NT * 4], float wgt, float (&chead)[3], float& sdf_acc, bool last,
                                            Ring& ring, const float* film_l, const float* s_wd, const float* s_wc,
-                                           const float* s_ws, float vx, float vy, float vz, int wave, int lane, int q4o STAMP_PARAM) {
+                                           const float* s_ws, float vx, float vy, float vz, float* stash_l, int wave, int lane, int q4o STAMP_PARAM) {
   constexpr int H = NT * 16;
   constexpr int TILE = 16 * H;          // floats (= 4-byte hi/lo pairs) of one o-tile's A fragments
   constexpr int SLAB = TILE * TPS;
@@ -342,12 +342,18 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
       __syncthreads();
     }
     STAMP(12);   // early waves: step barrier
+    if constexpr (STASH) {
+      // differentiable forward: the step's accumulators in register order [sl * TPS + tt][lane][4], for cips3d_nerf_bwd_fused.
+      // Issued after the step barrier, so that no store acknowledgement is waited for at it.
+#pragma unroll
+      for (int tt = 0; tt < TPS; ++tt) *reinterpret_cast<f32x4*>(stash_l + ((sl * TPS + tt) * 64 + lane) * 4) = acc[tt];
+    }
     ++ring.seq;
   }
 }
 
 // XG: explicit-geometry instantiation (compile-time so that the camera-driven hot path keeps its register allocation)
-template <int NT, int TPS, bool XG>
+template <int NT, int TPS, bool XG, bool STASH>
 __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) {
   constexpr int H = NT * 16;
   constexpr int SLAB = 16 * H * TPS;
@@ -502,6 +508,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     const int q4o = 4 * qd + opq;
 
     h8 Xh[NT / 2], Xl[NT / 2], Yh[NT / 2], Yl[NT / 2];
+    float* stash_s = nullptr;   // this task's stash rows of the sample (differentiable forward)
+    if constexpr (STASH) stash_s = P.stash + (((task0 + wave) * a.chunk + si) * D) * (int64_t)(16 * H);
     float sdf = 0.f;            // sigma head partial of this lane's units (taken where h_D is produced in fp32)
     // ---- layer 0: 3 -> H on the VALU, in D layout, split into the hi / lo B fragments of the first MFMA layer
 #pragma unroll
@@ -532,8 +540,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     STAMP(1);   // sample setup + layer 0
     // ---- hidden layers 1 .. D-1
     for (int l = 1; l < D; ++l) {
-      mfma_layer<NT, TPS, false>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc, s_ws,
-                                 vx, vy, vz, wave, lane, q4o STAMP_ARG);
+      mfma_layer<NT, TPS, false, STASH>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
+                                        s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
+                                        q4o STAMP_ARG);
 #pragma unroll
       for (int i = 0; i < NT / 2; ++i) { Xh[i] = Yh[i]; Xl[i] = Yl[i]; }
     }
@@ -553,8 +562,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     STAMP(3);   // sigma head + weight
     // ---- view layer -> features, folded into FA; rgb head partial sums
     float sdf_unused = 0.f;
-    mfma_layer<NT, TPS, true>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
-                              vx, vy, vz, wave, lane, q4o STAMP_ARG);
+    mfma_layer<NT, TPS, true, STASH>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
+                                     vx, vy, vz, STASH ? stash_s + (int64_t)(D - 1) * 16 * H : nullptr, wave, lane,
+                                     q4o STAMP_ARG);
     float c0 = chead[0], c1 = chead[1], c2 = chead[2];
     c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
@@ -565,6 +575,15 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     ax = fmaf(w, ptx, ax); ay = fmaf(w, pty, ay); az = fmaf(w, ptz, az);
     if (sg == N - 1) wlast = w;
     if (P.sdf && live && qd == 0) P.sdf[((int64_t)b * R + ray) * N + sg] = sdf;
+    if constexpr (STASH) {
+      if (live && qd == 0) {     // per-point inputs of the compositing backward, p = sample * R + ray
+        const int64_t Pn = (int64_t)R * N, p = (int64_t)sg * R + ray;
+        P.bwd_sdf[(int64_t)b * Pn + p] = sdf;
+        P.bwd_crgb[((int64_t)b * 3 + 0) * Pn + p] = c0;
+        P.bwd_crgb[((int64_t)b * 3 + 1) * Pn + p] = c1;
+        P.bwd_crgb[((int64_t)b * 3 + 2) * Pn + p] = c2;
+      }
+    }
   }
 
   STAMP(5);   // last compositing tail
@@ -765,7 +784,7 @@ __global__ void __launch_bounds__(256) nerf_finish4_kernel(const float* __restri
   }
 }
 
-template <int NT, int TPS, bool XG>
+template <int NT, int TPS, bool XG, bool STASH>
 int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
@@ -777,19 +796,20 @@ int launch_render_x(const NerfArgs& a, hipStream_t st) {
   if (hipError_t e = hipGetDevice(&dev_id); e != hipSuccess) return (int)e;
   const unsigned long long bit = 1ull << (dev_id & 63);
   if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG, STASH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
-  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG, STASH>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
   return cips3d_launch_status();
 }
 
 template <int NT, int TPS>
 int launch_render(const NerfArgs& a, hipStream_t st) {
-  return a.p.x_pts ? launch_render_x<NT, TPS, true>(a, st) : launch_render_x<NT, TPS, false>(a, st);
+  if (a.p.x_pts) return launch_render_x<NT, TPS, true, false>(a, st);
+  return a.p.stash ? launch_render_x<NT, TPS, false, true>(a, st) : launch_render_x<NT, TPS, false, false>(a, st);
 }
 
 }  // namespace
@@ -857,6 +877,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if (P.B < 0 || P.img_size <= 0 || P.n_samples <= 0 || P.depth < 1 || P.n_chunks < 1 ||
       P.n_chunks > P.n_samples)
     return CIPS3D_E_BADARG;
+  if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
   if (P.B == 0) return 0;
   NerfArgs a;
   a.p = P;

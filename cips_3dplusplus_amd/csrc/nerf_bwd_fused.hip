@@ -446,6 +446,60 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_stash_kernel(FusedArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------ g from the forward's stash
+// g[b][p] = <d_features[:, ray], f[:, p]>,  f = sin(gamma' a + c) of the view layer's stashed accumulators: all that is left to
+// rebuild when the differentiable forward (cips3d_nerf_render with cips3d_nerf_params.stash) filled the stash itself.
+// Same tasks as the render kernel; one pass over 1/depth of the stash.
+template <int NT>
+__global__ void __launch_bounds__(WAVES * 64) nerf_g_kernel(FusedArgs a) {
+  constexpr int H = NT * 16;
+  __shared__ __attribute__((aligned(16))) float s_gc[2 * H];
+  const cips3d_nerf_bwd_fused_params& P = a.p;
+  const cips3d_nerf_bwd_geom& G = P.geom;
+  const int D = P.depth, L = D + 1;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, qd = lane >> 4, pl = lane & 15;
+  const int64_t task0 = (int64_t)blockIdx.x * WAVES;
+  const int b = (int)(task0 / a.tasks_per_view);
+  const int tv = (int)(task0 % a.tasks_per_view) + wave;
+  const bool task_ok = tv < a.groups * P.n_chunks;
+  const int g = task_ok ? tv / P.n_chunks : 0;
+  const int c = task_ok ? tv % P.n_chunks : 0;
+  const int R = G.img_size * G.img_size, N = G.n_samples;
+  const int64_t Pn = (int64_t)R * N;
+  const int ray = g * RAYS + pl;
+  {
+    const float* film_b = P.film + ((int64_t)b * L + D) * 2 * H;
+    const float sinv = P.packed[(int64_t)D * H * H + 2 * (D - 1) + 1];
+    for (int i = tid; i < H; i += WAVES * 64) {
+      const float gm = film_b[i];
+      s_gc[i] = gm * sinv;
+      s_gc[H + i] = fmaf(gm, P.layer_bias[D * H + i], film_b[H + i]);
+    }
+  }
+  __syncthreads();
+  const float* dF_ray = a.dFt + ((int64_t)b * R + ray) * H;
+  const int64_t tg = task0 + wave;
+  for (int si = 0; si < a.chunk; ++si) {
+    const int sg = c * a.chunk + si;
+    if (!(task_ok && sg < N)) continue;
+    const float* st = P.stash + (((tg * a.chunk + si) * D) + (D - 1)) * (int64_t)(16 * H);
+    float acc = 0.f;
+#pragma unroll 4
+    for (int t = 0; t < NT; ++t) {
+      const int o4 = t * 16 + 4 * qd;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(st + (t * 64 + lane) * 4);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(dF_ray + o4);
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_gc + o4);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(s_gc + H + o4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = fmaf(d4[i], cips3d_sin(fmaf(g4[i], av[i], c4[i])), acc);
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    if (qd == 0) a.g[(int64_t)b * Pn + (int64_t)sg * R + ray] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward kernel
 template <int CTRL>
 __device__ __forceinline__ float dpp_perm(float v) {
@@ -799,7 +853,8 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
   }
   const cips3d_nerf_bwd_geom& G = P.geom;
   const unsigned wgs = (unsigned)((int64_t)G.B * a.tasks_per_view / WAVES);
-  hipLaunchKernelGGL((nerf_stash_kernel<NT, TPS>), dim3(wgs), dim3(WAVES * 64), lds_a, st, a);
+  if (P.fwd_sdf) hipLaunchKernelGGL((nerf_g_kernel<NT>), dim3(wgs), dim3(WAVES * 64), 0, st, a);
+  else hipLaunchKernelGGL((nerf_stash_kernel<NT, TPS>), dim3(wgs), dim3(WAVES * 64), lds_a, st, a);
   if (int rc = cips3d_launch_status()) return rc;
   if (int rc = cips3d_nerf_bwd_composite(&G, a.sdf, a.crgb, a.g, P.d_thumb, P.sigmoid_beta, a.wts, a.Tb, a.dsdf, a.dcrgb,
                                          a.ddnorm, st))
@@ -875,6 +930,11 @@ extern "C" int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* pp, voi
   a.dFt = take(B * R * H);
   a.sdf = take(B * Pn);
   a.crgb = take(3 * B * Pn);
+  if ((P.fwd_sdf != nullptr) != (P.fwd_crgb != nullptr)) return CIPS3D_E_BADARG;
+  if (P.fwd_sdf) {               // the differentiable forward filled the stash and these two
+    a.sdf = const_cast<float*>(P.fwd_sdf);
+    a.crgb = const_cast<float*>(P.fwd_crgb);
+  }
   a.g = take(B * Pn);
   a.wts = take(B * Pn);
   a.Tb = take(B * Pn);

@@ -196,6 +196,8 @@ def _nerf_params(kw):
         setattr(p, f, dev_ptr(kw.get(f), f, kw.get("x_pts") is not None))
     p.perturb_u = dev_ptr(kw.get("perturb_u"), "perturb_u", True)
     p.sdf = dev_ptr(kw.get("sdf"), "sdf", True)
+    for f in ("stash", "bwd_sdf", "bwd_crgb"):                        # differentiable forward (cips3d_nerf_bwd_fused's inputs)
+        setattr(p, f, dev_ptr(kw.get(f), f, True))
     for f in ("x_pts", "x_rays_d", "x_viewdirs", "x_z_vals"):          # explicit-geometry mode
         setattr(p, f, dev_ptr(kw.get(f), f, True))
     p.n_rays = int(kw.get("n_rays", 0))
@@ -735,16 +737,30 @@ def nerf_pack_weights_t(w_hidden, w_view, packed, hidden, depth):
 
 
 FUSED_NERF_BACKWARD = os.environ.get("CIPS3D_FUSED_NERF_BACKWARD", "1") != "0"   # A/B knob: 0 = the materialised sequence
+STASH_IN_FORWARD = os.environ.get("CIPS3D_STASH_IN_FORWARD", "1") != "0"         # A/B knob: 0 = the backward recomputes the forward
 
 
 def nerf_backward_fused_supported(hidden, depth, img_size, n_samples):
     return bool(_lib.load().cips3d_nerf_bwd_fused_supported(hidden, depth, img_size, n_samples))
 
 
+def nerf_forward_stash(B, img_size, n_samples, hidden, depth, device, n_chunks=None):
+    """Buffers a differentiable forward hands to cips3d_nerf_render (`stash`, `bwd_sdf`, `bwd_crgb`) and later, as `fwd`, to
+    nerf_backward_fused: dict(stash, sdf, crgb, n_chunks)."""
+    lib = _lib.load()
+    if n_chunks is None:
+        n_chunks = nerf_suggest_chunks(B, img_size, n_samples)
+    P = img_size * img_size * n_samples
+    return {"stash": torch.empty(int(lib.cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, hidden, depth, n_chunks)),
+                                 device=device),
+            "sdf": torch.empty(B, P, device=device), "crgb": torch.empty(B, 3, P, device=device), "n_chunks": n_chunks}
+
+
 def nerf_backward_fused(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, film, layer_bias, packed, packed_t, img_size,
-                        n_samples, static_viewdirs, d_features, d_thumb):
+                        n_samples, static_viewdirs, d_features, d_thumb, fwd=None):
     """The fused NeRF backward (csrc/nerf_bwd_fused.hip): returns (dfilm [B,L,2,H], dcam [B,3,4]); same contract as
-    nerf_backward."""
+    nerf_backward.  `fwd` = the nerf_forward_stash buffers a differentiable forward filled: the forward is then not
+    recomputed."""
     lib = _lib.load()
     dev = cam_poses.device
     B, H, D = cam_poses.shape[0], net.W, net.D
@@ -758,8 +774,12 @@ def nerf_backward_fused(net, sigmoid_beta, cam_poses, focals, near, far, perturb
     g.cam_poses, g.focals, g.near_, g.far_ = (dev_ptr(t) for t in keep[:4])
     g.perturb_u = dev_ptr(keep[4], "perturb_u", True)
     g.B, g.img_size, g.n_samples, g.static_viewdirs = B, img_size, n_samples, int(bool(static_viewdirs))
-    n_chunks = nerf_suggest_chunks(B, img_size, n_samples)
-    stash = torch.empty(int(lib.cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, H, D, n_chunks)), device=dev)
+    if fwd is not None:
+        n_chunks, stash = fwd["n_chunks"], fwd["stash"]
+        p.fwd_sdf, p.fwd_crgb = dev_ptr(fwd["sdf"]), dev_ptr(fwd["crgb"])
+    else:
+        n_chunks = nerf_suggest_chunks(B, img_size, n_samples)
+        stash = torch.empty(int(lib.cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, H, D, n_chunks)), device=dev)
     scratch = torch.empty(int(lib.cips3d_nerf_bwd_fused_scratch_floats(B, img_size, n_samples, H, D)), device=dev)
     dfilm, dcam = torch.empty(B, L, 2, H, device=dev), torch.empty(B, 3, 4, device=dev)
     p.w_first, p.packed, p.packed_t = dev_ptr(net.pts_linears[0].weight), dev_ptr(packed), dev_ptr(packed_t)

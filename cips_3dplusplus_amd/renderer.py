@@ -165,7 +165,7 @@ class VolumeFeatureRenderer(nn.Module):
 
     @torch.no_grad()
     def render(self, cam_poses, focals, near, far, styles, img_size, N_samples, perturb_u=None,
-               static_viewdirs=False, return_sdf=False, n_chunks=None, film=None):
+               static_viewdirs=False, return_sdf=False, n_chunks=None, film=None, stash=None):
         """cam_poses (B,3,4), focals/near/far (B,1,1), styles (B,D+1,style_dim)
         -> thumb_rgb (B,3,S,S), features (B,H,S,S), sdf (B,S,S,N,1)|None, mask (B,2,S,S), xyz (B,3,S,S)"""
         B = cam_poses.shape[0]
@@ -179,6 +179,8 @@ class VolumeFeatureRenderer(nn.Module):
             tab.run(B)
         else:                       # FiLM table computed by the caller (differentiable path: autograd.film_table)
             film = film.detach().float().contiguous()
+        if stash is not None:       # differentiable forward: hip.nerf_forward_stash buffers, filled for the fused backward
+            n_chunks = stash["n_chunks"]
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)
         R = img_size * img_size
@@ -190,7 +192,9 @@ class VolumeFeatureRenderer(nn.Module):
                         layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=img_size, n_samples=N_samples, hidden=H, depth=D,
-                        static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf)
+                        static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf,
+                        stash=None if stash is None else stash["stash"], bwd_sdf=None if stash is None else stash["sdf"],
+                        bwd_crgb=None if stash is None else stash["crgb"])
         if sdf is not None:
             sdf = sdf.view(B, img_size, img_size, N_samples, 1)
         return thumb, features, sdf, mask, xyz

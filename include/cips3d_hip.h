@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 10  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 11  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -182,6 +182,14 @@ typedef struct cips3d_nerf_params {
    * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes) */
   int32_t features_planes;
   int32_t pad_;
+  /* Differentiable forward (camera-driven mode only; all three or none): the render kernel additionally writes what
+   * cips3d_nerf_bwd_fused needs, so that the backward does not recompute the forward -- per MFMA layer the fp32 accumulators
+   * (`stash`: cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, hidden, depth, n_chunks) floats, the layout of that
+   * call, which must then use the same n_chunks) and per point, p = sample * R + ray, the sdf (`bwd_sdf` [B,P]) and the rgb
+   * logits (`bwd_crgb` [B,3,P]). */
+  float* stash;
+  float* bwd_sdf;
+  float* bwd_crgb;
 } cips3d_nerf_params;
 
 /* 1 when cips3d_nerf_render(p) will write p->o_* itself (o_* set, n_chunks == 8, LDS large enough), else 0 */
@@ -600,6 +608,11 @@ typedef struct cips3d_nerf_bwd_fused_params {
   float* dfilm;              /* out [B,L,2,H] */
   float* dcam;               /* out [B,3,4] */
   int32_t hidden, depth, n_chunks, pad_;
+  /* NULL: the call recomputes the forward (nerf_stash_kernel fills `stash`).  Both set: `stash` was filled by
+   * cips3d_nerf_render (cips3d_nerf_params.stash / bwd_sdf / bwd_crgb, same n_chunks) and these are its per-point outputs;
+   * only g = <d_features, feature> is then rebuilt, from the view layer's stash. */
+  const float* fwd_sdf;      /* [B,P] */
+  const float* fwd_crgb;     /* [B,3,P] */
 } cips3d_nerf_bwd_fused_params;
 
 /* 1 when the fused kernels cover the shape (hidden 32/64/128/256, R % 16 == 0, tables within the LDS) */

@@ -77,3 +77,28 @@ def test_unsupported_shapes_fall_back():
     assert not hip.nerf_backward_fused_supported(32, 2, 6, 6)      # 36 rays: not whole 16-ray groups
     lib = _lib.load()
     assert lib.cips3d_nerf_bwd_fused_stash_floats(2, 64, 24, 256, 6, 4) == 2 * 1024 * 6 * 6 * 16 * 256
+
+
+@pytest.mark.parametrize("hidden,depth,B,S,N", [(32, 2, 2, 8, 6), (256, 6, 2, 64, 24), (256, 9, 1, 16, 4)])
+def test_stash_filled_by_the_forward_gives_the_same_gradients(hidden, depth, B, S, N):
+    """Differentiable forward: cips3d_nerf_render writes the accumulator stash and the per-point sdf / rgb logits itself
+    (cips3d_nerf_params.stash / bwd_sdf / bwd_crgb), the backward only rebuilds g from the view layer's stash.  Same gradients
+    as when the backward recomputes the forward (the stash holds the same accumulators bit for bit; g is summed in a different
+    order), and the forward's own outputs do not change."""
+    r, cam, focal, near, far, film = _setup(hidden, depth, B, S)
+    H = r.hidden_dim
+    u = weights.det_unit_uniform("nbf.u2", (B, S, S, 1), 2).to(DEV)
+    dF = (1e-4 * weights.det_normal("nbf.dF2", (B, H, S, S), 1.0, 3)).to(DEV)
+    dT = (1e-3 * weights.det_normal("nbf.dT2", (B, 3, S, S), 1.0, 4)).to(DEV)
+    packed, layer_bias = r._derived_buffers()
+    args = (r.network, r.sigmoid_beta.detach(), cam, focal, near, far, u, film, layer_bias)
+    plain = r.render(cam, focal, near, far, None, S, N, perturb_u=u, film=film)
+    fwd = hip.nerf_forward_stash(B, S, N, H, depth, DEV)
+    kept = r.render(cam, focal, near, far, None, S, N, perturb_u=u, film=film, stash=fwd)
+    for a, b in zip(plain, kept):
+        if a is not None:
+            assert torch.equal(a, b)
+    f0, c0 = hip.nerf_backward_fused(*args, packed, r._packed_transposed(), S, N, False, dF, dT)
+    f1, c1 = hip.nerf_backward_fused(*args, packed, r._packed_transposed(), S, N, False, dF, dT, fwd=fwd)
+    assert float((f0 - f1).abs().max() / f0.abs().max()) < 1e-5
+    assert float((c0 - c1).abs().max() / c0.abs().max()) < 1e-5
