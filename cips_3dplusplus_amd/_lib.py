@@ -119,8 +119,8 @@ _SIGS = {
     "cips3d_rays_in_world": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_z_vals": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
     "cips3d_ray_points": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, C.c_void_p]),
-    "cips3d_volume_integration": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_f32p,
-                                          c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_volume_integration": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int,
+                                          c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_points_linear": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_f32p,
                                      C.c_void_p]),
     "cips3d_linear_bwd": (c_int, [c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_f32p, c_i64, c_int, c_int, c_int, c_f32, c_f32,

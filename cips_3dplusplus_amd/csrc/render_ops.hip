@@ -83,30 +83,38 @@ __global__ void __launch_bounds__(256) integrate_kernel(const float* __restrict_
                                                         const float* __restrict__ feat, const float* __restrict__ z,
                                                         const float* __restrict__ rays_d, const float* __restrict__ pts,
                                                         const float* __restrict__ sigmoid_beta, int64_t BR, int N, int C,
-                                                        float* __restrict__ rgb_map, float* __restrict__ feature_map,
-                                                        float* __restrict__ xyz, float* __restrict__ mask) {
+                                                        int flags, float* __restrict__ rgb_map,
+                                                        float* __restrict__ feature_map, float* __restrict__ xyz,
+                                                        float* __restrict__ mask) {
   __shared__ float s_w[4][256];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t r = (int64_t)blockIdx.x * 4 + wv;
   if (r >= BR) return;
-  const float beta = sigmoid_beta[0];
+  const bool raw_density = flags & CIPS3D_VI_RAW_DENSITY;
+  const float beta = raw_density ? 1.f : sigmoid_beta[0];
   const float dnorm = sqrtf((rays_d[r * 3] * rays_d[r * 3] + rays_d[r * 3 + 1] * rays_d[r * 3 + 1]) +
                             rays_d[r * 3 + 2] * rays_d[r * 3 + 2]);
   // alpha_k for this lane's samples, then the transmittance scan by lane 0 (N is small: 24 .. 128)
   for (int k = lane; k < N; k += 64) {
     const float delta = (k < N - 1 ? z[r * N + k + 1] - z[r * N + k] : 1e10f) * dnorm;
-    const float sigma = sigmoidf_exact(-sdf[r * N + k] / beta) / beta;
+    const float v = sdf[r * N + k];
+    // with_sdf: density = sigmoid(-sdf / beta) / beta (nerf_utils.py:276-286); else F.softplus of the raw output (:288-297;
+    // torch's threshold 20: identity above it)
+    const float sigma = raw_density ? (v > 20.f ? v : log1pf(expf(v))) : sigmoidf_exact(-v / beta) / beta;
     s_w[wv][k] = 1.f - expf(-sigma * delta);
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes are done
   if (lane == 0) {
-    float T = 1.f;
+    float T = 1.f, wsum = 0.f;
     for (int k = 0; k < N; ++k) {
       const float alpha = s_w[wv][k];
-      s_w[wv][k] = alpha * T;
+      const float w = alpha * T;
+      s_w[wv][k] = w;
+      if (k < N - 1) wsum += w;
       T *= (1.f - alpha) + 1e-10f;
     }
+    if (flags & CIPS3D_VI_FORCE_BACKGROUND) s_w[wv][N - 1] = 1.f - wsum;   // nerf_utils.py:309-310
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -182,17 +190,18 @@ extern "C" int cips3d_ray_points(const float* rays_o, const float* rays_d, const
 
 extern "C" int cips3d_volume_integration(const float* rgb, const float* sdf, const float* features, const float* z_vals,
                                          const float* rays_d, const float* pts, const float* sigmoid_beta, int64_t n_rays,
-                                         int N, int C, float* rgb_map, float* feature_map, float* xyz, float* mask,
-                                         void* stream) {
-  if (!rgb || !sdf || !z_vals || !rays_d || !pts || !sigmoid_beta || !rgb_map || !xyz || !mask || n_rays < 0 || N <= 0)
-    return CIPS3D_E_BADARG;
+                                         int N, int C, int flags, float* rgb_map, float* feature_map, float* xyz,
+                                         float* mask, void* stream) {
+  if (!rgb || !sdf || !z_vals || !rays_d || !pts || !rgb_map || !xyz || !mask || n_rays < 0 || N <= 0) return CIPS3D_E_BADARG;
+  if (!(flags & CIPS3D_VI_RAW_DENSITY) && !sigmoid_beta) return CIPS3D_E_BADARG;
+  if (flags & ~(CIPS3D_VI_RAW_DENSITY | CIPS3D_VI_FORCE_BACKGROUND)) return CIPS3D_E_BADARG;
   if (features && (!feature_map || C <= 0)) return CIPS3D_E_BADARG;
   if (N > 256) return CIPS3D_E_UNSUPP;
   if (features && ((C % 4) || (reinterpret_cast<uintptr_t>(features) & 15) || (reinterpret_cast<uintptr_t>(feature_map) & 15)))
     return CIPS3D_E_UNSUPP;
   if (n_rays == 0) return 0;
   hipLaunchKernelGGL(integrate_kernel, dim3((unsigned)ceil_div<int64_t>(n_rays, 4)), dim3(256), 0, as_stream(stream), rgb, sdf,
-                     features, z_vals, rays_d, pts, sigmoid_beta, n_rays, N, C, rgb_map, feature_map, xyz, mask);
+                     features, z_vals, rays_d, pts, sigmoid_beta, n_rays, N, C, flags, rgb_map, feature_map, xyz, mask);
   return cips3d_launch_status();
 }
 

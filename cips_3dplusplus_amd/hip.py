@@ -284,8 +284,12 @@ def ray_points(rays_o, rays_d, z, near=None, far=None, want_pts=True, want_norma
     return pts, ptsn
 
 
-def volume_integration(rgb, sdf, features, z, rays_d, pts, sigmoid_beta):
-    """[n,N,3], [n,N], [n,N,C]|None, [n,N], [n,3], [n,N,3] -> rgb_map [n,3], feature_map [n,C]|None, xyz [n,3], mask [n,2]."""
+VI_RAW_DENSITY, VI_FORCE_BACKGROUND = 1, 2
+
+
+def volume_integration(rgb, sdf, features, z, rays_d, pts, sigmoid_beta, raw_density=False, force_background=False):
+    """[n,N,3], [n,N], [n,N,C]|None, [n,N], [n,3], [n,N,3] -> rgb_map [n,3], feature_map [n,C]|None, xyz [n,3], mask [n,2].
+    raw_density: `sdf` is the raw density output (softplus branch, with_sdf=False); force_background: nerf_utils.py:309-310."""
     lib = _lib.load()
     n, N = z.shape
     dev = z.device
@@ -294,7 +298,9 @@ def volume_integration(rgb, sdf, features, z, rays_d, pts, sigmoid_beta):
     fmap = torch.empty(n, Cc, device=dev) if features is not None else None
     check(lib.cips3d_volume_integration(dev_ptr(rgb, "rgb"), dev_ptr(sdf, "sdf"), dev_ptr(features, "features", True),
                                         dev_ptr(z, "z_vals"), dev_ptr(rays_d, "rays_d"), dev_ptr(pts, "pts"),
-                                        dev_ptr(sigmoid_beta, "sigmoid_beta"), n, N, Cc, dev_ptr(rgb_map),
+                                        dev_ptr(sigmoid_beta, "sigmoid_beta", raw_density), n, N, Cc,
+                                        (VI_RAW_DENSITY if raw_density else 0) | (VI_FORCE_BACKGROUND if force_background else 0),
+                                        dev_ptr(rgb_map),
                                         dev_ptr(fmap, "feature_map", True), dev_ptr(xyz), dev_ptr(mask), stream_ptr()),
           "cips3d_volume_integration")
     return rgb_map, fmap, xyz, mask

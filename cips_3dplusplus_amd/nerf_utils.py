@@ -76,9 +76,14 @@ class Render(object):
     @torch.no_grad()
     def volume_integration(rgb, sdf, features, z_vals, rays_d, pts, with_sdf=True, sigmoid_beta=None, return_eikonal=False,
                            raw_noise_std=0., force_background=False):
-        """nerf_utils.py:231-338 (with_sdf branch) -> rgb_map, feature_map, xyz, mask (.., 2), eikonal_term."""
-        if not with_sdf or return_eikonal or force_background or raw_noise_std > 0:
-            raise NotImplementedError("only the with_sdf inference branch is on the generator path")
+        """nerf_utils.py:231-338 -> rgb_map, feature_map, xyz, mask (.., 2), eikonal_term (None).  with_sdf=False is the raw
+        density branch (softplus of the network output, optionally + raw_noise_std * randn, :288-297), force_background the
+        last-sample override (:309-310).  The eikonal term (a training regulariser built on autograd.grad, :270-275) is not
+        computed."""
+        if return_eikonal:
+            raise NotImplementedError("the eikonal term needs double backward (training-only)")
+        if with_sdf and sigmoid_beta is None:
+            raise ValueError("with_sdf=True needs sigmoid_beta")
         z, lead = _flat_rays(z_vals, 1)
         n, N = z.shape[0] * z.shape[1], z.shape[2]
         r3 = rgb.float().reshape(n, N, 3).contiguous()
@@ -86,7 +91,13 @@ class Render(object):
         f = None if features is None else features.float().reshape(n, N, features.shape[-1]).contiguous()
         d = rays_d.float().reshape(n, 3).contiguous()
         p = pts.float().reshape(n, N, 3).contiguous()
-        beta = sigmoid_beta if torch.is_tensor(sigmoid_beta) else torch.tensor([float(sigmoid_beta)], device=z.device)
-        rgb_map, fmap, xyz, mask = hip.volume_integration(r3, s1, f, z.view(n, N), d, p, beta.detach().float().reshape(1))
+        beta = None
+        if with_sdf:
+            beta = sigmoid_beta if torch.is_tensor(sigmoid_beta) else torch.tensor([float(sigmoid_beta)], device=z.device)
+            beta = beta.detach().float().reshape(1)
+        elif raw_noise_std > 0:
+            s1 = s1 + torch.randn_like(s1) * raw_noise_std
+        rgb_map, fmap, xyz, mask = hip.volume_integration(r3, s1, f, z.view(n, N), d, p, beta, raw_density=not with_sdf,
+                                                          force_background=bool(force_background))
         return (rgb_map.view(*lead, 3), None if fmap is None else fmap.view(*lead, -1), xyz.view(*lead, 3),
                 mask.view(*lead, 2), None)

@@ -471,12 +471,18 @@ int cips3d_z_vals(const float* near_, const float* far_, const float* perturb_u,
 /* Render.get_points (+ Render.normalize_points when pts_normalized != NULL) (:124-170): [B,R,N,3]; either output may be NULL */
 int cips3d_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* near_, const float* far_, int B,
                       int R, int N, float* pts, float* pts_normalized, void* stream);
-/* Render.volume_integration, with_sdf branch (:231-338): rgb [n_rays,N,3], sdf [n_rays,N], features [n_rays,N,C] or NULL,
+/* Render.volume_integration (:231-338): rgb [n_rays,N,3], sdf [n_rays,N], features [n_rays,N,C] or NULL,
  * z_vals [n_rays,N], rays_d [n_rays,3], pts [n_rays,N,3] -> rgb_map [n_rays,3], feature_map [n_rays,C], xyz [n_rays,3],
- * mask [n_rays,2] = (last weight, -|xyz|).  N <= 256, C % 4 == 0. */
+ * mask [n_rays,2] = (last weight, -|xyz|).  N <= 256, C % 4 == 0.
+ * flags: 0 = the with_sdf branch (density = sigmoid(-sdf / beta) / beta, :276-286);
+ *   CIPS3D_VI_RAW_DENSITY      `sdf` holds the network's raw density output, density = softplus(raw) (:288-297; the caller adds
+ *                              raw_noise_std * randn beforehand); sigmoid_beta may be NULL
+ *   CIPS3D_VI_FORCE_BACKGROUND the last sample takes the weight the others leave: w[N-1] = 1 - sum_{k<N-1} w[k] (:309-310) */
+#define CIPS3D_VI_RAW_DENSITY 1
+#define CIPS3D_VI_FORCE_BACKGROUND 2
 int cips3d_volume_integration(const float* rgb, const float* sdf, const float* features, const float* z_vals,
                               const float* rays_d, const float* pts, const float* sigmoid_beta, int64_t n_rays, int N, int C,
-                              float* rgb_map, float* feature_map, float* xyz, float* mask, void* stream);
+                              int flags, float* rgb_map, float* feature_map, float* xyz, float* mask, void* stream);
 
 /* Dense layer over a point-major tensor x [n_points, in] -> y [n_points, out] for the per-point module forwards of the
  * reference when they are called directly (LinearLayer / FiLMSiren, cips3d/volume_renderer.py:15-85):

@@ -129,8 +129,9 @@ def siren_points(sd, prefix, pts_n, viewdirs, styles, D):
     return rgb, sdf, feat
 
 
-def volume_integration(rgb, sdf, feat, z, rays_d, pts, sigmoid_beta):
-    """cips3d/nerf_utils.py:230-338 (with_sdf branch).
+def volume_integration(rgb, sdf, feat, z, rays_d, pts, sigmoid_beta, with_sdf=True, force_background=False):
+    """cips3d/nerf_utils.py:230-338: with_sdf branch (:276-286) or raw density through softplus (:288-297, noise-free);
+    force_background (:309-310).
 
     rgb (..,N,3) sdf (..,N,1) feat (..,N,C) z (..,N) rays_d (..,3) pts (..,N,3)
     -> rgb_map (..,3), feature_map (..,C), xyz (..,3), mask (..,2) = [w_last, -|xyz|]
@@ -138,11 +139,13 @@ def volume_integration(rgb, sdf, feat, z, rays_d, pts, sigmoid_beta):
     dnorm = rays_d.norm(dim=-1, keepdim=True)
     delta = torch.cat([z[..., 1:] - z[..., :-1],
                        torch.full_like(dnorm, 1e10)], dim=-1) * dnorm
-    sigma = torch.sigmoid(-sdf / sigmoid_beta) / sigmoid_beta
+    sigma = torch.sigmoid(-sdf / sigmoid_beta) / sigmoid_beta if with_sdf else F.softplus(sdf)
     alpha = 1 - torch.exp(-sigma * delta.unsqueeze(-1))
     trans = torch.cumprod(torch.cat([torch.ones_like(alpha[..., :1, :]), 1.0 - alpha + 1e-10],
                                     dim=-2), dim=-2)[..., :-1, :]
     w = alpha * trans
+    if force_background:
+        w = torch.cat([w[..., :-1, :], 1 - w[..., :-1, :].sum(dim=-2, keepdim=True)], dim=-2)
     rgb_map = -1 + 2 * (w * torch.sigmoid(rgb)).sum(-2)
     feature_map = (w * feat).sum(-2)
     xyz = (w * pts).sum(-2)

@@ -121,6 +121,16 @@ def g_siren():
     out.update(vi_z=z, vi_rays_d=rays_d, vi_pts=pts, vi_sdf=sdf2, vi_beta=beta,
                vi_rgb_map=rgb_map, vi_feature_map=fmap, vi_xyz=xyz, vi_mask=mask)
     save("siren", **out)
+    # the branches no released config takes: raw density (with_sdf=False, softplus) and force_background, separately and together
+    raw = torch.randn(B, R, N, 1) * 2.0
+    raw[0, 0] = 25.0       # above softplus's threshold
+    br = {"_src": "cips3d/nerf_utils.py:288-310", "rgb": rgb, "feat": feat, "z": z, "rays_d": rays_d, "pts": pts, "raw": raw,
+          "sdf": sdf2, "beta": beta}
+    for tag, kw in (("raw", dict(sdf=raw, with_sdf=False)), ("fb", dict(sdf=sdf2, sigmoid_beta=beta, force_background=True)),
+                    ("raw_fb", dict(sdf=raw, with_sdf=False, force_background=True))):
+        rm, fm, xz, mk, _ = ref_nerf.Render.volume_integration(rgb=rgb, features=feat, z_vals=z, rays_d=rays_d, pts=pts, **kw)
+        br.update({f"{tag}_rgb_map": rm, f"{tag}_feature_map": fm, f"{tag}_xyz": xz, f"{tag}_mask": mk})
+    save("vi_branches", **br)
 
 
 # ---------------------------------------------------------------- 4/5. ops

@@ -242,6 +242,21 @@ def test_modulated_conv_golden_generality_path(golden):
         assert maxdiff(y.cpu(), fx[f"mc_{tag}.y"]) < 3e-5, tag
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 1, 7), (1, 64, 5, 1), (3, 8, 1, 1)])
+def test_modulated_conv_on_one_pixel_wide_inputs(shape):
+    """model_v3.py:302-306: for height == 1 or width == 1 the reference replaces the grouped conv by a bmm over the pixels --
+    the same per-sample GEMM this package always runs for k = 1.  Checked against the oracle on such inputs."""
+    dec = _dec_mod()
+    B, cin, H, W = shape
+    g = torch.Generator().manual_seed(H * 10 + W)
+    m = dec.ModulatedConv2d(cin, 24, 1, 16)
+    sd = {"m." + k: v.clone() for k, v in m.state_dict().items()}
+    x, st = torch.randn(B, cin, H, W, generator=g), torch.randn(B, 16, generator=g)
+    y = m.to(DEV)(cu(x), cu(st))
+    ref = O.modulated_conv2d(sd, "m", x, st)
+    assert y.shape == ref.shape and maxdiff(y.cpu(), ref) < 3e-5
+
+
 def test_styled_conv_and_torgb_golden(golden):
     fx = golden("modconv")
     import cips_3dplusplus_amd.decoder as dec

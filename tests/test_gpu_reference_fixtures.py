@@ -75,6 +75,21 @@ def test_siren_fixture_on_hip(golden):
         assert maxdiff(a.cpu(), fx[k]) < 2e-5 * max(1.0, float(fx[k].abs().max())), k
 
 
+@pytest.mark.parametrize("tag,with_sdf,fb", [("raw", False, False), ("fb", True, True), ("raw_fb", False, True)])
+def test_volume_integration_unused_branches_on_hip(golden, tag, with_sdf, fb):
+    """Render.volume_integration with with_sdf=False (softplus of the raw density, incl. values above torch's threshold) and
+    force_background=True (nerf_utils.py:288-310) on the HIP op, against the reference's outputs."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    fx = golden("vi_branches")
+    out = Render.volume_integration(cu(fx["rgb"]), cu(fx["sdf"] if with_sdf else fx["raw"]), cu(fx["feat"]), cu(fx["z"]),
+                                    cu(fx["rays_d"]), cu(fx["pts"]), with_sdf=with_sdf,
+                                    sigmoid_beta=cu(fx["beta"]) if with_sdf else None, force_background=fb)
+    for a, k in zip(out[:4], ("rgb_map", "feature_map", "xyz", "mask")):
+        ref = fx[f"{tag}_{k}"]
+        assert a.shape == ref.shape, k
+        assert maxdiff(a.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), k
+
+
 @pytest.mark.parametrize("hidden,D", [(32, 2), (256, 2)])
 def test_fused_render_on_edge_rays(hidden, D):
     """The compositing edge regimes, forced INSIDE the fused render kernel: with the sdf head's weights zeroed the sdf of every

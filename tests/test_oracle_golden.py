@@ -74,6 +74,17 @@ def test_film_siren_and_compositing(golden):
     assert maxdiff(xyz, fx["vi_xyz"]) < TOL and maxdiff(mask, fx["vi_mask"]) < TOL
 
 
+@pytest.mark.parametrize("tag,with_sdf,fb", [("raw", False, False), ("fb", True, True), ("raw_fb", False, True)])
+def test_volume_integration_unused_branches(golden, tag, with_sdf, fb):
+    """Raw-density (softplus) and force_background branches of Render.volume_integration (nerf_utils.py:288-310) against the
+    reference's own outputs (tests/golden/vi_branches.npz)."""
+    fx = golden("vi_branches")
+    rm, fm, xyz, mask = O.volume_integration(fx["rgb"], fx["sdf"] if with_sdf else fx["raw"], fx["feat"], fx["z"], fx["rays_d"],
+                                             fx["pts"], fx["beta"], with_sdf=with_sdf, force_background=fb)
+    for a, k in ((rm, "rgb_map"), (fm, "feature_map"), (xyz, "xyz"), (mask, "mask")):
+        assert maxdiff(a, fx[f"{tag}_{k}"]) < TOL, k
+
+
 def test_ops(golden):
     fx = golden("ops")
     for name in fx["ufd_names"]:
