@@ -126,8 +126,11 @@ struct NerfArgs {
 
 // LDS floats of the render kernel: slab ring (or the 8 x 16 x H partial exchange of the fused finish, whichever is
 // larger) + per-view tables (which double as the 8 x 8 x 16 scalar exchange once the last sample is done)
+// pitch of one ray's partial in the exchange: H + 4 floats, so that the 16 rays of a wave start 16 bytes apart in the bank
+// pattern (at pitch H every ray of a quarter hit the same banks: 8-way conflicts on the writes, 16-way on the combining reads)
+__host__ __device__ constexpr int nerf_xf_pitch(int H) { return H + 4; }
 __host__ __device__ constexpr int nerf_ring_floats(int H, int TPS, bool fuse) {
-  return (fuse && WAVES * RAYS * H > 2 * 16 * H * TPS) ? WAVES * RAYS * H : 2 * 16 * H * TPS;
+  return (fuse && WAVES * RAYS * nerf_xf_pitch(H) > 2 * 16 * H * TPS) ? WAVES * RAYS * nerf_xf_pitch(H) : 2 * 16 * H * TPS;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,7 +607,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();                         // every wave is done with the ring and the tables
     {
-      float* d = xf + ((int64_t)(wave * RAYS + pl)) * H + 4 * qd;
+      float* d = xf + (wave * RAYS + pl) * nerf_xf_pitch(H) + 4 * qd;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
         *reinterpret_cast<f32x4*>(d + t * 16) = f32x4{FA[t * 4], FA[t * 4 + 1], FA[t * 4 + 2], FA[t * 4 + 3]};
@@ -627,7 +630,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < WAVES; ++cc) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xf + ((int64_t)(cc * RAYS + rr)) * H + 4 * cq);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(xf + (cc * RAYS + rr) * nerf_xf_pitch(H) + 4 * cq);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[e] = fmaf(Tp[cc], v[e], acc[e]);
         }
@@ -860,7 +863,7 @@ extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
   if (p->n_chunks != WAVES || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
   const int tables = L * 2 * H + 10 * H;
   if (tables < WAVES * 8 * RAYS) return 0;
-  return sizeof(float) * ((size_t)WAVES * RAYS * H + tables) <= 160 * 1024;
+  return sizeof(float) * ((size_t)nerf_ring_floats(H, H == 256 ? 4 : 2, true) + tables) <= 160 * 1024;
 }
 
 extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
