@@ -932,7 +932,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   const int b = blockIdx.z;
   const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W;
   const int tiles_x = OW / TW;
-  const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: in row-major
+  // tile order the horizontal neighbours of a tile -- whose FIR halo columns sit in the SAME 128-byte lines as its own
+  // first / last columns -- always ran on other XCDs, so every (channel, row) segment pulled three lines through its L2 for
+  // one line of unique data (FETCH_SIZE 2.5x the algorithmic bytes at C = 32; tools/calib/fetch_calibrate.hip shows the
+  // counter itself is exact for these load widths).  Here XCD k walks the k-th contiguous eighth of the tiles instead:
+  // neighbours in both directions share an L2 and are dispatched 8 (resp. 8 * tiles_x) workgroups apart.
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int ox0 = (bid % tiles_x) * TW, oy0 = (bid / tiles_x) * TH;
   // Per-lane index arithmetic stays in 32 bits (a 64 x 64-bit multiply is three quarter-rate VALU instructions): 64-bit
   // products only in the workgroup-uniform per-sample bases (the host refuses C * 4HW >= 2^31)
   const int HWlo = H * W, HWo = OH * OW;
