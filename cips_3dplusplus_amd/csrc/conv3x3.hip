@@ -54,7 +54,11 @@ __global__ void __launch_bounds__(256) modconv3x3_kernel(Conv3Args a) {
   const int H = a.H, W = a.W;
   const int OH = UP ? 2 * H : H, OW = UP ? 2 * W : W;
   const int tiles_x = (OW + TW - 1) / TW;
-  const int ox0 = (blockIdx.x % tiles_x) * TW, oy0 = (blockIdx.x / tiles_x) * TH;
+  // XCD-aware tile order (see fused_up_conv_kernel): XCD k walks the k-th contiguous eighth of the pixel tiles, so that the
+  // halo columns / rows of neighbouring tiles are found in its own L2 (workgroups go to the XCDs round-robin by linear id)
+  int bid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int ox0 = (bid % tiles_x) * TW, oy0 = (bid / tiles_x) * TH;
   const int m0 = blockIdx.y * (16 * WM);
   const int K = a.Cin, nstage = K / BK;
   const int HWi = H * W;
