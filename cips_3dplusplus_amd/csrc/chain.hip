@@ -19,6 +19,7 @@
 //
 // Bound: L2 -> LDS bytes (64 x 128 tiles: 384 KB per workgroup and layer) + the launch skeleton; the matrix time is ~1/5 of
 // the fp32 MFMA's.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -32,6 +33,21 @@ constexpr float kSplitInv = 1.f / 256.f;       // the modulate kernel scaled the
 
 __device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
+#ifdef CIPS3D_CHAIN_STAMPS
+// Diagnostic build only: per-phase cycle sums over all workgroups (wave 0), one batch of atomics per workgroup at its end.
+__device__ unsigned long long g_chain_stamps[8];
+extern "C" int cips3d_debug_read_chain_stamps(unsigned long long* out8) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_chain_stamps), 64);
+  unsigned long long z[8] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_chain_stamps), z, 64);
+  return 0;
+}
+#define CSTAMP(i) ts_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define CSTAMP(i)
+#endif
+
 struct ChainArgs {
   const _Float16* x;        // planes [B][Cin/8][2][HW][8]
   const float* wmp;         // split-packed weights
@@ -44,6 +60,10 @@ struct ChainArgs {
 
 template <int WM, int WGM, int WGN, int BK, int NS>
 __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a) {
+#ifdef CIPS3D_CHAIN_STAMPS
+  unsigned long long ts_[6];
+  CSTAMP(0);
+#endif
   constexpr int NW = WGM * WGN;
   constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
   constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;     // floats (4-byte hi/lo pairs)
@@ -125,19 +145,47 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  static_assert(NS == 2, "the operand loads ride behind the first stage's DMA: the loop's first wait must be vmcnt(0)");
+  // Ring of NS stages, loads NS - 1 stages ahead; the epilogue's operand loads go out first (older than every stage, so the
+  // first counted wait retires them).  What bounds this kernel (in-kernel stamps, tools/chain_stamps.py, 512 -> 512 at 64^2):
+  // 3.1k cycles to the first landed stage, 12.6k for the 8 K stages, 2.5k epilogue -- and inside a stage ~1000 cycles of
+  // waiting for the stage's data against ~450 of DMA issue and ~350 of fragment reads + MFMA issue.  A third ring slot,
+  // 32-deep stages with 4 or 6 slots, and issuing the DMA behind the MFMAs (all waves, or only the SIMD partners) change
+  // nothing or lose: the loop moves 48 KB per stage and CU in ~1600 cycles = 30 B/clk per CU = 18 TB/s chip-wide, which is
+  // the L2 -> LDS gather rate of this part (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU).  The
+  // launch is bound by L2 -> CU bandwidth for its 384 KB of operand tiles per CU, not by latency and not by the matrix pipe.
+  static_assert(NS >= 2 && (NS - 2) * PW <= 63, "counted vmcnt");
+  // (NS = 2: the operand loads ride BEHIND the first stage's DMA -- the loop's first wait is vmcnt(0) anyway, and in front
+  // of it they delayed the first stage: 0.367 -> 0.384 ms per forward; deeper rings: in front, older than every counted stage)
+  if (NS > 2) load_ops();
 #pragma unroll
   for (int s0 = 0; s0 < NS - 1; ++s0)
     if (s0 < nstage) stage_load(s0);
-  load_ops();                       // epilogue operands: retired by the first stage's vmcnt(0), consumed after the loop
+  if (NS == 2) load_ops();
 
+#ifdef CIPS3D_CHAIN_STAMPS
+  unsigned long long ph_[4] = {0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[i] += t_ - tp_; tp_ = t_; } while (0)
+#else
+#define PSTAMP(i)
+#endif
   for (int st = 0; st < nstage; ++st) {
     int younger = nstage - 1 - st;
     if (younger > NS - 2) younger = NS - 2;
-    if (younger >= 1) __builtin_amdgcn_s_waitcnt(vmcnt_imm(PW));
-    else __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+    // stage st has landed when at most the `younger` stages issued after it are still in flight
+    switch (younger) {
+      case 0: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
+      case 1: __builtin_amdgcn_s_waitcnt(vmcnt_imm(PW)); break;
+      case 2: __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PW)); break;
+      case 3: __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * PW)); break;
+      case 4: __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 * PW)); break;
+      default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(5 * PW)); break;
+    }
     __builtin_amdgcn_s_barrier();
+#ifdef CIPS3D_CHAIN_STAMPS
+    if (st == 0) CSTAMP(1);          // first stage landed
+#endif
     if (st + NS - 1 < nstage) stage_load(st + NS - 1);
+    PSTAMP(1);                         // DMA issue
     const float* sA = lds + (st % NS) * STAGE;
     const float* sB = sA + A_STAGE;
     h8 ah[KB][WM], al[KB][WM], bh[KB][4], bl[KB][4];
@@ -165,9 +213,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
           acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl[kb][c], acc[i][c], 0, 0, 0);
           acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
         }
+    PSTAMP(2);                         // fragment reads + MFMA issue
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
+  CSTAMP(2);                         // main loop
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
   float prgb[3][4];
 #pragma unroll
@@ -225,6 +275,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       }
     }
   }
+#ifdef CIPS3D_CHAIN_STAMPS
+  CSTAMP(3);                         // epilogue arithmetic + stores issued
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+  CSTAMP(4);                         // stores acknowledged
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_chain_stamps[i], ts_[i + 1] - ts_[i]);
+    atomicAdd(&g_chain_stamps[7], 1ull);
+    atomicAdd(&g_chain_stamps[4], ph_[0]);
+    atomicAdd(&g_chain_stamps[5], ph_[1]);
+    atomicAdd(&g_chain_stamps[6], ph_[2]);
+  }
+#endif
   if (!a.rgb_part) return;
   // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
   // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
@@ -335,6 +397,9 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
               noise_bstride, noise_w, bias, rgb_w, rgb_part};
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
   dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
-  hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), a);
+  static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)
+  if (cfg == 1) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 3>), grid, dim3(512), 0, as_stream(stream), a);
+  else if (cfg == 2) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 32, 4>), grid, dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), a);
   return cips3d_launch_status();
 }
