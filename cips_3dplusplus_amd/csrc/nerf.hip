@@ -56,15 +56,23 @@
 #ifndef CIPS3D_STAMP_WAVE
 #define CIPS3D_STAMP_WAVE 0      // the wave whose phases are summed (0..3 early-epilogue waves, 4..7 late)
 #endif
-#define STAMP_PARAM , unsigned long long& t_prev_
-#define STAMP_ARG , t_prev_
-// Diagnostic build only (never in the shipped library): per-phase cycle sums of wave 0 of every workgroup.
+// Diagnostic build only (never in the shipped library): per-phase cycle sums of one wave of every workgroup, accumulated in
+// scalar registers and flushed with one batch of atomics at the end of the kernel (stamps that did an atomic each slowed the
+// kernel 3x and distorted the barrier waits).
+struct StampState { unsigned long long t_prev; unsigned long long acc[16]; };
+#define STAMP_PARAM , StampState& stamps_
+#define STAMP_ARG , stamps_
 __device__ unsigned long long g_nerf_stamps[16];
 #define STAMP(i)                                                                         \
   do {                                                                                   \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                          \
-    if (wave == CIPS3D_STAMP_WAVE && lane == 0) atomicAdd(&g_nerf_stamps[i], t_ - t_prev_);              \
-    t_prev_ = __builtin_amdgcn_s_memtime();                                              \
+    stamps_.acc[i] += t_ - stamps_.t_prev;                                               \
+    stamps_.t_prev = t_;                                                                 \
+  } while (0)
+#define STAMP_FLUSH()                                                                    \
+  do {                                                                                   \
+    if (wave == CIPS3D_STAMP_WAVE && lane == 0)                                          \
+      for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_nerf_stamps[i_], stamps_.acc[i_]);    \
   } while (0)
 extern "C" int cips3d_debug_read_stamps(unsigned long long* out16) {
   hipDeviceSynchronize();
@@ -75,6 +83,7 @@ extern "C" int cips3d_debug_read_stamps(unsigned long long* out16) {
 }
 #else
 #define STAMP(i)
+#define STAMP_FLUSH()
 #define STAMP_PARAM
 #define STAMP_ARG
 #endif
@@ -269,22 +278,40 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    // per k-block: hi and lo fragments of the TPS tiles (2 x TPS ds_read_b128, lane-linear image), then the three
-    // products.  A v_mfma_f32_16x16x32_f16 chain issues back to back on one accumulator; the TPS tiles interleave anyway.
+    // Matrix block, software-pipelined over HALF k-blocks.  A wave issues in order, and with split products a k-block's
+    // 12 MFMAs are only ~190 cycles of pipe: reading all 8 fragments of a k-block and then waiting for them (the form of
+    // the fp32 kernel) left each wave's block bound by 8 LDS round trips -- ~3.2k cycles per step for 1.5k cycles of its own
+    // matrix work (in-kernel stamps).  Here the fragments of the next half (TPS/2 tiles x hi, lo = 4 ds_read_b128) are
+    // requested BEFORE the current half's 6 MFMAs, into the other of two fragment buffers: the same 32 fragment registers
+    // as before, one half k-block of lead.  The counted lgkmcnt waits are the compiler's; sched_barrier pins the order.
+    {
+      constexpr int HT = TPS / 2;                       // tiles per half
+      h8 fh[2][HT], fl[2][HT];
+      auto load_half = [&](int buf, int m, int half) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      h8 ah[TPS], al[TPS];
+        for (int t = 0; t < HT; ++t) {
+          const int tt = half * HT + t;
+          fh[buf][t] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m) * 64 + lane) * 4);
+          fl[buf][t] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m + 1) * 64 + lane) * 4);
+        }
+      };
+      load_half(0, 0, 0);
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) {
-        ah[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m) * 64 + lane) * 4);
-        al[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m + 1) * 64 + lane) * 4);
+      for (int g = 0; g < 2 * MB; ++g) {
+        const int m = g >> 1, half = g & 1, cur = g & 1;
+        if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise sinks the reads to just before their use)
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+          acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+          acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur][t], Xl[m], acc[half * HT + t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < HT; ++t)
+          acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tt], Xh[m], acc[tt], 0, 0, 0);
-#pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xl[m], acc[tt], 0, 0, 0);
-#pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xh[m], acc[tt], 0, 0, 0);
     }
     STAMP(9);    // matrix block
     if (late_epilogue) {
@@ -380,7 +407,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const unsigned long long clk_t0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef CIPS3D_STAMPS
-  unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+  StampState stamps_;
+  for (int i_ = 0; i_ < 16; ++i_) stamps_.acc[i_] = 0;
+  stamps_.t_prev = __builtin_amdgcn_s_memtime();
 #endif
 
   // ---- task decode (b is uniform over the workgroup: tasks_per_view is a multiple of WAVES)
@@ -678,6 +707,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       }
     }
     STAMP(6);   // fused finish
+    STAMP_FLUSH();
     return;
   }
   // ---- write the chunk partial: part[c][b][ch][ray]
@@ -697,6 +727,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       dst[(int64_t)(H + 6) * R] = wlast; dst[(int64_t)(H + 7) * R] = T;
     }
   }
+  STAMP_FLUSH();
 }
 
 // features[b][ch][ray] = sum_c (prod_{c'<c} T_c') * part[c][b][ch][ray]; same for rgb/xyz/w_last.

@@ -213,20 +213,37 @@ __device__ __forceinline__ void mfma_step(const float* slab, const h8 (&Xh)[NT /
   return;
 #endif
   constexpr int TILE = 16 * NT * 16;
+  // software-pipelined over half k-blocks (see nerf.hip:mfma_layer): the next half's fragments are requested before the current
+  // half's MFMAs, into the other of two fragment buffers
+  constexpr int HT = TPS / 2 > 0 ? TPS / 2 : 1;
+  constexpr int NH = TPS / HT;                    // halves per k-block
+  constexpr int NG = (NT / 2) * NH;
+  h8 fh[2][HT], fl[2][HT];
+  auto load_half = [&](int buf, int g) {
+    const int m = g / NH, half = g % NH;
 #pragma unroll
-  for (int m = 0; m < NT / 2; ++m) {
-    h8 ah[TPS], al[TPS];
-#pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) {
-      ah[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m) * 64 + lane) * 4);
-      al[tt] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m + 1) * 64 + lane) * 4);
+    for (int t = 0; t < HT; ++t) {
+      const int tt = half * HT + t;
+      fh[buf][t] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m) * 64 + lane) * 4);
+      fl[buf][t] = *reinterpret_cast<const h8*>(slab + tt * TILE + ((2 * m + 1) * 64 + lane) * 4);
     }
+  };
+  load_half(0, 0);
 #pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[tt], Xh[m], acc[tt], 0, 0, 0);
+  for (int g = 0; g < NG; ++g) {
+    const int m = g / NH, half = g % NH, cur = g & 1;
+    if (g + 1 < NG) load_half(cur ^ 1, g + 1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xl[m], acc[tt], 0, 0, 0);
+    for (int t = 0; t < HT; ++t)
+      acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
 #pragma unroll
-    for (int tt = 0; tt < TPS; ++tt) acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[tt], Xh[m], acc[tt], 0, 0, 0);
+    for (int t = 0; t < HT; ++t)
+      acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur][t], Xl[m], acc[half * HT + t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < HT; ++t)
+      acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
