@@ -299,6 +299,11 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
       for (int g = 0; g < 2 * MB; ++g) {
         const int m = g >> 1, half = g & 1, cur = g & 1;
+        // The compiler drains lgkmcnt to 0 at every wait (it does not count these reads), so the wait for the CURRENT half's
+        // fragments is provoked here, in front of the next half's reads -- where they are the only ones in flight and have
+        // had the previous half's MFMAs to land -- instead of behind them.
+#pragma unroll
+        for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));
         if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise sinks the reads to just before their use)
 #pragma unroll

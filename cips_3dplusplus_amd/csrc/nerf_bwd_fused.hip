@@ -232,6 +232,8 @@ __device__ __forceinline__ void mfma_step(const float* slab, const h8 (&Xh)[NT /
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int m = g / NH, half = g % NH, cur = g & 1;
+#pragma unroll
+    for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));   // the wait sits here (nerf.hip)
     if (g + 1 < NG) load_half(cur ^ 1, g + 1);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
