@@ -278,14 +278,20 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    // Matrix block, software-pipelined over HALF k-blocks.  A wave issues in order, and with split products a k-block's
-    // 12 MFMAs are only ~190 cycles of pipe: reading all 8 fragments of a k-block and then waiting for them (the form of
-    // the fp32 kernel) left each wave's block bound by 8 LDS round trips -- ~3.2k cycles per step for 1.5k cycles of its own
-    // matrix work (in-kernel stamps).  Here the fragments of the next half (TPS/2 tiles x hi, lo = 4 ds_read_b128) are
-    // requested BEFORE the current half's 6 MFMAs, into the other of two fragment buffers: the same 32 fragment registers
-    // as before, one half k-block of lead.  The counted lgkmcnt waits are the compiler's; sched_barrier pins the order.
-    {
-      constexpr int HT = TPS / 2;                       // tiles per half
+    // Matrix block, software-pipelined over half k-blocks.  History, all measured: 8 reads -> wait -> 12 MFMAs per k-block
+    // (the form of the fp32 kernel) left each wave bound by 8 LDS round trips per step -- ~3.2k cycles for 1.5k of its own
+    // matrix work (in-kernel stamps) -- 92.0 us; the next half's 4 reads requested before the current half's 6 MFMAs, through
+    // the compiler (which drains lgkmcnt to 0 at every wait, the fresh prefetch included) 89.2 us; the wait provoked in FRONT
+    // of the next reads (below) 87.3 us, matrix block ~2.0k cycles per step; inline-asm reads three groups ahead with
+    // hand-counted waits (CIPS3D_ASM_FRAGS) another 0.9 us.
+#ifndef CIPS3D_ASM_FRAGS
+#define CIPS3D_ASM_FRAGS 0      // 1: nerf_mlp.h:matrix_block (inline-asm reads three groups ahead, hand-counted waits): 87.6 against
+#endif                          // 88.5 us on one box -- not worth leaving the compiler's hazard handling (see matrix_block)
+#if CIPS3D_ASM_FRAGS
+    matrix_block<NT, TPS>(slab, Xh, Xl, acc, lane);
+#else
+    {     // A/B form: reads one half k-block ahead through the compiler, its wait provoked in front of the next reads
+      constexpr int HT = TPS / 2;
       h8 fh[2][HT], fl[2][HT];
       auto load_half = [&](int buf, int m, int half) {
 #pragma unroll
@@ -299,13 +305,10 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
       for (int g = 0; g < 2 * MB; ++g) {
         const int m = g >> 1, half = g & 1, cur = g & 1;
-        // The compiler drains lgkmcnt to 0 at every wait (it does not count these reads), so the wait for the CURRENT half's
-        // fragments is provoked here, in front of the next half's reads -- where they are the only ones in flight and have
-        // had the previous half's MFMAs to land -- instead of behind them.
 #pragma unroll
         for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));
         if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
-        __builtin_amdgcn_sched_barrier(0);                // (the scheduler otherwise sinks the reads to just before their use)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < HT; ++t)
           acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
@@ -318,6 +321,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+#endif
     STAMP(9);    // matrix block
     if (late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's piece of slab seq+1 has landed
