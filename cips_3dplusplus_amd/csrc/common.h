@@ -99,10 +99,29 @@ __device__ static inline float cos_hw(float x) {
   r = fmaf(k, -TWO_PI_LO, r);
   return __builtin_amdgcn_cosf(r * INV_2PI);
 }
+// sin(x) / cos(x) without a reduction of our own (the default since round 2): t = x / (2 pi) in revolutions, v_fract_f32
+// (exact) takes it into [0, 1), v_sin_f32 / v_cos_f32 evaluate there -- 3 VALU slots + the quarter-rate instruction instead
+// of 6 + it (render kernel 87.1 -> 81.9 us with sin_hw_direct's two, same box).  What it adds to the argument is the
+// rounding of the product t (half an ulp of t: 3e-6 rad for |x| in [50, 100], 1.5e-6 in [25, 50]) -- the size of the
+// rounding the reference's own fp32 evaluation of gamma * pre + beta makes twice.  Measured on the D = 8 renderer against
+// fp64: features 5.93e-5 with it, 5.80e-5 with the exact reduction, 5.84e-5 for the fp32 oracle itself
+// (tests/test_gpu_split_fp16.py::test_split_nerf_is_as_accurate_as_fp32).  The fract keeps every magnitude inside the
+// instruction's domain (|t| < 256 without it).
+__device__ static inline float sin_hw_direct(float x) {
+  return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.159154943091895336f));
+}
+__device__ static inline float cos_hw_direct(float x) {
+  return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.159154943091895336f));
+}
 #ifdef CIPS3D_EXACT_SINE
 #define cips3d_sin sin_accurate
-#else
+#define cips3d_cos cosf
+#elif defined(CIPS3D_REDUCED_SINE)
 #define cips3d_sin sin_hw
+#define cips3d_cos cos_hw
+#else
+#define cips3d_sin sin_hw_direct
+#define cips3d_cos cos_hw_direct
 #endif
 
 // Split-fp16: x = hi + lo with hi = fp16(x), lo = fp16(x - hi) (22 significant bits; see nerf.hip / decoder.hip / chain.hip).

@@ -37,7 +37,7 @@
 #include "nerf_mlp.h"
 
 #ifdef CIPS3D_BWD_NO_COS         // timing-only ablation
-#define cos_hw(x) ((x) * 0.001f)
+#define cips3d_cos(x) ((x) * 0.001f)
 #endif
 
 namespace {
@@ -665,7 +665,7 @@ __device__ __forceinline__ void bwd_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)
       for (int i = 0; i < 4; ++i) {
         const float av = st[tt][i];
         const float u = fmaf(wsg[tt][i], dsdf, acc[tt][i] * uscale);
-        const float uc = u * cos_hw(fmaf(g4[i], av, c4[i]));
+        const float uc = u * cips3d_cos(fmaf(g4[i], av, c4[i]));
         e1[i] = uc * av;
         e2[i] = uc;
         yv[tt * 4 + i] = uc * g4[i];
@@ -797,7 +797,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_bwd_kernel(FusedArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float u = fmaf(w, d4[i], fmaf(wc2[i], dc2, fmaf(wc1[i], dc1, wc0[i] * dc0)));
-            const float uc = u * cos_hw(fmaf(g4[i], av[i], c4[i]));
+            const float uc = u * cips3d_cos(fmaf(g4[i], av[i], c4[i]));
             e1[i] = uc * av[i];
             e2[i] = uc;
             const float y = uc * g4[i];
