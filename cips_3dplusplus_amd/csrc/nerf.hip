@@ -615,7 +615,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     cr = fmaf(w, sigmoidf_acc(c0), cr); cg = fmaf(w, sigmoidf_acc(c1), cg); cb = fmaf(w, sigmoidf_acc(c2), cb);
     ax = fmaf(w, ptx, ax); ay = fmaf(w, pty, ay); az = fmaf(w, ptz, az);
     if (sg == N - 1) wlast = w;
-    if (P.sdf && live && qd == 0) P.sdf[((int64_t)b * R + ray) * N + sg] = sdf;
+    if (P.sdf && live && qd == 0) {
+      int ray_o = ray;                       // (opaque: keeps the 64-bit per-lane address out of the loop-invariant spills)
+      asm volatile("" : "+v"(ray_o));
+      P.sdf[((int64_t)b * R + ray_o) * N + sg] = sdf;
+    }
     if constexpr (STASH) {
       if (live && qd == 0) {     // per-point inputs of the compositing backward, p = sample * R + ray
         const int64_t Pn = (int64_t)R * N, p = (int64_t)sg * R + ray;
@@ -656,7 +660,10 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       else { e[6 * RAYS] = wlast; e[7 * RAYS] = T; }
     }
     __syncthreads();
-    const int rr = tid & 15;                 // ray of the group
+    int rr = tid & 15;                       // ray of the group
+    // (opaque: the output addresses derived from it were otherwise computed before the sample loop and kept in spilled
+    // 64-bit registers across it -- 2.1 MB of scratch traffic per launch for nothing)
+    asm volatile("" : "+v"(rr));
     const int gray = g * RAYS + rr;
     if (gray < R) {
       float Tp[WAVES];
@@ -721,7 +728,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
   // ---- write the chunk partial: part[c][b][ch][ray]
   if (ray_ok) {
-    float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray;
+    int ray_o = ray;
+    asm volatile("" : "+v"(ray_o));
+    float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray_o;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
