@@ -470,8 +470,15 @@ extern "C" int cips3d_noise_bias_act_bwd(const float* dy, const float* y, const 
   if (HW % 4) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   hipStream_t st = as_stream(stream);
-  if (dbias) { hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
-  if (dnoise_w) { hipError_t e = hipMemsetAsync(scratch_c, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
+  // the per-channel accumulators are zeroed with ONE memset when the caller laid them out back to back (dbias, scratch_c):
+  // every memset is a launch of its own, and the inversion step is as much launch-bound as it is GPU-bound
+  if (dbias && dnoise_w && scratch_c == dbias + C) {
+    hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * 2 * C, st);
+    if (e != hipSuccess) return (int)e;
+  } else {
+    if (dbias) { hipError_t e = hipMemsetAsync(dbias, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
+    if (dnoise_w) { hipError_t e = hipMemsetAsync(scratch_c, 0, sizeof(float) * C, st); if (e != hipSuccess) return (int)e; }
+  }
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st, dy,
                      y, dx, dbias, noise, noise_bstride, dnoise_w ? scratch_c : nullptr, C, HW);
   if (dnoise_w) hipLaunchKernelGGL(sum_to_scalar_kernel, dim3(1), dim3(256), 0, st, scratch_c, C, dnoise_w);
@@ -490,9 +497,10 @@ extern "C" int cips3d_torgb_bwd(const float* drgb, const float* x, const float* 
   if (HW % 4) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   hipStream_t st = as_stream(stream);
-  hipError_t e = hipMemsetAsync(dwm, 0, sizeof(float) * (size_t)B * 3 * C, st);
+  const bool adjacent = dbias && dbias == dwm + (size_t)B * 3 * C;       // one memset for both (see cips3d_noise_bias_act_bwd)
+  hipError_t e = hipMemsetAsync(dwm, 0, sizeof(float) * ((size_t)B * 3 * C + (adjacent ? 3 : 0)), st);
   if (e != hipSuccess) return (int)e;
-  if (dbias) { e = hipMemsetAsync(dbias, 0, sizeof(float) * 3, st); if (e != hipSuccess) return (int)e; }
+  if (dbias && !adjacent) { e = hipMemsetAsync(dbias, 0, sizeof(float) * 3, st); if (e != hipSuccess) return (int)e; }
   hipLaunchKernelGGL(torgb_bwd_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0, st,
                      drgb, x, wm, dx, dwm, dbias, C, HW);
   return cips3d_launch_status();

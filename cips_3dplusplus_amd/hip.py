@@ -603,8 +603,12 @@ def noise_bias_act_bwd(dy, y, noise, noise_w, need_dnoise=False, need_dnw=True, 
     nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
     dnoise = torch.empty_like(noise) if (need_dnoise and noise is not None) else None
     dnw = torch.empty(1, device=dev) if (need_dnw and noise is not None) else None
-    db = torch.empty(Cc, device=dev) if need_db else None
-    scratch = torch.empty(Cc, device=dev) if dnw is not None else None
+    if need_db and dnw is not None:       # back to back: the library zeroes both with one memset
+        both = torch.empty(2 * Cc, device=dev)
+        db, scratch = both[:Cc], both[Cc:]
+    else:
+        db = torch.empty(Cc, device=dev) if need_db else None
+        scratch = torch.empty(Cc, device=dev) if dnw is not None else None
     check(lib.cips3d_noise_bias_act_bwd(dev_ptr(dy, "dy"), dev_ptr(y, "y"), dev_ptr(noise, "noise", True), nb,
                                         dev_ptr(noise_w, "noise_w", True), dev_ptr(dx), dev_ptr(dnoise, "dnoise", True),
                                         dev_ptr(dnw, "dnw", True), dev_ptr(db, "db", True), dev_ptr(scratch, "scratch", True),
@@ -618,8 +622,9 @@ def torgb_bwd(drgb, x, wm, need_db=True):
     B, Cc = x.shape[:2]
     HW = x[0, 0].numel()
     dx = torch.empty_like(x)
-    dwm = torch.empty(B, 3, Cc, device=x.device)
-    db = torch.empty(3, device=x.device) if need_db else None
+    both = torch.empty(B * 3 * Cc + 3, device=x.device)      # dwm and dbias back to back: one memset in the library
+    dwm = both[:B * 3 * Cc].view(B, 3, Cc)
+    db = both[B * 3 * Cc:] if need_db else None
     check(lib.cips3d_torgb_bwd(dev_ptr(drgb, "drgb"), dev_ptr(x, "x"), dev_ptr(wm, "wm"), dev_ptr(dx), dev_ptr(dwm),
                                dev_ptr(db, "db", True), B, Cc, HW, stream_ptr()), "cips3d_torgb_bwd")
     return dx, dwm, db
