@@ -84,13 +84,14 @@ class Conv1x1Fn(Function):
     """Per-sample GEMM y[b] = wm[b] x[b] (x [B,Cin,H,W]); backward = the same GEMM on wm^T + the pixel-contraction GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wm, packed=None):
+    def forward(ctx, x, wm, packed=None, packed_t=None):
         x = _c(x)
         wm = _c(wm)
         Cout = wm.shape[1]
         sp = _split_ok(wm.shape[2])          # `packed` (from modulate_all) is split-packed under the same condition
         y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), Cout, epilogue=0, split=sp)
         ctx.save_for_backward(x, wm)
+        ctx.packed_t = packed_t              # fragments of wm^T from the same table launch (else packed in the backward)
         return y
 
     @staticmethod
@@ -99,10 +100,11 @@ class Conv1x1Fn(Function):
         dy = _c(dy)
         dx = dwm = None
         if ctx.needs_input_grad[0]:          # gradient operand: fp32 MFMA (hip.SPLIT_BACKWARD explains)
-            dx = hip.modconv1x1(dy, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0)
+            pt = ctx.packed_t if ctx.packed_t is not None else hip.pack_weights(wm, transpose=True)
+            dx = hip.modconv1x1(dy, pt, wm.shape[2], epilogue=0)
         if ctx.needs_input_grad[1]:
             dwm = hip.gemm_wgrad(dy, x)
-        return dx, dwm, None
+        return dx, dwm, None, None
 
 
 class Conv1x1ActFn(Function):
@@ -110,8 +112,9 @@ class Conv1x1ActFn(Function):
     (cips3d_modconv1x1, epilogue 1); backward = NoiseBiasActFn's followed by Conv1x1Fn's."""
 
     @staticmethod
-    def forward(ctx, x, wm, packed, noise, noise_w, bias):
+    def forward(ctx, x, wm, packed, noise, noise_w, bias, packed_t=None):
         x, wm, noise = _c(x), _c(wm), _c(noise)
+        ctx.packed_t = packed_t
         sp = _split_ok(wm.shape[2])
         y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), wm.shape[1], epilogue=1,
                            noise=noise, noise_w=noise_w, bias=bias, split=sp)
@@ -121,11 +124,12 @@ class Conv1x1ActFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, wm, y, noise, noise_w = ctx.saved_tensors
-        n_x, n_wm, _, n_noise, n_nw, n_b = ctx.needs_input_grad
+        n_x, n_wm, _, n_noise, n_nw, n_b = ctx.needs_input_grad[:6]
         dpre, dnoise, dnw, db = hip.noise_bias_act_bwd(_c(dy), y, noise, noise_w, need_dnoise=n_noise, need_dnw=n_nw, need_db=n_b)
-        dx = hip.modconv1x1(dpre, hip.pack_weights(wm, transpose=True), wm.shape[2], epilogue=0) if n_x else None
+        pt = ctx.packed_t if ctx.packed_t is not None else (hip.pack_weights(wm, transpose=True) if n_x else None)
+        dx = hip.modconv1x1(dpre, pt, wm.shape[2], epilogue=0) if n_x else None
         dwm = hip.gemm_wgrad(dpre, x) if n_wm else None
-        return dx, dwm, None, dnoise, dnw, db
+        return dx, dwm, None, dnoise, dnw, db, None
 
 
 class NoiseBiasActFn(Function):
@@ -244,19 +248,21 @@ def modulate_all(dec, s_list):
         packs = [isinstance(m, StyledConv) and hip.modconv1x1_supported(m.conv.in_channel, m.conv.out_channel, 4096) for m, _ in seq]
         plain = torch.empty(sum(plain_n), device=dev)
         packed = torch.empty(sum(n for n, p in zip(plain_n, packs) if p), device=dev)
+        packed_t = torch.empty_like(packed)      # fragments of wm^T: the data-gradient GEMMs' A operands, same launch
         descs, rows, so, po, ko = [], 0, 0, 0, 0
         layout = []
         for (m, _), cin, n, pk in zip(seq, sizes, plain_n, packs):
             conv = m.conv
-            for want_packed in ((False, True) if pk else (False,)):
+            for want_packed in ((0, 1, 2) if pk else (0,)):            # 0 plain, 1 packed (forward), 2 packed transpose
                 d = _lib.ModulateDesc()
                 d.W = conv.weight.data_ptr()
                 d.s = s_stage.data_ptr() + 4 * so
-                d.out = (packed.data_ptr() + 4 * ko) if want_packed else (plain.data_ptr() + 4 * po)
+                d.out = (plain.data_ptr() + 4 * po, packed.data_ptr() + 4 * ko, packed_t.data_ptr() + 4 * ko)[want_packed]
                 d.s_stride = cin
                 d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
                 d.flags = ((hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if want_packed else 0) |
-                           (hip.MOD_SPLIT if (want_packed and _split_ok(conv.in_channel)) else 0))
+                           (hip.MOD_SPLIT if (want_packed == 1 and _split_ok(conv.in_channel)) else 0) |
+                           (hip.MOD_TRANSPOSE if want_packed == 2 else 0))
                 d.scale = conv.scale
                 d.row_begin = rows
                 rows += conv.out_channel
@@ -267,15 +273,17 @@ def modulate_all(dec, s_list):
             ko += n if pk else 0
         arr = (_lib.ModulateDesc * len(descs))(*descs)
         tab_dev = torch.frombuffer(bytearray(bytes(memoryview(arr))), dtype=torch.uint8).to(dev)
-        ent = (key, s_stage, plain, packed, tab_dev, len(descs), rows, layout)
+        ent = (key, s_stage, plain, packed, tab_dev, len(descs), rows, layout, packed_t)
         dec._grad_mod_table = ent
-    _, s_stage, plain, packed, tab_dev, n_desc, rows, layout = ent
+    _, s_stage, plain, packed, tab_dev, n_desc, rows, layout, packed_t = ent
     torch.cat([t.reshape(-1) for t in s_list], out=s_stage)
     _lib.check(_lib.load().cips3d_modulate_table(tab_dev.data_ptr(), n_desc, rows, B, _lib.stream_ptr()), "cips3d_modulate_table")
     plain_now = plain.clone()            # saved by Conv1x1Fn / ToRGBFn for their backward: must outlive the next forward
+    packed_t_now = packed_t.clone()      # read by the backward of this forward
     out = {}
     for (m, _), (po, n, ko) in zip(seq, layout):
-        out[id(m)] = (plain_now[po:po + n], packed[ko:ko + n] if ko is not None else None)
+        out[id(m)] = (plain_now[po:po + n], packed[ko:ko + n] if ko is not None else None,
+                      packed_t_now[ko:ko + n] if ko is not None else None)
     return out
 
 
@@ -297,11 +305,12 @@ def styled_conv(sc, x, style, noise, s=None, pre=None):
         s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
     wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate, pre[0] if pre else None)
     packed = pre[1] if (pre and x.shape[2] * x.shape[3] % 4 == 0) else None
+    packed_t = pre[2] if (pre and packed is not None and len(pre) > 2) else None
     if not conv.upsample:
         if noise is None:
             noise = torch.randn(x.shape[0], 1, x.shape[2], x.shape[3], device=x.device)
-        return Conv1x1ActFn.apply(x, wm, packed, noise, sc.noise.weight, sc.activate.bias)
-    y = Conv1x1Fn.apply(x, wm, packed)
+        return Conv1x1ActFn.apply(x, wm, packed, noise, sc.noise.weight, sc.activate.bias, packed_t)
+    y = Conv1x1Fn.apply(x, wm, packed, packed_t)
     y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
     if noise is None:
         noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], device=y.device)

@@ -166,6 +166,9 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
       blk[((q << 4) | (o & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
+    } else if (packed & 64) {     // fragments of wm^T (ksq == 1): row = input channel, k = output unit (backward.hip:pack_kernel)
+      const int i = e;
+      wm[(((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 4) + (o >> 4)) * 256 + (((o & 3) << 4) | (i & 15)) * 4 + ((o >> 2) & 3)] = v;
     } else if (packed) {
       const int i = ksq == 1 ? e : e / ksq;
       const int tap = ksq == 1 ? 0 : ((packed & 8) ? ksq - 1 - e % ksq : e % ksq);
@@ -220,7 +223,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 56)) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 120)) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1378,8 +1381,9 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 56)) : 0;   // bit 3: flipped taps, bit 4: split-fp16, bit 5: split16
+  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 120)) : 0;   // bit 3: flipped taps, bit 4: split-fp16, bit 5: split16, bit 6: transposed
   if ((packed & 32) && (ksq != 1 || (packed & 24))) return CIPS3D_E_UNSUPP;
+  if ((packed & 64) && (ksq != 1 || (packed & 63) != 1)) return CIPS3D_E_UNSUPP;
   if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
   if ((packed & 16) && (ksq != 1 || (packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
   if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;

@@ -18,6 +18,7 @@ MOD_CHAINED = 4       # with MOD_PACKED: k-steps in the MFMA D-layout order (cip
 MOD_FLIP = 8          # with MOD_PACKED and ksq = 9: taps stored 180 degrees rotated (up-sampling branch of cips3d_modconv3x3)
 MOD_SPLIT = 16        # with MOD_PACKED and ksq = 1: fp16 hi + lo fragments of 2^8 wm for the split-fp16 GEMM mode (GEMM_SPLIT)
 MOD_SPLIT16 = 32      # with MOD_PACKED [| MOD_CHAINED]: split-fp16 fragments for the fused up-sampling stage (16-channel k-groups)
+MOD_TRANSPOSE = 64    # with MOD_PACKED and ksq = 1 (fp32 fragments): the packed form of wm^T (data-gradient GEMM operand)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).

@@ -235,6 +235,9 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  * CIPS3D_GEMM_SPLIT mode (16-channel k-groups, v_mfma_f32_16x16x16_f16): the element <-> channel map of the fp32 layout, each
  * lane's 16 bytes = {fp16 hi x 4 | fp16 lo x 4} of 2^8 wm */
 #define CIPS3D_MOD_SPLIT16    32
+/* with CIPS3D_MOD_PACKED and ksq == 1 (fp32 fragments only): the packed form of wm^T ([Cin x Cout]: the A operand of the
+ * data-gradient GEMM dx = wm^T dy) instead of wm's -- what cips3d_pack_weights(transpose = 1) makes from the plain matrix */
+#define CIPS3D_MOD_TRANSPOSE  64
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
