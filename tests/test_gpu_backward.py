@@ -2,12 +2,14 @@
 vs torch autograd through the CPU oracle on the same seeded inputs, and vs gradients of the imported reference
 (tests/golden/backward.npz).  Gradient tolerance: 2e-4 of the gradient's own max-abs (+1e-6), fp32 accumulation order
 differs (fp32 atomics in the reductions)."""
+import math
+
 import pytest
 import torch
 
 import cips_3dplusplus_amd as pkg
 from cips_3dplusplus_amd import autograd as AG
-from cips_3dplusplus_amd import configs, hip
+from cips_3dplusplus_amd import _lib, configs, hip
 from oracle import path as O
 
 pytestmark = pytest.mark.gpu
@@ -329,3 +331,21 @@ def test_flip_inversion_loop_reduces_loss():
     d0, d1 = G.decoder.state_dict(), out["decoder_state_dict"]
     assert any(not torch.equal(d0[k], d1[k]) for k in d0 if d0[k].is_floating_point())
     assert all(torch.equal(a, b) for a, b in zip(G.renderer.state_dict().values(), out["render_state_dict"].values()))
+
+
+def test_modulate_transpose_packing_equals_pack_weights():
+    """CIPS3D_MOD_TRANSPOSE: the modulate kernel writes the A fragments of wm^T directly -- bit for bit what
+    cips3d_pack_weights(transpose = 1) makes from the plain modulated matrix (the data-gradient GEMM's operand)."""
+    g = torch.Generator().manual_seed(3)
+    B, cout, cin = 2, 64, 96
+    W = cu(torch.randn(1, cout, cin, 1, 1, generator=g))
+    s = cu(1.0 + 0.3 * torch.randn(B, cin, generator=g))
+    for demod in (True, False):
+        plain = hip.modulate_weights(W, s, cin, B, cout, cin, 1, 1.0 / math.sqrt(cin), demod, packed=False)
+        ref = hip.pack_weights(plain.view(B, cout, cin), transpose=True)
+        lib = _lib.load()
+        out = torch.empty(B * cout * cin, device=DEV)
+        flags = (hip.MOD_DEMODULATE if demod else 0) | hip.MOD_PACKED | hip.MOD_TRANSPOSE
+        _lib.check(lib.cips3d_modulate_weights(W.data_ptr(), s.data_ptr(), cin, out.data_ptr(), B, cout, cin, 1,
+                                               1.0 / math.sqrt(cin), flags, torch.cuda.current_stream().cuda_stream), "mod")
+        assert torch.equal(out, ref.reshape(-1))
