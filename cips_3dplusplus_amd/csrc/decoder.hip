@@ -903,6 +903,18 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
+#ifdef CIPS3D_FUSED_STAMPS
+// Diagnostic build only: per-phase cycle sums of wave 0 of every workgroup of the fused up-sampling stages, slot = log2(C) - 5
+// (C = 32, 64, 128, 256), accumulated in registers, flushed at the end of the workgroup.
+__device__ unsigned long long g_fused_stamps[4][8];
+#define FSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); fst_[i] += t_ - ftp_; ftp_ = t_; } while (0)
+#define FSTAMP_FLUSH() do { if (tid == 0 && (blockIdx.x & 31) == 0) {   /* every 32nd workgroup: the atomics must not become the load */ constexpr int sl_ = C == 32 ? 0 : C == 64 ? 1 : C == 128 ? 2 : 3; \
+    for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&g_fused_stamps[sl_][i_], fst_[i_]); atomicAdd(&g_fused_stamps[sl_][7], 1ull); } } while (0)
+#else
+#define FSTAMP(i)
+#define FSTAMP_FLUSH()
+#endif
+
 template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, int PREC, bool NEXT = false, bool XPREF = false,
           bool LATE_OPS = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
@@ -926,6 +938,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   __shared__ float s_wrgb[3 * C];
 
   const int tid = threadIdx.x;
+#ifdef CIPS3D_FUSED_STAMPS
+  unsigned long long fst_[7] = {0, 0, 0, 0, 0, 0, 0}, ftp_ = __builtin_amdgcn_s_memtime();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int wm_i = wave / WGN, wn_i = wave % WGN;
@@ -997,26 +1012,35 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // low-resolution window (rows oy0/2-1 .. oy0/2+TH/2, columns ox0/2-1 .. ox0/2+TW/2) lies inside the image take loads
   // without edge predication (workgroup-uniform branch; 87 % of the tiles at 1024^2).
   const bool interior = oy0 / 2 >= 1 && oy0 / 2 + TH / 2 < H && ox0 / 2 >= 1 && ox0 / 2 + TW / 2 < W;
-  float pv[BPT][3][4];
-  auto patch_load = [&](int st) {
+  // Two patch register sets when the K loop has >= 3 stages and it pays (C = 256): the patches of stage
+  // st + 2 are requested at the START of stage st and filtered at the END of stage st + 1 -- two stages of lead.  With one
+  // stage of lead (the form C = 64 keeps) a stage lasted as long as a patch round trip: in-kernel stamps (tools/
+  // fused_stamps.py) showed 5.6k cycles per stage at C = 256 for 1.5k cycles of matrix work.
+#ifndef CIPS3D_FUSED_DEEP
+#define CIPS3D_FUSED_DEEP 1      // A/B knob
+#endif
+  constexpr bool DEEP = CIPS3D_FUSED_DEEP && NSTAGE >= 3 && C >= 256;   // same-box A/B: C = 256 24.4 -> 22.9 us; C = 128 (252 VGPRs with it) 25.2 -> 25.5: off there
+  float pv[BPT][3][4], pw[BPT][3][4];
+  auto patch_load_into = [&](int st, float (&pset)[BPT][3][4]) {
 #pragma unroll
     for (int u = 0; u < BPT; ++u) {
       const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
       const ylo_t* src = reinterpret_cast<const ylo_t*>(a.y_lo) + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo;
-      if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
-      else up2_load(src, H, W, oy0 / 2 + by, ox0 / 4 + qx, pv[u]);
+      if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
+      else up2_load(src, H, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
     }
   };
-  auto patch_store = [&](int st, float* dst) {
+  auto patch_load = [&](int st) { patch_load_into(st, pv); };
+  auto patch_store_from = [&](int st, float* dst, float (&pset)[BPT][3][4]) {
 #pragma unroll
     for (int u = 0; u < BPT; ++u) {
       const int g = tid + NT * u;
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
       float o[2][4];
-      up2_fir(pv[u], kf, o);
+      up2_fir(pset[u], kf, o);
       const float bs = a.bias1[st * BK + ch];
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
@@ -1032,7 +1056,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
     }
   };
+  auto patch_store = [&](int st, float* dst) { patch_store_from(st, dst, pv); };
   patch_load(0);
+  if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
 
   // noise of the first conv for this tile (scaled), ToRGB weights
   if (tid < BN / 4) {
@@ -1056,9 +1082,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  FSTAMP(0);        // operand requests, noise staged, first barrier
   patch_store(0, sB);
   __syncthreads();
-#pragma unroll 1
+  FSTAMP(1);        // FIR + activation + split of stage 0 into LDS (waits for its patches), barrier
+#pragma unroll (DEEP ? NSTAGE : 1)
   for (int st = 0; st < NSTAGE; ++st) {
     const float* cur = sB + (NBUF > 1 ? (st & 1) : 0) * BK * BN + nloc;
     f32x4 afr[KQ][WM];
@@ -1073,7 +1101,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int i = 0; i < WM; ++i)
           afr_next[kq][i] = *reinterpret_cast<const f32x4*>(
               ab + (((wm_i * WM + i) * (C / 16) + (st + 1) * KQ + kq) * 256 + lane * 4));
-      patch_load(st + 1);
+      if (!DEEP) patch_load(st + 1);
+    }
+    if (DEEP && st + 2 < NSTAGE) {           // set st & 1 was filtered into LDS at the end of stage st - 1: free
+      if (st & 1) patch_load_into(st + 2, pw);
+      else patch_load_into(st + 2, pv);
     }
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) {
@@ -1114,10 +1146,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
       }
     }
-    if (NBUF > 1 && st + 1 < NSTAGE) patch_store(st + 1, sB + ((st + 1) & 1) * BK * BN);
+    if (NBUF > 1 && st + 1 < NSTAGE) {
+      if (DEEP && ((st + 1) & 1)) patch_store_from(st + 1, sB + ((st + 1) & 1) * BK * BN, pw);
+      else patch_store(st + 1, sB + ((st + 1) & 1) * BK * BN);
+    }
     __syncthreads();
   }
 
+  FSTAMP(2);        // K loop (conv2 MFMAs, next stage's patches)
   // ---- epilogue of conv2: this lane holds channels o = (wm_i*WM+i)*16 + 4q + r at pixels (oy, ox .. ox+3)
   if (LATE) { load_epilogue_ops(); load_skip_ops(); }
   float prgb[3][4];
@@ -1152,6 +1188,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
     }
   }
+  FSTAMP(3);        // conv2 epilogue (noise, bias, leaky ReLU, ToRGB partial sums, out2 store)
   // ---- NEXT: the next stage's low-resolution GEMM y_next = Wn out2 from the registers.  acc[i][c][r] is channel
   // 16 (wm_i WM + i) + 4 q + r of pixel c: with Wn in the chained pack that IS the B operand of k-step r of k-group
   // (wm_i WM + i).  Each wave row covers its own WM k-groups (split K); rows 1.. park their partial in the (now free) B
@@ -1289,7 +1326,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(sp + (t * 4 + c) * 256) = accn[t][c];
     }
   }
-  if (!a.wm_rgb && !NEXT) return;
+  FSTAMP(4);        // chained next-stage GEMM (MFMAs)
+  if (!a.wm_rgb && !NEXT) { FSTAMP_FLUSH(); return; }
   // ---- ToRGB: reduce over the 4 lane quarters, then over the WGM wave rows through LDS
   if (a.wm_rgb) {
 #pragma unroll
@@ -1335,7 +1373,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
               f32x4{accn[t][0][r] * ys, accn[t][1][r] * ys, accn[t][2][r] * ys, accn[t][3][r] * ys};
       }
   }
-  if (!a.wm_rgb) return;
+  FSTAMP(5);        // partial exchange of the chained GEMM / ToRGB through LDS, y_next store
+  if (!a.wm_rgb) { FSTAMP_FLUSH(); return; }
   if (rgb_lane) {                     // quarter q finishes colour channel q
     const int ch = q;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1361,6 +1400,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     }
     *reinterpret_cast<f32x4*>(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox)) = v;
   }
+  FSTAMP(6);        // rgb: bias, FIR of the skip, store
+  FSTAMP_FLUSH();
 }
 
 template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false, bool XPREF = false, bool LATE = false>
@@ -1375,6 +1416,16 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef CIPS3D_FUSED_STAMPS
+extern "C" int cips3d_debug_read_fused_stamps(unsigned long long* out32) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_fused_stamps), 256);
+  unsigned long long z[32] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(g_fused_stamps), z, 256);
+  return 0;
+}
+#endif
 
 extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm, int B, int Cout,
                                        int Cin, int ksq, float scale, int demodulate, void* stream) {

@@ -1,4 +1,4 @@
-# A/B of render-kernel build flags on ONE box: usage  bash tools/nerf_ab.sh "<flags A>" "<flags B>" ...
+# A/B of build flags (render kernel, chain GEMM, fused stages) on ONE box: usage  bash tools/nerf_ab.sh "<flags A>" "<flags B>" ...
 export TMPDIR=/tmp
 i=0
 for f in "$@"; do
@@ -9,6 +9,6 @@ for f in "$@"; do
 import csv,glob
 f=glob.glob('gpurun_out/ab$i/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if 'nerf_render' in r['Name'] or 'chain_gemm' in r['Name']: print('  ', r['Name'][27:70], r['Calls'], round(float(r['AverageNs'])/1e3,2))
+    if 'nerf_render' in r['Name'] or 'chain_gemm' in r['Name'] or 'fused_up' in r['Name']: print('  ', r['Name'][27:82], r['Calls'], round(float(r['AverageNs'])/1e3,2))
 PY
 done
