@@ -171,8 +171,14 @@ class ForwardWorkload:
         from cips_3dplusplus_amd import hip
         for _ in range(warmup):
             self.step()
-        hip.KERNEL_EVENTS_STRIDE = EVENT_STRIDE
-        hip.prepare_event_pairs(repeats * (steps // EVENT_STRIDE + 2))
+        # Short regions (the driver's --steps 20) time ONE launch per region, the one in the middle: every record drains the
+        # queue (~6-10 us), and three of them in a 7 ms window are 0.4 % of it; long regions keep one launch in eight.
+        stride = EVENT_STRIDE if steps >= 64 else max(1, steps)
+        hip.KERNEL_EVENTS_STRIDE = stride
+        hip.KERNEL_EVENTS_PHASE = stride // 2
+        hip._event_calls.pop("nerf_render", None)           # (the phase counts calls from here)
+        hip.prepare_event_pairs(repeats * (steps // stride + 2))
+        self.event_stride = stride
         events, elapsed = [], []
         for _ in range(repeats):
             self.barrier()
@@ -218,7 +224,7 @@ class ForwardWorkload:
                 "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src,
                 "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
-                "timed_every_nth_step": EVENT_STRIDE}
+                "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE)}
 
 
 def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24):

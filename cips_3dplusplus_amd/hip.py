@@ -26,6 +26,7 @@ KERNEL_EVENTS = {}
 # An event record between two kernels drains the queue (~6 us bubble on MI355X), so a bench that times every launch slows
 # the step it measures by 2-3 %: collect on every n-th call only, with event handles created ahead of the timed region.
 KERNEL_EVENTS_STRIDE = 1
+KERNEL_EVENTS_PHASE = 0      # the call within each stride that is timed (0 = the first; a bench picks a mid-region one)
 _EVENT_POOL = []
 _event_calls = {}
 
@@ -45,7 +46,8 @@ def want_events(name):
         return None
     k = _event_calls.get(name, 0)
     _event_calls[name] = k + 1
-    return lst if k % max(1, KERNEL_EVENTS_STRIDE) == 0 else None
+    st = max(1, KERNEL_EVENTS_STRIDE)
+    return lst if k % st == KERNEL_EVENTS_PHASE % st else None
 
 
 def event_pair():
