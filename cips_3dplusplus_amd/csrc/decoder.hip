@@ -903,6 +903,9 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
+#ifndef CIPS3D_C32_MINW
+#define CIPS3D_C32_MINW 8      // A/B knob: waves per SIMD the C = 32 stage is compiled for
+#endif
 #ifdef CIPS3D_FUSED_STAMPS
 // Diagnostic build only: per-phase cycle sums of wave 0 of every workgroup of the fused up-sampling stages, slot = log2(C) - 5
 // (C = 32, 64, 128, 256), accumulated in registers, flushed at the end of the workgroup.
@@ -934,7 +937,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   static_assert((BK * NBLK) % NT == 0 && BPT >= 1, "block split");
   __shared__ __attribute__((aligned(16))) float sB[NBUF * BK * BN];
   __shared__ __attribute__((aligned(16))) float s_nz1[BN];
-  __shared__ __attribute__((aligned(16))) float s_red[WGM * 3 * BN];
+  // (the last stage has no chained GEMM: its B tile is dead when the ToRGB partials are exchanged, so they take its place --
+  // 3 KB of LDS less per workgroup, which with <= 64 VGPRs admits an eighth workgroup per CU)
+  __shared__ __attribute__((aligned(16))) float s_red_own[NEXT ? WGM * 3 * BN : 4];
+  float* s_red = NEXT ? s_red_own : sB;
   __shared__ float s_wrgb[3 * C];
 
   const int tid = threadIdx.x;
@@ -1602,7 +1608,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     // C = 32 (one K stage): with the epilogue's operands (noise2, bias2, skip patch) requested after the MFMAs instead of up
     // front the kernel needs 71 instead of 93 registers: seven instead of five resident waves per SIMD, -6 us at 1024^2
-    case 32: return launch_fused<32, 1, 2, 2, 1, 32, 6, false, false, true>(a, st);   // 2 rows x 64, 4 waves     46 us @1024^2
+    case 32: return launch_fused<32, 1, 2, 2, 1, 32, CIPS3D_C32_MINW, false, false, true>(a, st);   // 2 rows x 64, 4 waves     46 us @1024^2
     case 64: return launch_fused<64, 2, 2, 2, 1, 16, 4>(a, st);      // 2 rows x 64, 4 waves, BK 16     42 us @512^2
     case 128: return launch_fused<128, 4, 2, 4, 1, 32, 2>(a, st);    // 4 rows x 64                     33 us @256^2
     case 256: return launch_fused<256, 2, 8, 1, 2, 64, 2>(a, st);    // 2 rows x 32: 256 workgroups at 128^2
