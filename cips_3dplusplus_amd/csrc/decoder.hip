@@ -903,6 +903,9 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
+#ifndef CIPS3D_C64_MINW
+#define CIPS3D_C64_MINW 4
+#endif
 #ifndef CIPS3D_C32_MINW
 #define CIPS3D_C32_MINW 8      // A/B knob: waves per SIMD the C = 32 stage is compiled for
 #endif
@@ -1025,7 +1028,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #ifndef CIPS3D_FUSED_DEEP
 #define CIPS3D_FUSED_DEEP 1      // A/B knob
 #endif
-  constexpr bool DEEP = CIPS3D_FUSED_DEEP && NSTAGE >= 3 && C >= 256;   // same-box A/B: C = 256 24.4 -> 22.9 us; C = 128 (252 VGPRs with it) 25.2 -> 25.5: off there
+#ifndef CIPS3D_DEEP_MIN_C
+#define CIPS3D_DEEP_MIN_C 256
+#endif
+  constexpr bool DEEP = CIPS3D_FUSED_DEEP && NSTAGE >= 3 && C >= CIPS3D_DEEP_MIN_C && (C != 128);   // same-box A/B: C = 256 24.4 -> 22.9 us; C = 128 (252 VGPRs with it) 25.2 -> 25.5: off there
   float pv[BPT][3][4], pw[BPT][3][4];
   auto patch_load_into = [&](int st, float (&pset)[BPT][3][4]) {
 #pragma unroll
@@ -1601,7 +1607,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
     // with the partials added through LDS (C = 128: a tie, kept)
     // (last template flag: epilogue operands requested after the MFMAs -- at C = 64 / 128 that removes the spills of the
     // chained form, -2 us / neutral; at C = 256 it measured +1 us and stays off)
-    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, 4, true, true, true>(a, st)
+    return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, CIPS3D_C64_MINW, true, true, true>(a, st)
            : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false, true>(a, st)
                       : launch_fused<256, 2, 8, 1, 2, 64, 2, true, true>(a, st);
   switch (C) {
