@@ -238,3 +238,34 @@ def test_config5_at_stated_size_backward(golden):
     assert n_checked > 60
     print(f"config 5 at stated size: loss {float(loss):.4f}, worst gradient error {worst:.2e} of its max-abs "
           f"({n_checked} decoder parameters)")
+
+
+def _headline_inputs(B, seed=21):
+    from cips_3dplusplus_amd.camera import Camera
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=0)
+    zs, _, _ = weights.synth_inputs(cfg, batch=B, seed=seed)
+    zs = [cu(z) for z in zs]
+    locs = cu(torch.tensor([[0.25, 0.1], [-0.3, -0.05], [0.1, 0.12], [0.0, 0.0]])[:B])
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=locs, fov_ang=6, dist_radius=0.12)
+    nb = G.create_noise_bufs(64, DEV)
+    u = cu(weights.det_unit_uniform("prop.u", (B, 64, 64, 1), 3))
+    return G, zs, (e, f, n, fa), nb, u
+
+
+def test_headline_forward_is_deterministic_and_batch_independent():
+    """Size-independent properties at the bench's own size (FFHQ 1024^2, D=2, 64x64 rays x 24 samples): the same inputs give
+    the same bits on every call (no atomics, no run-dependent reduction order anywhere on the forward path), and a view's
+    image does not depend on what else is in the batch (every kernel of the path works per sample; only the workgroup ->
+    tile order of the planes GEMM differs between batch sizes, so this is exact up to its fp32 accumulation order)."""
+    G, zs, (e, f, n, fa), nb, u = _headline_inputs(2)
+    kw = dict(img_size=64, noise_bufs=nb, nerf_cfg=dict(N_samples=24, perturb=True, static_viewdirs=False))
+    run = lambda sl: G(zs=[z[sl] for z in zs], cam_poses=e[sl], focals=f[sl], near=n[sl], far=fa[sl], perturb_u=u[sl], **kw)
+    both = run(slice(0, 2))
+    again = run(slice(0, 2))
+    for k in ("rgb", "thumb_rgb", "mask", "depth"):
+        assert torch.equal(both[k], again[k]), k
+    for i in range(2):
+        one = run(slice(i, i + 1))
+        assert maxdiff(one["rgb"].cpu(), both["rgb"][i:i + 1].cpu()) < 2e-5 * float(both["rgb"].abs().max()), i
+        assert maxdiff(one["thumb_rgb"].cpu(), both["thumb_rgb"][i:i + 1].cpu()) < 1e-6, i
