@@ -142,6 +142,25 @@ class ForwardWorkload:
             return self.G(zs=self.zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1,
                           noise_bufs=self.noise_bufs, nerf_cfg=self.nerf_cfg)["rgb"]
 
+    def fp32_equivalence(self):
+        """One view rendered with the decoder on split-fp16 products (the default) and on the fp32 matrix instruction
+        ("fp32_exact"), same latents / camera / jitter / noise: how far apart the two images are.  (The render kernel has only
+        the split form; its distance to fp64 is pinned by tests/test_gpu_split_fp16.py: no larger than plain fp32's.)"""
+        e, f, n, fa, _ = self.cam
+        nb = self.G.create_noise_bufs(64, self.dev)
+        u = torch.rand(self.B, 64, 64, 1, device=self.dev)
+        kw = dict(zs=self.zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1, noise_bufs=nb, perturb_u=u,
+                  nerf_cfg=self.nerf_cfg)
+        with torch.no_grad():
+            a = self.G(**kw)["rgb"]
+            self.G.set_decoder_precision("fp32_exact")
+            b = self.G(**kw)["rgb"]
+            self.G.set_decoder_precision(self.precision)
+        return {"max_abs_rgb_difference_split_vs_fp32_mfma_decoder": float((a - b).abs().max()),
+                "rgb_max_abs": float(b.abs().max()),
+                "note": "split-fp16 = three exact fp16 products per fp32 product, fp32 accumulate; against fp64 it errs no more "
+                        "than the fp32 instruction (tests/test_gpu_split_fp16.py); parity bar of the path: 1e-3 max-abs"}
+
     def step(self):
         from cips_3dplusplus_amd import hip
         from cips_3dplusplus_amd.multiview import gather_views_async
@@ -357,6 +376,9 @@ def main():
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
             "roofline": wl.roofline(kern_ms, n_ev),
         }
+        if world == 1 and a.decoder_precision == "fp32":
+            # the default arithmetic (split-fp16 products) against the fp32 matrix instruction on this run's own inputs
+            line["fp32_equivalence"] = wl.fp32_equivalence()
         if world > 1:
             line["rccl_ranks"] = torch.distributed.get_world_size()
             line["dist_backend"] = backend + (" (RCCL)" if backend == "nccl" else " (ranks share devices: not an RCCL measurement)")
