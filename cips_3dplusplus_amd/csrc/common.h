@@ -113,6 +113,9 @@ __device__ static inline float sin_hw_direct(float x) {
 __device__ static inline float cos_hw_direct(float x) {
   return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.159154943091895336f));
 }
+// sin(2 pi t): the argument already in revolutions (render kernel with CIPS3D_FILM_REVOLUTIONS: 1 / 2 pi folded into the
+// staged FiLM table)
+__device__ static inline float sin_revolutions(float t) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(t)); }
 #ifdef CIPS3D_EXACT_SINE
 #define cips3d_sin sin_accurate
 #define cips3d_cos cosf

@@ -121,6 +121,20 @@ extern "C" int cips3d_debug_read_clock(unsigned long long* out2) {
 }
 #endif
 
+// CIPS3D_FILM_REVOLUTIONS: the staged FiLM table carries gamma' / 2 pi and c / 2 pi, so that the epilogue's FMA yields the
+// sine argument in revolutions and v_sin_f32(fract(.)) takes it as it is -- one multiplication less per activation.  The extra
+// rounding (of gamma' / 2 pi, once per table entry) perturbs the argument by |x| 2^-24 relative, the size of an ulp of gamma.
+#ifndef CIPS3D_FILM_REVOLUTIONS
+#define CIPS3D_FILM_REVOLUTIONS 1
+#endif
+#if CIPS3D_FILM_REVOLUTIONS && !defined(CIPS3D_EXACT_SINE) && !defined(CIPS3D_REDUCED_SINE)
+#define FILM_UNIT 0.159154943091895336f
+#define FILM_SIN sin_revolutions
+#else
+#define FILM_UNIT 1.f
+#define FILM_SIN cips3d_sin
+#endif
+
 namespace {
 
 struct NerfArgs {
@@ -340,7 +354,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         const f32x4 w2 = *reinterpret_cast<const f32x4*>(s_wc + 2 * H + o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float f = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
+          const float f = FILM_SIN(fmaf(g4[i], acc[tt][i], c4[i]));
           res[tt * 4 + i] = fmaf(wgt, f, FA[sl * R + tt * 4 + i]);
           chead[0] = fmaf(w0[i], f, chead[0]);
           chead[1] = fmaf(w1[i], f, chead[1]);
@@ -348,7 +362,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
+        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = FILM_SIN(fmaf(g4[i], acc[tt][i], c4[i]));
         if (last) {     // h_D: sigma head partial (volume_renderer.py:148) from the fp32 values, before they are split
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
 #pragma unroll
@@ -445,8 +459,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     for (int i = tid; i < L * H; i += WAVES * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
-      s_film[(l * 2) * H + o] = l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm;
-      s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]);
+      s_film[(l * 2) * H + o] = (l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm) * FILM_UNIT;
+      s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]) * FILM_UNIT;
     }
     const float view_scale = scales[2 * (D - 1)];
     for (int i = tid; i < 3 * H; i += WAVES * 64) {
@@ -567,7 +581,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
-          v8[hf * 4 + i] = cips3d_sin(fmaf(g4[i], pre, c4[i]));
+          v8[hf * 4 + i] = FILM_SIN(fmaf(g4[i], pre, c4[i]));
         }
         if (D == 1) {           // no hidden MFMA layer: this is h_D
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
