@@ -40,6 +40,18 @@
 #define cips3d_cos(x) ((x) * 0.001f)
 #endif
 
+// the forward recompute evaluates FiLM + sine like the render kernel (nerf.hip: CIPS3D_FILM_REVOLUTIONS)
+#ifndef CIPS3D_FILM_REVOLUTIONS
+#define CIPS3D_FILM_REVOLUTIONS 1
+#endif
+#if CIPS3D_FILM_REVOLUTIONS && !defined(CIPS3D_EXACT_SINE) && !defined(CIPS3D_REDUCED_SINE)
+#define STASH_FILM_UNIT 0.159154943091895336f
+#define STASH_FILM_SIN sin_revolutions
+#else
+#define STASH_FILM_UNIT 1.f
+#define STASH_FILM_SIN cips3d_sin
+#endif
+
 namespace {
 
 struct FusedArgs {
@@ -192,15 +204,18 @@ __device__ __forceinline__ Ray make_ray(const cips3d_nerf_bwd_geom& G, int b, in
 }
 
 // stage the FiLM table of view b: s_film[l][0][o] = gamma' (gamma 2^-s for the MFMA layers), s_film[l][1][o] = gamma bias + beta
-__device__ __forceinline__ void stage_film(const cips3d_nerf_bwd_fused_params& P, int b, int H, int D, float* s_film, int tid) {
+// `unit`: 1 for radians (the backward kernel: its y = uc gamma' needs gamma' itself), 1 / 2 pi for the forward recompute, which
+// evaluates the sines exactly as the render kernel does (nerf.hip, CIPS3D_FILM_REVOLUTIONS) so that both fill the same stash
+__device__ __forceinline__ void stage_film(const cips3d_nerf_bwd_fused_params& P, int b, int H, int D, float* s_film, int tid,
+                                           float unit = 1.f) {
   const int L = D + 1;
   const float* film_b = P.film + (int64_t)b * L * 2 * H;
   const float* scales = P.packed + (int64_t)D * H * H;
   for (int i = tid; i < L * H; i += WAVES * 64) {
     const int l = i / H, o = i - l * H;
     const float gm = film_b[(l * 2) * H + o];
-    s_film[(l * 2) * H + o] = l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm;
-    s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]);
+    s_film[(l * 2) * H + o] = (l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm) * unit;
+    s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]) * unit;
   }
 }
 
@@ -308,7 +323,7 @@ __device__ __forceinline__ void stash_layer(const h8 (&Xh)[NT / 2], const h8 (&X
         const f32x4 d4 = *reinterpret_cast<const f32x4*>(dF_ray + o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float f = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
+          const float f = STASH_FILM_SIN(fmaf(g4[i], acc[tt][i], c4[i]));
           gdot = fmaf(d4[i], f, gdot);
           chead[0] = fmaf(w0[i], f, chead[0]);
           chead[1] = fmaf(w1[i], f, chead[1]);
@@ -316,7 +331,7 @@ __device__ __forceinline__ void stash_layer(const h8 (&Xh)[NT / 2], const h8 (&X
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = cips3d_sin(fmaf(g4[i], acc[tt][i], c4[i]));
+        for (int i = 0; i < 4; ++i) res[tt * 4 + i] = STASH_FILM_SIN(fmaf(g4[i], acc[tt][i], c4[i]));
         if (last) {
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
 #pragma unroll
@@ -379,7 +394,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_stash_kernel(FusedArgs a) 
   const int N = G.n_samples;
   const int64_t Pn = (int64_t)R * N;
   const int ray = g * RAYS + pl;                       // R % 16 == 0: always a valid ray
-  stage_film(P, b, H, D, s_film, tid);
+  stage_film(P, b, H, D, s_film, tid, STASH_FILM_UNIT);
   for (int i = tid; i < 10 * H; i += WAVES * 64) s_tab[i] = a.tables[i];
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
@@ -427,7 +442,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_stash_kernel(FusedArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
-          v8[hf * 4 + i] = cips3d_sin(fmaf(g4[i], pre, c4[i]));
+          v8[hf * 4 + i] = STASH_FILM_SIN(fmaf(g4[i], pre, c4[i]));
         }
         if (D == 1) {
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
