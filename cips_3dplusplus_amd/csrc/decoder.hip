@@ -903,6 +903,9 @@ struct FusedArgs {
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
 // store is serial, so throughput comes from co-resident workgroups).
+#ifndef CIPS3D_C128_LATE
+#define CIPS3D_C128_LATE true
+#endif
 #ifndef CIPS3D_C64_MINW
 #define CIPS3D_C64_MINW 4
 #endif
@@ -1608,7 +1611,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
     // (last template flag: epilogue operands requested after the MFMAs -- at C = 64 / 128 that removes the spills of the
     // chained form, -2 us / neutral; at C = 256 it measured +1 us and stays off)
     return C == 64    ? launch_fused<64, 2, 2, 2, 1, 16, CIPS3D_C64_MINW, true, true, true>(a, st)
-           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false, true>(a, st)
+           : C == 128 ? launch_fused<128, 4, 2, 2, 1, 32, 2, true, false, CIPS3D_C128_LATE>(a, st)
                       : launch_fused<256, 2, 8, 1, 2, 64, 2, true, true>(a, st);
   switch (C) {
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
