@@ -445,6 +445,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int S = P.img_size;
   const int R = P.n_rays > 0 ? P.n_rays : S * S;
   const int ray = g * RAYS + pl;
+  // the lane's ray re-derived where it is needed after the set-up (sdf / per-point stores, the chunk partial): kept in a
+  // register across the sample loop it was the kernel's one scratch spill (8 bytes a lane written by every wave)
+  auto ray_again = [&]() -> int {
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return g * RAYS + (t & 15);
+  };
   const bool ray_ok = task_ok && ray < R;
   const int rayc = ray < R ? ray : R - 1;
 
@@ -503,7 +510,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
   const float dnorm = sqrtf((dx * dx + dy * dy) + dz * dz);
   const float u = (P.perturb_u && !explicit_geom) ? P.perturb_u[bray] : 0.f;
-  const float* xz = explicit_geom ? P.x_z_vals + bray * P.n_samples : nullptr;
   // Wave-uniform floats that come out of the VALU live in VGPRs and, under this kernel's register pressure, get spilled
   // to scratch and reloaded one dependent round trip at a time at every sample start: pin them in SGPRs.
   auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
@@ -517,7 +523,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     return nearv * (1.f - t) + farv * t;
   };
   auto zsample = [&](int k) -> float {
-    if (xz) return xz[k < N ? k : N - 1];
+    if (explicit_geom) {         // (opaque row index: the 64-bit row pointer would be a loop-invariant scratch spill)
+      int64_t br = bray;
+      asm volatile("" : "+v"(br));
+      return P.x_z_vals[br * N + (k < N ? k : N - 1)];
+    }
     const float z0 = zbase(k);
     return P.perturb_u ? z0 + (zbase(k + 1) - z0) * u : z0;
   };
@@ -630,13 +640,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     ax = fmaf(w, ptx, ax); ay = fmaf(w, pty, ay); az = fmaf(w, ptz, az);
     if (sg == N - 1) wlast = w;
     if (P.sdf && live && qd == 0) {
-      int ray_o = ray;                       // (opaque: keeps the 64-bit per-lane address out of the loop-invariant spills)
-      asm volatile("" : "+v"(ray_o));
-      P.sdf[((int64_t)b * R + ray_o) * N + sg] = sdf;
+      P.sdf[((int64_t)b * R + ray_again()) * N + sg] = sdf;
     }
     if constexpr (STASH) {
       if (live && qd == 0) {     // per-point inputs of the compositing backward, p = sample * R + ray
-        const int64_t Pn = (int64_t)R * N, p = (int64_t)sg * R + ray;
+        const int64_t Pn = (int64_t)R * N, p = (int64_t)sg * R + ray_again();
         P.bwd_sdf[(int64_t)b * Pn + p] = sdf;
         P.bwd_crgb[((int64_t)b * 3 + 0) * Pn + p] = c0;
         P.bwd_crgb[((int64_t)b * 3 + 1) * Pn + p] = c1;
@@ -742,18 +750,19 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
   // ---- write the chunk partial: part[c][b][ch][ray]
   if (ray_ok) {
-    int ray_o = ray;
-    asm volatile("" : "+v"(ray_o));
+    int tid_o = threadIdx.x;               // (opaque: the lane's ray and quarter are re-derived, not kept across the loop)
+    asm volatile("" : "+v"(tid_o));
+    const int ray_o = g * RAYS + (tid_o & 15), qe = (tid_o >> 4) & 3;
     float* dst = P.part + ((int64_t)(c * P.B + b) * (H + 8)) * R + ray_o;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) dst[(int64_t)(t * 16 + 4 * qd + r) * R] = FA[t * 4 + r];
-    if (qd == 0) {
+      for (int r = 0; r < 4; ++r) dst[(int64_t)(t * 16 + 4 * qe + r) * R] = FA[t * 4 + r];
+    if (qe == 0) {
       dst[(int64_t)(H + 0) * R] = cr; dst[(int64_t)(H + 1) * R] = cg;
-    } else if (qd == 1) {
+    } else if (qe == 1) {
       dst[(int64_t)(H + 2) * R] = cb; dst[(int64_t)(H + 3) * R] = ax;
-    } else if (qd == 2) {
+    } else if (qe == 2) {
       dst[(int64_t)(H + 4) * R] = ay; dst[(int64_t)(H + 5) * R] = az;
     } else {
       dst[(int64_t)(H + 6) * R] = wlast; dst[(int64_t)(H + 7) * R] = T;
