@@ -113,6 +113,10 @@ _SIGS = {
     "cips3d_from_planes": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_modconv1x1_planes": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64,
                                          c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "cips3d_to_planes16": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_from_planes16": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_modconv1x1_planes16": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p,
+                                           c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "cips3d_modconv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cips3d_modconv3x3": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_int, c_f32p,
                                   c_i64, c_f32p, c_f32p, C.c_void_p]),
@@ -156,7 +160,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 11           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 12           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

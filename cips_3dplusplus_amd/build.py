@@ -55,9 +55,13 @@ def up_to_date():
         return fh.read().strip() == source_hash()
 
 
+# per-file flags (chain.hip: see the build note in its header)
+FILE_FLAGS = {"chain.hip": ["-fno-slp-vectorize"]}
+
+
 def _compile(src, keep_temps):
     obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-    cmd = [hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    cmd = [hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     if keep_temps:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ)

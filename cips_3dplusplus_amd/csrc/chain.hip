@@ -19,6 +19,19 @@
 //
 // Bound: L2 -> LDS bytes (64 x 128 tiles: 384 KB per workgroup and layer) + the launch skeleton; the matrix time is ~1/5 of
 // the fp32 MFMA's.
+//
+// bf16 decoder mode (BASELINE config 3; NP = 1 below): the same kernel on ONE plane of bf16 -- "planes16",
+// P16[b][C/8][HW][8] (bf16), weights cips3d_modulate_weights(CIPS3D_MOD_PACKED | CIPS3D_MOD_BF16) -- and one
+// v_mfma_f32_16x16x32_bf16 per k-block and tile: half the operand bytes of a launch that is bound by them.  The mode's
+// definition (both GEMM operands rounded to bf16, fp32 accumulation; oracle/path.py:modulated_conv2d bf16_gemm) makes the
+// stored bf16 activation exactly the operand the next layer's GEMM would have rounded to, so nothing changes numerically
+// against the fp32-stored form of the mode; the folded ToRGB still reads the unrounded fp32 registers.
+//
+// Build note: this file is compiled with -fno-slp-vectorize (build.py).  With SLP on, hipcc pairs the ToRGB fold's channel-1 /
+// channel-2 accumulations into v_pk_fma_f32 chains; in the bf16 kernel (two workgroups per CU) the LOW lane of those chains
+// (channel 2) then came out wrong for isolated 16-pixel column tiles, differently from run to run (tools: 300-600 of 393k
+// partial sums per launch at batch 4; never with one workgroup per CU, never with scalar FMAs; the LDS exchange and the
+// operand loads were ruled out one by one).  Scalar FMAs cost nothing measurable here.
 #include <stdlib.h>
 #include "common.h"
 
@@ -28,6 +41,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
 
 constexpr float kSplitInv = 1.f / 256.f;       // the modulate kernel scaled the weights by 2^8
 
@@ -49,16 +63,17 @@ extern "C" int cips3d_debug_read_chain_stamps(unsigned long long* out8) {
 #endif
 
 struct ChainArgs {
-  const _Float16* x;        // planes [B][Cin/8][2][HW][8]
-  const float* wmp;         // split-packed weights
-  void* out;                // planes (out_fmt 1), fp32 NCHW (0) or bf16 NCHW (2)
+  const _Float16* x;        // planes [B][Cin/8][2][HW][8] (fp16 hi / lo), or planes16 [B][Cin/8][HW][8] (bf16; NP = 1)
+  const float* wmp;         // split-packed (NP = 2) or bf16-packed (NP = 1) weights
+  void* out;                // planes (out_fmt 1), fp32 NCHW (0), bf16 NCHW (2) or planes16 (3)
   int out_fmt;
   int B, Cin, Cout; int HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
   const float* rgb_w; float* rgb_part;
 };
 
-template <int WM, int WGM, int WGN, int BK, int NS>
+// NP = planes per operand: 2 = split-fp16 (hi, lo; three fp16 MFMAs per tile and k-block), 1 = bf16 (one bf16 MFMA)
+template <int WM, int WGM, int WGN, int BK, int NS, int NP = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a) {
 #ifdef CIPS3D_CHAIN_STAMPS
   unsigned long long ts_[6];
@@ -66,10 +81,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #endif
   constexpr int NW = WGM * WGN;
   constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
-  constexpr int A_STAGE = BM * BK, B_STAGE = BK * BN, STAGE = A_STAGE + B_STAGE;     // floats (4-byte hi/lo pairs)
+  constexpr int A_STAGE = BM * BK * NP / 2, B_STAGE = BK * BN * NP / 2, STAGE = A_STAGE + B_STAGE;   // floats (NP 2-byte planes)
   constexpr int A_PIECES = A_STAGE / 256, B_PIECES = B_STAGE / 256, PIECES = A_PIECES + B_PIECES;
   constexpr int PW = PIECES / NW;
-  constexpr int KQ = BK / 16, KB = BK / 32;
+  constexpr int KB = BK / 32, KQ = KB * NP;      // KQ = 1 KB A pieces per o-tile and stage
   static_assert(PIECES % NW == 0 && BK % 32 == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
 
@@ -82,8 +97,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int HW = a.HW, K = a.Cin;
   const int nstage = K / BK;
-  const _Float16* xb = a.x + (int64_t)b * K * HW * 2;            // (Cin/8) * 2 planes * HW * 8 halves
-  const float* ab = a.wmp + (int64_t)b * a.Cout * K;
+  const _Float16* xb = a.x + (int64_t)b * K * HW * NP;           // (Cin/8) * NP planes * HW * 8 two-byte elements
+  const float* ab = a.wmp + (int64_t)b * a.Cout * K * NP / 2;   // 2-byte elements, NP planes
 
   auto stage_load = [&](int st) {
     float* dstA = lds + (st % NS) * STAGE;
@@ -94,15 +109,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       const int piece = j * NW + wave;
       if (piece < A_PIECES) {
         const int ot_l = piece / KQ, kq_l = piece % KQ;
-        const float* src = ab + ((((m0 >> 4) + ot_l) * (K >> 4) + (k0 >> 4) + kq_l) * 256 + lane * 4);
+        const float* src = ab + ((((m0 >> 4) + ot_l) * ((K >> 5) * NP) + (k0 >> 5) * NP + kq_l) * 256 + lane * 4);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
       } else {
         const int pb = piece - A_PIECES;
-        const int row = pb / (BN / 64), chunk = pb % (BN / 64);     // row = (channel block of the stage) * 2 + plane
+        const int row = pb / (BN / 64), chunk = pb % (BN / 64);     // row = (channel block of the stage) * NP + plane
         int n = n0 + chunk * 64 + lane;
         if (n > HW - 1) n = HW - 1;                                  // clamp: those columns are never stored
-        const _Float16* src = xb + (((int64_t)((k0 >> 3) * 2 + row) * HW + n) * 8);
+        const _Float16* src = xb + (((int64_t)((k0 >> 3) * NP + row) * HW + n) * 8);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
       }
@@ -188,31 +203,52 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
     PSTAMP(1);                         // DMA issue
     const float* sA = lds + (st % NS) * STAGE;
     const float* sB = sA + A_STAGE;
-    h8 ah[KB][WM], al[KB][WM], bh[KB][4], bl[KB][4];
+    if constexpr (NP == 2) {
+      h8 ah[KB][WM], al[KB][WM], bh[KB][4], bl[KB][4];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
+      for (int kb = 0; kb < KB; ++kb) {
 #pragma unroll
-      for (int i = 0; i < WM; ++i) {
-        ah[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb) * 256 + lane * 4);
-        al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {      // row (4 kb + q) * 2 + plane, pixel nl + 16 c: [row][BN px][4 floats]
-        bh[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 0) * BN + nl + 16 * c) * 4);
-        bl[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 1) * BN + nl + 16 * c) * 4);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-      for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
-          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl[kb][c], acc[i][c], 0, 0, 0);
-          acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+        for (int i = 0; i < WM; ++i) {
+          ah[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb) * 256 + lane * 4);
+          al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
         }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // row (4 kb + q) * 2 + plane, pixel nl + 16 c: [row][BN px][4 floats]
+          bh[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 0) * BN + nl + 16 * c) * 4);
+          bl[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 1) * BN + nl + 16 * c) * 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl[kb][c], acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+          }
+    } else {
+      bf8 af[KB][WM], bf[KB][4];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          af[kb][i] = *reinterpret_cast<const bf8*>(sA + ((wm_i * WM + i) * KQ + kb) * 256 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)        // row 4 kb + q (channel block), pixel nl + 16 c
+          bf[kb][c] = *reinterpret_cast<const bf8*>(sB + ((kb * 4 + q) * BN + nl + 16 * c) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][i], bf[kb][c], acc[i][c], 0, 0, 0);
+    }
     PSTAMP(2);                         // fragment reads + MFMA issue
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -232,7 +268,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = acc[i][c][r] * kSplitInv;
+        v[r] = NP == 2 ? acc[i][c][r] * kSplitInv : acc[i][c][r];
         if (a.epilogue == 1) v[r] = lrelu02((v[r] + nz[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
       }
       if (a.rgb_part) {
@@ -256,6 +292,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
                           ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
           *reinterpret_cast<h4*>(dst) = hi;
           *reinterpret_cast<h4*>(dst + (int64_t)HW * 8) = lo;
+        } else if (a.out_fmt == 3) {
+          // planes16: the same channel block / element positions, one bf16 plane (round to nearest even: the operand rounding
+          // of the bf16 mode)
+          unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) +
+                                (((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * HW + npx[c]) * 8 + 4 * (q & 1);
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const bf16x2_t p0 = __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t);
+          const bf16x2_t p1 = __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t);
+          *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
         } else if (a.out_fmt == 2) {
           unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -354,6 +401,42 @@ __global__ void __launch_bounds__(256) from_planes_kernel(const _Float16* __rest
   }
 }
 
+// fp32 [B][C][HW] -> planes16 [B][C/8][HW][8] (bf16, round to nearest even) and back (exact)
+__global__ void __launch_bounds__(256) to_planes16_kernel(const float* __restrict__ x, unsigned short* __restrict__ p, int B,
+                                                          int C, int HW) {
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int64_t total = (int64_t)B * (C / 8) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % HW);
+    const int64_t bc = i / HW;               // b * (C/8) + cb
+    u32x4_t w;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const bf16x2_t pr = __builtin_convertvector(f32x2_t{x[(bc * 8 + e) * HW + n], x[(bc * 8 + e + 1) * HW + n]}, bf16x2_t);
+      w[e >> 1] = __builtin_bit_cast(unsigned, pr);
+    }
+    *reinterpret_cast<u32x4_t*>(p + (bc * HW + n) * 8) = w;
+  }
+}
+
+__global__ void __launch_bounds__(256) from_planes16_kernel(const unsigned short* __restrict__ p, float* __restrict__ x, int B,
+                                                            int C, int HW) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const int64_t total = (int64_t)B * (C / 8) * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % HW);
+    const int64_t bc = i / HW;
+    const u32x4_t w = *reinterpret_cast<const u32x4_t*>(p + (bc * HW + n) * 8);
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      x[(bc * 8 + e) * HW + n] = __uint_as_float(w[e >> 1] << 16);
+      x[(bc * 8 + e + 1) * HW + n] = __uint_as_float(w[e >> 1] & 0xffff0000u);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int cips3d_planes_supported(int Cin, int Cout, int64_t HW) {
@@ -380,6 +463,52 @@ extern "C" int cips3d_from_planes(const void* planes, float* x, int B, int C, in
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const _Float16*>(planes), x, B, C, (int)HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_to_planes16(const float* x, void* planes16, int B, int C, int64_t HW, void* stream) {
+  if (!x || !planes16 || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (C % 8 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(to_planes16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
+                     reinterpret_cast<unsigned short*>(planes16), B, C, (int)HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_from_planes16(const void* planes16, float* x, int B, int C, int64_t HW, void* stream) {
+  if (!x || !planes16 || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (C % 8 != 0) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(from_planes16_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned short*>(planes16), x, B, C, (int)HW);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* wm, void* out, int out_format, int B, int Cin,
+                                          int Cout, int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
+                                          const float* noise_w, const float* bias, const float* rgb_w, float* rgb_part,
+                                          int* n_row_blocks, void* stream) {
+  if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
+  static const int cfg = getenv("CIPS3D_CHAIN16_CFG") ? atoi(getenv("CIPS3D_CHAIN16_CFG")) : 0;   // A/B knob
+  if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / 64 : 0;
+  if (!x_planes16 || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if ((out_format != 0 && out_format != 2 && out_format != 3) || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && !bias))
+    return CIPS3D_E_BADARG;
+  if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  ChainArgs a{reinterpret_cast<const _Float16*>(x_planes16), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
+              noise_bstride, noise_w, bias, rgb_w, rgb_part};
+  // 64 x 128 tiles, 64-deep stages of 24 KB in a 3-slot ring (72 KB: two workgroups per CU).  Same-box sweep (rocprofv3, 512 -> 512
+  // at 64^2): batch 1 7.45 us / batch 4 17.4 us; a 2-slot ring 8.0 / 17.5; 128-deep stages 7.4 / 24.2 (one workgroup per CU);
+  // 128 x 128 tiles (2/3 of the operand bytes per flop) 9.6 / 19.8; 64 x 64 tiles 7.5 / 19.9.
+  dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
+  if (cfg == 1) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2, 1>), grid, dim3(512), 0, as_stream(stream), a);
+  else if (cfg == 2) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 128, 2, 1>), grid, dim3(512), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 3, 1>), grid, dim3(512), 0, as_stream(stream), a);
   return cips3d_launch_status();
 }
 

@@ -116,6 +116,8 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
 //   packed + split (ksq == 1, Cin % 32 == 0; CIPS3D_MOD_SPLIT): A fragments of v_mfma_f32_16x16x32_f16, hi and lo fp16 halves of
 //           2^8 wm:  wms[b][ot][kb][plane][lane][j] (fp16) = plane(2^8 wm[b][ot*16 + (lane&15)][32 kb + 8 (lane>>4) + j]) -- one
 //           o-tile x 32-channel block = 2 x 1 KiB = the bytes of the two fp32 k-groups it replaces (same LDS-DMA pieces)
+//   packed + bf16 (ksq == 1, Cin % 32 == 0; CIPS3D_MOD_BF16): A fragments of v_mfma_f32_16x16x32_bf16 in the same positions,
+//           one plane of bf16(wm) (round to nearest even), unscaled: wmb[b][ot][kb][lane][j] -- for cips3d_modconv1x1_planes16
 //   packed, ksq == 9 (the 3x3 implicit GEMM, conv3x3.hip): the same fragment order per tap, tap-major:
 //           wmp[b][t'][ot][kq][lane][j], t' = t, or 8 - t with CIPS3D_MOD_FLIP (the transposed conv of the up-sampling branch)
 // ------------------------------------------------------------------------------------------------
@@ -166,6 +168,12 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
       blk[((q << 4) | (o & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
+    } else if (packed & 128) {    // bf16 fragments of v_mfma_f32_16x16x32_bf16 (ksq == 1): the split layout's positions, one plane
+      const int i = e;
+      const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;
+      const __bf16 r = (__bf16)v;                                            // round to nearest even (the bf16 mode's operand rounding)
+      unsigned short* blk = reinterpret_cast<unsigned short*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 512);
+      blk[((q << 4) | (o & 15)) * 8 + j] = __builtin_bit_cast(unsigned short, r);
     } else if (packed & 64) {     // fragments of wm^T (ksq == 1): row = input channel, k = output unit (backward.hip:pack_kernel)
       const int i = e;
       wm[(((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 4) + (o >> 4)) * 256 + (((o & 3) << 4) | (i & 15)) * 4 + ((o >> 2) & 3)] = v;
@@ -223,7 +231,7 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
   }
   const cips3d_modulate_desc d = table[lo];
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 120)) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 248)) : 0, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1447,11 +1455,12 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if (!W || !s || !wm || B < 0 || Cout <= 0 || Cin <= 0 || ksq <= 0) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   // negative ksq is not used; the packed layout is selected with the high bit of `demodulate`
-  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 120)) : 0;   // bit 3: flipped taps, bit 4: split-fp16, bit 5: split16, bit 6: transposed
+  const int packed = (demodulate & 2) ? (((demodulate & 4) ? 2 : 1) | (demodulate & 248)) : 0;   // bit 3: flipped taps, bit 4: split-fp16, bit 5: split16, bit 6: transposed, bit 7: bf16
   if ((packed & 32) && (ksq != 1 || (packed & 24))) return CIPS3D_E_UNSUPP;
   if ((packed & 64) && (ksq != 1 || (packed & 63) != 1)) return CIPS3D_E_UNSUPP;
   if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
   if ((packed & 16) && (ksq != 1 || (packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
+  if ((packed & 128) && (ksq != 1 || (packed & 127) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
   if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;
   const int64_t rows = (int64_t)B * Cout;
   hipLaunchKernelGGL(modulate_kernel, dim3((unsigned)ceil_div<int64_t>(rows, 4)), dim3(256), 0, as_stream(stream), W,

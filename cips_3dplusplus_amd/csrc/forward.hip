@@ -105,15 +105,21 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   np.o_features = P.features; np.o_thumb = IO.thumb; np.o_xyz = IO.xyz; np.o_mask = IO.mask;
   const bool fused_finish = cips3d_nerf_fuses_finish(&np) != 0;
   // the first decoder layer reads split-fp16 planes (flags bit 2): the render kernel's fused finish writes them directly,
-  // the stand-alone finish writes fp32 into the spare activation buffer and a conversion pass follows
+  // the stand-alone finish writes fp32 into the spare activation buffer and a conversion pass follows.  bf16 planes16
+  // (flags bit 5) always take the conversion pass.
   const bool feat_planes = (P.layers[0].flags & 4) != 0;
-  np.features_planes = (feat_planes && fused_finish) ? 1 : 0;
+  const bool feat_p16 = feat_planes && (P.layers[0].flags & 32) != 0;
+  np.features_planes = (feat_planes && !feat_p16 && fused_finish) ? 1 : 0;
+  float* feat32 = (feat_planes && !np.features_planes) ? P.act[1] : P.features;
+  np.o_features = feat32;
   TRY(cips3d_nerf_render(&np, stream));
   if (IO.ev_nerf_stop) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_stop), as_stream(stream));
-  if (!fused_finish) {
-    float* feat32 = feat_planes ? P.act[1] : P.features;
+  if (!fused_finish)
     TRY(cips3d_nerf_finish(np.part, np.n_chunks, B, np.img_size, np.hidden, feat32, IO.thumb, IO.xyz, IO.mask, stream));
-    if (feat_planes) TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, (int64_t)np.img_size * np.img_size, stream));
+  if (feat_planes && !np.features_planes) {
+    const int64_t hw0 = (int64_t)np.img_size * np.img_size;
+    if (feat_p16) TRY(cips3d_to_planes16(feat32, P.features, B, np.hidden, hw0, stream));
+    else TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, hw0, stream));
   }
 
   // ---- decoder (model_v3.py:592-637)
@@ -159,7 +165,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
         if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
         if (!ylo_ready) {
-          if (L.flags & 4)       // the run's last activation arrives as planes
+          if ((L.flags & 4) && (L.flags & 32))       // the run's last activation arrives as planes16 (bf16 mode)
+            TRY(cips3d_modconv1x1_planes16(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+          else if (L.flags & 4)  // ... as split-fp16 planes
             TRY(cips3d_modconv1x1_planes(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, stream));
           else
@@ -199,12 +208,18 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const bool fold = has_rgb && li + 1 != P.n_dec_layers - 1 && T->Cin == L.Cout && P.rgb_part &&
                           fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
                           (fold_slots == 0 || (fold_H == L.H && fold_W == L.W));
-        const int fmt = (L.flags & 8) ? 1 : 0;          // planes for the next layer of the run, or fp32 when the run ends here
-        if (!(L.flags & 2) || (fmt == 1 && has_rgb && !fold)) return CIPS3D_E_BADARG;   // the plan promised otherwise
+        const bool p16 = (L.flags & 32) != 0;           // bf16 mode: planes16 and CIPS3D_MOD_BF16 weights
+        const int fmt = (L.flags & 8) ? (p16 ? 3 : 1) : 0;   // planes for the next layer of the run, or fp32 when the run ends here
+        if ((!p16 && !(L.flags & 2)) || (fmt != 0 && has_rgb && !fold)) return CIPS3D_E_BADARG;   // the plan promised otherwise
         int nblk = 0;
-        TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
-                                     fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
-                                     stream));
+        if (p16)
+          TRY(cips3d_modconv1x1_planes16(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
+                                         fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr,
+                                         &nblk, stream));
+        else
+          TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
+                                       fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
+                                       stream));
         if (fold) {
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;

@@ -19,6 +19,7 @@ MOD_FLIP = 8          # with MOD_PACKED and ksq = 9: taps stored 180 degrees rot
 MOD_SPLIT = 16        # with MOD_PACKED and ksq = 1: fp16 hi + lo fragments of 2^8 wm for the split-fp16 GEMM mode (GEMM_SPLIT)
 MOD_SPLIT16 = 32      # with MOD_PACKED [| MOD_CHAINED]: split-fp16 fragments for the fused up-sampling stage (16-channel k-groups)
 MOD_TRANSPOSE = 64    # with MOD_PACKED and ksq = 1 (fp32 fragments): the packed form of wm^T (data-gradient GEMM operand)
+MOD_BF16 = 128        # with MOD_PACKED and ksq = 1: bf16 A fragments for modconv1x1_planes16 (bf16 decoder mode)
 
 # bench.py sets this to a list to collect (start, end) event pairs around the dominant kernel's launch;
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -344,12 +345,12 @@ def nerf_finish(part, n_chunks, B, img_size, hidden, n_rays=None):
 
 
 def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packed, s_offset=0, out=None, flip=False,
-                     split=False):
+                     split=False, bf16=False):
     lib = _lib.load()
     if out is None:
         out = torch.empty(B * Cout * Cin * ksq, device=W.device, dtype=torch.float32)
     flags = ((MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0) | (MOD_FLIP if flip else 0) |
-             (MOD_SPLIT if split else 0))
+             (MOD_SPLIT if split else 0) | (MOD_BF16 if bf16 else 0))
     check(lib.cips3d_modulate_weights(dev_ptr(W, "W"), dev_ptr(s, "s") + 4 * s_offset, s_stride, dev_ptr(out), B, Cout, Cin,
                                       ksq, float(scale), flags, stream_ptr()), "cips3d_modulate_weights")
     return out
@@ -469,6 +470,46 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
                                        dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), None, stream_ptr()),
           "cips3d_modconv1x1_planes")
     return out
+
+
+def to_planes16(x):
+    """fp32 [B,C,H,W] -> planes16 (torch.bfloat16 tensor [B, C/8, H*W, 8]; round to nearest even)."""
+    lib = _lib.load()
+    B, Cc, H, W = x.shape
+    p = torch.empty(B, Cc // 8, H * W, 8, device=x.device, dtype=torch.bfloat16)
+    check(lib.cips3d_to_planes16(dev_ptr(x, "x"), p.data_ptr(), B, Cc, H * W, stream_ptr()), "cips3d_to_planes16")
+    return p
+
+
+def from_planes16(p, H, W):
+    lib = _lib.load()
+    B, C8 = p.shape[0], p.shape[1]
+    x = torch.empty(B, C8 * 8, H, W, device=p.device, dtype=torch.float32)
+    check(lib.cips3d_from_planes16(dev_ptr(p, "planes16", dtype=torch.bfloat16), dev_ptr(x), B, C8 * 8, H * W, stream_ptr()),
+          "cips3d_from_planes16")
+    return x
+
+
+def modconv1x1_planes16(xp, wm_bf16, Cout, HW, out_format="planes16", epilogue=0, noise=None, noise_w=None, bias=None,
+                        rgb_w=None, rgb_part=None):
+    """1x1 modulated conv of the bf16 decoder mode on planes16 (csrc/chain.hip, NP = 1).  xp from to_planes16 / a previous
+    call; wm_bf16 from modulate_weights(..., packed=True, bf16=True).  out_format: "planes16" | "fp32" | "bf16" ([B,Cout,HW]).
+    Returns (out, number of rgb_part row-block slots written)."""
+    lib = _lib.load()
+    B, Cin = xp.shape[0], xp.shape[1] * 8
+    fmt = {"fp32": 0, "bf16": 2, "planes16": 3}[out_format]
+    if fmt == 3:
+        out = torch.empty(B, Cout // 8, HW, 8, device=xp.device, dtype=torch.bfloat16)
+    else:
+        out = torch.empty(B, Cout, HW, device=xp.device, dtype=torch.bfloat16 if fmt == 2 else torch.float32)
+    nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    nblk = C.c_int(0)
+    check(lib.cips3d_modconv1x1_planes16(dev_ptr(xp, "x_planes16", dtype=torch.bfloat16), dev_ptr(wm_bf16, "wm"), out.data_ptr(),
+                                         fmt, B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
+                                         dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
+                                         dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), C.byref(nblk),
+                                         stream_ptr()), "cips3d_modconv1x1_planes16")
+    return out, nblk.value
 
 
 def modconv3x3_supported(Cin, Cout, H, W, up):

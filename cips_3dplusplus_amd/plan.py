@@ -54,6 +54,8 @@ CHAIN_STAGES = os.environ.get("CIPS3D_CHAIN_STAGES", "1") != "0"
 # The run of StyledConvs at the NeRF resolution keeps its activations as split-fp16 planes (csrc/chain.hip); 0 = every layer
 # reads / writes fp32 and splits in registers (A/B knob)
 PLANES_RUN = os.environ.get("CIPS3D_PLANES", "1") != "0"
+# ... and as one bf16 plane in the bf16 decoder modes (cips3d_modconv1x1_planes16); 0 = fp32 activations, rounded in registers
+PLANES16_RUN = os.environ.get("CIPS3D_PLANES16", "1") != "0"
 
 
 class PlanUnsupported(RuntimeError):
@@ -180,16 +182,20 @@ class ForwardPlan:
         # The run of equal-resolution StyledConvs at the NeRF resolution keeps its activations as split-fp16 planes
         # (csrc/chain.hip): the render kernel writes the feature map as planes, every layer of the run reads and writes them,
         # the ToRGBs in between are folded from registers, and the first up-sampling conv's low-resolution GEMM reads them.
-        if use_split and PLANES_RUN:
+        # In the bf16 modes the run keeps ONE bf16 plane ("planes16", cips3d_modconv1x1_planes16): the stored activation is the
+        # rounded operand of the next GEMM, so the mode's results do not change while its operand bytes halve.
+        use_p16 = bool(getattr(dec, "bf16", False)) and PLANES16_RUN
+        if (use_split and PLANES_RUN) or use_p16:
             hw = img_size * img_size
-            ok_conv = lambda c: (c is not None and c.get("split") and c["kind"] in (0, 1) and c["H"] == img_size   # noqa: E731
+            mine = (lambda c: c["packed"] and not c.get("chained")) if use_p16 else (lambda c: c.get("split"))  # noqa: E731
+            ok_conv = lambda c: (c is not None and mine(c) and c["kind"] in (0, 1) and c["H"] == img_size   # noqa: E731
                                  and bool(lib.cips3d_planes_supported(c["Cin"], c["Cout"], hw)))
             i, n_fold = 0, 0
             while i < len(layer_info) and ok_conv(layer_info[i]):
                 li = layer_info[i]
                 if li["kind"] == 1:
                     if fused_stage(i):
-                        li["planes_in"] = True
+                        li["planes_in"], li["p16"] = True, use_p16
                     break
                 nxt = layer_info[i + 1] if i + 1 < len(layer_info) else None
                 has_rgb = nxt is not None and nxt["kind"] == 2
@@ -197,7 +203,7 @@ class ForwardPlan:
                 j = i + (2 if has_rgb else 1)
                 nconv = layer_info[j] if j < len(layer_info) else None
                 next_takes = ok_conv(nconv) and (nconv["kind"] == 0 or fused_stage(j))
-                li["planes_in"] = True
+                li["planes_in"], li["p16"] = True, use_p16
                 li["planes_out"] = bool(next_takes and (not has_rgb or foldable))
                 if has_rgb and foldable:
                     n_fold += 1
@@ -217,7 +223,7 @@ class ForwardPlan:
             d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
             d.flags = (hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if info["packed"] else 0) | (
                 hip.MOD_CHAINED if info.get("chained") else 0) | (hip.MOD_SPLIT if info.get("split") else 0) | (
-                hip.MOD_SPLIT16 if info.get("split16") else 0)
+                hip.MOD_SPLIT16 if info.get("split16") else 0) | (hip.MOD_BF16 if info.get("p16") else 0)
             d.scale = conv.scale
             d.row_begin = rows
             rows += conv.out_channel
@@ -225,7 +231,8 @@ class ForwardPlan:
             L.kind, L.Cin, L.Cout, L.H, L.W, L.noise_index = (info["kind"], info["Cin"], info["Cout"], info["H"],
                                                               info["W"], info["noise_index"])
             L.flags = ((1 if info.get("chained") else 0) | (2 if info.get("split") else 0) | (4 if info.get("planes_in") else 0) |
-                       (8 if info.get("planes_out") else 0) | (16 if info.get("split16") else 0))
+                       (8 if info.get("planes_out") else 0) | (16 if info.get("split16") else 0) |
+                       (32 if info.get("p16") else 0))
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 11  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 12  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -238,6 +238,9 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
 /* with CIPS3D_MOD_PACKED and ksq == 1 (fp32 fragments only): the packed form of wm^T ([Cin x Cout]: the A operand of the
  * data-gradient GEMM dx = wm^T dy) instead of wm's -- what cips3d_pack_weights(transpose = 1) makes from the plain matrix */
 #define CIPS3D_MOD_TRANSPOSE  64
+/* with CIPS3D_MOD_PACKED and ksq == 1 (Cin % 32 == 0): bf16 A fragments (bf16(wm), round to nearest even, unscaled) for
+ * cips3d_modconv1x1_planes16 -- the bf16 decoder mode's form of CIPS3D_MOD_SPLIT */
+#define CIPS3D_MOD_BF16       128
 /* OR-ed into `epilogue` of cips3d_modconv1x1 / into `skip_up` of cips3d_fused_up_conv: bf16 compute mode of the GEMM
  * (operands rounded to bf16 in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulate; storage stays fp32).  This is the
  * decoder precision of BASELINE config 3; the default (flag absent) is exact fp32. */
@@ -363,6 +366,18 @@ int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, i
                              int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                              const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
 
+/* The bf16 decoder mode's form of the same run (BASELINE config 3: both GEMM operands rounded to bf16, fp32 accumulate --
+ * the reference has no bf16 mode; the semantics are oracle/path.py:modulated_conv2d(bf16_gemm=True) over
+ * models/model_v3.py:218-314).  "planes16" = [B][C/8][HW][8] bf16: one plane of the layout above, 2 bytes per value.  The stored
+ * activation IS the rounded operand of the next layer's GEMM, so results equal the fp32-stored bf16 mode's.
+ * wm: CIPS3D_MOD_PACKED | CIPS3D_MOD_BF16.  out_format: 0 fp32 [B,Cout,HW], 2 bf16 [B,Cout,HW], 3 planes16.  The other
+ * arguments as cips3d_modconv1x1_planes (rgb_part row blocks of 64). */
+int cips3d_to_planes16(const float* x, void* planes16, int B, int C, int64_t HW, void* stream);  /* C % 8 == 0 */
+int cips3d_from_planes16(const void* planes16, float* x, int B, int C, int64_t HW, void* stream);
+int cips3d_modconv1x1_planes16(const void* x_planes16, const float* wm, void* out, int out_format, int B, int Cin, int Cout,
+                               int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
+                               const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
+
 /* 3x3 ModulatedConv2d (models/model_v3.py:264-314, decoder_cfg.kernel_size = 3) as an LDS-tiled implicit GEMM on MFMA.
  *   up = 0: out [B,Cout,H,W] = conv2d(x, wm, padding 1)                                           (:296-311)
  *   up = 1: out [B,Cout,2H,2W] = Blur(conv_transpose2d(x, wm, stride 2)), fir = the Blur's 4x4 taps (:280-291); the FIR is
@@ -396,6 +411,7 @@ typedef struct cips3d_dec_layer {
                               computed by the previous stage's kernel (cips3d_fused_up_conv_next);
                               bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode;
                               bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes);
+                              bit 5 (with bit 2 / 3): the planes are bf16 planes16 and wm is CIPS3D_MOD_BF16-packed (cips3d_modconv1x1_planes16);
                               bit 4: wm is CIPS3D_MOD_SPLIT16-packed (conv2 / chained up-conv of a fused stage run in CIPS3D_GEMM_SPLIT mode) */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */

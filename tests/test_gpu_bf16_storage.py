@@ -113,3 +113,130 @@ def test_generator_bf16_storage_vs_oracle_and_fp32():
     assert p_s > 35.0
     G.set_decoder_precision("fp32")
     assert torch.equal(G(**kw)["rgb"], r32)
+
+
+# ------------------------------------------------------------------------------ planes16: the 64^2 run on one bf16 plane
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("B,C,Cout,H,W", [(1, 512, 512, 64, 64), (4, 512, 512, 64, 64), (2, 256, 512, 16, 16), (3, 64, 128, 8, 10),
+                                           (1, 128, 64, 4, 5)])
+def test_planes16_layer_vs_rounded_operands(B, C, Cout, H, W):
+    """cips3d_modconv1x1_planes16 (csrc/chain.hip, NP = 1) against its definition: both operands rounded to bf16 (round to
+    nearest even), exact products, fp32 accumulation; NoiseInjection + bias + leaky ReLU and the folded ToRGB on the unrounded
+    fp32 result; planes16 / bf16 exits are the RNE rounding of the fp32 exit.  Covers batches, ragged pixel counts and both
+    noise strides."""
+    HW = H * W
+    x = cu(weights.det_normal("p16.x", (B, C, H, W), 2.0, 1) * (1.0 + 5.0 * weights.det_unit_uniform("p16.m", (B, C, 1, 1), 2)))
+    p = hip.to_planes16(x)
+    assert p.shape == (B, C // 8, HW, 8) and p.dtype == torch.bfloat16
+    # layout: channel 8 cb + e of pixel n lives at [b, cb, n, e]; the values are the RNE roundings
+    assert torch.equal(p.permute(0, 1, 3, 2).reshape(B, C, HW), x.to(torch.bfloat16).reshape(B, C, HW))
+    assert torch.equal(hip.from_planes16(p, H, W), _bf(x))
+    scale = 1.0 / math.sqrt(C)
+    Wt = cu(weights.det_normal("p16.W", (1, Cout, C, 1, 1), 1.0, 3))
+    s = cu(1.0 + weights.det_uniform("p16.s", (B, C), 0.4, 4))
+    bias = cu(weights.det_uniform("p16.b", (Cout,), 0.3, 5))
+    nw = torch.full((1,), 0.2, device=DEV)
+    wm = hip.modulate_weights(Wt, s, C, B, Cout, C, 1, scale, True, False).view(B, Cout, C)
+    wm16 = hip.modulate_weights(Wt, s, C, B, Cout, C, 1, scale, True, True, bf16=True)
+    ref = torch.bmm(_bf(wm).double(), _bf(x).reshape(B, C, HW).double())            # exact products, fp64 sum
+    rng = float(ref.abs().max())
+    o32, _ = hip.modconv1x1_planes16(p, wm16, Cout, HW, "fp32")
+    assert maxdiff(o32.double(), ref) < 3e-6 * rng
+    o16, _ = hip.modconv1x1_planes16(p, wm16, Cout, HW, "bf16")
+    assert torch.equal(o16, o32.to(torch.bfloat16))
+    for per_sample_noise in (False, True):
+        nz = cu(weights.det_normal("p16.n", (B if per_sample_noise else 1, 1, H, W), 1.0, 6))
+        Wr = cu(weights.det_normal("p16.Wr", (1, 3, Cout, 1, 1), 1.0, 7))
+        wr = hip.modulate_weights(Wr, cu(1.0 + weights.det_uniform("p16.sr", (B, Cout), 0.3, 8)), Cout, B, 3, Cout, 1,
+                                  1.0 / math.sqrt(Cout), False, False)
+        part = torch.full((Cout // 64, B, 3, HW), float("nan"), device=DEV)
+        out_p, nblk = hip.modconv1x1_planes16(p, wm16, Cout, HW, "planes16", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr,
+                                              rgb_part=part)
+        assert nblk == Cout // 64
+        act = torch.nn.functional.leaky_relu(ref + (0.2 * nz.double()).reshape(-1, 1, HW) + bias.double().view(1, -1, 1), 0.2) * math.sqrt(2.0)
+        got = hip.from_planes16(out_p, H, W).reshape(B, Cout, HW)
+        arng = float(act.abs().max())
+        # the stored value is the bf16 rounding of the fp32 activation: half a bf16 ulp (2^-9 relative) + the fp32 error
+        assert bool(((got.double() - act).abs() <= 2.0 ** -8 * act.abs() + 3e-6 * arng).all())
+        assert float((got.double() - _bf(act.float()).double()).abs().mean()) < 2e-6 * arng      # ... and nearly always THE rounding
+        rgb_ref = torch.bmm(wr.view(B, 3, Cout).double(), act)
+        assert maxdiff(part[:nblk].sum(0).double(), rgb_ref) < 3e-6 * float(rgb_ref.abs().max()) + 3e-6 * arng
+    # a second layer on the stored planes16 == the definition applied to the stored (rounded) activation
+    if Cout % 64 == 0 and C % 64 == 0:
+        W2 = cu(weights.det_normal("p16.W2", (1, C, Cout, 1, 1), 1.0, 9))
+        s2 = cu(1.0 + weights.det_uniform("p16.s2", (B, Cout), 0.4, 10))
+        wm2 = hip.modulate_weights(W2, s2, Cout, B, C, Cout, 1, 1.0 / math.sqrt(Cout), True, False).view(B, C, Cout)
+        wm2_16 = hip.modulate_weights(W2, s2, Cout, B, C, Cout, 1, 1.0 / math.sqrt(Cout), True, True, bf16=True)
+        o2, _ = hip.modconv1x1_planes16(out_p, wm2_16, C, HW, "fp32")
+        ref2 = torch.bmm(_bf(wm2).double(), hip.from_planes16(out_p, H, W).reshape(B, Cout, HW).double())
+        assert maxdiff(o2.double(), ref2) < 3e-6 * float(ref2.abs().max())
+
+
+def test_planes16_entry_point_refusals():
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(1, 8, 64, 8, device=DEV, dtype=torch.bfloat16)
+    w = torch.zeros(64 * 64, device=DEV)
+    o = torch.zeros(1, 64, 64, device=DEV)
+    args = (1, 64, 64, 64, 0, None, 0, None, None, None, None, None, st)
+    assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 1, *args) != 0          # split planes out: not here
+    assert lib.cips3d_modconv1x1_planes16(None, w.data_ptr(), o.data_ptr(), 0, *args) != 0
+    assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 0, 1, 32, 64, 64, 0, None, 0, None, None, None,
+                                          None, None, st) != 0                                                 # Cin % 64
+    assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 0, 1, 64, 64, 64, 1, None, 0, None, None, None,
+                                          None, None, st) != 0                                                 # epilogue without bias
+    assert lib.cips3d_to_planes16(o.data_ptr(), x.data_ptr(), 1, 60, 64, st) != 0                              # C % 8
+    # CIPS3D_MOD_BF16 needs the plain packed layout and Cin % 32 == 0
+    Wt = torch.zeros(64, 48, device=DEV)
+    s = torch.ones(1, 48, device=DEV)
+    assert lib.cips3d_modulate_weights(Wt.data_ptr(), s.data_ptr(), 48, w.data_ptr(), 1, 64, 48, 1, 1.0, 1 | 2 | 128, st) != 0
+    assert lib.cips3d_modulate_weights(Wt.data_ptr(), s.data_ptr(), 48, w.data_ptr(), 1, 64, 64, 1, 1.0, 1 | 2 | 16 | 128, st) != 0
+
+
+def test_bf16_modes_run_the_64sq_layers_on_planes16():
+    """Both bf16 precisions plan conv1 + convs.0-7 and the first low-resolution GEMM on planes16 (flags bits 2 / 3 / 5).  The
+    stored bf16 value IS the operand the fp32-stored form of the mode rounds to (test_planes16_layer_vs_rounded_operands), so
+    the two forms differ by fp32 summation order only -- which in a bf16 network is not small: a sum that lands on the other
+    side of a rounding boundary (p ~ 5e-4 per value) moves an activation by a whole bf16 ulp, and after a few layers the
+    rounding noise of the two evaluations is decorrelated pixel by pixel.  Measured at 1024^2 (tools, round 2): planes16 and
+    the fp32-stored form are 3.5e-3 apart (mean abs, range 11.2), each of them 7.3e-3 from the CPU oracle's bf16 evaluation
+    (a third summation order), all three 1.24e-2 from exact fp32.  Bounds: the two forms are closer to each other than
+    half the mode's own error, and equally far from fp32."""
+    from cips_3dplusplus_amd import plan as _plan
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=2)
+    zs, nb, _ = weights.synth_inputs(cfg, seed=6)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[-0.3, 0.1]], device=DEV))
+    kw = dict(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    r32 = G(**kw)["rgb"].clone()
+    old = _plan.PLANES16_RUN
+    try:
+        for prec in ("bf16", "bf16_storage"):
+            G.set_decoder_precision(prec)
+            _plan.PLANES16_RUN = True
+            G._plans = {}
+            a = G(**kw)["rgb"].clone()
+            pl = list(G._plans.values())[0].plan
+            kinds = [(pl.layers[i].kind, pl.layers[i].flags) for i in range(pl.n_dec_layers)]
+            convs64 = [fl for k, fl in kinds if k == 0][:9]
+            assert all((fl & 4) and (fl & 8) and (fl & 32) for fl in convs64), kinds
+            first_up = [fl for k, fl in kinds if k == 1][0]
+            assert (first_up & 4) and (first_up & 32), kinds
+            _plan.PLANES16_RUN = False
+            G._plans = {}
+            b = G(**kw)["rgb"].clone()
+            pl2 = list(G._plans.values())[0].plan
+            assert not any(pl2.layers[i].flags & 32 for i in range(pl2.n_dec_layers))
+            d_ab, d_a, d_b = float((a - b).abs().mean()), float((a - r32).abs().mean()), float((b - r32).abs().mean())
+            print(f"{prec}: planes16 vs fp32-stored {d_ab:.3e}; vs exact fp32 {d_a:.3e} / {d_b:.3e} (range {float(r32.abs().max()):.1f})")
+            assert d_ab < 0.5 * d_b, prec
+            assert abs(d_a - d_b) < 0.05 * d_b, prec
+            assert maxdiff(a, b) < 2e-2 * float(r32.abs().max()), prec
+    finally:
+        _plan.PLANES16_RUN = old
+        G._plans = {}
+        G.set_decoder_precision("fp32")
