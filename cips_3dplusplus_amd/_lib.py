@@ -117,6 +117,9 @@ _SIGS = {
     "cips3d_from_planes16": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_modconv1x1_planes16": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p,
                                            c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+    "cips3d_rng_fill": (c_int, [C.c_uint64, C.c_uint64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p]),
+    "cips3d_rng_fill_threads": (c_i64, [c_i64, c_i64]),
+    "cips3d_rng_words": (c_int, [C.c_uint64, C.c_uint64, C.c_void_p, c_i64, C.c_void_p]),
     "cips3d_modconv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cips3d_modconv3x3": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_int, c_f32p,
                                   c_i64, c_f32p, c_f32p, C.c_void_p]),
@@ -160,7 +163,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 12           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 13           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

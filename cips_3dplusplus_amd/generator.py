@@ -179,7 +179,7 @@ class Generator(nn.Module):
         return ent
 
     def _planned_forward(self, plan, zs, cam_poses, focals, near, far, perturb_u, noise_bufs, truncation, style_render,
-                         style_decoder, return_sdf, return_xyz):
+                         style_decoder, return_sdf, return_xyz, fresh_perturb=False):
         from . import hip
         B = plan.B
         z_r = z_d = mean_r = mean_d = None
@@ -201,7 +201,7 @@ class Generator(nn.Module):
             z_r, z_d, cam_poses.float().contiguous(), focals.float().reshape(B).contiguous(),
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
-            float(truncation), mean_r, mean_d, return_sdf, events)
+            float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb)
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
                 "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
                 "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
@@ -309,8 +309,9 @@ class Generator(nn.Module):
         B = cam_poses.shape[0]
         dev = cam_poses.device
         N = int(nerf_cfg["N_samples"])
-        if nerf_cfg.get("perturb", False) and perturb_u is None:
-            perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)   # one jitter per ray (nerf_utils.py:110)
+        # one jitter per ray (nerf_utils.py:110), drawn where it is consumed: the one-call path draws it together with the
+        # decoder's fresh noise (plan.run), the per-op path below on its own
+        fresh_perturb = bool(nerf_cfg.get("perturb", False)) and perturb_u is None
         if not nerf_cfg.get("perturb", False):
             perturb_u = None
 
@@ -326,7 +327,10 @@ class Generator(nn.Module):
                     recompute_mean or not hasattr(self, "style_render_mean") or not hasattr(self, "style_decoder_mean")):
                 self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, dev)
             return self._planned_forward(plan, zs, cam_poses, per_view(focals), per_view(near), per_view(far), perturb_u,
-                                         noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz)
+                                         noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz,
+                                         fresh_perturb=fresh_perturb)
+        if fresh_perturb:
+            perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)
 
         # ---- per-op path (k=3 / untiled shapes / style mixing): same kernels, launched one by one
         style_render, style_decoder = self.mapping_networks(

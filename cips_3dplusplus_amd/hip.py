@@ -512,6 +512,41 @@ def modconv1x1_planes16(xp, wm_bf16, Cout, HW, out_format="planes16", epilogue=0
     return out, nblk.value
 
 
+# Fresh noise (NoiseInjection maps, per-ray jitter) from the library's own generator (csrc/rng.hip) in one launch; 0 = torch's
+# randn / rand, two launches (A/B knob).  Either way the stream is a function of torch's seed and generator state.
+FAST_RNG = os.environ.get("CIPS3D_FAST_RNG", "1") != "0"
+
+
+def rng_fill(n_normal, n_uniform, device, seed=None, base=None):
+    """(normal [n_normal] ~ N(0,1), uniform [n_uniform] ~ U[0,1)) fp32 tensors from cips3d_rng_fill (None for a zero count).
+    With seed / base omitted the state is torch's: key = the device generator's initial_seed(), counter base = its Philox
+    offset, which is advanced by what the call consumes -- torch.manual_seed / get_rng_state / set_rng_state govern this
+    stream like torch's own draws."""
+    lib = _lib.load()
+    device = torch.device(device)
+    normal = torch.empty(n_normal, device=device, dtype=torch.float32) if n_normal else None
+    uniform = torch.empty(n_uniform, device=device, dtype=torch.float32) if n_uniform else None
+    if n_normal == 0 and n_uniform == 0:
+        return normal, uniform
+    if seed is None:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        gen = torch.cuda.default_generators[idx]
+        seed, base = gen.initial_seed(), gen.get_offset()
+        threads = int(lib.cips3d_rng_fill_threads(n_normal, n_uniform))
+        gen.set_offset(base + 4 * ((threads + 3) // 4))              # torch keeps the offset a multiple of 4
+    check(lib.cips3d_rng_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(base), dev_ptr(normal, "normal", True), n_normal,
+                              dev_ptr(uniform, "uniform", True), n_uniform, stream_ptr()), "cips3d_rng_fill")
+    return normal, uniform
+
+
+def rng_words(seed, base, n_threads, device):
+    """The raw Philox words of threads 0 .. n_threads-1 as an int64 tensor [n_threads, 4] (tests)."""
+    out = torch.empty(n_threads, 4, device=device, dtype=torch.int32)
+    check(_lib.load().cips3d_rng_words(int(seed) & 0xFFFFFFFFFFFFFFFF, int(base), out.data_ptr(), n_threads, stream_ptr()),
+          "cips3d_rng_words")
+    return out.to(torch.int64) & 0xFFFFFFFF
+
+
 def modconv3x3_supported(Cin, Cout, H, W, up):
     return bool(_lib.load().cips3d_modconv3x3_supported(Cin, Cout, H, W, int(bool(up))))
 

@@ -301,9 +301,21 @@ class ForwardPlan:
                 bool(getattr(G.decoder, "split", False)))
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
-            events=None):
+            events=None, fresh_perturb=False):
+        """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
+        one cips3d_rng_fill launch when both are fresh."""
         lib = _lib.load()
         B, S, dev = self.B, self.img_size, self.device
+        fresh_noise = noise_bufs is None or all(nb is None for nb in noise_bufs)
+        keep = None
+        if fresh_perturb:
+            if perturb_u is not None:
+                raise RuntimeError("fresh_perturb with an explicit perturb_u")
+            if hip.FAST_RNG:
+                keep, perturb_u = hip.rng_fill(B * self.noise_total if fresh_noise else 0, B * S * S, dev)
+                perturb_u = perturb_u.view(B, S * S)
+            else:
+                perturb_u = torch.rand(B, S * S, device=dev)
         io = ForwardIO()
         io.z_r = dev_ptr(z_r, "zs[0]", allow_none=True)
         io.z_d = dev_ptr(z_d, "zs[1]", allow_none=True)
@@ -316,10 +328,10 @@ class ForwardPlan:
         R = S * S
         sdf = torch.empty(B, R, self.N, device=dev) if return_sdf else None
         io.sdf = dev_ptr(sdf, "sdf", allow_none=True)
-        keep = None
-        if noise_bufs is None or all(nb is None for nb in noise_bufs):
+        if fresh_noise:
             # fresh N(0,1) noise for every layer and sample: one generator launch for the whole decoder
-            keep = torch.randn(B * self.noise_total, device=dev)
+            if keep is None:
+                keep = hip.rng_fill(B * self.noise_total, 0, dev)[0] if hip.FAST_RNG else torch.randn(B * self.noise_total, device=dev)
             off = 0
             for i, s in enumerate(self.noise_sizes):
                 io.noise[i] = keep.data_ptr() + 4 * off

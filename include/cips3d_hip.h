@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 12  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 13  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -655,6 +655,18 @@ int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* p, void* stream);
  * (cips3d/nerf_utils.py:344-436,466-564; focal / near / far do not depend on the angles). */
 int cips3d_camera_params_bwd(const float* locations, const float* up, const float* dextrinsics, int B, float* dlocations,
                              void* stream);
+
+/* Fresh noise of one forward in one launch: n_normal N(0,1) values (every NoiseInjection map, models/model_v3.py:334-336
+ * `image.new_empty(batch, 1, height, width).normal_()`) and n_uniform U[0,1) values (the per-ray jitter, cips3d/nerf_utils.py:110
+ * `torch.rand(B, h, w, 1)`).  The reference takes both from torch's global generator and pins no stream; this draws them from
+ * Philox4x32-10 with key = seed and counter = (base + thread, 'CIPS', 0) -- csrc/rng.hip, restated in oracle/rng.py.  A call
+ * consumes cips3d_rng_fill_threads(n_normal, n_uniform) counter values from `base` on; the caller advances its offset by that
+ * (the Python binding keeps it in torch's generator state: seed = initial_seed(), base = get_offset()).  Either count may be 0.
+ * cips3d_rng_words: the raw 4 x 32-bit words of threads 0 .. n_threads-1 (tests). */
+int cips3d_rng_fill(uint64_t seed, uint64_t base, float* normal, int64_t n_normal, float* uniform, int64_t n_uniform,
+                    void* stream);
+int64_t cips3d_rng_fill_threads(int64_t n_normal, int64_t n_uniform);
+int cips3d_rng_words(uint64_t seed, uint64_t base, uint32_t* out, int64_t n_threads, void* stream);
 
 #ifdef __cplusplus
 }
