@@ -163,7 +163,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 13           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 14           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -23,7 +23,14 @@ struct cips3d_linear_args {
   int B, in_dim, out_dim; float w_scale, b_scale; int pixelnorm, lrelu; float act_gain, out_scale, out_shift;
   const float* trunc_mean; float trunc_psi; int out_repeat; int64_t out_repeat_stride;
 };
-int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream);
+// a slice [t0, t1) of the threads of one cips3d_rng_fill call, hosted by another launch (rng_device.h)
+struct cips3d_rng_job {
+  unsigned seed_lo, seed_hi; unsigned long long base;
+  float* normal; long long n_normal; float* uniform; long long n_uniform;
+  long long t0, t1;
+};
+int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream,
+                       const cips3d_rng_job* job = nullptr);
 int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_desc* table_dev, int n_desc, int total_rows,
                             void* stream);
 

@@ -75,9 +75,25 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                                  (last && trunc) ? IO.mean_d : nullptr, IO.trunc_psi, last ? P.n_latent : 1, P.style_dim_d};
       x = out; xs = P.style_dim_d;
     }
+    // fresh draws of this call: slices of one cips3d_rng_fill ride on the paired launches; none of those: a launch of its own
+    const bool want_rng = IO.rng_n_normal > 0 || IO.rng_n_uniform > 0;
+    if (IO.rng_n_normal < 0 || IO.rng_n_uniform < 0 || (IO.rng_n_normal > 0 && !IO.rng_normal) ||
+        (IO.rng_n_uniform > 0 && !IO.rng_uniform))
+      return CIPS3D_E_BADARG;
+    const int n_pair = nr < nd ? nr : nd;
+    const long long rng_threads = want_rng ? cips3d_rng_fill_threads(IO.rng_n_normal, IO.rng_n_uniform) : 0;
+    if (want_rng && n_pair == 0)
+      TRY(cips3d_rng_fill(IO.rng_seed, IO.rng_base, IO.rng_normal, IO.rng_n_normal, IO.rng_uniform, IO.rng_n_uniform, stream));
     for (int i = 0; i < (nr > nd ? nr : nd); ++i) {
       if (i < nr && i < nd) {
-        TRY(cips3d_linear_pair(ar[i], ad[i], stream));
+        cips3d_rng_job job{(unsigned)IO.rng_seed, (unsigned)(IO.rng_seed >> 32), (unsigned long long)IO.rng_base, IO.rng_normal,
+                           (long long)IO.rng_n_normal, IO.rng_uniform, (long long)IO.rng_n_uniform, 0, 0};
+        if (want_rng) {      // slice i of n_pair, in whole blocks of 256 threads
+          const long long per = ((rng_threads + n_pair - 1) / n_pair + 255) / 256 * 256;
+          job.t0 = per * i < rng_threads ? per * i : rng_threads;
+          job.t1 = per * (i + 1) < rng_threads ? per * (i + 1) : rng_threads;
+        }
+        TRY(cips3d_linear_pair(ar[i], ad[i], stream, want_rng ? &job : nullptr));
       } else if (i == nr && nr > 0 && P.film_n > 0) {
         // the renderer's W+ is complete: its FiLM heads share the launch of the decoder chain's next layer
         TRY(cips3d_linear_and_table(ad[i], P.film_table, P.film_n, P.film_rows, stream));

@@ -8,6 +8,7 @@
 // lanes stride the row in 16-byte pieces, butterfly reduction; the batch loops inside the wave so W
 // is read once per launch whatever B is.
 #include "common.h"
+#include "rng_device.h"
 
 namespace {
 
@@ -52,9 +53,16 @@ __global__ void __launch_bounds__(256) linear_kernel(cips3d_linear_args a) {
 }
 
 // two independent layers (the i-th layers of the two mapping networks) in one launch: blocks [0, blocks_a) run `a`
-__global__ void __launch_bounds__(256) linear_pair_kernel(cips3d_linear_args a, cips3d_linear_args b, int blocks_a) {
+// Blocks from blocks_ab on host a slice of the forward's fresh-noise draw (cips3d_rng_job): the two layers are ~190 work
+// groups waiting on one dependent load each, the chip is otherwise idle for the ~4.6 us of this launch.
+__global__ void __launch_bounds__(256) linear_pair_kernel(cips3d_linear_args a, cips3d_linear_args b, int blocks_a, int blocks_ab,
+                                                          cips3d_rng_job job) {
   if ((int)blockIdx.x < blocks_a) linear_rows(a, blockIdx.x * 4 + (threadIdx.x >> 6));
-  else linear_rows(b, (blockIdx.x - blocks_a) * 4 + (threadIdx.x >> 6));
+  else if ((int)blockIdx.x < blocks_ab) linear_rows(b, (blockIdx.x - blocks_a) * 4 + (threadIdx.x >> 6));
+  else {
+    const long long t = job.t0 + (long long)(blockIdx.x - blocks_ab) * 256 + threadIdx.x;
+    if (t < job.t1) rng_fill_thread(job.seed_lo, job.seed_hi, job.base, job.normal, job.n_normal, job.uniform, job.n_uniform, t);
+  }
 }
 
 __device__ __forceinline__ void linear_rows(const cips3d_linear_args& a, int row) {
@@ -183,9 +191,12 @@ extern "C" int cips3d_linear(const float* x, int64_t x_stride, const float* W, c
 }
 
 // library-internal (forward.hip): two layers, one launch
-int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream) {
+int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b, void* stream, const cips3d_rng_job* job) {
   const int ba = ceil_div(a.out_dim, 4), bb = ceil_div(b.out_dim, 4);
-  hipLaunchKernelGGL(linear_pair_kernel, dim3(ba + bb), dim3(256), 0, as_stream(stream), a, b, ba);
+  cips3d_rng_job j{};
+  int br = 0;
+  if (job && job->t1 > job->t0) { j = *job; br = (int)ceil_div<long long>(j.t1 - j.t0, 256); }
+  hipLaunchKernelGGL(linear_pair_kernel, dim3(ba + bb + br), dim3(256), 0, as_stream(stream), a, b, ba, ba + bb, j);
   return cips3d_launch_status();
 }
 

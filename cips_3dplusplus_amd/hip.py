@@ -517,6 +517,18 @@ def modconv1x1_planes16(xp, wm_bf16, Cout, HW, out_format="planes16", epilogue=0
 FAST_RNG = os.environ.get("CIPS3D_FAST_RNG", "1") != "0"
 
 
+def rng_reserve(n_normal, n_uniform, device):
+    """(seed, base) of a cips3d_rng_fill draw of these counts taken from torch's generator for `device`, whose Philox offset is
+    advanced by what the draw consumes (torch keeps the offset a multiple of 4)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    gen = torch.cuda.default_generators[idx]
+    seed, base = gen.initial_seed(), gen.get_offset()
+    threads = int(_lib.load().cips3d_rng_fill_threads(n_normal, n_uniform))
+    gen.set_offset(base + 4 * ((threads + 3) // 4))
+    return int(seed) & 0xFFFFFFFFFFFFFFFF, int(base)
+
+
 def rng_fill(n_normal, n_uniform, device, seed=None, base=None):
     """(normal [n_normal] ~ N(0,1), uniform [n_uniform] ~ U[0,1)) fp32 tensors from cips3d_rng_fill (None for a zero count).
     With seed / base omitted the state is torch's: key = the device generator's initial_seed(), counter base = its Philox
@@ -529,11 +541,7 @@ def rng_fill(n_normal, n_uniform, device, seed=None, base=None):
     if n_normal == 0 and n_uniform == 0:
         return normal, uniform
     if seed is None:
-        idx = device.index if device.index is not None else torch.cuda.current_device()
-        gen = torch.cuda.default_generators[idx]
-        seed, base = gen.initial_seed(), gen.get_offset()
-        threads = int(lib.cips3d_rng_fill_threads(n_normal, n_uniform))
-        gen.set_offset(base + 4 * ((threads + 3) // 4))              # torch keeps the offset a multiple of 4
+        seed, base = rng_reserve(n_normal, n_uniform, device)
     check(lib.cips3d_rng_fill(int(seed) & 0xFFFFFFFFFFFFFFFF, int(base), dev_ptr(normal, "normal", True), n_normal,
                               dev_ptr(uniform, "uniform", True), n_uniform, stream_ptr()), "cips3d_rng_fill")
     return normal, uniform

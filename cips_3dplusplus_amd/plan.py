@@ -45,7 +45,9 @@ class ForwardIO(C.Structure):
                 ("perturb_u", C.c_void_p), ("sdf", C.c_void_p),
                 ("noise", C.c_void_p * MAX_DEC), ("noise_bstride", C.c_int64 * MAX_DEC),
                 ("rgb", C.c_void_p), ("thumb", C.c_void_p), ("xyz", C.c_void_p), ("mask", C.c_void_p),
-                ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p)]
+                ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p),
+                ("rng_seed", C.c_uint64), ("rng_base", C.c_uint64), ("rng_normal", C.c_void_p), ("rng_n_normal", C.c_int64),
+                ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -311,12 +313,19 @@ class ForwardPlan:
         if fresh_perturb:
             if perturb_u is not None:
                 raise RuntimeError("fresh_perturb with an explicit perturb_u")
-            if hip.FAST_RNG:
-                keep, perturb_u = hip.rng_fill(B * self.noise_total if fresh_noise else 0, B * S * S, dev)
-                perturb_u = perturb_u.view(B, S * S)
-            else:
+            if not hip.FAST_RNG:
                 perturb_u = torch.rand(B, S * S, device=dev)
         io = ForwardIO()
+        if hip.FAST_RNG and (fresh_noise or fresh_perturb):
+            # the draw is made by the forward call itself (cips3d_forward_io.rng_*: spread over the mapping launches)
+            n_n, n_u = (B * self.noise_total if fresh_noise else 0), (B * S * S if fresh_perturb else 0)
+            io.rng_seed, io.rng_base = hip.rng_reserve(n_n, n_u, dev)
+            if n_n:
+                keep = torch.empty(n_n, device=dev)
+                io.rng_normal, io.rng_n_normal = keep.data_ptr(), n_n
+            if n_u:
+                perturb_u = torch.empty(B, S * S, device=dev)
+                io.rng_uniform, io.rng_n_uniform = perturb_u.data_ptr(), n_u
         io.z_r = dev_ptr(z_r, "zs[0]", allow_none=True)
         io.z_d = dev_ptr(z_d, "zs[1]", allow_none=True)
         io.mean_r = dev_ptr(mean_r, "style_render_mean", allow_none=True)
@@ -331,7 +340,7 @@ class ForwardPlan:
         if fresh_noise:
             # fresh N(0,1) noise for every layer and sample: one generator launch for the whole decoder
             if keep is None:
-                keep = hip.rng_fill(B * self.noise_total, 0, dev)[0] if hip.FAST_RNG else torch.randn(B * self.noise_total, device=dev)
+                keep = torch.randn(B * self.noise_total, device=dev)
             off = 0
             for i, s in enumerate(self.noise_sizes):
                 io.noise[i] = keep.data_ptr() + 4 * off

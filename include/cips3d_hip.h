@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 13  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 14  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -467,6 +467,13 @@ typedef struct cips3d_forward_io {
   float* mask;             /* [B, 2, S, S]: background weight, -|xyz| */
   void* ev_nerf_start;     /* optional hipEvent_t recorded on `stream` right before / after the render kernel */
   void* ev_nerf_stop;
+  /* optional: the call makes the fresh draws itself -- exactly cips3d_rng_fill(rng_seed, rng_base, rng_normal, rng_n_normal,
+   * rng_uniform, rng_n_uniform), its threads spread over the mapping networks' launches (whose few latency-bound work groups
+   * leave the chip idle) or, without those, as a launch of its own; the caller points noise[] / perturb_u into the two arrays.
+   * Both counts 0: no draw. */
+  uint64_t rng_seed, rng_base;
+  float* rng_normal; int64_t rng_n_normal;
+  float* rng_uniform; int64_t rng_n_uniform;
 } cips3d_forward_io;
 
 int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io, void* stream);

@@ -127,3 +127,40 @@ def test_forward_with_fresh_noise_and_jitter_is_reproducible_and_matches_torchs_
         assert torch.equal(x, G(**kw, noise_bufs=nb, perturb_u=u)["rgb"])
     finally:
         hip.FAST_RNG = old
+
+
+@pytest.mark.parametrize("given_styles", [False, True])
+def test_the_forwards_own_draw_is_cips3d_rng_fill(given_styles):
+    """cips3d_forward_io.rng_*: the one-call forward makes the draw itself, its threads spread over the mapping networks'
+    launches (or as a launch of its own when the caller passes W+ styles and there are none) -- the values are those of one
+    cips3d_rng_fill(seed, base) whatever the slicing: the image equals the forward on explicit noise / jitter cut from it."""
+    cfg = configs.ffhq_G_cfg(256, 2)
+    G = pkg.build_generator(cfg, DEV, seed=5)
+    B, S = 3, 64
+    g = torch.Generator(device=DEV).manual_seed(21)
+    zs = [torch.randn(B, 256, device=DEV, generator=g), torch.randn(B, 256, device=DEV, generator=g)]
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=0.2 * torch.randn(B, 2, device=DEV, generator=g))
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=S, near=n, far=fa, nerf_cfg=dict(N_samples=8, perturb=True, static_viewdirs=False))
+    if given_styles:
+        s_r, s_d = G.mapping_networks(zs=zs, truncation=1, inject_index=None)
+        kw.update(zs=[None, None], style_render=s_r, style_decoder=s_d)
+    old = hip.FAST_RNG
+    try:
+        hip.FAST_RNG = True
+        torch.manual_seed(909)
+        gen = torch.cuda.default_generators[torch.cuda.current_device()]
+        torch.randn(5, device=DEV)                        # a non-zero offset to start from
+        seed, base = gen.initial_seed(), gen.get_offset()
+        a = G(**kw)
+        plan = list(G._plans.values())[0]
+        total = B * plan.noise_total
+        assert gen.get_offset() == base + 4 * (((total + 3) // 4 + (B * S * S + 3) // 4 + 3) // 4)
+        normal, uniform = hip.rng_fill(total, B * S * S, DEV, seed=seed, base=base)
+        nb, off = [], 0
+        for s in plan.noise_sizes:
+            nb.append(normal[off:off + B * s * s].view(B, 1, s, s).contiguous())
+            off += B * s * s
+        b = G(**kw, noise_bufs=nb, perturb_u=uniform.view(B, S, S, 1))
+        assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["thumb_rgb"], b["thumb_rgb"])
+    finally:
+        hip.FAST_RNG = old

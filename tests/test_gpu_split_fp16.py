@@ -254,3 +254,26 @@ def test_fused_stage_split_products_agree_with_fp32(C, H, B):
     for name, a, b in zip(("out2", "rgb", "y_next"), res[False], res[True]):
         d, rng = float((a - b).abs().max()), float(a.abs().max())
         assert d < 2e-6 * max(rng, 1.0), (name, d, rng)
+
+
+@pytest.mark.parametrize("Cout,Cin,B,demod", [(512, 512, 2, True), (64, 256, 1, True), (32, 1024, 2, False), (64, 96, 3, True),
+                                                (16, 32, 1, True), (32, 2048, 1, True)])
+def test_split_and_bf16_weight_fragments_are_the_plain_matrix_rearranged(Cout, Cin, B, demod):
+    """CIPS3D_MOD_SPLIT / CIPS3D_MOD_BF16 fragments (8 consecutive channels per 16-byte piece) hold exactly the plain
+    modulated matrix: hi / lo halves of
+    2^8 wm, resp. its RNE bf16 rounding, at [ot][kb][plane][(q << 4) | (o & 15)][j] with channel = 32 kb + 8 q + j."""
+    W = cu(weights.det_normal("mf.W", (1, Cout, Cin, 1, 1), 1.0, Cout + Cin))
+    s = cu(1.0 + weights.det_uniform("mf.s", (B, Cin), 0.5, 3))
+    scale = 1.0 / math.sqrt(Cin)
+    plain = hip.modulate_weights(W, s, Cin, B, Cout, Cin, 1, scale, demod, False).view(B, Cout, Cin)
+    # [B, ot, o16, kb, q, j] -> [B, ot, kb, q, o16, j]
+    frag = plain.view(B, Cout // 16, 16, Cin // 32, 4, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+    sp = hip.modulate_weights(W, s, Cin, B, Cout, Cin, 1, scale, demod, True, split=True)
+    got = sp.view(torch.float16).view(B, Cout // 16, Cin // 32, 2, 4, 16, 8)
+    x = frag * 256.0
+    hi = x.to(torch.float16)
+    lo = (x - hi.float()).to(torch.float16)
+    assert torch.equal(got[:, :, :, 0], hi) and torch.equal(got[:, :, :, 1], lo)
+    bf = hip.modulate_weights(W, s, Cin, B, Cout, Cin, 1, scale, demod, True, bf16=True)
+    got16 = bf.view(torch.bfloat16)[: B * Cout * Cin].view(B, Cout // 16, Cin // 32, 4, 16, 8)
+    assert torch.equal(got16, frag.to(torch.bfloat16))
