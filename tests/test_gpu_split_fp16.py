@@ -257,7 +257,7 @@ def test_fused_stage_split_products_agree_with_fp32(C, H, B):
 
 
 @pytest.mark.parametrize("Cout,Cin,B,demod", [(512, 512, 2, True), (64, 256, 1, True), (32, 1024, 2, False), (64, 96, 3, True),
-                                                (16, 32, 1, True), (32, 2048, 1, True)])
+                                                (32, 32, 1, True), (32, 2048, 1, True)])
 def test_split_and_bf16_weight_fragments_are_the_plain_matrix_rearranged(Cout, Cin, B, demod):
     """CIPS3D_MOD_SPLIT / CIPS3D_MOD_BF16 fragments (8 consecutive channels per 16-byte piece) hold exactly the plain
     modulated matrix: hi / lo halves of
