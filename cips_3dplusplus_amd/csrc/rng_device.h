@@ -48,6 +48,8 @@ __device__ __forceinline__ void rng_fill_thread(unsigned seed_lo, unsigned seed_
     dst = uniform; first = 4 * (t - qn); n = n_uniform;
   }
   if (first + 4 <= n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
+    // (plain stores: non-temporal ones were measured -- the noise then reaches the up-sampling stages from HBM instead of the
+    // L2 / infinity cache, C = 32 stage 35.8 -> 38.4 us, 0.3477 -> 0.3520 ms per view on one box)
     *reinterpret_cast<float4*>(dst + first) = make_float4(v[0], v[1], v[2], v[3]);
   } else {
 #pragma unroll
