@@ -240,3 +240,24 @@ def test_bf16_modes_run_the_64sq_layers_on_planes16():
         _plan.PLANES16_RUN = old
         G._plans = {}
         G.set_decoder_precision("fp32")
+
+
+def test_config3_forward_is_deterministic():
+    """Batch 4 at 1024^2 in both bf16 precisions: repeated forwards on fixed inputs are bit-identical.  (Two workgroups of the
+    bf16 chain kernel share a CU at this batch size -- the occupancy under which the packed-FMA form of its ToRGB fold returned
+    run-to-run different sums; chain.hip is built without SLP vectorisation since.)"""
+    G = pkg.build_generator(configs.ffhq_G_cfg(1024, 2), DEV, seed=0)
+    B = 4
+    g = torch.Generator(device=DEV).manual_seed(3)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=0.2 * torch.randn(B, 2, device=DEV, generator=g))
+    zs = [torch.randn(B, 256, device=DEV, generator=g), torch.randn(B, 256, device=DEV, generator=g)]
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=G.create_noise_bufs(64, DEV),
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    try:
+        for prec in ("bf16", "bf16_storage"):
+            G.set_decoder_precision(prec)
+            ref = G(**kw)["rgb"].clone()
+            for _ in range(25):
+                assert torch.equal(G(**kw)["rgb"], ref), prec
+    finally:
+        G.set_decoder_precision("fp32")
