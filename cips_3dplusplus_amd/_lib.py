@@ -29,7 +29,20 @@ class LinearDesc(C.Structure):
 class ModulateDesc(C.Structure):
     _fields_ = [("W", C.c_void_p), ("s", C.c_void_p), ("out", C.c_void_p), ("s_stride", C.c_int64),
                 ("Cout", C.c_int32), ("Cin", C.c_int32), ("ksq", C.c_int32), ("flags", C.c_int32),
-                ("scale", C.c_float), ("row_begin", C.c_int32)]
+                ("scale", C.c_float), ("row_begin", C.c_int32),
+                ("lconst", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p),
+                ("n_bias", C.c_int32), ("pad_", C.c_int32)]
+
+
+class Range(C.Structure):
+    """cips3d_range: range tracking of the split-fp16 modes (include/cips3d_hip.h)."""
+    _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
+                ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p)]
+
+
+AMAX_SLOTS, AMAX_STRIDE = 16, 16
+AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE          # floats per (tensor, sample) of an amax array
+FEATURES_EXP = -14
 
 
 class NerfParams(C.Structure):
@@ -44,6 +57,7 @@ class NerfParams(C.Structure):
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
                 ("features_planes", C.c_int32), ("pad_", C.c_int32),
+                ("features_exp", C.c_void_p), ("features_amax", C.c_void_p),
                 ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p)]
 
 
@@ -86,12 +100,14 @@ _SIGS = {
     "cips3d_nerf_finish_rays": (c_int, [c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_modulate_weights": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_int, c_int, c_int, c_int, c_f32, c_int,
                                         C.c_void_p]),
-    "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, c_f32, C.c_void_p]),
+    "cips3d_absmax": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
+    "cips3d_range_consts": (c_int, [c_f32p, c_int, c_f32p, c_f32, c_f32p, c_f32, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
     "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
-                                  c_f32p, C.c_void_p]),
+                                  c_f32p, C.c_void_p, C.c_void_p]),
     "cips3d_modconv1x1_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
-                                        c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+                                        c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_torgb_reduce": (c_int, [c_f32p, c_int, C.c_void_p, c_int, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),
     "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32p, c_f32p,
                                    C.c_void_p]),
@@ -99,24 +115,24 @@ _SIGS = {
     "cips3d_fused_up_conv_supported": (c_int, [c_int, c_int, c_int]),
     "cips3d_fused_up_conv": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int,
-                                     C.c_void_p]),
+                                     C.c_void_p, C.c_void_p]),
     "cips3d_fused_up_conv_chains": (c_int, [c_int]),
     "cips3d_fused_up_conv_next": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
                                           c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int,
-                                          c_int, C.c_void_p]),
+                                          c_int, C.c_void_p, C.c_void_p]),
     "cips3d_torgb": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_f32p, c_int, c_int, c_int, c_int,
                              C.c_void_p]),
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
     "cips3d_planes_supported": (c_int, [c_int, c_int, c_i64]),
-    "cips3d_to_planes": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, C.c_void_p]),
-    "cips3d_from_planes": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_to_planes": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, c_f32p, C.c_void_p, C.c_void_p]),
+    "cips3d_from_planes": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p, C.c_void_p]),
     "cips3d_modconv1x1_planes": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64,
-                                         c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+                                         c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_to_planes16": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_from_planes16": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_modconv1x1_planes16": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p,
-                                           c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
+                                           c_i64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_rng_fill": (c_int, [C.c_uint64, C.c_uint64, c_f32p, c_i64, c_f32p, c_i64, C.c_void_p]),
     "cips3d_rng_fill_threads": (c_i64, [c_i64, c_i64]),
     "cips3d_rng_words": (c_int, [C.c_uint64, C.c_uint64, C.c_void_p, c_i64, C.c_void_p]),
@@ -163,7 +179,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 14           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 15           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 
@@ -171,7 +187,7 @@ def _struct_table():
     """index of cips3d_sizeof_struct -> the ctypes mirror of that struct (plan.py holds the two big ones)."""
     from . import plan
     return {0: plan.GeneratorPlan, 1: plan.ForwardIO, 2: NerfParams, 3: LinearDesc, 4: ModulateDesc, 5: plan.DecLayer,
-            6: NerfBwdGeom, 7: NerfBwdFusedParams}
+            6: NerfBwdGeom, 7: NerfBwdFusedParams, 8: Range}
 
 
 def load(build_if_missing=True):

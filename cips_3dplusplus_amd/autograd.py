@@ -277,7 +277,7 @@ def modulate_all(dec, s_list):
         dec._grad_mod_table = ent
     _, s_stage, plain, packed, tab_dev, n_desc, rows, layout, packed_t = ent
     torch.cat([t.reshape(-1) for t in s_list], out=s_stage)
-    _lib.check(_lib.load().cips3d_modulate_table(tab_dev.data_ptr(), n_desc, rows, B, _lib.stream_ptr()), "cips3d_modulate_table")
+    _lib.check(_lib.load().cips3d_modulate_table(tab_dev.data_ptr(), n_desc, rows, B, 0.0, _lib.stream_ptr()), "cips3d_modulate_table")
     plain_now = plain.clone()            # saved by Conv1x1Fn / ToRGBFn for their backward: must outlive the next forward
     packed_t_now = packed_t.clone()      # read by the backward of this forward
     out = {}

@@ -60,7 +60,9 @@ FILE_FLAGS = {"chain.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src, keep_temps):
-    obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+    # per-process object names: two builders that slipped past the lock (different checkouts of one tree on a shared
+    # file system) never write the same file
+    obj = os.path.join(OBJ, src.replace(".hip", f".{os.getpid()}.o"))
     cmd = [hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     if keep_temps:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
@@ -71,9 +73,27 @@ def _compile(src, keep_temps):
 
 
 def build_library(force=False, keep_temps=False, verbose=False):
+    """Compile + link under an exclusive lock.  Several ranks of one job (bench.py --gpus N, torchrun) may find the library
+    stale at the same moment: the first one in builds, the others wait on the lock and then find it up to date.  `force`
+    means "rebuild unless somebody else just did": the hash is re-checked after the lock is taken."""
+    import fcntl
+    import time
     if not force and up_to_date():
         return LIB
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".build.lock"), "w") as lock:
+        t_wait = time.time()
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            # built by another process while this one waited for the lock (or, unforced, nothing to do)
+            if up_to_date() and (not force or os.path.getmtime(STAMP) >= t_wait):
+                return LIB
+            return _build_locked(keep_temps, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(keep_temps, verbose):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
         results = list(ex.map(lambda s: _compile(s, keep_temps), srcs))
@@ -81,13 +101,20 @@ def build_library(force=False, keep_temps=False, verbose=False):
     if verbose:
         for _, log in results:
             sys.stderr.write(log)
-    r = subprocess.run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", LIB + ".tmp"],
+    tmp = f"{LIB}.{os.getpid()}.tmp"
+    r = subprocess.run([hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", tmp],
                        capture_output=True, text=True)
+    for o in objs:
+        try:
+            os.remove(o)
+        except OSError:
+            pass
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(LIB + ".tmp", LIB)
-    with open(STAMP, "w") as fh:
+    os.replace(tmp, LIB)                    # atomic: a concurrent dlopen sees the old or the new file, never a torn one
+    with open(STAMP + f".{os.getpid()}", "w") as fh:
         fh.write(source_hash() + "\n")
+    os.replace(STAMP + f".{os.getpid()}", STAMP)
     return LIB
 
 

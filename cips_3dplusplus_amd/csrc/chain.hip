@@ -16,6 +16,12 @@
 //   epilogue        x 2^-8 (exact), NoiseInjection + bias + leaky ReLU, optional folded ToRGB partial sums (as
 //                   cips3d_modconv1x1_torgb), then either planes again (the next layer of the run) or fp32 / bf16 NCHW (the
 //                   low-resolution GEMM that feeds the first fused up-sampling stage).
+//   range           planes hold x * 2^-e, one exponent per (tensor, sample) (cips3d_range, common.h): the input's exponent comes
+//                   from its producer (x_exp) and is undone on the accumulators together with the weights' 2^-8; the output's
+//                   is chosen here, by every workgroup alike, from the rigorous bound |out| <= c1 max|in| + c0 (the measured
+//                   maximum of the input, the layer's constants), folded into the sqrt(2) of the activation -- no instruction
+//                   per value -- and written to out_exp for the consumer.  Every workgroup also raises out_amax to the
+//                   largest |out| it stored (one atomic per workgroup), the next layer's max|in|.
 //
 // Bound: L2 -> LDS bytes (64 x 128 tiles: 384 KB per workgroup and layer) + the launch skeleton; the matrix time is ~1/5 of
 // the fp32 MFMA's.
@@ -70,6 +76,8 @@ struct ChainArgs {
   int B, Cin, Cout; int HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
   const float* rgb_w; float* rgb_part;
+  // range tracking (all optional): cips3d_range
+  const float* x_amax; const int* x_exp; const float* lconst; float* out_amax; int* out_exp;
 };
 
 // NP = planes per operand: 2 = split-fp16 (hi, lo; three fp16 MFMAs per tile and k-block), 1 = bf16 (one bf16 MFMA)
@@ -87,6 +95,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   constexpr int KB = BK / 32, KQ = KB * NP;      // KQ = 1 KB A pieces per o-tile and stage
   static_assert(PIECES % NW == 0 && BK % 32 == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+  __shared__ unsigned s_amax[2];                  // workgroup maximum of |out| and its arrival count (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,6 +103,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int q = lane >> 4, col = lane & 15;
   const int b = blockIdx.z;
+  if (tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }       // (visible to every wave after the first stage barrier)
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int HW = a.HW, K = a.Cin;
   const int nstage = K / BK;
@@ -134,7 +144,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   f32x4 bias4[WM];
   f32x4 wrgb[WM][3];
   float nw = 0.f;
+  float kin = NP == 2 ? kSplitInv : 1.f;     // accumulator -> true value: the weights' 2^-8 and the input planes' 2^e
+  float kout = 1.f, kback = 1.f;             // true value -> what this launch stores (2^-e' for a planes output) and back
   auto load_ops = [&]() {
+    if constexpr (NP == 2) {
+      if (a.x_exp) kin = cips3d_uniform(kin * cips3d_pow2(a.x_exp[b]));
+      if (a.out_fmt == 1 && a.lconst) {
+        const float m_in = cips3d_amax_load(a.x_amax + b * CIPS3D_AMAX_FLOATS);
+        const float* lc = a.lconst + b * 4;             // (uniform address: scalar loads)
+        const int e = cips3d_split_exp(fmaf(fmaxf(lc[1], 1.41421356237309515f * lc[2]), m_in, lc[0]));
+        kout = cips3d_uniform(cips3d_pow2(-e));
+        kback = cips3d_uniform(cips3d_pow2(e));
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.out_exp[b] = e;
+      }
+    }
     if (a.epilogue == 1) {
       if (a.noise && a.noise_w) {
         nw = a.noise_w[0];
@@ -262,6 +285,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
     for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
+  // v below is the STORED value, out * kout (kout = 1 unless the output is planes): the power of two rides on the constants
+  // the epilogue multiplies by anyway, the ToRGB partial sums and the recorded maximum are taken from v and scaled back once
+  const float kact = 1.41421356237309515f * kout;
+  const float kraw = kin * kout;
+  float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const int obase = m0 + (wm_i * WM + i) * 16;
@@ -270,9 +298,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        v[r] = NP == 2 ? acc[i][c][r] * kSplitInv : acc[i][c][r];
-        if (a.epilogue == 1) v[r] = lrelu02((v[r] + nz[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
+        if (a.epilogue == 1) v[r] = lrelu02((acc[i][c][r] * kin + nz[c] * nw) + bias4[i][r]) * kact;
+        else v[r] = acc[i][c][r] * kraw;
       }
+      if (npx[c] < HW) mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
       if (a.rgb_part) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
@@ -336,6 +365,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
     atomicAdd(&g_chain_stamps[6], ph_[2]);
   }
 #endif
+  if (a.out_amax)
+    cips3d_amax_workgroup(s_amax, mx * kback, NW, a.out_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.y * gridDim.x + blockIdx.x);
   if (!a.rgb_part) return;
   // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
   // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
@@ -343,7 +374,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      float v = prgb[ch][c];
+      float v = prgb[ch][c] * kback;
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
       prgb[ch][c] = v;
@@ -370,16 +401,30 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 }
 
 // fp32 [B][C][HW] -> planes [B][C/8][2][HW][8]; one thread per (channel block, pixel)
+// (the sample's maximum, every slot read by the thread itself: the samples of a wave may differ)
+__device__ __forceinline__ float amax_of_sample(const float* __restrict__ slots) {
+  float m = 0.f;
+  for (int s_ = 0; s_ < CIPS3D_AMAX_SLOTS; ++s_) m = fmaxf(m, slots[s_ * CIPS3D_AMAX_STRIDE]);
+  return m;
+}
+
 __global__ void __launch_bounds__(256) to_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ p, int B, int C,
-                                                        int HW) {
-  const int64_t total = (int64_t)B * (C / 8) * HW;
+                                                        int HW, const float* __restrict__ x_amax, int* __restrict__ exp_out) {
+  const int64_t total = (int64_t)B * (C / 8) * HW, per = (int64_t)(C / 8) * HW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % HW);
     const int64_t bc = i / HW;               // b * (C/8) + cb
+    float k = 1.f;
+    if (x_amax) {                            // planes of x * 2^-e, the sample's maximum just below 2^15 (cips3d_range)
+      const int b = (int)(i / per);
+      const int e_ = cips3d_split_exp(amax_of_sample(x_amax + (int64_t)b * CIPS3D_AMAX_FLOATS));
+      k = cips3d_pow2(-e_);
+      if (i == b * per) exp_out[b] = e_;
+    }
     h8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float v = x[(bc * 8 + e) * HW + n];
+      const float v = x[(bc * 8 + e) * HW + n] * k;
       _Float16 h_, l_;
       cips3d_split16(v, h_, l_);
       hi[e] = h_;
@@ -391,15 +436,16 @@ __global__ void __launch_bounds__(256) to_planes_kernel(const float* __restrict_
 }
 
 __global__ void __launch_bounds__(256) from_planes_kernel(const _Float16* __restrict__ p, float* __restrict__ x, int B, int C,
-                                                          int HW) {
-  const int64_t total = (int64_t)B * (C / 8) * HW;
+                                                          int HW, const int* __restrict__ exps) {
+  const int64_t total = (int64_t)B * (C / 8) * HW, per = (int64_t)(C / 8) * HW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % HW);
     const int64_t bc = i / HW;
+    const float k = exps ? cips3d_pow2(exps[i / per]) : 1.f;
     const h8 hi = *reinterpret_cast<const h8*>(p + ((bc * 2) * HW + n) * 8);
     const h8 lo = *reinterpret_cast<const h8*>(p + ((bc * 2 + 1) * HW + n) * 8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[(bc * 8 + e) * HW + n] = (float)hi[e] + (float)lo[e];
+    for (int e = 0; e < 8; ++e) x[(bc * 8 + e) * HW + n] = ((float)hi[e] + (float)lo[e]) * k;
   }
 }
 
@@ -446,25 +492,26 @@ extern "C" int cips3d_planes_supported(int Cin, int Cout, int64_t HW) {
          (int64_t)(Cin > Cout ? Cin : Cout) * HW * 2 + 1024 < ((int64_t)1 << 31);
 }
 
-extern "C" int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, void* stream) {
-  if (!x || !planes || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+extern "C" int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, const float* x_amax, int32_t* exp_out,
+                                void* stream) {
+  if (!x || !planes || B < 0 || C <= 0 || HW <= 0 || ((x_amax == nullptr) != (exp_out == nullptr))) return CIPS3D_E_BADARG;
   if (C % 8 != 0) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
-                     reinterpret_cast<_Float16*>(planes), B, C, (int)HW);
+                     reinterpret_cast<_Float16*>(planes), B, C, (int)HW, x_amax, exp_out);
   return cips3d_launch_status();
 }
 
-extern "C" int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, void* stream) {
+extern "C" int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, const int32_t* exp, void* stream) {
   if (!x || !planes || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   if (C % 8 != 0) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(from_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                     reinterpret_cast<const _Float16*>(planes), x, B, C, (int)HW);
+                     reinterpret_cast<const _Float16*>(planes), x, B, C, (int)HW, exp);
   return cips3d_launch_status();
 }
 
@@ -493,7 +540,7 @@ extern "C" int cips3d_from_planes16(const void* planes16, float* x, int B, int C
 extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* wm, void* out, int out_format, int B, int Cin,
                                           int Cout, int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
                                           const float* noise_w, const float* bias, const float* rgb_w, float* rgb_part,
-                                          int* n_row_blocks, void* stream) {
+                                          int* n_row_blocks, const cips3d_range* rg, void* stream) {
   if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
   static const int cfg = getenv("CIPS3D_CHAIN16_CFG") ? atoi(getenv("CIPS3D_CHAIN16_CFG")) : 0;   // A/B knob
   if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / 64 : 0;
@@ -503,7 +550,7 @@ extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* w
   if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   ChainArgs a{reinterpret_cast<const _Float16*>(x_planes16), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
-              noise_bstride, noise_w, bias, rgb_w, rgb_part};
+              noise_bstride, noise_w, bias, rgb_w, rgb_part, nullptr, nullptr, nullptr, rg ? rg->out_amax : nullptr, nullptr};
   // 64 x 128 tiles, 64-deep stages of 24 KB in a 3-slot ring (72 KB: two workgroups per CU).  Same-box sweep (rocprofv3, 512 -> 512
   // at 64^2): batch 1 7.45 us / batch 4 17.4 us; a 2-slot ring 8.0 / 17.5; 128-deep stages 7.4 / 24.2 (one workgroup per CU);
   // 128 x 128 tiles (2/3 of the operand bytes per flop) 9.6 / 19.8; 64 x 64 tiles 7.5 / 19.9.
@@ -517,15 +564,18 @@ extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* w
 extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, int out_format, int B, int Cin,
                                         int Cout, int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
                                         const float* noise_w, const float* bias, const float* rgb_w, float* rgb_part,
-                                        int* n_row_blocks, void* stream) {
+                                        int* n_row_blocks, const cips3d_range* rg, void* stream) {
   if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
   if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / 64 : 0;
   if (!x_planes || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   if (out_format < 0 || out_format > 2 || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && !bias)) return CIPS3D_E_BADARG;
   if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
+  // a planes output needs its bound: the input's maximum, the layer's constants and somewhere to leave the exponent
+  if (rg && out_format == 1 && (!rg->x_amax || !rg->lconst || !rg->out_exp)) return CIPS3D_E_BADARG;
   ChainArgs a{reinterpret_cast<const _Float16*>(x_planes), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
-              noise_bstride, noise_w, bias, rgb_w, rgb_part};
+              noise_bstride, noise_w, bias, rgb_w, rgb_part, rg ? rg->x_amax : nullptr, rg ? rg->x_exp : nullptr,
+              (rg && out_format == 1) ? rg->lconst : nullptr, rg ? rg->out_amax : nullptr, rg ? rg->out_exp : nullptr};
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
   dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
   static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)

@@ -33,6 +33,10 @@ int cips3d_linear_pair(const cips3d_linear_args& a, const cips3d_linear_args& b,
                        const cips3d_rng_job* job = nullptr);
 int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_desc* table_dev, int n_desc, int total_rows,
                             void* stream);
+// cips3d_linear_table whose launch also zeroes `zero_n` 32-bit words at `zero_ptr` (the forward's range workspace: the amax
+// slots every later kernel of the call raises with atomicMax)
+int cips3d_linear_table_zero(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int B, float* zero_ptr,
+                             int zero_n, void* stream);
 
 // floor division for possibly negative numerators (b > 0)
 __host__ __device__ static inline int floor_div_i(int a, int b) {
@@ -142,4 +146,50 @@ __device__ static inline void cips3d_split16(float x, _Float16& hi, _Float16& lo
   asm volatile("" : "+v"(x));
   hi = (_Float16)x;
   lo = (_Float16)(x - (float)hi);
+}
+
+// ---- Range tracking of the decoder's split-fp16 operands (include/cips3d_hip.h: cips3d_range).
+// fp16 has 5 exponent bits: an unscaled pair (hi, lo) overflows at |x| >= 65520 and loses fp32's relative accuracy below
+// |x| ~ 2^-3 (lo turns subnormal; the pair's absolute floor is 2^-25).  The reference's fp32 convolution
+// (models/model_v3.py:296-312) has neither limit, so every decoder activation is split as x * 2^-e with a power of two per
+// (tensor, sample) that puts a RIGOROUS bound of max|x| just below 2^15; the consumer multiplies its accumulators by 2^e
+// (exact).  The bound of a tensor a kernel produces itself comes from the measured maximum of the kernel's input (amax
+// slots, raised with atomicMax by the producing epilogue) and the layer's constants (lconst): |out| <= c1 * max|in| + c0.
+// With max|x| within ~2^6 of the bound the pair's floor sits >= 34 bits below max|x| -- under fp32's own accumulation error
+// whatever the magnitude of the data is.
+__device__ static inline float cips3d_pow2(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }   // e in [-126, 127]
+// e with bound * 2^-e in [2^14, 2^15): bound = m 2^k (m in [1, 2)) -> e = k - 14; zero / subnormal / inf / nan bounds clamp
+__device__ static inline int cips3d_split_exp(float bound) {
+  int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 127 - 14;
+  return e < -100 ? -100 : (e > 100 ? 100 : e);
+}
+__device__ static inline float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+// max over the CIPS3D_AMAX_SLOTS slots of one sample, as a wave-uniform value.  `slots` must be a wave-uniform address: the
+// sixteen loads are then scalar loads (no vector register, no vmcnt slot -- the counted waits of the GEMM rings do not see
+// them) and the scale factors derived from the result live in SGPRs through the kernel.
+__device__ static inline float cips3d_amax_load(const float* __restrict__ slots) {
+  float m = slots[0];
+#pragma unroll
+  for (int s_ = 1; s_ < CIPS3D_AMAX_SLOTS; ++s_) m = fmaxf(m, slots[s_ * CIPS3D_AMAX_STRIDE]);
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
+}
+__device__ static inline float cips3d_uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+// raise slot `slot` of a sample to v (v >= 0; non-negative floats order like their bit patterns).  No return value.
+__device__ static inline void cips3d_amax_raise(float* __restrict__ slots, float v, int slot) {
+  atomicMax(reinterpret_cast<unsigned*>(slots) + (slot & (CIPS3D_AMAX_SLOTS - 1)) * CIPS3D_AMAX_STRIDE, __float_as_uint(v));
+}
+// Workgroup maximum without a barrier: every wave folds its maximum into an LDS word and then counts itself in; the LDS unit
+// serves a wave's two operations in order, so the wave whose count comes back as n_waves - 1 sees every wave's maximum and
+// makes the workgroup's ONE global atomic.  s_red = {max, count}, zeroed before the workgroup's first barrier.
+// (the lane id is taken from mbcnt here: a `lane` kept alive to the end of a kernel for this call costs a register)
+__device__ static inline void cips3d_amax_workgroup(unsigned* s_red, float v, int n_waves, float* __restrict__ slots, int slot) {
+  v = wave_max(v);
+  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+    atomicMax(&s_red[0], __float_as_uint(v));
+    if (atomicAdd(&s_red[1], 1u) == (unsigned)(n_waves - 1)) cips3d_amax_raise(slots, __uint_as_float(atomicMax(&s_red[0], 0u)), slot);
+  }
 }

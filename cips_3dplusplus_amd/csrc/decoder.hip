@@ -121,9 +121,42 @@ __device__ __forceinline__ s16x4 pack_bf16(float a0, float a1, float a2, float a
 //   packed, ksq == 9 (the 3x3 implicit GEMM, conv3x3.hip): the same fragment order per tap, tap-major:
 //           wmp[b][t'][ot][kq][lane][j], t' = t, or 8 - t with CIPS3D_MOD_FLIP (the transposed conv of the up-sampling branch)
 // ------------------------------------------------------------------------------------------------
+// Range constants of a StyledConv (cips3d_range): lconst = {c0, c1, l1, 0} with |out| <= max(c1, sqrt(2) l1) max|in| + c0.
+//   c0 = sqrt(2) (|noise_w| noise_bound + max |bias|)       (leaky ReLU * sqrt(2) is 1-Lipschitz * sqrt(2) through 0)
+//   c1 = sqrt(2) w_gain; a demodulated row has unit L2 norm, so its L1 norm is <= sqrt(Cin ksq) = w_gain; with a FIR
+//        (the conv's GEMM result is up-sampled before the activation; the result's own maximum is measured) the gain is
+//        the FIR's largest polyphase L1 norm (1 for [1,3,3,1])
+//   l1 : raised by the rows of a non-demodulated conv to their L1 norm (modulate_row); left 0 otherwise
+// One wave.
+__device__ __forceinline__ void layer_consts(const float* __restrict__ bias, int n_bias, const float* __restrict__ noise_w,
+                                             float noise_bound, float w_gain, const float* __restrict__ fir,
+                                             float* __restrict__ lconst, int lane) {
+  float bm = 0.f;
+  if (bias)
+    for (int i = lane; i < n_bias; i += 64) bm = fmaxf(bm, fabsf(bias[i]));
+  bm = wave_max(bm);
+  float gain = w_gain;
+  if (fir) {
+    gain = 0.f;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) {
+      const int py = ph >> 1, px = ph & 1;
+      float g = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) g += fabsf(fir[(py + 2 * (t >> 1)) * 4 + px + 2 * (t & 1)]);
+      gain = fmaxf(gain, g);
+    }
+  }
+  if (lane == 0) {
+    const float nwa = noise_w ? fabsf(noise_w[0]) : 0.f;
+    lconst[0] = 1.41421356237309515f * (nwa * noise_bound + bm);
+    lconst[1] = 1.41421356237309515f * gain;
+  }
+}
+
 __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb,
                                              float* __restrict__ wm, int b, int o, int Cout, int Cin, int ksq,
-                                             float scale, int demod, int packed, int lane) {
+                                             float scale, int demod, int packed, int lane, float* __restrict__ l1_out = nullptr) {
   const int len = Cin * ksq;
   const float* w = W + (int64_t)o * len;
   // (A 16-byte-store form of the split / bf16 layouts -- 8 consecutive channels per lane, bit-identical output -- was built
@@ -148,6 +181,17 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
   }
   if (demod) ss = wave_sum(ss);
   const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
+  if (!demod && l1_out) {     // no unit norm to lean on: the row's L1 norm bounds |sum_i wm_oi x_i| / max|x| (cips3d_range)
+    float l1 = 0.f;
+    if (cached) {
+#pragma unroll
+      for (int m = 0; m < MAXV; ++m) l1 += fabsf(vreg[m]);
+    } else {
+      for (int e = lane; e < len; e += 64) l1 += fabsf((scale * w[e]) * sb[e / ksq]);
+    }
+    l1 = wave_sum(l1);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(l1_out), __float_as_uint(l1));
+  }
   auto put = [&](int e, float v) {
     if (demod) v *= d;
     if (packed & 32) {            // split-fp16 fragments of the fused stages: 16-channel k-groups, [lane][hi x4 | lo x4]
@@ -216,7 +260,7 @@ __global__ void __launch_bounds__(256) modulate_kernel(const float* __restrict__
 
 // every conv of the decoder in one launch: grid.x covers the table's rows, grid.y the samples
 __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modulate_desc* __restrict__ table, int n_desc,
-                                                             int total_rows) {
+                                                             int total_rows, float noise_bound) {
   const int lane = threadIdx.x & 63;
   const int grow = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (grow >= total_rows) return;
@@ -233,8 +277,35 @@ __global__ void __launch_bounds__(256) modulate_table_kernel(const cips3d_modula
     }
   }
   const cips3d_modulate_desc d = table[lo];
+  if (d.lconst && grow == d.row_begin)
+    layer_consts(d.bias, d.n_bias, d.noise_w, noise_bound, sqrtf((float)(d.Cin * d.ksq)), d.fir, d.lconst + b * 4, lane);
   modulate_row(d.W, d.s + (int64_t)b * d.s_stride, d.out, b, grow - d.row_begin, d.Cout, d.Cin, d.ksq, d.scale,
-               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 248)) : 0, lane);
+               d.flags & 1, (d.flags & 2) ? (((d.flags & 4) ? 2 : 1) | (d.flags & 248)) : 0, lane,
+               d.lconst ? d.lconst + b * 4 + 2 : nullptr);
+}
+
+// cips3d_range_consts: the same constants for one layer from the per-op path; cips3d_absmax: amax slots of an existing tensor
+__global__ void __launch_bounds__(64) range_consts_kernel(const float* __restrict__ bias, int n_bias, const float* __restrict__ noise_w,
+                                                          float noise_bound, const float* __restrict__ noise_amax, float w_gain,
+                                                          const float* __restrict__ fir, float* __restrict__ lconst) {
+  float* lc = lconst + blockIdx.x * 4;
+  if (threadIdx.x == 0) { lc[2] = 0.f; lc[3] = 0.f; }
+  if (noise_amax) noise_bound = fmaxf(noise_bound, cips3d_amax_load(noise_amax));
+  layer_consts(bias, n_bias, noise_w, noise_bound, w_gain, fir, lc, threadIdx.x);
+}
+
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax) {
+  const int b = blockIdx.y;
+  const float* xb = x + (int64_t)b * n;
+  float m = 0.f;
+  const int64_t n4 = (reinterpret_cast<uintptr_t>(xb) & 15) == 0 ? n / 4 : 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(xb)[i];
+    m = fmaxf(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))), m);
+  }
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(xb[i]));
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) cips3d_amax_raise(amax + (int64_t)b * CIPS3D_AMAX_FLOATS, m, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -255,6 +326,9 @@ struct GemmArgs {
   // BM output rows, rgb_part[blockIdx.y][b][3][HW]; cips3d_torgb_reduce adds the row blocks (and layers) in a fixed order.
   const float* rgb_w;       // plain [B][3][Cout] modulated ToRGB weights (no demodulation)
   float* rgb_part;          // [Cout/BM][B][3][HW]
+  // range tracking (cips3d_range): split mode splits x * 2^-e, e from the measured maximum of x; any mode records max |out|
+  const float* x_amax;      // [B][CIPS3D_AMAX_FLOATS] or NULL (e = 0)
+  float* out_amax;          // [B][CIPS3D_AMAX_FLOATS] or NULL
 };
 
 // s_waitcnt immediate that waits until at most n vector-memory operations of this wave are outstanding
@@ -285,6 +359,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   // peak at any tile shape).  Waits are counted (vmcnt(N) leaves the younger stages in flight) and the
   // barrier is the raw s_barrier: __syncthreads() would drain every outstanding DMA.
   __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
+  __shared__ unsigned s_amax[2];              // workgroup maximum of |out| and its arrival count (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -292,6 +367,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * BM;
+  if (tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }
+  // split mode: the activations are split as x * kx, kx = 2^-e with max|x| 2^-e in [2^14, 2^15) (the measured maximum of x;
+  // common.h, cips3d_range); the accumulators come back with kin = 2^-8 2^e
+  float kx = 1.f, kin = kSplitInv;
+  if constexpr (SPLIT) {
+    if (a.x_amax) {
+      const int e = cips3d_split_exp(cips3d_amax_load(a.x_amax + b * CIPS3D_AMAX_FLOATS));
+      kx = cips3d_uniform(cips3d_pow2(-e));
+      kin = cips3d_uniform(kSplitInv * cips3d_pow2(e));
+    }
+  }
   // per-lane index arithmetic in 32 bits (the host refuses max(Cin, Cout) * HW >= 2^31); 64-bit products only in the
   // workgroup-uniform sample bases
   const int n0 = blockIdx.x * BN;
@@ -411,7 +497,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
         for (int c = 0; c < 4; ++c) {
           float v8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v8[j] = b8[kb][j][c];
+          for (int j = 0; j < 8; ++j) v8[j] = b8[kb][j][c] * kx;
           h8 bh, bl;
           split8(v8, bh, bl);
 #pragma unroll
@@ -465,8 +551,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4*q + r][pixel ncol + c]
   const bool col_ok = ncol < HW;
-  if (!col_ok && !a.rgb_part) return;
+  if (!col_ok && !a.rgb_part && !a.out_amax) return;
   float* ob = a.out + (int64_t)b * a.Cout * HW + ncol;
+  float mx = 0.f;
   float prgb[3][4];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
@@ -480,13 +567,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       if constexpr (SPLIT) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] *= kSplitInv;           // exact: the weights carried 2^8
+        for (int c = 0; c < 4; ++c) v[c] *= kin;                 // exact: the weights carried 2^8, the activations 2^-e
       }
       if (a.epilogue == 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
       }
       if (col_ok) {
+        mx = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), mx);
         if (a.out_bf16)
           *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.Cout * HW + ncol + (obase + r) * HW) =
               pack_bf16(v[0], v[1], v[2], v[3]);
@@ -503,6 +591,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       }
     }
   }
+  if (a.out_amax)
+    cips3d_amax_workgroup(s_amax, mx, NW, a.out_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.y * gridDim.x + blockIdx.x);
   if (!a.rgb_part) return;
   // ---- ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows through
   // LDS (the ring is free: every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
@@ -910,6 +1000,9 @@ struct FusedArgs {
                  // 3: fp32-equivalent split-fp16 products (CIPS3D_GEMM_SPLIT; wm2 / wm_next CIPS3D_MOD_SPLIT16-packed)
   // optional (NEXT instantiation): the next stage's low-resolution GEMM y_next = wm_next (C/2 x C, chained pack) out2
   const float* wm_next; float* y_next;
+  // range tracking (split mode; cips3d_range): amax of y_lo, the constants of conv1 / conv2; max |y_next| recorded (out2 is
+  // not tracked: 64 registers is all the C = 32 stage has -- a split GEMM that reads a stored out2 measures it, cips3d_absmax)
+  const float* x_amax; const float* lconst1; const float* lconst2; float* next_amax;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
@@ -959,8 +1052,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   __shared__ __attribute__((aligned(16))) float s_red_own[NEXT ? WGM * 3 * BN : 4];
   float* s_red = NEXT ? s_red_own : sB;
   __shared__ float s_wrgb[3 * C];
+  __shared__ unsigned s_amax[2];                 // {max, count} of |y_next| (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
+  if (NEXT && tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }     // (before the first barrier below)
 #ifdef CIPS3D_FUSED_STAMPS
   unsigned long long fst_[7] = {0, 0, 0, 0, 0, 0, 0}, ftp_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -986,6 +1081,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // products only in the workgroup-uniform per-sample bases (the host refuses C * 4HW >= 2^31)
   const int HWlo = H * W, HWo = OH * OW;
   const int oy = oy0 + wn_i * RW + lrow, ox = ox0 + lx4 * 4;
+
+  // scale factors of the split operands (cips3d_range); set right before the first patch_store below
+  float kact1 = 1.41421356237309515f, k2in = kSplitInv, kact2 = 1.41421356237309515f, kback2 = 1.f, kyn = kSplitInv;
 
   // Everything that does not depend on a barrier is requested first: conv2's first A fragments, its noise / bias.
   const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
@@ -1073,7 +1171,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * TW + qx * 4);
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * 1.41421356237309515f;
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * kact1;
         if constexpr (SPLIT) {          // split once here; every wave row reads the packed halves
 #pragma unroll
           for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c]);
@@ -1109,6 +1207,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   FSTAMP(0);        // operand requests, noise staged, first barrier
+  // Range of the split operands (cips3d_range, common.h).  act1 is split as act1 2^-e1, e1 from the bound
+  // U1 = c1 max|y_lo| + c0 (conv1's constants: FIR gain, noise, bias); conv2's accumulators come back with 2^-8 2^e1.  In the
+  // chained form out2 is split as out2 2^-e2, U2 = c1' U1 + c0' (conv2's constants), and y_next comes back with 2^-8 2^e2.
+  // Both powers of two ride on the sqrt(2) of the activations: no instruction per value.
+  if constexpr (SPLIT) {
+    if (a.x_amax) {
+      const float m_in = cips3d_amax_load(a.x_amax + b * CIPS3D_AMAX_FLOATS);
+      const float* l1 = a.lconst1 + b * 4;            // (uniform address: scalar loads)
+      const float u1 = fmaf(l1[1], m_in, l1[0]);
+      const int e1 = cips3d_split_exp(u1);
+      kact1 = cips3d_uniform(1.41421356237309515f * cips3d_pow2(-e1));
+      k2in = cips3d_uniform(kSplitInv * cips3d_pow2(e1));
+      if (NEXT) {
+        const float* l2 = a.lconst2 + b * 4;
+        const int e2 = cips3d_split_exp(fmaf(fmaxf(l2[1], 1.41421356237309515f * l2[2]), u1, l2[0]));
+        kact2 = cips3d_uniform(1.41421356237309515f * cips3d_pow2(-e2));
+        kback2 = cips3d_uniform(cips3d_pow2(e2));
+        kyn = cips3d_uniform(kSplitInv * kback2);
+      }
+    }
+  }
+
   patch_store(0, sB);
   __syncthreads();
   FSTAMP(1);        // FIR + activation + split of stage 0 into LDS (waits for its patches), barrier
@@ -1183,6 +1303,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // ---- epilogue of conv2: this lane holds channels o = (wm_i*WM+i)*16 + 4q + r at pixels (oy, ox .. ox+3)
   if (LATE) { load_epilogue_ops(); load_skip_ops(); }
   float prgb[3][4];
+  float mxn = 0.f;
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
@@ -1195,15 +1316,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       f32x4 v = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
       if constexpr (SPLIT) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] *= kSplitInv;           // exact: conv2's weights carried 2^8
+        for (int c = 0; c < 4; ++c) v[c] *= k2in;                // exact: conv2's weights carried 2^8, act1 2^-e1
       }
+      // (chained split form: v = out2 2^-e2 from here on -- the B operand of the next GEMM; the ToRGB sums are scaled back once)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * 1.41421356237309515f;
+      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * kact2;
       if (NEXT) {   // keep the activated value where the accumulator was: it is the next GEMM's B operand
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][c][r] = v[c];
       }
-      if (a.out2) *reinterpret_cast<f32x4*>(a.out2 + (int64_t)b * C * HWo + ((obase + r) * HWo + oy * OW + ox)) = v;
+      if (a.out2) {
+        if constexpr (NEXT && SPLIT) {
+          *reinterpret_cast<f32x4*>(a.out2 + (int64_t)b * C * HWo + ((obase + r) * HWo + oy * OW + ox)) =
+              f32x4{v[0] * kback2, v[1] * kback2, v[2] * kback2, v[3] * kback2};
+        } else {
+          *reinterpret_cast<f32x4*>(a.out2 + (int64_t)b * C * HWo + ((obase + r) * HWo + oy * OW + ox)) = v;
+        }
+      }
       if (a.wm_rgb) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -1294,11 +1423,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       ylo_t* yn = reinterpret_cast<ylo_t*>(a.y_next) + (int64_t)b * (C / 2) * HWo + (((wm_i * TPW + tp) * 16 + 4 * q) * HWo + oy * OW + ox);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        constexpr float ys = SPLIT ? kSplitInv : 1.f;        // the chained weights carried 2^8 as well
-        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + r * HWo) = pack_bf16(accx[tp][0][r], accx[tp][1][r], accx[tp][2][r], accx[tp][3][r]);
-        else *reinterpret_cast<f32x4*>(yn + r * HWo) = f32x4{accx[tp][0][r] * ys, accx[tp][1][r] * ys, accx[tp][2][r] * ys, accx[tp][3][r] * ys};
+        const float ys = SPLIT ? kyn : 1.f;                  // the chained weights carried 2^8 as well, out2 2^-e2
+        const f32x4 yv = {accx[tp][0][r] * ys, accx[tp][1][r] * ys, accx[tp][2][r] * ys, accx[tp][3][r] * ys};
+        mxn = fmaxf(fmaxf(fmaxf(fabsf(yv[0]), fabsf(yv[1])), fmaxf(fabsf(yv[2]), fabsf(yv[3]))), mxn);
+        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + r * HWo) = pack_bf16(yv[0], yv[1], yv[2], yv[3]);
+        else *reinterpret_cast<f32x4*>(yn + r * HWo) = yv;
       }
     }
+    if (a.next_amax) cips3d_amax_workgroup(s_amax, mxn, WGM * WGN, a.next_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.x);
   }
   f32x4 accn[OTN][4];
   if (NEXT && !XCHG) {
@@ -1363,7 +1495,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         float v = prgb[ch][c];
         v += __shfl_xor(v, 16, 64);
         v += __shfl_xor(v, 32, 64);
-        prgb[ch][c] = v;
+        prgb[ch][c] = (NEXT && SPLIT) ? v * kback2 : v;
       }
     if (q == 0) {
 #pragma unroll
@@ -1391,13 +1523,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     for (int t = 0; t < OTN; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        constexpr float ys = SPLIT ? kSplitInv : 1.f;
-        if constexpr (YB)
-          *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(accn[t][0][r], accn[t][1][r], accn[t][2][r], accn[t][3][r]);
-        else
-          *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) =
-              f32x4{accn[t][0][r] * ys, accn[t][1][r] * ys, accn[t][2][r] * ys, accn[t][3][r] * ys};
+        const float ys = SPLIT ? kyn : 1.f;
+        const f32x4 yv = {accn[t][0][r] * ys, accn[t][1][r] * ys, accn[t][2][r] * ys, accn[t][3][r] * ys};
+        mxn = fmaxf(fmaxf(fmaxf(fabsf(yv[0]), fabsf(yv[1])), fmaxf(fabsf(yv[2]), fabsf(yv[3]))), mxn);
+        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(yv[0], yv[1], yv[2], yv[3]);
+        else *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = yv;
       }
+    if (a.next_amax) cips3d_amax_workgroup(s_amax, mxn, WGN, a.next_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.x);
   }
   FSTAMP(5);        // partial exchange of the chained GEMM / ToRGB through LDS, y_next store
   if (!a.wm_rgb) { FSTAMP_FLUSH(); return; }
@@ -1471,12 +1603,32 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   return cips3d_launch_status();
 }
 
-extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B,
+extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B, float noise_bound,
                                      void* stream) {
-  if (!table_dev || n_desc <= 0 || total_rows <= 0 || B < 0) return CIPS3D_E_BADARG;
+  if (!table_dev || n_desc <= 0 || total_rows <= 0 || B < 0 || !(noise_bound >= 0.f)) return CIPS3D_E_BADARG;
   if (B == 0) return 0;
   hipLaunchKernelGGL(modulate_table_kernel, dim3((unsigned)ceil_div(total_rows, 4), (unsigned)B), dim3(256), 0,
-                     as_stream(stream), table_dev, n_desc, total_rows);
+                     as_stream(stream), table_dev, n_desc, total_rows, noise_bound);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream) {
+  if (!x || !amax || B < 0 || n <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(float) * CIPS3D_AMAX_FLOATS * (size_t)B, as_stream(stream));
+  if (e != hipSuccess) return (int)e;
+  int64_t blocks = ceil_div<int64_t>(n, 256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, as_stream(stream), x, n, amax);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, float noise_bound, const float* noise_amax,
+                                   float w_gain, const float* fir, float* lconst, int B, void* stream) {
+  if (!lconst || B < 0 || n_bias < 0 || (n_bias > 0 && !bias) || !(noise_bound >= 0.f) || !(w_gain >= 0.f)) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(range_consts_kernel, dim3((unsigned)B), dim3(64), 0, as_stream(stream), bias, n_bias, noise_w, noise_bound,
+                     noise_amax, w_gain, fir, lconst);
   return cips3d_launch_status();
 }
 
@@ -1488,9 +1640,9 @@ extern "C" int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW) {
 
 extern "C" int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
                                  int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
-                                 const float* bias, void* stream) {
+                                 const float* bias, const cips3d_range* rg, void* stream) {
   return cips3d_modconv1x1_torgb(x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, nullptr,
-                                 nullptr, nullptr, stream);
+                                 nullptr, nullptr, rg, stream);
 }
 
 // rows per workgroup of the tile configuration cips3d_modconv1x1 picks for this Cout (= row blocks of the ToRGB partials)
@@ -1504,7 +1656,7 @@ static int gemm_block_rows(int Cout) {
 extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW,
                                        int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                                        const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks,
-                                       void* stream) {
+                                       const cips3d_range* rg, void* stream) {
   if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
   if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / gemm_block_rows(Cout) : 0;
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
@@ -1517,7 +1669,8 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
   if (epilogue == 1 && !bias) return CIPS3D_E_BADARG;
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
-  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, out_bf16, rgb_w, rgb_part};
+  GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, out_bf16, rgb_w, rgb_part,
+             rg ? rg->x_amax : nullptr, rg ? rg->out_amax : nullptr};
   hipStream_t st = as_stream(stream);
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
   if (dbg_cfg && !rgb_part && Cout % 128 == 0) {      // (the ToRGB fold needs the default tiling: gemm_block_rows)
@@ -1587,9 +1740,9 @@ extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const f
                                     const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
                                     int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
                                     const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
-                                    float* rgb, int B, int C, int H, int W, void* stream) {
+                                    float* rgb, int B, int C, int H, int W, const cips3d_range* rg, void* stream) {
   return cips3d_fused_up_conv_next(y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2,
-                                   bias2, out2, wm_rgb, bias_rgb, skip, skip_up, rgb, nullptr, nullptr, B, C, H, W, stream);
+                                   bias2, out2, wm_rgb, bias_rgb, skip, skip_up, rgb, nullptr, nullptr, B, C, H, W, rg, stream);
 }
 
 extern "C" int cips3d_fused_up_conv_chains(int C) { return C == 64 || C == 128 || C == 256; }
@@ -1599,7 +1752,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
                                          int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
                                          const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
                                          float* rgb, const float* wm_next, float* y_next, int B, int C, int H, int W,
-                                         void* stream) {
+                                         const cips3d_range* rg, void* stream) {
   if (!y_lo || !fir || !bias1 || !wm2 || !bias2 || B < 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
   if ((wm_next == nullptr) != (y_next == nullptr)) return CIPS3D_E_BADARG;
   if (wm_next && !cips3d_fused_up_conv_chains(C)) return CIPS3D_E_UNSUPP;
@@ -1610,7 +1763,10 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W,
               (skip_up & CIPS3D_GEMM_SPLIT) ? 3 : (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next,
-              y_next};
+              y_next, rg ? rg->x_amax : nullptr, rg ? rg->lconst : nullptr, rg ? rg->lconst2 : nullptr,
+              rg ? rg->next_amax : nullptr};
+  // split mode with range tracking: the bound of act1 needs conv1's constants, the chained form conv2's as well
+  if ((skip_up & CIPS3D_GEMM_SPLIT) && rg && rg->x_amax && (!rg->lconst || (wm_next && !rg->lconst2))) return CIPS3D_E_BADARG;
   if ((skip_up & CIPS3D_Y_BF16) && !(skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;   // bf16 storage implies bf16 operands
   if ((skip_up & CIPS3D_GEMM_SPLIT) && (skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;
   hipStream_t st = as_stream(stream);

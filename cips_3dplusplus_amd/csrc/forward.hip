@@ -23,6 +23,7 @@ extern "C" int64_t cips3d_sizeof_struct(int which) {
     case 5: return (int64_t)sizeof(cips3d_dec_layer);
     case 6: return (int64_t)sizeof(cips3d_nerf_bwd_geom);
     case 7: return (int64_t)sizeof(cips3d_nerf_bwd_fused_params);
+    case 8: return (int64_t)sizeof(cips3d_range);
     default: return -1;
   }
 }
@@ -109,8 +110,14 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
 
   // ---- style heads: FiLM gamma/beta of every SIREN layer; every decoder modulation; modulated weights
   if (!film_done) TRY(cips3d_linear_table(P.film_table, P.film_n, P.film_rows, B, stream));
-  TRY(cips3d_linear_table(P.mod_table, P.mod_n, P.mod_rows, B, stream));
-  TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, stream));
+  // Range tracking of the split-fp16 decoder (cips3d_range): the workspace -- amax slots every producing epilogue raises with
+  // atomicMax, planes exponents, layer constants -- is zeroed by the launch of the modulation heads; the modulate table then
+  // writes every layer's constants with this call's bound of |noise| (6: cips3d_rng_fill's draws stay below 5.89).
+  const bool ranged = P.range_ws != nullptr;
+  if (ranged && (P.range_ws_words <= 0 || P.range_ws_words > (1 << 30) || !P.feat_amax || !P.feat_exp || !P.tmp_amax)) return CIPS3D_E_BADARG;
+  if (ranged) TRY(cips3d_linear_table_zero(P.mod_table, P.mod_n, P.mod_rows, B, P.range_ws, (int)P.range_ws_words, stream));
+  else TRY(cips3d_linear_table(P.mod_table, P.mod_n, P.mod_rows, B, stream));
+  TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, IO.noise_bound > 0.f ? IO.noise_bound : 6.f, stream));
 
   // ---- NeRF: rays -> samples -> FiLM-SIREN -> compositing
   cips3d_nerf_params np = P.nerf;
@@ -126,6 +133,8 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const bool feat_planes = (P.layers[0].flags & 4) != 0;
   const bool feat_p16 = feat_planes && (P.layers[0].flags & 32) != 0;
   np.features_planes = (feat_planes && !feat_p16 && fused_finish) ? 1 : 0;
+  np.features_exp = ranged ? P.feat_exp : nullptr;
+  np.features_amax = ranged ? P.feat_amax : nullptr;
   float* feat32 = (feat_planes && !np.features_planes) ? P.act[1] : P.features;
   np.o_features = feat32;
   TRY(cips3d_nerf_render(&np, stream));
@@ -135,11 +144,24 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   if (feat_planes && !np.features_planes) {
     const int64_t hw0 = (int64_t)np.img_size * np.img_size;
     if (feat_p16) TRY(cips3d_to_planes16(feat32, P.features, B, np.hidden, hw0, stream));
-    else TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, hw0, stream));
+    else {
+      if (ranged) TRY(cips3d_absmax(feat32, B, (int64_t)np.hidden * hw0, P.feat_amax, stream));
+      TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, hw0, ranged ? P.feat_amax : nullptr, ranged ? P.feat_exp : nullptr, stream));
+    }
   }
 
   // ---- decoder (model_v3.py:592-637)
   const float* x = P.features;
+  // range rows of x (ranged plans): the measured maximum of its true values and, for planes, the exponent they were stored with.
+  // x_amax == nullptr: no producer tracked this tensor -- a split GEMM that reads it measures it first (amax_of)
+  const float* x_amax = ranged ? P.feat_amax : nullptr;
+  const int32_t* x_exp = ranged ? P.feat_exp : nullptr;
+  auto amax_of = [&](const float* t, int C, int64_t hw) -> int {
+    if (!ranged || x_amax) return 0;
+    const int rc = cips3d_absmax(t, B, (int64_t)C * hw, P.tmp_amax, stream);
+    x_amax = P.tmp_amax;
+    return rc;
+  };
   const float* skip = nullptr;
   int act_i = 0, skip_i = 0;
   float* ylo_cur = P.y_lo;                       // low-resolution GEMM result of the stage being run
@@ -180,17 +202,25 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const float* nz2 = L2.noise_index >= 0 ? IO.noise[L2.noise_index] : nullptr;
         const int64_t nbs2 = L2.noise_index >= 0 ? IO.noise_bstride[L2.noise_index] : 0;
         if ((L.flags & 1) && !ylo_ready) return CIPS3D_E_BADARG;     // chained weights without the stage that chains them
+        // ranged: y_lo's maximum lives in the up-conv's amax row (written by whoever computes y_lo)
+        const bool stage_ranged = ranged && L.amax && L.lconst && L2.lconst;
         if (!ylo_ready) {
+          cips3d_range rg{};
+          rg.out_amax = stage_ranged ? L.amax : nullptr;
           if ((L.flags & 4) && (L.flags & 32))       // the run's last activation arrives as planes16 (bf16 mode)
             TRY(cips3d_modconv1x1_planes16(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
-                                           nullptr, nullptr, nullptr, nullptr, nullptr, stream));
-          else if (L.flags & 4)  // ... as split-fp16 planes
+                                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream));
+          else if (L.flags & 4) {  // ... as split-fp16 planes
+            rg.x_exp = x_exp;
             TRY(cips3d_modconv1x1_planes(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
-                                         nullptr, nullptr, nullptr, nullptr, nullptr, stream));
-          else
+                                         nullptr, nullptr, nullptr, nullptr, nullptr, ranged ? &rg : nullptr, stream));
+          } else {
+            if (L.flags & 2) TRY(amax_of(x, L.Cin, (int64_t)L.H * L.W));
+            rg.x_amax = x_amax;
             TRY(cips3d_modconv1x1(x, L.wm, ylo_cur, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
                                   0 | gemm_flag | ybf_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
-                                  stream));
+                                  ranged ? &rg : nullptr, stream));
+          }
         }
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
@@ -203,12 +233,20 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         // flags bit 4: conv2's (and the chained up-conv's) weights are CIPS3D_MOD_SPLIT16-packed: the stage runs split-fp16
         const int stage_split = (L2.flags & 16) ? CIPS3D_GEMM_SPLIT : 0;
         if (chain && ((LN->flags & 16) != (L2.flags & 16))) return CIPS3D_E_BADARG;
+        if (stage_split && ranged && (!stage_ranged || (chain && !LN->amax))) return CIPS3D_E_BADARG;   // the plan owes the rows
+        cips3d_range srg{};
+        if (stage_ranged) {
+          srg.x_amax = L.amax; srg.lconst = L.lconst; srg.lconst2 = L2.lconst;
+          srg.next_amax = chain ? LN->amax : nullptr;
+        }
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
                                       L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split, rgb, chain ? LN->wm : nullptr,
-                                      chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stream));
+                                      chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stage_ranged ? &srg : nullptr, stream));
         ylo_ready = chain;
         if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }
         x = out2;
+        x_amax = nullptr;                // (a stored out2 is not tracked: its reader measures it)
+        x_exp = nullptr;
         act_i ^= 1;
         skip = rgb;
         skip_i ^= 1;
@@ -228,14 +266,22 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         const int fmt = (L.flags & 8) ? (p16 ? 3 : 1) : 0;   // planes for the next layer of the run, or fp32 when the run ends here
         if ((!p16 && !(L.flags & 2)) || (fmt != 0 && has_rgb && !fold)) return CIPS3D_E_BADARG;   // the plan promised otherwise
         int nblk = 0;
+        cips3d_range rg{};
+        const bool lr = ranged && !p16;
+        if (lr) {
+          if (!x_amax || !x_exp || !L.amax || !L.aexp || !L.lconst) return CIPS3D_E_BADARG;      // the plan owes the rows
+          rg.x_amax = x_amax; rg.x_exp = x_exp; rg.lconst = L.lconst; rg.out_amax = L.amax; rg.out_exp = L.aexp;
+        }
         if (p16)
           TRY(cips3d_modconv1x1_planes16(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
                                          fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr,
-                                         &nblk, stream));
+                                         &nblk, nullptr, stream));
         else
           TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
                                        fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
-                                       stream));
+                                       lr ? &rg : nullptr, stream));
+        x_amax = lr ? L.amax : nullptr;
+        x_exp = (lr && fmt == 1) ? L.aexp : nullptr;
         if (fold) {
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;
@@ -253,10 +299,16 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                           fold_nb < CIPS3D_TORGB_FOLD_MAX && fold_slots + 16 <= P.rgb_part_slots &&
                           (fold_slots == 0 || (fold_H == L.H && fold_W == L.W));
         const int split_flag = (L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0;
+        cips3d_range rg{};
+        if (split_flag) TRY(amax_of(x, L.Cin, hw));
+        rg.x_amax = x_amax;
+        rg.out_amax = (ranged && L.amax) ? L.amax : nullptr;
+        x_amax = rg.out_amax;            // (of this layer's output, from here on)
+        x_exp = nullptr;
         if (fold) {
           int nblk = 0;
           TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, T->wm,
-                                      P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, stream));
+                                      P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, ranged ? &rg : nullptr, stream));
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;
           fold_H = L.H; fold_W = L.W;
@@ -265,13 +317,20 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           ++li;                                  // the ToRGB layer is done (its sum is pending in the slots)
           continue;
         }
-        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, stream));
+        TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias,
+                              ranged ? &rg : nullptr, stream));
       } else {
         if (L.flags & 1) return CIPS3D_E_BADARG;   // chained packs only exist for stages that take the fused route above
         if (L.flags & 4) return CIPS3D_E_BADARG;   // planes reach an up-conv only on the fused route (the plan guarantees it)
+        cips3d_range rg{};
+        if (L.flags & 2) TRY(amax_of(x, L.Cin, (int64_t)L.H * L.W));
+        rg.x_amax = x_amax;
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
-                              0 | gemm_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr, stream));
+                              0 | gemm_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
+                              ranged ? &rg : nullptr, stream));
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));
+        x_amax = nullptr;                // (the FIR's output is not tracked: its reader measures it)
+        x_exp = nullptr;
       }
       x = out;
       act_i ^= 1;

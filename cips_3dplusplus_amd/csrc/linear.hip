@@ -112,6 +112,14 @@ __global__ void __launch_bounds__(256) linear_table_kernel(const cips3d_linear_d
   table_rows(table, n_desc, total_rows, B, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
+// a table of heads + blocks that zero a small array (the forward's range workspace, forward.hip)
+__global__ void __launch_bounds__(256) linear_table_zero_kernel(const cips3d_linear_desc* __restrict__ table, int n_desc,
+                                                                int total_rows, int B, int blocks_t, float* __restrict__ zero_ptr,
+                                                                int zero_n) {
+  if ((int)blockIdx.x < blocks_t) { table_rows(table, n_desc, total_rows, B, blockIdx.x * 4 + (threadIdx.x >> 6)); return; }
+  for (int i = ((int)blockIdx.x - blocks_t) * 256 + threadIdx.x; i < zero_n; i += ((int)gridDim.x - blocks_t) * 256) zero_ptr[i] = 0.f;
+}
+
 // one mapping layer and an independent table of heads in one launch: blocks [0, blocks_a) run the layer
 __global__ void __launch_bounds__(256) linear_and_table_kernel(cips3d_linear_args a, int blocks_a,
                                                                const cips3d_linear_desc* __restrict__ table, int n_desc,
@@ -206,6 +214,18 @@ int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_des
   const int ba = ceil_div(a.out_dim, 4);
   hipLaunchKernelGGL(linear_and_table_kernel, dim3(ba + ceil_div(total_rows, 4)), dim3(256), 0, as_stream(stream), a, ba,
                      table_dev, n_desc, total_rows, a.B);
+  return cips3d_launch_status();
+}
+
+int cips3d_linear_table_zero(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int B, float* zero_ptr,
+                             int zero_n, void* stream) {
+  if (!table_dev || n_desc <= 0 || total_rows <= 0 || B < 0 || !zero_ptr || zero_n <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  const int bt = ceil_div(total_rows, 4);
+  int bz = ceil_div(zero_n, 1024);
+  if (bz > 64) bz = 64;
+  hipLaunchKernelGGL(linear_table_zero_kernel, dim3(bt + bz), dim3(256), 0, as_stream(stream), table_dev, n_desc, total_rows, B, bt,
+                     zero_ptr, zero_n);
   return cips3d_launch_status();
 }
 

@@ -360,17 +360,101 @@ def modconv1x1_supported(Cin, Cout, HW):
     return bool(_lib.load().cips3d_modconv1x1_supported(Cin, Cout, HW))
 
 
+# ---- range tracking of the split-fp16 modes (cips3d_range, include/cips3d_hip.h): every split happens on x * 2^-e with a power
+# of two per (tensor, sample) taken from a bound of max|x|, so that the decoder's default arithmetic keeps fp32's exponent
+# range.  amax arrays are [B, AMAX_FLOATS] fp32 tensors; a kernel that produced a tensor leaves its amax attached to it
+# (`tag_amax`), a split GEMM that reads an untagged tensor measures it first (one HBM pass).
+AMAX_FLOATS = _lib.AMAX_FLOATS
+NOISE_BOUND_RNG = 6.0        # cips3d_rng_fill: |n| <= sqrt(50 ln 2) = 5.89
+NOISE_BOUND_TORCH = 7.0      # torch.randn on the device: Box-Muller on 32-bit uniforms, |n| <= 6.8
+
+
+def new_amax(B, device):
+    return torch.zeros(B, AMAX_FLOATS, device=device, dtype=torch.float32)
+
+
+def absmax(x, B=None):
+    """amax array of x viewed as [B, -1] (B defaults to x.shape[0])."""
+    B = x.shape[0] if B is None else B
+    x = x.contiguous()
+    amax = torch.empty(B, AMAX_FLOATS, device=x.device, dtype=torch.float32)
+    check(_lib.load().cips3d_absmax(dev_ptr(x, "x"), B, x.numel() // B, dev_ptr(amax), stream_ptr()), "cips3d_absmax")
+    return amax
+
+
+def amax_value(amax):
+    """[B] tensor of the maxima an amax array holds (tests, diagnostics)."""
+    return amax.view(amax.shape[0], _lib.AMAX_SLOTS, _lib.AMAX_STRIDE)[:, :, 0].max(dim=1).values
+
+
+def tag_amax(t, amax):
+    """Remember the amax array of tensor t (valid while t is not modified in place)."""
+    t._cips3d_amax = (amax, t._version)
+    return t
+
+
+def amax_of(t, measure=True):
+    tag = getattr(t, "_cips3d_amax", None)
+    if tag is not None and tag[1] == t._version and tag[0].shape[0] == t.shape[0]:
+        return tag[0]
+    return absmax(t) if measure else None
+
+
+_const_amax = {}
+
+
+def const_amax(B, bound, device):
+    """amax array of a tensor whose bound is known a priori (sines: 1)."""
+    key = (B, float(bound), str(device))
+    t = _const_amax.get(key)
+    if t is None:
+        t = _const_amax[key] = torch.full((B, AMAX_FLOATS), float(bound), device=device, dtype=torch.float32)
+    return t
+
+
+def range_consts(B, bias, noise_w, w_gain, fir=None, noise=None, noise_bound=0.0):
+    """lconst [B, 4] of one StyledConv (cips3d_range_consts).  The bound of |noise| is measured from `noise` (a device tensor)
+    when given -- no host round trip -- and / or taken from `noise_bound`."""
+    lib = _lib.load()
+    dev = bias.device
+    lconst = torch.empty(B, 4, device=dev, dtype=torch.float32)
+    na = absmax(noise, B=1) if noise is not None else None
+    bflat = bias.contiguous().view(-1)
+    check(lib.cips3d_range_consts(dev_ptr(bflat, "bias"), bflat.numel(), dev_ptr(noise_w, "noise_w", True), float(noise_bound),
+                                  dev_ptr(na, "noise_amax", True), float(w_gain), dev_ptr(fir, "fir", True), dev_ptr(lconst), B,
+                                  stream_ptr()), "cips3d_range_consts")
+    return lconst
+
+
+def _range(**kw):
+    rg = _lib.Range()
+    keep = []
+    for k, v in kw.items():
+        if v is not None:
+            keep.append(v)
+            setattr(rg, k, v.data_ptr())
+    return rg, keep
+
+
 GEMM_BF16 = 0x100      # CIPS3D_GEMM_BF16: bf16 compute mode of the decoder GEMMs (BASELINE config 3)
 Y_BF16 = 0x200         # CIPS3D_Y_BF16: the pre-FIR low-resolution GEMM result of an up-sampling stage is stored as bf16
 GEMM_SPLIT = 0x400     # CIPS3D_GEMM_SPLIT: fp32-equivalent split-fp16 products (weights packed with MOD_SPLIT)
 
 
 def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False, out_bf16=False,
-               split=False):
+               split=False, x_amax=None, track=None):
     """out_bf16 (epilogue 0 only): the result is stored as a torch.bfloat16 tensor (CIPS3D_Y_BF16).
-    split: fp32-equivalent split-fp16 products; wm_packed must come from modulate_weights(..., packed=True, split=True)."""
+    split: fp32-equivalent split-fp16 products; wm_packed must come from modulate_weights(..., packed=True, split=True).
+    The activations are split as x * 2^-e (cips3d_range): x_amax = the amax array of x, else the one attached to x by the kernel
+    that made it, else measured here.  track (default: split): leave the output's amax attached to the result."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
+    if split and x_amax is None:
+        x_amax = amax_of(x)
+    if track is None:
+        track = split
+    out_amax = new_amax(B, x.device) if (track and not out_bf16) else None
+    rg, _keep = _range(x_amax=x_amax if split else None, out_amax=out_amax)
     odt = torch.bfloat16 if out_bf16 else torch.float32
     if out is None:
         out = torch.empty(B, Cout, H, W, device=x.device, dtype=odt)
@@ -382,7 +466,9 @@ def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=No
     check(lib.cips3d_modconv1x1(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out, "out", dtype=odt), B, Cin, Cout, H * W,
                                 epilogue | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if out_bf16 else 0) | (GEMM_SPLIT if split else 0),
                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
-                                stream_ptr()), "cips3d_modconv1x1")
+                                C.byref(rg), stream_ptr()), "cips3d_modconv1x1")
+    if out_amax is not None:
+        tag_amax(out, out_amax)
     return out
 
 
@@ -434,12 +520,18 @@ def planes_supported(Cin, Cout, HW):
     return bool(_lib.load().cips3d_planes_supported(Cin, Cout, HW))
 
 
-def to_planes(x):
-    """fp32 [B,C,H,W] -> split-fp16 planes (torch.float16 tensor [B, C/8, 2, H*W, 8]: hi plane, lo plane; x = hi + lo)."""
+def to_planes(x, ranged=True):
+    """fp32 [B,C,H,W] -> split-fp16 planes (torch.float16 tensor [B, C/8, 2, H*W, 8]: hi plane, lo plane) of x * 2^-e, e one
+    power of two per sample that puts max|x| into [2^14, 2^15) (cips3d_range).  The exponents ([B] int32) and the amax array
+    travel as attributes of the result (`.cips3d_exp`, `.cips3d_amax`); ranged=False stores x itself (e = 0)."""
     lib = _lib.load()
     B, Cc, H, W = x.shape
     p = torch.empty(B, Cc // 8, 2, H * W, 8, device=x.device, dtype=torch.float16)
-    check(lib.cips3d_to_planes(dev_ptr(x, "x"), p.data_ptr(), B, Cc, H * W, stream_ptr()), "cips3d_to_planes")
+    amax = amax_of(x) if ranged else None
+    exps = torch.zeros(B, device=x.device, dtype=torch.int32) if ranged else None
+    check(lib.cips3d_to_planes(dev_ptr(x, "x"), p.data_ptr(), B, Cc, H * W, dev_ptr(amax, "amax", True),
+                               exps.data_ptr() if ranged else None, stream_ptr()), "cips3d_to_planes")
+    p.cips3d_exp, p.cips3d_amax = exps, amax
     return p
 
 
@@ -447,28 +539,54 @@ def from_planes(p, H, W):
     lib = _lib.load()
     B, C8 = p.shape[0], p.shape[1]
     x = torch.empty(B, C8 * 8, H, W, device=p.device, dtype=torch.float32)
-    check(lib.cips3d_from_planes(dev_ptr(p, "planes", dtype=torch.float16), dev_ptr(x), B, C8 * 8, H * W, stream_ptr()),
-          "cips3d_from_planes")
+    exps = getattr(p, "cips3d_exp", None)
+    check(lib.cips3d_from_planes(dev_ptr(p, "planes", dtype=torch.float16), dev_ptr(x), B, C8 * 8, H * W,
+                                 exps.data_ptr() if exps is not None else None, stream_ptr()), "cips3d_from_planes")
     return x
 
 
 def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, noise=None, noise_w=None, bias=None,
-                      rgb_w=None, rgb_part=None):
-    """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call; wm_split from
-    modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW])."""
+                      rgb_w=None, rgb_part=None, demodulated=True, lconst=None):
+    """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call (its exponents and amax
+    array are read from its attributes; a planes output carries its own); wm_split from
+    modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW]).
+    demodulated: the weights were demodulated (unit row norm -> the sqrt(Cin) gain of the output bound); for others pass lconst
+    from a modulate table that measured the row L1 norms."""
     lib = _lib.load()
     B, Cin = xp.shape[0], xp.shape[1] * 8
+    dev = xp.device
     fmt = {"fp32": 0, "planes": 1, "bf16": 2}[out_format]
     if fmt == 1:
-        out = torch.empty(B, Cout // 8, 2, HW, 8, device=xp.device, dtype=torch.float16)
+        out = torch.empty(B, Cout // 8, 2, HW, 8, device=dev, dtype=torch.float16)
     else:
-        out = torch.empty(B, Cout, HW, device=xp.device, dtype=torch.bfloat16 if fmt == 2 else torch.float32)
+        out = torch.empty(B, Cout, HW, device=dev, dtype=torch.bfloat16 if fmt == 2 else torch.float32)
     nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    x_exp, x_amax = getattr(xp, "cips3d_exp", None), getattr(xp, "cips3d_amax", None)
+    ranged = x_exp is not None
+    rg, _keep = None, None
+    if ranged:
+        if lconst is None and fmt == 1:
+            if not demodulated:
+                raise RuntimeError("a planes output of a non-demodulated conv needs the layer's lconst (row L1 norms)")
+            if epilogue == 1:
+                lconst = range_consts(B, bias, noise_w, Cin ** 0.5, noise=noise)
+            else:
+                lconst = range_consts(B, torch.zeros(1, device=dev), None, Cin ** 0.5)
+                lconst[:, 1] /= 2.0 ** 0.5      # no activation: |out| <= sqrt(Cin) max|x|
+        out_amax = new_amax(B, dev)
+        out_exp = torch.zeros(B, device=dev, dtype=torch.int32) if fmt == 1 else None
+        rg, _keep = _range(x_amax=x_amax, x_exp=x_exp, lconst=lconst if fmt == 1 else None, out_amax=out_amax, out_exp=out_exp)
     check(lib.cips3d_modconv1x1_planes(dev_ptr(xp, "x_planes", dtype=torch.float16), dev_ptr(wm_split, "wm"), out.data_ptr(), fmt,
                                        B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
                                        dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
-                                       dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), None, stream_ptr()),
+                                       dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), None,
+                                       C.byref(rg) if rg is not None else None, stream_ptr()),
           "cips3d_modconv1x1_planes")
+    if ranged:
+        if fmt == 1:
+            out.cips3d_exp, out.cips3d_amax = out_exp, out_amax
+        elif fmt == 0:
+            tag_amax(out, out_amax)
     return out
 
 
@@ -508,7 +626,7 @@ def modconv1x1_planes16(xp, wm_bf16, Cout, HW, out_format="planes16", epilogue=0
                                          fmt, B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
                                          dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
                                          dev_ptr(rgb_w, "rgb_w", True), dev_ptr(rgb_part, "rgb_part", True), C.byref(nblk),
-                                         stream_ptr()), "cips3d_modconv1x1_planes16")
+                                         None, stream_ptr()), "cips3d_modconv1x1_planes16")
     return out, nblk.value
 
 
@@ -583,13 +701,21 @@ def fused_up_conv_chains(C_):
 
 
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
-                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None, split=False):
+                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None, split=False, ranged=True):
     """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv).
     wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next.
     A torch.bfloat16 `y_lo` selects the bf16-storage form (CIPS3D_Y_BF16, needs bf16=True): y_next is then bf16 as well.
-    split: fp32-equivalent split-fp16 products; wm2_packed / wm_next must then be MOD_SPLIT16-packed."""
+    split: fp32-equivalent split-fp16 products; wm2_packed / wm_next must then be MOD_SPLIT16-packed.  The stage's operands are
+    then split under power-of-two scales from rigorous bounds (cips3d_range): y_lo's amax array is taken from its tag or
+    measured, the two layers' constants are made here (noise bounds measured on the device); out2 / y_next leave tagged."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
+    rg, _keep, next_amax = None, None, None
+    if split and ranged:
+        lc1 = range_consts(B, bias1, noise_w1, 0.0, fir=fir, noise=noise1)
+        lc2 = range_consts(B, bias2, noise_w2, Cc ** 0.5, noise=noise2)
+        next_amax = new_amax(B, y_lo.device) if wm_next is not None else None
+        rg, _keep = _range(x_amax=amax_of(y_lo), lconst=lc1, lconst2=lc2, next_amax=next_amax)
     dev = y_lo.device
     ydt = y_lo.dtype
     if ydt == torch.bfloat16 and not bf16:
@@ -609,7 +735,10 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
                                         int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if ydt == torch.bfloat16 else 0) |
                                         (GEMM_SPLIT if split else 0),
                                         dev_ptr(rgb, "rgb", True), dev_ptr(wm_next, "wm_next", True),
-                                        dev_ptr(y_next, "y_next", True, dtype=ydt), B, Cc, H, W, stream_ptr()), "cips3d_fused_up_conv_next")
+                                        dev_ptr(y_next, "y_next", True, dtype=ydt), B, Cc, H, W,
+                                        C.byref(rg) if rg is not None else None, stream_ptr()), "cips3d_fused_up_conv_next")
+    if next_amax is not None:
+        tag_amax(y_next, next_amax)
     if wm_next is not None:
         return out2, rgb, y_next
     return out2, rgb
@@ -772,8 +901,10 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
         packed.append(pack_weights(Wb, split=split))            # forward recompute: activations in [-1, 1]
         packed_t.append(pack_weights(Wb, transpose=True))       # data gradients: fp32 MFMA (see SPLIT_BACKWARD)
 
+    sine_amax = const_amax(B, 1.0, dev)         # the recompute's GEMM inputs are FiLM sines
+
     def gemm(x, pk, sp=False):
-        return modconv1x1(x.view(B, H, P, 1), pk, H, epilogue=0, split=sp).view(B, H, P)
+        return modconv1x1(x.view(B, H, P, 1), pk, H, epilogue=0, split=sp, x_amax=sine_amax, track=False).view(B, H, P)
 
     for l in range(1, L):
         acc = gemm(hh[l - 1], packed[l - 1], split)

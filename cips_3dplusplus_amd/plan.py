@@ -17,7 +17,8 @@ MAX_DEC = 40
 class DecLayer(C.Structure):
     _fields_ = [("kind", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("noise_index", C.c_int32), ("flags", C.c_int32), ("pad_", C.c_int32), ("wm", C.c_void_p),
-                ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p)]
+                ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p),
+                ("amax", C.c_void_p), ("aexp", C.c_void_p), ("lconst", C.c_void_p)]
 
 
 class GeneratorPlan(C.Structure):
@@ -35,7 +36,9 @@ class GeneratorPlan(C.Structure):
                 ("layers", DecLayer * MAX_DEC),
                 ("act", C.c_void_p * 2), ("y_lo", C.c_void_p), ("y_lo2", C.c_void_p), ("skip", C.c_void_p * 2),
                 ("rgb_part", C.c_void_p),
-                ("rgb_part_slots", C.c_int64)]
+                ("rgb_part_slots", C.c_int64),
+                ("range_ws", C.c_void_p), ("range_ws_words", C.c_int64), ("feat_amax", C.c_void_p), ("feat_exp", C.c_void_p),
+                ("tmp_amax", C.c_void_p)]
 
 
 class ForwardIO(C.Structure):
@@ -47,7 +50,8 @@ class ForwardIO(C.Structure):
                 ("rgb", C.c_void_p), ("thumb", C.c_void_p), ("xyz", C.c_void_p), ("mask", C.c_void_p),
                 ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p),
                 ("rng_seed", C.c_uint64), ("rng_base", C.c_uint64), ("rng_normal", C.c_void_p), ("rng_n_normal", C.c_int64),
-                ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64)]
+                ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
+                ("noise_bound", C.c_float), ("pad2_", C.c_int32)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -215,6 +219,20 @@ class ForwardPlan:
         wm_buf = torch.empty(sum(wm_sizes), device=dev)
         wm_tab = (_lib.ModulateDesc * len(seq))()
         rows, woff = 0, 0
+        # Range workspace of a split-fp16 decoder (cips3d_range): per StyledConv an amax array, the exponent of its planes
+        # output and its bound constants; the feature map's rows; one scratch amax array.  One buffer, zeroed by every forward.
+        AF = _lib.AMAX_FLOATS
+        per_layer = B * (AF + 1 + 4)
+        n_sc = sum(1 for li in layer_info if li["kind"] in (0, 1))
+        range_ws = torch.zeros(n_sc * per_layer + B * (2 * AF + 1), device=dev) if use_split else None
+        self.ranged = range_ws is not None
+        rw = range_ws.data_ptr() if self.ranged else 0
+        if self.ranged:
+            p.range_ws, p.range_ws_words = rw, range_ws.numel()
+            tail = rw + 4 * n_sc * per_layer
+            p.feat_amax, p.tmp_amax, p.feat_exp = tail, tail + 4 * B * AF, tail + 4 * 2 * B * AF
+            self._keep.append(range_ws)
+        sc_i = 0
         for idx, (info, off) in enumerate(zip(layer_info, offs)):
             conv = info["conv"]
             d = wm_tab[idx]
@@ -239,6 +257,12 @@ class ForwardPlan:
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)
             L.fir = dev_ptr(info["fir"], allow_none=True)
+            if self.ranged and info["kind"] in (0, 1):
+                base = rw + 4 * sc_i * per_layer
+                L.amax, L.aexp, L.lconst = base, base + 4 * B * AF, base + 4 * B * (AF + 1)
+                d.lconst, d.bias, d.n_bias = L.lconst, L.bias, conv.out_channel
+                d.noise_w, d.fir = L.noise_w, L.fir
+                sc_i += 1
             woff += wm_sizes[idx]
         p.n_dec_layers = len(seq)
         wm_tab_dev = _upload(wm_tab).to(dev)
@@ -302,6 +326,31 @@ class ForwardPlan:
                 bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)),
                 bool(getattr(G.decoder, "split", False)))
 
+    def _noise_bound(self, noise_bufs, fresh_noise):
+        """Upper bound of |noise| over the call (cips3d_forward_io.noise_bound; the bound constants of a ranged plan): known
+        for fresh draws; caller-supplied maps are measured on the device once per (storage, version)."""
+        if not getattr(self, "ranged", False):
+            return 0.0
+        if fresh_noise:
+            return hip.NOISE_BOUND_RNG if hip.FAST_RNG else hip.NOISE_BOUND_TORCH
+        cache = self.__dict__.setdefault("_nb_cache", {})
+        bound = hip.NOISE_BOUND_TORCH if any(nb is None for nb in noise_bufs) else 0.0
+        todo = []
+        for nb in noise_bufs:
+            if nb is None:
+                continue
+            key = (nb.data_ptr(), nb._version, nb.numel())
+            if key in cache:
+                bound = max(bound, cache[key])
+            else:
+                todo.append((key, hip.absmax(nb.detach().float().contiguous(), B=1)))
+        for key, am in todo:        # (one synchronisation for all of them)
+            if len(cache) > 256:
+                cache.clear()
+            cache[key] = float(hip.amax_value(am)[0])
+            bound = max(bound, cache[key])
+        return bound
+
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
             events=None, fresh_perturb=False):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
@@ -316,6 +365,7 @@ class ForwardPlan:
             if not hip.FAST_RNG:
                 perturb_u = torch.rand(B, S * S, device=dev)
         io = ForwardIO()
+        io.noise_bound = self._noise_bound(noise_bufs, fresh_noise)
         if hip.FAST_RNG and (fresh_noise or fresh_perturb):
             # the draw is made by the forward call itself (cips3d_forward_io.rng_*: spread over the mapping launches)
             n_n, n_u = (B * self.noise_total if fresh_noise else 0), (B * S * S if fresh_perturb else 0)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 14  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 15  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -118,6 +118,11 @@ int cips3d_linear_table_bwd(const cips3d_linear_desc* table_dev, int n_desc, int
                             const float* out_base, const float* dy_base, const float* x_base, float* dx_base,
                             const int64_t* w_offsets_dev, float* dW, float* db, void* stream);
 
+#define CIPS3D_AMAX_SLOTS 16      /* see cips3d_range below: slots of one (tensor, sample), each on a 64-byte line of its own */
+#define CIPS3D_AMAX_STRIDE 16     /* floats between slots */
+#define CIPS3D_AMAX_FLOATS (CIPS3D_AMAX_SLOTS * CIPS3D_AMAX_STRIDE)
+#define CIPS3D_FEATURES_EXP (-14)
+
 /* ------------------------------------------------------------------ camera */
 
 /* locations [B,2] = (azim, elev); fov_deg [B] or NULL (then fov_deg_scalar); up [B,3] or NULL
@@ -179,9 +184,13 @@ typedef struct cips3d_nerf_params {
    * ignored and `part` + cips3d_nerf_finish is the way. */
   float* o_features; float* o_thumb; float* o_xyz; float* o_mask;
   /* != 0 (fused finish only): o_features receives the feature map as split-fp16 planes [B][H/8][hi|lo][R][8] (fp16), the
-   * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes) */
+   * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes).  The planes hold features * 2^14
+   * (CIPS3D_FEATURES_EXP: a feature is a convex combination of sines, |f| <= 1); when given, features_exp[b] receives that
+   * exponent and every slot of features_amax[b] the bound 1.0 (see cips3d_range) */
   int32_t features_planes;
   int32_t pad_;
+  int32_t* features_exp;    /* [B] or NULL */
+  float* features_amax;     /* [B][CIPS3D_AMAX_FLOATS] or NULL */
   /* Differentiable forward (camera-driven mode only; all three or none): the render kernel additionally writes what
    * cips3d_nerf_bwd_fused needs, so that the backward does not recompute the forward -- per MFMA layer the fp32 accumulators
    * (`stash`: cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, hidden, depth, n_chunks) floats, the layout of that
@@ -212,6 +221,41 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
                             float* thumb_rgb, float* xyz, float* mask, void* stream);
 
 /* ------------------------------------------------------------------ decoder */
+
+/* Range tracking of the split-fp16 modes (CIPS3D_GEMM_SPLIT, planes).  An fp32 activation is carried as two fp16 numbers; fp16
+ * has 5 exponent bits, the reference's fp32 convolution (models/model_v3.py:296-312) 8.  Every split therefore happens on
+ * x * 2^-e with one power of two per (tensor, sample) that puts a rigorous bound of max|x| into [2^14, 2^15); the consumer
+ * undoes it exactly on its accumulators.  Two kinds of small per-sample device arrays carry what the kernels need:
+ *   amax  [B][CIPS3D_AMAX_FLOATS] fp32: max |x| of a tensor's true values = the maximum over its CIPS3D_AMAX_SLOTS slots
+ *         (slot s at float s * CIPS3D_AMAX_STRIDE: one 64-byte line each, so that the atomics of different workgroups do not
+ *         queue on one line).  The producing epilogue raises a slot with one atomicMax per workgroup (the caller zeroes the
+ *         array before the producer runs); cips3d_absmax fills it for a tensor that exists already.
+ *   exp   [B] int32: the exponent e a planes tensor was stored with (stored value = x * 2^-e), written by its producer.
+ *   lconst[B][4] fp32 {c0, c1, l1, -}: the layer's bound constants, |out| <= max(c1, sqrt(2) l1) * max|in| + c0 with
+ *         c0 = sqrt(2) (|noise_w| * noise_bound + max|bias|), c1 = sqrt(2) * (sqrt(Cin) for a demodulated conv; the FIR's
+ *         largest polyphase gain for the 2x up-sampler), l1 = the largest row L1 norm of a NON-demodulated weight (measured
+ *         by the modulate kernel, else 0).  Written by cips3d_range_consts or by cips3d_modulate_table.
+ * A kernel that must scale values it produces itself (planes output, the intermediates of a fused up-sampling stage) uses
+ * bound = c1 * amax(in) + c0; a kernel that splits an existing fp32 tensor uses bound = amax(in).
+ * Passing rg == NULL keeps e = 0 everywhere (legal only for callers that know max|x| of every operand to lie in
+ * [2^-3, 6e4]); the Python host always passes it. */
+typedef struct cips3d_range {
+  const float* x_amax;     /* [B][CIPS3D_AMAX_FLOATS] of the input activation (required)                                        */
+  const int32_t* x_exp;    /* [B] planes input: its exponent                                                        */
+  const float* lconst;     /* [B][4] of this layer (planes output; conv1 of a fused stage)                         */
+  const float* lconst2;    /* [B][4] of conv2 of a fused stage (needed when wm_next != NULL)                       */
+  float* out_amax;         /* [B][CIPS3D_AMAX_FLOATS] or NULL: raised to max |out| (GEMM entry points; not the fused stage)      */
+  int32_t* out_exp;        /* [B] planes output: receives the exponent this launch chose                            */
+  float* next_amax;        /* [B][CIPS3D_AMAX_FLOATS] or NULL: raised to max |y_next| (fused stage with wm_next)                 */
+} cips3d_range;
+/* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
+int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
+/* lconst[b] = {c0, c1, 0, 0} from a layer's parameters (device pointers; noise_w / bias / fir may be NULL):
+ * c1 = sqrt(2) * (fir ? largest polyphase gain of the 4x4 FIR : w_gain), w_gain = sqrt(Cin) for a demodulated conv.
+ * The bound of |noise| is max(noise_bound, the maximum of noise_amax), noise_amax = the slots of ONE sample written by
+ * cips3d_absmax over the whole noise tensor (or NULL): no host round trip for a noise map that exists only on the device. */
+int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, float noise_bound, const float* noise_amax,
+                        float w_gain, const float* fir, float* lconst, int B, void* stream);
 
 /* Modulated (and optionally demodulated) weights of one conv for every sample:
  *   wm[b][o][i][t] = scale * W[o][i][t] * s[b][i];  wm[b][o] *= rsqrt(sum wm[b][o]^2 + 1e-8)
@@ -270,9 +314,18 @@ typedef struct cips3d_modulate_desc {
   int32_t Cout, Cin, ksq, flags;
   float scale;
   int32_t row_begin;     /* exclusive prefix sum of Cout over the table */
+  /* range constants of the layer this conv belongs to (all optional; lconst NULL = none wanted): the launch writes
+   * lconst[b] = {c0, c1, l1, 0} (see cips3d_range) -- c0 / c1 by the wave of row 0, l1 raised by every row of a
+   * non-demodulated conv (lconst must then be zero before the launch) */
+  float* lconst;         /* [B][4] */
+  const float* bias;     /* [n_bias] FusedLeakyReLU bias of the StyledConv */
+  const float* noise_w;  /* [1] */
+  const float* fir;      /* [16]: the conv up-samples; c1 follows the FIR, not the weight */
+  int32_t n_bias, pad_;
 } cips3d_modulate_desc;
 
-int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B,
+/* noise_bound: an upper bound of |noise| over every noise map of the call (cips3d_rng_fill draws stay below 5.77) */
+int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int n_desc, int total_rows, int B, float noise_bound,
                           void* stream);
 
 /* 1 when cips3d_modconv1x1 tiles this shape (Cin % 32 == 0, Cout % 32 == 0, HW % 4 == 0). */
@@ -286,7 +339,7 @@ int cips3d_modconv1x1_supported(int Cin, int Cout, int64_t HW);
  * per-sample [B,HW] (noise_bstride = HW). */
 int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
                       int64_t HW, int epilogue, const float* noise, int64_t noise_bstride,
-                      const float* noise_w, const float* bias, void* stream);
+                      const float* noise_w, const float* bias, const cips3d_range* rg, void* stream);
 
 /* The same GEMM with the ToRGB that FOLLOWS this conv folded into its epilogue (models/model_v3.py:602-632: ToRGB reads
  * the conv's output): every workgroup also writes the partial sums of its block of output rows,
@@ -297,8 +350,9 @@ int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Ci
 #define CIPS3D_TORGB_FOLD_MAX 8
 int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int64_t HW, int epilogue,
                             const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
-                            const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
-/* out[b][r][n] = skip[b][r][n] + sum_{s < n_slots} part[s][b][r][n] + sum_{k < n_bias} biases[k][r]
+                            const float* rgb_w, float* rgb_part, int* n_row_blocks, const cips3d_range* rg, void* stream);
+/* (rg: CIPS3D_GEMM_SPLIT splits x * 2^-e, e from rg->x_amax; every mode raises rg->out_amax to max |out| when given)
+ * out[b][r][n] = skip[b][r][n] + sum_{s < n_slots} part[s][b][r][n] + sum_{k < n_bias} biases[k][r]
  * (part = consecutive slots of [B,3,HW]; biases = HOST array of device pointers to [3]; skip may be NULL) */
 int cips3d_torgb_reduce(const float* part, int n_slots, const float* const* biases, int n_bias, const float* skip, float* out,
                         int B, int64_t HW, void* stream);
@@ -341,12 +395,15 @@ int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, const float* 
                               const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
                               int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
                               const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up, float* rgb,
-                              const float* wm_next, float* y_next, int B, int C, int H, int W, void* stream);
+                              const float* wm_next, float* y_next, int B, int C, int H, int W, const cips3d_range* rg,
+                              void* stream);
 int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
                          const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
                          int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
                          const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up, float* rgb,
-                         int B, int C, int H, int W, void* stream);
+                         int B, int C, int H, int W, const cips3d_range* rg, void* stream);
+/* (rg, CIPS3D_GEMM_SPLIT mode: x_amax = amax of y_lo, lconst = conv1's constants, lconst2 = conv2's; next_amax <- max |y_next|.
+ * out2 is not tracked -- the register budget of the C = 32 stage; use cips3d_absmax before a split GEMM reads a stored out2) */
 
 /* General k x k modulated convolution (k odd, padding k/2), direct form; used for k = 3 configs.
  * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
@@ -360,11 +417,14 @@ int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int C
  * 2 bf16 [B,Cout,HW].  epilogue / noise / bias / rgb_w / rgb_part / n_row_blocks as cips3d_modconv1x1_torgb (row blocks of 64).
  * cips3d_planes_supported: Cin % 64 == 0, Cout % 64 == 0. */
 int cips3d_planes_supported(int Cin, int Cout, int64_t HW);
-int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, void* stream);      /* C % 8 == 0 */
-int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, void* stream);
+/* x_amax [B][CIPS3D_AMAX_FLOATS] (cips3d_absmax) -> planes of x * 2^-e, e -> exp_out[b]; both NULL: e = 0.  C % 8 == 0 */
+int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, const float* x_amax, int32_t* exp_out, void* stream);
+int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, const int32_t* exp, void* stream);
+/* rg: x_exp (input planes), x_amax + lconst (-> the exponent of a planes output, written to out_exp), out_amax */
 int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, int out_format, int B, int Cin, int Cout,
                              int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
-                             const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
+                             const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, const cips3d_range* rg,
+                             void* stream);
 
 /* The bf16 decoder mode's form of the same run (BASELINE config 3: both GEMM operands rounded to bf16, fp32 accumulate --
  * the reference has no bf16 mode; the semantics are oracle/path.py:modulated_conv2d(bf16_gemm=True) over
@@ -376,7 +436,10 @@ int cips3d_to_planes16(const float* x, void* planes16, int B, int C, int64_t HW,
 int cips3d_from_planes16(const void* planes16, float* x, int B, int C, int64_t HW, void* stream);
 int cips3d_modconv1x1_planes16(const void* x_planes16, const float* wm, void* out, int out_format, int B, int Cin, int Cout,
                                int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
-                               const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, void* stream);
+                               const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, const cips3d_range* rg,
+                               void* stream);
+/* (planes16: bf16 has fp32's exponent range, no scaling; rg->out_amax is still raised when given -- an fp32 / bf16 exit of the
+ * run feeds a fused stage that may run split) */
 
 /* 3x3 ModulatedConv2d (models/model_v3.py:264-314, decoder_cfg.kernel_size = 3) as an LDS-tiled implicit GEMM on MFMA.
  *   up = 0: out [B,Cout,H,W] = conv2d(x, wm, padding 1)                                           (:296-311)
@@ -418,6 +481,10 @@ typedef struct cips3d_dec_layer {
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */
   const float* noise_w;    /* NoiseInjection.weight [1] (StyledConv) */
   const float* fir;        /* 4x4 FIR (blur.kernel / upsample.kernel) for kinds 1 and 3 */
+  /* range workspace rows of this layer (cips3d_range; StyledConvs of a plan whose decoder runs split-fp16, else NULL) */
+  float* amax;             /* [B][CIPS3D_AMAX_FLOATS] max |output| (kind 1: of the low-resolution GEMM result y_lo) */
+  int32_t* aexp;           /* [B] exponent of a planes output */
+  float* lconst;           /* [B][4] written by the modulate table */
 } cips3d_dec_layer;
 
 typedef struct cips3d_generator_plan {
@@ -447,6 +514,12 @@ typedef struct cips3d_generator_plan {
   float* skip[2];                /* RGB skip ping-pong, each >= B*3*Hout*Wout floats */
   float* rgb_part;               /* ToRGB partial-sum slots, each [B,3,H0*W0] at the input resolution (or NULL: no folding) */
   int64_t rgb_part_slots;        /* capacity in slots */
+  /* range workspace (NULL: the decoder does not run split-fp16): zeroed by every forward before its first use */
+  float* range_ws;               /* range_ws_words 32-bit words holding every layer's amax / aexp / lconst rows */
+  int64_t range_ws_words;
+  float* feat_amax;              /* [B][CIPS3D_AMAX_FLOATS] of the NeRF feature map (inside range_ws) */
+  int32_t* feat_exp;             /* [B] */
+  float* tmp_amax;               /* [B][CIPS3D_AMAX_FLOATS] scratch for tensors no producer tracked */
 } cips3d_generator_plan;
 
 typedef struct cips3d_forward_io {
@@ -474,6 +547,8 @@ typedef struct cips3d_forward_io {
   uint64_t rng_seed, rng_base;
   float* rng_normal; int64_t rng_n_normal;
   float* rng_uniform; int64_t rng_n_uniform;
+  float noise_bound;       /* upper bound of |noise[i][...]| over the call (0: the rng draw's own bound, 5.77, is used) */
+  int32_t pad2_;
 } cips3d_forward_io;
 
 int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io, void* stream);

@@ -181,13 +181,13 @@ def test_planes16_entry_point_refusals():
     x = torch.zeros(1, 8, 64, 8, device=DEV, dtype=torch.bfloat16)
     w = torch.zeros(64 * 64, device=DEV)
     o = torch.zeros(1, 64, 64, device=DEV)
-    args = (1, 64, 64, 64, 0, None, 0, None, None, None, None, None, st)
+    args = (1, 64, 64, 64, 0, None, 0, None, None, None, None, None, None, st)
     assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 1, *args) != 0          # split planes out: not here
     assert lib.cips3d_modconv1x1_planes16(None, w.data_ptr(), o.data_ptr(), 0, *args) != 0
     assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 0, 1, 32, 64, 64, 0, None, 0, None, None, None,
-                                          None, None, st) != 0                                                 # Cin % 64
+                                          None, None, None, st) != 0                                           # Cin % 64
     assert lib.cips3d_modconv1x1_planes16(x.data_ptr(), w.data_ptr(), o.data_ptr(), 0, 1, 64, 64, 64, 1, None, 0, None, None, None,
-                                          None, None, st) != 0                                                 # epilogue without bias
+                                          None, None, None, st) != 0                                           # epilogue without bias
     assert lib.cips3d_to_planes16(o.data_ptr(), x.data_ptr(), 1, 60, 64, st) != 0                              # C % 8
     # CIPS3D_MOD_BF16 needs the plain packed layout and Cin % 32 == 0
     Wt = torch.zeros(64, 48, device=DEV)

@@ -886,7 +886,7 @@ def test_modconv1x1_torgb_fold_vs_oracle():
     xg, nzg = cu(x), cu(nz)
     _lib.check(lib.cips3d_modconv1x1_torgb(xg.data_ptr(), wm.data_ptr(), out.data_ptr(), B, cin, cout, hw * hw, 1, nzg.data_ptr(), 0,
                                            sc.noise.weight.data_ptr(), sc.activate.bias.data_ptr(), wrgb.data_ptr(),
-                                           part.data_ptr(), C.byref(nblk), hip.stream_ptr()), "cips3d_modconv1x1_torgb")
+                                           part.data_ptr(), C.byref(nblk), None, hip.stream_ptr()), "cips3d_modconv1x1_torgb")
     assert nblk.value == 1                      # Cout = 128 -> one 128-row block
     rgb = torch.empty(B, 3, hw, hw, device=DEV)
     biases = (C.c_void_p * 1)(tr.bias.data_ptr())

@@ -108,11 +108,17 @@ def test_planes_roundtrip_and_chain_gemm():
     p = hip.to_planes(x)
     assert p.shape == (B, C // 8, 2, HW, 8) and p.dtype == torch.float16
     back = hip.from_planes(p, H, H)
-    # 22 significant bits, and an absolute floor of half an fp16 subnormal step (2^-25) for residuals below fp16's normal range
-    assert bool(((back - x).abs() <= 2.5e-7 * x.abs() + 3.1e-8).all())
+    # The planes hold x * 2^-e, max|x| 2^-e in [2^14, 2^15) per sample (cips3d_range): 22 significant bits, and an absolute floor
+    # of half an fp16 subnormal step (2^-25) in the SCALED domain, i.e. 2^-39 of the sample's maximum
+    mx = x.abs().amax(dim=(1, 2, 3), keepdim=True)
+    assert bool(((back - x).abs() <= 2.5e-7 * x.abs() + mx * 2.0 ** -39).all())
     # planes layout: channel 8 cb + e of pixel n lives at [b, cb, plane, n, e]
-    hi = x.to(torch.float16)
+    e = p.cips3d_exp.to(torch.float32).view(B, 1, 1, 1)
+    hi = (x * torch.exp2(-e)).to(torch.float16)
     assert torch.equal(p[:, :, 0].permute(0, 1, 3, 2).reshape(B, C, HW), hi.reshape(B, C, HW))
+    raw = hip.to_planes(x, ranged=False)                 # e = 0: the halves of x itself
+    assert torch.equal(raw[:, :, 0].permute(0, 1, 3, 2).reshape(B, C, HW), x.to(torch.float16).reshape(B, C, HW))
+    assert bool(((hip.from_planes(raw, H, H) - x).abs() <= 2.5e-7 * x.abs() + 3.1e-8).all())
     scale = 1.0 / math.sqrt(C)
     nw = torch.full((1,), 0.2, device=DEV)
     cur_p, cur_x = p, x
@@ -134,7 +140,7 @@ def test_planes_roundtrip_and_chain_gemm():
             nb = HW if nz.shape[0] == B else 0
             _lib.check(lib.cips3d_modconv1x1_torgb(cur_x.data_ptr(), wm_x.data_ptr(), ref.data_ptr(), B, C, Cout, HW, 1, nz.data_ptr(),
                                                    nb, nw.data_ptr(), bias.data_ptr(), wr.data_ptr(), part_ref.data_ptr(), None,
-                                                   torch.cuda.current_stream().cuda_stream), "ref")
+                                                   None, torch.cuda.current_stream().cuda_stream), "ref")
             part = torch.zeros_like(part_ref)
             out_p = hip.modconv1x1_planes(cur_p, wm_s, Cout, HW, "planes", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr,
                                           rgb_part=part)

@@ -2,13 +2,14 @@
 usage: python tools/kernel_regs.py nerf_bwd_fused.hip [substring]"""
 import os, re, subprocess, sys
 here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, here)
+from cips_3dplusplus_amd.build import FLAGS, FILE_FLAGS      # the shipped flags, per-file ones included
 src = sys.argv[1]
 sub = sys.argv[2] if len(sys.argv) > 2 else ""
 stem = os.path.splitext(src)[0]
 os.makedirs("/tmp/kregs", exist_ok=True)
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-gpu-rdc",
-                "-save-temps=obj", "-c", os.path.join(here, "cips_3dplusplus_amd/csrc", src), "-o", f"/tmp/kregs/{stem}.o"]
-               + os.environ.get("CIPS3D_HIPCC_FLAGS", "").split(), check=True)
+subprocess.run(["/opt/rocm/bin/hipcc", *FLAGS, *FILE_FLAGS.get(src, []), "-save-temps=obj", "-c",
+                os.path.join(here, "cips_3dplusplus_amd/csrc", src), "-o", f"/tmp/kregs/{stem}.o"], check=True, cwd="/tmp/kregs")
 s = open(f"/tmp/kregs/{stem}-hip-amdgcn-amd-amdhsa-gfx950.s").read()
 for b in s.split("  - .agpr_count:")[1:]:
     g = lambda k: re.search(r"\." + k + r":\s+(\S+)", b).group(1)
