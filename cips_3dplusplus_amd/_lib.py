@@ -36,13 +36,15 @@ class ModulateDesc(C.Structure):
 
 class Range(C.Structure):
     """cips3d_range: range tracking of the split-fp16 modes (include/cips3d_hip.h)."""
-    _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
-                ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p)]
+    _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("x_exp_const", C.c_int32), ("x_max_const", C.c_float),
+                ("x_pmax", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
+                ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p), ("out_pmax", C.c_void_p)]
 
 
-AMAX_SLOTS, AMAX_STRIDE = 16, 16
+AMAX_SLOTS, AMAX_STRIDE = 8, 64                 # CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE (re-read from the library by load())
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE          # floats per (tensor, sample) of an amax array
 FEATURES_EXP = -14
+PLANES_EXP_BLOCK = 128
 
 
 class NerfParams(C.Structure):
@@ -57,7 +59,6 @@ class NerfParams(C.Structure):
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
                 ("features_planes", C.c_int32), ("pad_", C.c_int32),
-                ("features_exp", C.c_void_p), ("features_amax", C.c_void_p),
                 ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p)]
 
 
@@ -102,6 +103,7 @@ _SIGS = {
                                         C.c_void_p]),
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, c_f32, C.c_void_p]),
     "cips3d_absmax": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
+    "cips3d_amax_layout": (c_int, [C.POINTER(c_int), C.POINTER(c_int)]),
     "cips3d_range_consts": (c_int, [c_f32p, c_int, c_f32p, c_f32, c_f32p, c_f32, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
     "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,
@@ -125,7 +127,7 @@ _SIGS = {
     "cips3d_modconv_kxk": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                    C.c_void_p]),
     "cips3d_planes_supported": (c_int, [c_int, c_int, c_i64]),
-    "cips3d_to_planes": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, c_f32p, C.c_void_p, C.c_void_p]),
+    "cips3d_to_planes": (c_int, [c_f32p, C.c_void_p, c_int, c_int, c_i64, c_f32p, C.c_void_p, c_f32p, C.c_void_p]),
     "cips3d_from_planes": (c_int, [C.c_void_p, c_f32p, c_int, c_int, c_i64, C.c_void_p, C.c_void_p]),
     "cips3d_modconv1x1_planes": (c_int, [C.c_void_p, c_f32p, C.c_void_p, c_int, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64,
                                          c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -214,6 +216,10 @@ def load(build_if_missing=True):
         if lib.cips3d_sizeof_struct(which) != C.sizeof(st):
             raise RuntimeError(f"layout mismatch for {st.__name__}: library {lib.cips3d_sizeof_struct(which)} bytes, "
                                f"binding {C.sizeof(st)} bytes")
+    global AMAX_SLOTS, AMAX_STRIDE, AMAX_FLOATS
+    sl, st = C.c_int(0), C.c_int(0)
+    lib.cips3d_amax_layout(C.byref(sl), C.byref(st))
+    AMAX_SLOTS, AMAX_STRIDE, AMAX_FLOATS = sl.value, st.value, sl.value * st.value
     _lib = lib
     return lib
 

@@ -16,12 +16,23 @@
 //   epilogue        x 2^-8 (exact), NoiseInjection + bias + leaky ReLU, optional folded ToRGB partial sums (as
 //                   cips3d_modconv1x1_torgb), then either planes again (the next layer of the run) or fp32 / bf16 NCHW (the
 //                   low-resolution GEMM that feeds the first fused up-sampling stage).
-//   range           planes hold x * 2^-e, one exponent per (tensor, sample) (cips3d_range, common.h): the input's exponent comes
-//                   from its producer (x_exp) and is undone on the accumulators together with the weights' 2^-8; the output's
-//                   is chosen here, by every workgroup alike, from the rigorous bound |out| <= c1 max|in| + c0 (the measured
-//                   maximum of the input, the layer's constants), folded into the sqrt(2) of the activation -- no instruction
-//                   per value -- and written to out_exp for the consumer.  Every workgroup also raises out_amax to the
-//                   largest |out| it stored (one atomic per workgroup), the next layer's max|in|.
+//   range           planes hold x * 2^-e with one exponent per (sample, block of 128 pixels) -- GEMM columns are independent, so
+//                   a pixel block may carry a scale of its own (cips3d_range, common.h).  The input block's exponent comes from
+//                   its producer (x_exp) and is undone on the accumulators together with the weights' 2^-8.  The output's is
+//                   chosen HERE from the rigorous bound |out| <= c1 max|in| + c0 (the layer's constants) with max|in| taken
+//                   over this workgroup's own pixel block only: the producing launch left the maximum of every
+//                   (16 channels x 64 pixels) patch it stored in a small side array (x_pmax: one plain store per wave, no
+//                   atomics, nothing to zero), a wave reads the 2 x Cin/16 entries of its pixel block with ONE load in front
+//                   of the main loop and reduces them in registers; the eight workgroups of a pixel block read the same
+//                   entries and so agree on the exponent without talking to each other.  It rides on the sqrt(2) of the
+//                   activation -- no instruction per value -- and row block 0 writes it to out_exp for the consumer; every
+//                   wave leaves its own patch maximum in out_pmax.
+//                   (Forms measured on the way: per-sample maxima through atomicMax slots and scalar loads, 14.6 us per layer
+//                   against 11.1 -- most of it was NOT the atomics but the 8 bytes of __shared__ for the workgroup reduction,
+//                   which moved the ring off LDS offset 0 and the allocation past 96 KB: 2.3 us; max|in| from the hi halves
+//                   the main loop reads anyway: +0.9 us per layer, its instructions sit between a wave's MFMAs and the stage
+//                   barrier in front of the next DMA issue.)  The fp32 / bf16 exit of the run raises out_amax (per-sample
+//                   slots) for the fused up-sampling stage that reads it.
 //
 // Bound: L2 -> LDS bytes (64 x 128 tiles: 384 KB per workgroup and layer) + the launch skeleton; the matrix time is ~1/5 of
 // the fp32 MFMA's.
@@ -76,9 +87,13 @@ struct ChainArgs {
   int B, Cin, Cout; int HW;
   int epilogue; const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
   const float* rgb_w; float* rgb_part;
-  // range tracking (all optional): cips3d_range
-  const float* x_amax; const int* x_exp; const float* lconst; float* out_amax; int* out_exp;
+  // range tracking (all optional): cips3d_range.  x_exp / out_exp: [B][ceil(HW / 128)] per pixel block; x_exp NULL: x_exp_const.
+  // x_pmax / out_pmax: [B][ceil(HW / 64)][C / 16] patch maxima; x_pmax NULL: max|in| = x_max_const
+  const int* x_exp; int x_exp_const; const float* x_pmax; float x_max_const; const float* lconst; float* out_amax; int* out_exp;
+  float* out_pmax;
 };
+
+
 
 // NP = planes per operand: 2 = split-fp16 (hi, lo; three fp16 MFMAs per tile and k-block), 1 = bf16 (one bf16 MFMA)
 template <int WM, int WGM, int WGN, int BK, int NS, int NP = 2>
@@ -94,8 +109,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   constexpr int PW = PIECES / NW;
   constexpr int KB = BK / 32, KQ = KB * NP;      // KQ = 1 KB A pieces per o-tile and stage
   static_assert(PIECES % NW == 0 && BK % 32 == 0, "tile shape");
+  static_assert(NP != 2 || BN == CIPS3D_PLANES_EXP_BLOCK, "one planes exponent per workgroup pixel block");
   __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
-  __shared__ unsigned s_amax[2];                  // workgroup maximum of |out| and its arrival count (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -103,10 +118,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int q = lane >> 4, col = lane & 15;
   const int b = blockIdx.z;
-  if (tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }       // (visible to every wave after the first stage barrier)
+
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int HW = a.HW, K = a.Cin;
   const int nstage = K / BK;
+  // 4 * NW LDS words for the workgroup reductions after the main loop (max|in| of the pixel block; max|out| of an fp32 exit).
+  // They live in the ring slot the LAST K stage does not use -- dead for every wave once it is past that stage's barrier.  (A
+  // separate __shared__ array moved the ring off LDS offset 0 and rounded the allocation up past 96 KB: every layer of the
+  // run was 2.3 us, 20 %, slower for it.)
+  float* s_part = lds + (nstage % NS) * STAGE;
   const _Float16* xb = a.x + (int64_t)b * K * HW * NP;           // (Cin/8) * NP planes * HW * 8 two-byte elements
   const float* ab = a.wmp + (int64_t)b * a.Cout * K * NP / 2;   // 2-byte elements, NP planes
 
@@ -146,16 +166,34 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   float nw = 0.f;
   float kin = NP == 2 ? kSplitInv : 1.f;     // accumulator -> true value: the weights' 2^-8 and the input planes' 2^e
   float kout = 1.f, kback = 1.f;             // true value -> what this launch stores (2^-e' for a planes output) and back
+  float lc0 = 0.f, lc1 = 0.f;                // the layer's bound constants (planes output)
+  float pin = 0.f;                           // this lane's entries of the input's patch maxima (planes output)
+  // a planes output under range tracking: the exponent follows from max|in| of this pixel block and the layer's constants
+#ifndef CIPS3D_CHAIN_AB
+#define CIPS3D_CHAIN_AB 0        // timing-only ablations: 1 no range work at all, 2 no patch-maxima store, 3 no patch-maxima load
+#endif
+  const bool track = CIPS3D_CHAIN_AB != 1 && NP == 2 && a.out_fmt == 1 && a.lconst;
   auto load_ops = [&]() {
     if constexpr (NP == 2) {
-      if (a.x_exp) kin = cips3d_uniform(kin * cips3d_pow2(a.x_exp[b]));
-      if (a.out_fmt == 1 && a.lconst) {
-        const float m_in = cips3d_amax_load(a.x_amax + b * CIPS3D_AMAX_FLOATS);
-        const float* lc = a.lconst + b * 4;             // (uniform address: scalar loads)
-        const int e = cips3d_split_exp(fmaf(fmaxf(lc[1], 1.41421356237309515f * lc[2]), m_in, lc[0]));
-        kout = cips3d_uniform(cips3d_pow2(-e));
-        kback = cips3d_uniform(cips3d_pow2(e));
-        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) a.out_exp[b] = e;
+      const int nblk = (HW + BN - 1) / BN;
+      const int e_in = a.x_exp ? a.x_exp[b * nblk + blockIdx.x] : a.x_exp_const;      // (uniform address: a scalar load)
+      kin = cips3d_uniform(kin * cips3d_pow2(e_in));
+      if (track) {
+        const float* lc = a.lconst + b * 4;
+        lc0 = lc[0];
+        lc1 = fmaxf(lc[1], 1.41421356237309515f * lc[2]);
+        if (a.x_pmax && CIPS3D_CHAIN_AB != 3) {      // the 2 x Cin/16 patch maxima of this pixel block are contiguous: one load per wave (Cin <= 512)
+          const int n_half = (HW + 63) / 64, per = K >> 4;
+          const int n_ent = (2 * (int)blockIdx.x + 1 < n_half ? 2 : 1) * per;
+          const float* pp = a.x_pmax + ((int64_t)b * n_half + 2 * blockIdx.x) * per;
+          for (int i = lane; i < n_ent; i += 64) pin = fmaxf(pin, pp[i]);
+        } else {
+          // no patch maxima: the caller's constant, or what the input's own exponent says -- its producer put a bound of ITS
+          // output below 2^15 2^e_in.  That is a bound of a bound (another ~2^5 of slack: the stored values then top out near
+          // 2^5 instead of 2^10, still > 27 bits above the pair's floor), so a run alternates: every other layer leaves patch
+          // maxima for its consumer (forward.hip), which halves what the tracking costs (0.45 us per writing layer)
+          pin = a.x_max_const > 0.f ? a.x_max_const : cips3d_pow2(e_in + 15);
+        }
       }
     }
     if (a.epilogue == 1) {
@@ -279,6 +317,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   }
 
   CSTAMP(2);                         // main loop
+  if (track) {
+    // max|in| of the pixel block from the lanes' entries (wave-uniform, no LDS), the bound, the exponent, its powers of two
+    const float m_in = cips3d_wave_max_uniform(pin);
+    const int e = cips3d_split_exp(fmaf(lc1, m_in * 1.000001f, lc0));
+    kout = cips3d_uniform(cips3d_pow2(-e));
+    kback = cips3d_uniform(cips3d_pow2(e));
+    if (blockIdx.y == 0 && tid == 0) a.out_exp[b * ((HW + BN - 1) / BN) + blockIdx.x] = e;
+  }
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
   float prgb[3][4];
 #pragma unroll
@@ -288,7 +334,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   // v below is the STORED value, out * kout (kout = 1 unless the output is planes): the power of two rides on the constants
   // the epilogue multiplies by anyway, the ToRGB partial sums and the recorded maximum are taken from v and scaled back once
   const float kact = 1.41421356237309515f * kout;
-  const float kraw = kin * kout;
+  const float kpre = a.epilogue == 1 ? kin : kin * kout;      // (one uniform multiplier: no branch per value)
   float mx = 0.f;
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
@@ -298,10 +344,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (a.epilogue == 1) v[r] = lrelu02((acc[i][c][r] * kin + nz[c] * nw) + bias4[i][r]) * kact;
-        else v[r] = acc[i][c][r] * kraw;
+        v[r] = acc[i][c][r] * kpre;
+        if (a.epilogue == 1) v[r] = lrelu02((v[r] + nz[c] * nw) + bias4[i][r]) * kact;
       }
-      if (npx[c] < HW) mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
+      // (columns past HW repeat the last pixel without its noise: a value the patch maximum may include -- it only has to bound)
+      mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
       if (a.rgb_part) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
@@ -365,8 +412,17 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
     atomicAdd(&g_chain_stamps[6], ph_[2]);
   }
 #endif
-  if (a.out_amax)
-    cips3d_amax_workgroup(s_amax, mx * kback, NW, a.out_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.y * gridDim.x + blockIdx.x);
+  if (CIPS3D_CHAIN_AB != 1 && CIPS3D_CHAIN_AB != 2 && a.out_pmax && n0 + wn_i * 64 < HW) {
+    // this wave's patch (16 WM channels x 64 pixels): its largest |out|, one plain store per 16 channels
+    static_assert(BN == 64 * WGN, "a wave column = one 64-pixel half block");
+    const float m = cips3d_wave_max_uniform(mx * kback);
+    if (lane < WM)
+      a.out_pmax[((int64_t)b * ((HW + 63) / 64) + (n0 >> 6) + wn_i) * (a.Cout >> 4) + (m0 >> 4) + wm_i * WM + lane] = m;
+  }
+  if (a.out_amax) {        // fp32 / bf16 exit: the workgroup's largest |out| raises one slot of the sample's amax array
+    const float m = cips3d_workgroup_max(mx * kback, s_part, wave, lane, NW);
+    if (tid == 0) cips3d_amax_raise_if(a.out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
+  }
   if (!a.rgb_part) return;
   // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
   // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
@@ -409,17 +465,24 @@ __device__ __forceinline__ float amax_of_sample(const float* __restrict__ slots)
 }
 
 __global__ void __launch_bounds__(256) to_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ p, int B, int C,
-                                                        int HW, const float* __restrict__ x_amax, int* __restrict__ exp_out) {
+                                                        int HW, const float* __restrict__ x_amax, int* __restrict__ exp_out,
+                                                        float* __restrict__ pmax_out) {
   const int64_t total = (int64_t)B * (C / 8) * HW, per = (int64_t)(C / 8) * HW;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % HW);
     const int64_t bc = i / HW;               // b * (C/8) + cb
     float k = 1.f;
-    if (x_amax) {                            // planes of x * 2^-e, the sample's maximum just below 2^15 (cips3d_range)
-      const int b = (int)(i / per);
+    if (x_amax) {                            // planes of x * 2^-e, the sample's maximum just below 2^15 (cips3d_range); every
+      const int b = (int)(i / per);          // pixel block of the sample gets that exponent
       const int e_ = cips3d_split_exp(amax_of_sample(x_amax + (int64_t)b * CIPS3D_AMAX_FLOATS));
       k = cips3d_pow2(-e_);
-      if (i == b * per) exp_out[b] = e_;
+      const int nblk = (HW + CIPS3D_PLANES_EXP_BLOCK - 1) / CIPS3D_PLANES_EXP_BLOCK;
+      if (i - b * per < nblk) exp_out[b * nblk + (int)(i - b * per)] = e_;
+      if (pmax_out) {                        // every (16 channels x 64 pixels) patch gets the sample's maximum
+        const int n_pm = ((HW + 63) / 64) * (C >> 4);
+        const float am = amax_of_sample(x_amax + (int64_t)b * CIPS3D_AMAX_FLOATS);
+        for (int64_t j = i - b * per; j < n_pm; j += per) pmax_out[(int64_t)b * n_pm + j] = am;
+      }
     }
     h8 hi, lo;
 #pragma unroll
@@ -441,7 +504,8 @@ __global__ void __launch_bounds__(256) from_planes_kernel(const _Float16* __rest
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int n = (int)(i % HW);
     const int64_t bc = i / HW;
-    const float k = exps ? cips3d_pow2(exps[i / per]) : 1.f;
+    const float k = exps ? cips3d_pow2(exps[(i / per) * ((HW + CIPS3D_PLANES_EXP_BLOCK - 1) / CIPS3D_PLANES_EXP_BLOCK) +
+                                            n / CIPS3D_PLANES_EXP_BLOCK]) : 1.f;
     const h8 hi = *reinterpret_cast<const h8*>(p + ((bc * 2) * HW + n) * 8);
     const h8 lo = *reinterpret_cast<const h8*>(p + ((bc * 2 + 1) * HW + n) * 8);
 #pragma unroll
@@ -493,14 +557,16 @@ extern "C" int cips3d_planes_supported(int Cin, int Cout, int64_t HW) {
 }
 
 extern "C" int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, const float* x_amax, int32_t* exp_out,
-                                void* stream) {
-  if (!x || !planes || B < 0 || C <= 0 || HW <= 0 || ((x_amax == nullptr) != (exp_out == nullptr))) return CIPS3D_E_BADARG;
+                                float* pmax_out, void* stream) {
+  if (!x || !planes || B < 0 || C <= 0 || HW <= 0 || ((x_amax == nullptr) != (exp_out == nullptr)) || (pmax_out && !x_amax))
+    return CIPS3D_E_BADARG;
+  if (pmax_out && C % 16 != 0) return CIPS3D_E_UNSUPP;
   if (C % 8 != 0) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   int64_t blocks = ceil_div<int64_t>((int64_t)B * (C / 8) * HW, 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(to_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x,
-                     reinterpret_cast<_Float16*>(planes), B, C, (int)HW, x_amax, exp_out);
+                     reinterpret_cast<_Float16*>(planes), B, C, (int)HW, x_amax, exp_out, pmax_out);
   return cips3d_launch_status();
 }
 
@@ -550,7 +616,8 @@ extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* w
   if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   ChainArgs a{reinterpret_cast<const _Float16*>(x_planes16), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
-              noise_bstride, noise_w, bias, rgb_w, rgb_part, nullptr, nullptr, nullptr, rg ? rg->out_amax : nullptr, nullptr};
+              noise_bstride, noise_w, bias, rgb_w, rgb_part, nullptr, 0, nullptr, 0.f, nullptr, rg ? rg->out_amax : nullptr, nullptr,
+              nullptr};
   // 64 x 128 tiles, 64-deep stages of 24 KB in a 3-slot ring (72 KB: two workgroups per CU).  Same-box sweep (rocprofv3, 512 -> 512
   // at 64^2): batch 1 7.45 us / batch 4 17.4 us; a 2-slot ring 8.0 / 17.5; 128-deep stages 7.4 / 24.2 (one workgroup per CU);
   // 128 x 128 tiles (2/3 of the operand bytes per flop) 9.6 / 19.8; 64 x 64 tiles 7.5 / 19.9.
@@ -571,11 +638,14 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
   if (out_format < 0 || out_format > 2 || (epilogue != 0 && epilogue != 1) || (epilogue == 1 && !bias)) return CIPS3D_E_BADARG;
   if (!cips3d_planes_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
-  // a planes output needs its bound: the input's maximum, the layer's constants and somewhere to leave the exponent
-  if (rg && out_format == 1 && (!rg->x_amax || !rg->lconst || !rg->out_exp)) return CIPS3D_E_BADARG;
+  // a planes output needs its bound: the layer's constants and somewhere to leave the exponents
+  if (rg && out_format == 1 && (!rg->lconst || !rg->out_exp)) return CIPS3D_E_BADARG;
   ChainArgs a{reinterpret_cast<const _Float16*>(x_planes), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
-              noise_bstride, noise_w, bias, rgb_w, rgb_part, rg ? rg->x_amax : nullptr, rg ? rg->x_exp : nullptr,
-              (rg && out_format == 1) ? rg->lconst : nullptr, rg ? rg->out_amax : nullptr, rg ? rg->out_exp : nullptr};
+              noise_bstride, noise_w, bias, rgb_w, rgb_part, rg ? rg->x_exp : nullptr, rg ? rg->x_exp_const : 0,
+              rg ? rg->x_pmax : nullptr, rg ? rg->x_max_const : 0.f, (rg && out_format == 1) ? rg->lconst : nullptr,
+              (rg && out_format != 1) ? rg->out_amax : nullptr, rg ? rg->out_exp : nullptr,
+              (rg && out_format == 1) ? rg->out_pmax : nullptr};
+  if (rg && out_format == 1 && rg->x_pmax && Cin > 512) return CIPS3D_E_UNSUPP;
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
   dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
   static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)

@@ -172,6 +172,9 @@ __device__ static inline float wave_max(float v) {
 // sixteen loads are then scalar loads (no vector register, no vmcnt slot -- the counted waits of the GEMM rings do not see
 // them) and the scale factors derived from the result live in SGPRs through the kernel.
 __device__ static inline float cips3d_amax_load(const float* __restrict__ slots) {
+#ifdef CIPS3D_RANGE_NO_LOAD      // timing-only ablation
+  return 1.f;
+#endif
   float m = slots[0];
 #pragma unroll
   for (int s_ = 1; s_ < CIPS3D_AMAX_SLOTS; ++s_) m = fmaxf(m, slots[s_ * CIPS3D_AMAX_STRIDE]);
@@ -182,14 +185,48 @@ __device__ static inline float cips3d_uniform(float v) { return __uint_as_float(
 __device__ static inline void cips3d_amax_raise(float* __restrict__ slots, float v, int slot) {
   atomicMax(reinterpret_cast<unsigned*>(slots) + (slot & (CIPS3D_AMAX_SLOTS - 1)) * CIPS3D_AMAX_STRIDE, __float_as_uint(v));
 }
-// Workgroup maximum without a barrier: every wave folds its maximum into an LDS word and then counts itself in; the LDS unit
-// serves a wave's two operations in order, so the wave whose count comes back as n_waves - 1 sees every wave's maximum and
-// makes the workgroup's ONE global atomic.  s_red = {max, count}, zeroed before the workgroup's first barrier.
-// (the lane id is taken from mbcnt here: a `lane` kept alive to the end of a kernel for this call costs a register)
-__device__ static inline void cips3d_amax_workgroup(unsigned* s_red, float v, int n_waves, float* __restrict__ slots, int slot) {
-  v = wave_max(v);
-  if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
-    atomicMax(&s_red[0], __float_as_uint(v));
-    if (atomicAdd(&s_red[1], 1u) == (unsigned)(n_waves - 1)) cips3d_amax_raise(slots, __uint_as_float(atomicMax(&s_red[0], 0u)), slot);
-  }
+// max over the 16 lanes of a DPP row, in every lane of the row (xor 1, xor 2, mirror within 8, mirror within 16), for v >= 0:
+// non-negative floats order like their bit patterns, so the maxima are integer ones -- four v_max_u32_dpp, where fmaxf would
+// add a canonicalising v_max per operand -- and no LDS round trips
+__device__ static inline float cips3d_row16_max(float v) {
+  unsigned u = __float_as_uint(v);
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, true));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xf, 0xf, true));
+  u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true));
+  return __uint_as_float(u);
+}
+__device__ static inline float cips3d_readlanes4_max(float v) {          // max of lanes 0, 16, 32, 48 (wave-uniform), v >= 0
+  const unsigned a = max((unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0), (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const unsigned b = max((unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32), (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return __uint_as_float(max(a, b));
+}
+// Workgroup maximum of v (>= 0) as a wave-uniform value in every wave: DPP row maxima, one LDS word per (wave, row) -- no
+// atomics, nothing to initialise -- one barrier, then lane i < 4 n_waves reads word i.  s_part: 4 * n_waves floats of LDS that
+// nobody else touches between the call and the next barrier of the caller; n_waves <= 16.  Every wave of the workgroup calls.
+__device__ static inline float cips3d_workgroup_max(float v, float* s_part, int wave, int lane, int n_waves) {
+  v = cips3d_row16_max(v);
+  if ((lane & 15) == 0) s_part[wave * 4 + (lane >> 4)] = v;
+  __syncthreads();
+  float m = lane < 4 * n_waves ? s_part[lane] : 0.f;
+  return cips3d_readlanes4_max(cips3d_row16_max(m));
+}
+// wave maximum of v (>= 0) as a wave-uniform value: four DPP steps and four readlanes, no LDS
+__device__ static inline float cips3d_wave_max_uniform(float v) { return cips3d_readlanes4_max(cips3d_row16_max(v)); }
+// `seen`: what cips3d_amax_peek returned for this slot some time ago (0: always raise).  The slot only ever grows, so a
+// workgroup whose maximum does not exceed a value the slot already held has nothing to tell it.
+__device__ static inline void cips3d_amax_raise_if(float* __restrict__ slots, float m, int slot, float seen = 0.f) {
+#ifdef CIPS3D_RANGE_NO_RECORD    // timing-only ablation
+  return;
+#endif
+  if (!(m <= seen)) cips3d_amax_raise(slots, m, slot);          // (a NaN maximum is recorded too)
+}
+// the slot's value as the device sees it now (an agent-scope load: served past this XCD's L2 copy); a stale answer only costs
+// an atomic that was not needed
+__device__ static inline float cips3d_amax_peek(const float* __restrict__ slots, int slot) {
+#ifdef CIPS3D_RANGE_NO_PEEK
+  return 0.f;
+#endif
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(slots) + (slot & (CIPS3D_AMAX_SLOTS - 1)) * CIPS3D_AMAX_STRIDE,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }

@@ -359,7 +359,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   // peak at any tile shape).  Waits are counted (vmcnt(N) leaves the younger stages in flight) and the
   // barrier is the raw s_barrier: __syncthreads() would drain every outstanding DMA.
   __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
-  __shared__ unsigned s_amax[2];              // workgroup maximum of |out| and its arrival count (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,7 +366,6 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   const int wm_i = wave / WGN, wn_i = wave % WGN;
   const int b = blockIdx.z;
   const int m0 = blockIdx.y * BM;
-  if (tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }
   // split mode: the activations are split as x * kx, kx = 2^-e with max|x| 2^-e in [2^14, 2^15) (the measured maximum of x;
   // common.h, cips3d_range); the accumulators come back with kin = 2^-8 2^e
   float kx = 1.f, kin = kSplitInv;
@@ -591,8 +589,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       }
     }
   }
-  if (a.out_amax)
-    cips3d_amax_workgroup(s_amax, mx, NW, a.out_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.y * gridDim.x + blockIdx.x);
+  if (a.out_amax) {        // the workgroup's largest |out| raises one slot of the sample's amax array (cips3d_range); the LDS
+    // words live in the ring slot the last K stage did not use (a __shared__ array of their own would move the ring)
+    const float m = cips3d_workgroup_max(mx, lds + (nstage % NS) * STAGE, wave, lane, NW);
+    if (tid == 0) cips3d_amax_raise_if(a.out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
+  }
   if (!a.rgb_part) return;
   // ---- ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows through
   // LDS (the ring is free: every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
@@ -1052,10 +1053,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   __shared__ __attribute__((aligned(16))) float s_red_own[NEXT ? WGM * 3 * BN : 4];
   float* s_red = NEXT ? s_red_own : sB;
   __shared__ float s_wrgb[3 * C];
-  __shared__ unsigned s_amax[2];                 // {max, count} of |y_next| (cips3d_amax_workgroup)
 
   const int tid = threadIdx.x;
-  if (NEXT && tid == 0) { s_amax[0] = 0u; s_amax[1] = 0u; }     // (before the first barrier below)
 #ifdef CIPS3D_FUSED_STAMPS
   unsigned long long fst_[7] = {0, 0, 0, 0, 0, 0, 0}, ftp_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -1430,7 +1429,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         else *reinterpret_cast<f32x4*>(yn + r * HWo) = yv;
       }
     }
-    if (a.next_amax) cips3d_amax_workgroup(s_amax, mxn, WGM * WGN, a.next_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.x);
+    if (a.next_amax) {     // the workgroup's largest |y_next| raises one slot of the sample's amax array; s_nz1 is dead (K loop over)
+      static_assert(!NEXT || 4 * WGM * WGN <= BN, "the reduction words fit the noise tile");
+      const float m = cips3d_workgroup_max(mxn, s_nz1, wave, lane, WGM * WGN);
+      if (tid == 0) cips3d_amax_raise_if(a.next_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.x);
+    }
   }
   f32x4 accn[OTN][4];
   if (NEXT && !XCHG) {
@@ -1529,7 +1532,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         if constexpr (YB) *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(yv[0], yv[1], yv[2], yv[3]);
         else *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = yv;
       }
-    if (a.next_amax) cips3d_amax_workgroup(s_amax, mxn, WGN, a.next_amax + b * CIPS3D_AMAX_FLOATS, blockIdx.x);
+  }
+  if (NEXT && !XCHG && a.next_amax) {     // (only wave row 0 stored: the other rows bring 0)
+    const float m = cips3d_workgroup_max(mxn, s_nz1, wave, lane, WGM * WGN);
+    if (tid == 0) cips3d_amax_raise_if(a.next_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.x);
   }
   FSTAMP(5);        // partial exchange of the chained GEMM / ToRGB through LDS, y_next store
   if (!a.wm_rgb) { FSTAMP_FLUSH(); return; }
@@ -1610,6 +1616,12 @@ extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int 
   hipLaunchKernelGGL(modulate_table_kernel, dim3((unsigned)ceil_div(total_rows, 4), (unsigned)B), dim3(256), 0,
                      as_stream(stream), table_dev, n_desc, total_rows, noise_bound);
   return cips3d_launch_status();
+}
+
+extern "C" int cips3d_amax_layout(int* slots, int* stride) {
+  if (slots) *slots = CIPS3D_AMAX_SLOTS;
+  if (stride) *stride = CIPS3D_AMAX_STRIDE;
+  return 0;
 }
 
 extern "C" int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream) {

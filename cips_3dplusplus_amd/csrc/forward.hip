@@ -133,8 +133,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   const bool feat_planes = (P.layers[0].flags & 4) != 0;
   const bool feat_p16 = feat_planes && (P.layers[0].flags & 32) != 0;
   np.features_planes = (feat_planes && !feat_p16 && fused_finish) ? 1 : 0;
-  np.features_exp = ranged ? P.feat_exp : nullptr;
-  np.features_amax = ranged ? P.feat_amax : nullptr;
+  if (feat_planes && !feat_p16 && !ranged) return CIPS3D_E_BADARG;      // split-fp16 planes carry exponents: the plan owes the rows
   float* feat32 = (feat_planes && !np.features_planes) ? P.act[1] : P.features;
   np.o_features = feat32;
   TRY(cips3d_nerf_render(&np, stream));
@@ -146,16 +145,19 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
     if (feat_p16) TRY(cips3d_to_planes16(feat32, P.features, B, np.hidden, hw0, stream));
     else {
       if (ranged) TRY(cips3d_absmax(feat32, B, (int64_t)np.hidden * hw0, P.feat_amax, stream));
-      TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, hw0, ranged ? P.feat_amax : nullptr, ranged ? P.feat_exp : nullptr, stream));
+      TRY(cips3d_to_planes(feat32, P.features, B, np.hidden, hw0, ranged ? P.feat_amax : nullptr, ranged ? P.feat_exp : nullptr,
+                           ranged ? P.feat_pmax : nullptr, stream));
     }
   }
 
   // ---- decoder (model_v3.py:592-637)
   const float* x = P.features;
-  // range rows of x (ranged plans): the measured maximum of its true values and, for planes, the exponent they were stored with.
-  // x_amax == nullptr: no producer tracked this tensor -- a split GEMM that reads it measures it first (amax_of)
-  const float* x_amax = ranged ? P.feat_amax : nullptr;
-  const int32_t* x_exp = ranged ? P.feat_exp : nullptr;
+  // range rows of x (ranged plans).  fp32 x: the measured maximum of its values (x_amax; nullptr: no producer tracked this tensor
+  // -- a split GEMM that reads it measures it first, amax_of).  Planes x: the exponents of its pixel blocks (x_exp; nullptr: the
+  // render kernel's feature planes, CIPS3D_FEATURES_EXP everywhere)
+  const float* x_amax = nullptr;
+  const int32_t* x_exp = (ranged && feat_planes && !np.features_planes && !feat_p16) ? P.feat_exp : nullptr;
+  const float* x_pmax = x_exp ? P.feat_pmax : nullptr;      // patch maxima of planes x (nullptr: the feature planes, |f| <= 1)
   auto amax_of = [&](const float* t, int C, int64_t hw) -> int {
     if (!ranged || x_amax) return 0;
     const int rc = cips3d_absmax(t, B, (int64_t)C * hw, P.tmp_amax, stream);
@@ -212,6 +214,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                                            nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream));
           else if (L.flags & 4) {  // ... as split-fp16 planes
             rg.x_exp = x_exp;
+            rg.x_exp_const = CIPS3D_FEATURES_EXP;
             TRY(cips3d_modconv1x1_planes(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, ranged ? &rg : nullptr, stream));
           } else {
@@ -269,8 +272,13 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         cips3d_range rg{};
         const bool lr = ranged && !p16;
         if (lr) {
-          if (!x_amax || !x_exp || !L.amax || !L.aexp || !L.lconst) return CIPS3D_E_BADARG;      // the plan owes the rows
-          rg.x_amax = x_amax; rg.x_exp = x_exp; rg.lconst = L.lconst; rg.out_amax = L.amax; rg.out_exp = L.aexp;
+          if (!L.amax || !L.aexp || !L.lconst) return CIPS3D_E_BADARG;      // the plan owes the rows
+          if (fmt == 1 && !L.pmax) return CIPS3D_E_BADARG;
+          // every other layer of the run leaves patch maxima for its consumer; the layers in between derive max|in| from the
+          // input's exponent (chain.hip: a bound of a bound, ~2^5 looser -- and half the tracking cost of the run)
+          rg.x_exp = x_exp; rg.x_exp_const = CIPS3D_FEATURES_EXP; rg.x_pmax = x_pmax; rg.x_max_const = x_exp ? 0.f : 1.f;
+          rg.lconst = L.lconst; rg.out_exp = L.aexp; rg.out_pmax = (fmt == 1 && !x_pmax) ? L.pmax : nullptr;
+          rg.out_amax = fmt == 1 ? nullptr : L.amax;       // (the exit's per-sample maximum, for the fused stage that reads it)
         }
         if (p16)
           TRY(cips3d_modconv1x1_planes16(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
@@ -280,8 +288,9 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
                                        fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
                                        lr ? &rg : nullptr, stream));
-        x_amax = lr ? L.amax : nullptr;
+        x_amax = (lr && fmt != 1) ? L.amax : nullptr;
         x_exp = (lr && fmt == 1) ? L.aexp : nullptr;
+        x_pmax = (lr && fmt == 1) ? rg.out_pmax : nullptr;
         if (fold) {
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;

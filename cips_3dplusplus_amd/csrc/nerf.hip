@@ -722,10 +722,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
           for (int e = 0; e < 4; ++e) o[(int64_t)e * R] = acc[e];
         }
       }
-      if (P.features_planes && g == 0 && P.features_exp && P.features_amax && tid <= CIPS3D_AMAX_SLOTS) {
-        if (tid == CIPS3D_AMAX_SLOTS) P.features_exp[b] = CIPS3D_FEATURES_EXP;
-        else P.features_amax[b * CIPS3D_AMAX_FLOATS + tid * CIPS3D_AMAX_STRIDE] = 1.f;
-      }
       const int k = tid >> 4;                // scalar channel 0..6 for the first 7 x 16 threads
       if (k < 7) {
         float acc = 0.f;

@@ -364,20 +364,25 @@ def modconv1x1_supported(Cin, Cout, HW):
 # of two per (tensor, sample) taken from a bound of max|x|, so that the decoder's default arithmetic keeps fp32's exponent
 # range.  amax arrays are [B, AMAX_FLOATS] fp32 tensors; a kernel that produced a tensor leaves its amax attached to it
 # (`tag_amax`), a split GEMM that reads an untagged tensor measures it first (one HBM pass).
-AMAX_FLOATS = _lib.AMAX_FLOATS
+def amax_floats():
+    """floats per sample of an amax array (CIPS3D_AMAX_SLOTS * CIPS3D_AMAX_STRIDE of the loaded library)"""
+    _lib.load()
+    return _lib.AMAX_FLOATS
+
+
 NOISE_BOUND_RNG = 6.0        # cips3d_rng_fill: |n| <= sqrt(50 ln 2) = 5.89
 NOISE_BOUND_TORCH = 7.0      # torch.randn on the device: Box-Muller on 32-bit uniforms, |n| <= 6.8
 
 
 def new_amax(B, device):
-    return torch.zeros(B, AMAX_FLOATS, device=device, dtype=torch.float32)
+    return torch.zeros(B, amax_floats(), device=device, dtype=torch.float32)
 
 
 def absmax(x, B=None):
     """amax array of x viewed as [B, -1] (B defaults to x.shape[0])."""
     B = x.shape[0] if B is None else B
     x = x.contiguous()
-    amax = torch.empty(B, AMAX_FLOATS, device=x.device, dtype=torch.float32)
+    amax = torch.empty(B, amax_floats(), device=x.device, dtype=torch.float32)
     check(_lib.load().cips3d_absmax(dev_ptr(x, "x"), B, x.numel() // B, dev_ptr(amax), stream_ptr()), "cips3d_absmax")
     return amax
 
@@ -408,7 +413,7 @@ def const_amax(B, bound, device):
     key = (B, float(bound), str(device))
     t = _const_amax.get(key)
     if t is None:
-        t = _const_amax[key] = torch.full((B, AMAX_FLOATS), float(bound), device=device, dtype=torch.float32)
+        t = _const_amax[key] = torch.full((B, amax_floats()), float(bound), device=device, dtype=torch.float32)
     return t
 
 
@@ -522,16 +527,19 @@ def planes_supported(Cin, Cout, HW):
 
 def to_planes(x, ranged=True):
     """fp32 [B,C,H,W] -> split-fp16 planes (torch.float16 tensor [B, C/8, 2, H*W, 8]: hi plane, lo plane) of x * 2^-e, e one
-    power of two per sample that puts max|x| into [2^14, 2^15) (cips3d_range).  The exponents ([B] int32) and the amax array
-    travel as attributes of the result (`.cips3d_exp`, `.cips3d_amax`); ranged=False stores x itself (e = 0)."""
+    power of two per sample that puts max|x| into [2^14, 2^15) (cips3d_range).  The exponents ([B, blocks of 128 pixels] int32:
+    the format allows one per pixel block, this conversion writes the sample's everywhere) travel as an attribute of the
+    result (`.cips3d_exp`); ranged=False stores x itself (e = 0)."""
     lib = _lib.load()
     B, Cc, H, W = x.shape
     p = torch.empty(B, Cc // 8, 2, H * W, 8, device=x.device, dtype=torch.float16)
     amax = amax_of(x) if ranged else None
-    exps = torch.zeros(B, device=x.device, dtype=torch.int32) if ranged else None
+    nblk = (H * W + _lib.PLANES_EXP_BLOCK - 1) // _lib.PLANES_EXP_BLOCK
+    exps = torch.zeros(B, nblk, device=x.device, dtype=torch.int32) if ranged else None
+    pmax = torch.zeros(B, (H * W + 63) // 64, Cc // 16, device=x.device) if (ranged and Cc % 16 == 0) else None
     check(lib.cips3d_to_planes(dev_ptr(x, "x"), p.data_ptr(), B, Cc, H * W, dev_ptr(amax, "amax", True),
-                               exps.data_ptr() if ranged else None, stream_ptr()), "cips3d_to_planes")
-    p.cips3d_exp, p.cips3d_amax = exps, amax
+                               exps.data_ptr() if ranged else None, dev_ptr(pmax, "pmax", True), stream_ptr()), "cips3d_to_planes")
+    p.cips3d_exp, p.cips3d_pmax = exps, pmax
     return p
 
 
@@ -547,8 +555,8 @@ def from_planes(p, H, W):
 
 def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, noise=None, noise_w=None, bias=None,
                       rgb_w=None, rgb_part=None, demodulated=True, lconst=None):
-    """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call (its exponents and amax
-    array are read from its attributes; a planes output carries its own); wm_split from
+    """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call (its exponents are read
+    from its attribute; a planes output carries its own); wm_split from
     modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW]).
     demodulated: the weights were demodulated (unit row norm -> the sqrt(Cin) gain of the output bound); for others pass lconst
     from a modulate table that measured the row L1 norms."""
@@ -561,7 +569,7 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
     else:
         out = torch.empty(B, Cout, HW, device=dev, dtype=torch.bfloat16 if fmt == 2 else torch.float32)
     nb = HW if (noise is not None and noise.shape[0] == B and B > 1) else 0
-    x_exp, x_amax = getattr(xp, "cips3d_exp", None), getattr(xp, "cips3d_amax", None)
+    x_exp, x_pmax = getattr(xp, "cips3d_exp", None), getattr(xp, "cips3d_pmax", None)
     ranged = x_exp is not None
     rg, _keep = None, None
     if ranged:
@@ -573,9 +581,13 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
             else:
                 lconst = range_consts(B, torch.zeros(1, device=dev), None, Cin ** 0.5)
                 lconst[:, 1] /= 2.0 ** 0.5      # no activation: |out| <= sqrt(Cin) max|x|
-        out_amax = new_amax(B, dev)
-        out_exp = torch.zeros(B, device=dev, dtype=torch.int32) if fmt == 1 else None
-        rg, _keep = _range(x_amax=x_amax, x_exp=x_exp, lconst=lconst if fmt == 1 else None, out_amax=out_amax, out_exp=out_exp)
+        out_amax = new_amax(B, dev) if fmt != 1 else None
+        nblk = (HW + _lib.PLANES_EXP_BLOCK - 1) // _lib.PLANES_EXP_BLOCK
+        out_exp = torch.zeros(B, nblk, device=dev, dtype=torch.int32) if fmt == 1 else None
+        out_pmax = torch.zeros(B, (HW + 63) // 64, Cout // 16, device=dev) if fmt == 1 else None
+        # (x_pmax None: the kernel bounds max|in| by what the input's exponent encodes -- looser, still rigorous)
+        rg, _keep = _range(x_exp=x_exp, x_pmax=x_pmax if fmt == 1 else None, lconst=lconst if fmt == 1 else None,
+                           out_amax=out_amax, out_exp=out_exp, out_pmax=out_pmax)
     check(lib.cips3d_modconv1x1_planes(dev_ptr(xp, "x_planes", dtype=torch.float16), dev_ptr(wm_split, "wm"), out.data_ptr(), fmt,
                                        B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
                                        dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
@@ -584,7 +596,7 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
           "cips3d_modconv1x1_planes")
     if ranged:
         if fmt == 1:
-            out.cips3d_exp, out.cips3d_amax = out_exp, out_amax
+            out.cips3d_exp, out.cips3d_pmax = out_exp, out_pmax
         elif fmt == 0:
             tag_amax(out, out_amax)
     return out

@@ -18,7 +18,7 @@ class DecLayer(C.Structure):
     _fields_ = [("kind", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("noise_index", C.c_int32), ("flags", C.c_int32), ("pad_", C.c_int32), ("wm", C.c_void_p),
                 ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p),
-                ("amax", C.c_void_p), ("aexp", C.c_void_p), ("lconst", C.c_void_p)]
+                ("amax", C.c_void_p), ("aexp", C.c_void_p), ("pmax", C.c_void_p), ("lconst", C.c_void_p)]
 
 
 class GeneratorPlan(C.Structure):
@@ -38,7 +38,7 @@ class GeneratorPlan(C.Structure):
                 ("rgb_part", C.c_void_p),
                 ("rgb_part_slots", C.c_int64),
                 ("range_ws", C.c_void_p), ("range_ws_words", C.c_int64), ("feat_amax", C.c_void_p), ("feat_exp", C.c_void_p),
-                ("tmp_amax", C.c_void_p)]
+                ("feat_pmax", C.c_void_p), ("tmp_amax", C.c_void_p)]
 
 
 class ForwardIO(C.Structure):
@@ -221,17 +221,26 @@ class ForwardPlan:
         rows, woff = 0, 0
         # Range workspace of a split-fp16 decoder (cips3d_range): per StyledConv an amax array, the exponent of its planes
         # output and its bound constants; the feature map's rows; one scratch amax array.  One buffer, zeroed by every forward.
-        AF = _lib.AMAX_FLOATS
-        per_layer = B * (AF + 1 + 4)
+        AF = hip.amax_floats()
+        nblk = (img_size * img_size + _lib.PLANES_EXP_BLOCK - 1) // _lib.PLANES_EXP_BLOCK      # planes exponents per sample
+        per_layer = B * (AF + nblk + 4)
         n_sc = sum(1 for li in layer_info if li["kind"] in (0, 1))
-        range_ws = torch.zeros(n_sc * per_layer + B * (2 * AF + 1), device=dev) if use_split else None
+        range_ws = torch.zeros(n_sc * per_layer + B * (2 * AF + nblk), device=dev) if use_split else None
         self.ranged = range_ws is not None
         rw = range_ws.data_ptr() if self.ranged else 0
         if self.ranged:
             p.range_ws, p.range_ws_words = rw, range_ws.numel()
             tail = rw + 4 * n_sc * per_layer
             p.feat_amax, p.tmp_amax, p.feat_exp = tail, tail + 4 * B * AF, tail + 4 * 2 * B * AF
-            self._keep.append(range_ws)
+            # patch maxima of the planes tensors (one array per layer of the run + the feature map's for the conversion pass):
+            # fully rewritten by their producer every forward, never zeroed
+            n_half = (img_size * img_size + 63) // 64
+            pm_words = B * n_half * (max(li["Cout"] for li in layer_info if li["kind"] in (0, 1)) // 16 + 1)
+            n_pl = sum(1 for li in layer_info if li.get("planes_out"))
+            pmax_ws = torch.zeros((n_pl + 1) * pm_words, device=dev)
+            p.feat_pmax = pmax_ws.data_ptr() + 4 * n_pl * pm_words
+            self._keep += [range_ws, pmax_ws]
+        pl_i = 0
         sc_i = 0
         for idx, (info, off) in enumerate(zip(layer_info, offs)):
             conv = info["conv"]
@@ -259,10 +268,13 @@ class ForwardPlan:
             L.fir = dev_ptr(info["fir"], allow_none=True)
             if self.ranged and info["kind"] in (0, 1):
                 base = rw + 4 * sc_i * per_layer
-                L.amax, L.aexp, L.lconst = base, base + 4 * B * AF, base + 4 * B * (AF + 1)
+                L.amax, L.aexp, L.lconst = base, base + 4 * B * AF, base + 4 * B * (AF + nblk)
                 d.lconst, d.bias, d.n_bias = L.lconst, L.bias, conv.out_channel
                 d.noise_w, d.fir = L.noise_w, L.fir
                 sc_i += 1
+                if info.get("planes_out"):
+                    L.pmax = pmax_ws.data_ptr() + 4 * pl_i * pm_words
+                    pl_i += 1
             woff += wm_sizes[idx]
         p.n_dec_layers = len(seq)
         wm_tab_dev = _upload(wm_tab).to(dev)

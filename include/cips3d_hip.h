@@ -118,10 +118,15 @@ int cips3d_linear_table_bwd(const cips3d_linear_desc* table_dev, int n_desc, int
                             const float* out_base, const float* dy_base, const float* x_base, float* dx_base,
                             const int64_t* w_offsets_dev, float* dW, float* db, void* stream);
 
-#define CIPS3D_AMAX_SLOTS 16      /* see cips3d_range below: slots of one (tensor, sample), each on a 64-byte line of its own */
-#define CIPS3D_AMAX_STRIDE 16     /* floats between slots */
+#ifndef CIPS3D_AMAX_SLOTS
+#define CIPS3D_AMAX_SLOTS 8       /* see cips3d_range below: slots of one (tensor, sample) */
+#endif
+#ifndef CIPS3D_AMAX_STRIDE
+#define CIPS3D_AMAX_STRIDE 64     /* floats between slots: 256 bytes, the slots of an array sit in different memory channels */
+#endif
 #define CIPS3D_AMAX_FLOATS (CIPS3D_AMAX_SLOTS * CIPS3D_AMAX_STRIDE)
 #define CIPS3D_FEATURES_EXP (-14)
+#define CIPS3D_PLANES_EXP_BLOCK 128   /* pixels that share one exponent of a split-fp16 planes tensor */
 
 /* ------------------------------------------------------------------ camera */
 
@@ -184,13 +189,11 @@ typedef struct cips3d_nerf_params {
    * ignored and `part` + cips3d_nerf_finish is the way. */
   float* o_features; float* o_thumb; float* o_xyz; float* o_mask;
   /* != 0 (fused finish only): o_features receives the feature map as split-fp16 planes [B][H/8][hi|lo][R][8] (fp16), the
-   * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes).  The planes hold features * 2^14
-   * (CIPS3D_FEATURES_EXP: a feature is a convex combination of sines, |f| <= 1); when given, features_exp[b] receives that
-   * exponent and every slot of features_amax[b] the bound 1.0 (see cips3d_range) */
+   * input format of cips3d_modconv1x1_planes, instead of fp32 [B,H,R] (same bytes).  The planes hold features * 2^14: every
+   * pixel block has the exponent CIPS3D_FEATURES_EXP (cips3d_range.x_exp_const; a feature is a convex combination of sines,
+   * |f| <= 1) */
   int32_t features_planes;
   int32_t pad_;
-  int32_t* features_exp;    /* [B] or NULL */
-  float* features_amax;     /* [B][CIPS3D_AMAX_FLOATS] or NULL */
   /* Differentiable forward (camera-driven mode only; all three or none): the render kernel additionally writes what
    * cips3d_nerf_bwd_fused needs, so that the backward does not recompute the forward -- per MFMA layer the fp32 accumulators
    * (`stash`: cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, hidden, depth, n_chunks) floats, the layout of that
@@ -230,26 +233,39 @@ int cips3d_nerf_finish_rays(const float* part, int n_chunks, int B, int n_rays, 
  *         (slot s at float s * CIPS3D_AMAX_STRIDE: one 64-byte line each, so that the atomics of different workgroups do not
  *         queue on one line).  The producing epilogue raises a slot with one atomicMax per workgroup (the caller zeroes the
  *         array before the producer runs); cips3d_absmax fills it for a tensor that exists already.
- *   exp   [B] int32: the exponent e a planes tensor was stored with (stored value = x * 2^-e), written by its producer.
+ *   exp   [B][ceil(HW / CIPS3D_PLANES_EXP_BLOCK)] int32: the exponents a planes tensor was stored with, one per block of 128
+ *         consecutive pixels (stored value = x * 2^-e; GEMM columns are independent, so every pixel block may have its own),
+ *         written by its producer.
+ *   pmax  [B][ceil(HW / 64)][C / 16] fp32: max |x| of every (16 channels x 64 pixels) patch of a planes tensor, written by its
+ *         producer with one plain store per wave (no atomics, nothing to zero).  cips3d_modconv1x1_planes takes max|in| of a
+ *         128-pixel block from the 2 x Cin/16 entries that cover it, so a planes OUTPUT's exponent needs no word from any
+ *         other workgroup of the launch.
  *   lconst[B][4] fp32 {c0, c1, l1, -}: the layer's bound constants, |out| <= max(c1, sqrt(2) l1) * max|in| + c0 with
  *         c0 = sqrt(2) (|noise_w| * noise_bound + max|bias|), c1 = sqrt(2) * (sqrt(Cin) for a demodulated conv; the FIR's
  *         largest polyphase gain for the 2x up-sampler), l1 = the largest row L1 norm of a NON-demodulated weight (measured
  *         by the modulate kernel, else 0).  Written by cips3d_range_consts or by cips3d_modulate_table.
  * A kernel that must scale values it produces itself (planes output, the intermediates of a fused up-sampling stage) uses
- * bound = c1 * amax(in) + c0; a kernel that splits an existing fp32 tensor uses bound = amax(in).
+ * bound = c1 * max|in| + c0; a kernel that splits an existing fp32 tensor uses bound = amax(in).
  * Passing rg == NULL keeps e = 0 everywhere (legal only for callers that know max|x| of every operand to lie in
  * [2^-3, 6e4]); the Python host always passes it. */
 typedef struct cips3d_range {
-  const float* x_amax;     /* [B][CIPS3D_AMAX_FLOATS] of the input activation (required)                                        */
-  const int32_t* x_exp;    /* [B] planes input: its exponent                                                        */
+  const float* x_amax;     /* [B][CIPS3D_AMAX_FLOATS] of an fp32 input activation (split GEMM, fused stage)        */
+  const int32_t* x_exp;    /* planes input: its exponents [B][blocks]; NULL: every block has x_exp_const            */
+  int32_t x_exp_const;     /* (the NeRF feature map: CIPS3D_FEATURES_EXP)                                           */
+  float x_max_const;       /* planes input without x_pmax: a bound of max|x| the caller vouches for (feature map: 1);
+                              0: 2^(e + 15), the bound the input's own exponent encodes (looser by ~2^5)             */
+  const float* x_pmax;     /* planes input: its patch maxima [B][ceil(HW/64)][Cin/16], or NULL (x_max_const)        */
   const float* lconst;     /* [B][4] of this layer (planes output; conv1 of a fused stage)                         */
   const float* lconst2;    /* [B][4] of conv2 of a fused stage (needed when wm_next != NULL)                       */
   float* out_amax;         /* [B][CIPS3D_AMAX_FLOATS] or NULL: raised to max |out| (GEMM entry points; not the fused stage)      */
-  int32_t* out_exp;        /* [B] planes output: receives the exponent this launch chose                            */
+  int32_t* out_exp;        /* planes output: receives the exponents this launch chose, [B][blocks]                  */
   float* next_amax;        /* [B][CIPS3D_AMAX_FLOATS] or NULL: raised to max |y_next| (fused stage with wm_next)                 */
+  float* out_pmax;         /* planes output: receives its patch maxima [B][ceil(HW/64)][Cout/16]                    */
 } cips3d_range;
 /* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
 int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
+/* CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE as the library was built (a binding sizes its amax arrays from these) */
+int cips3d_amax_layout(int* slots, int* stride);
 /* lconst[b] = {c0, c1, 0, 0} from a layer's parameters (device pointers; noise_w / bias / fir may be NULL):
  * c1 = sqrt(2) * (fir ? largest polyphase gain of the 4x4 FIR : w_gain), w_gain = sqrt(Cin) for a demodulated conv.
  * The bound of |noise| is max(noise_bound, the maximum of noise_amax), noise_amax = the slots of ONE sample written by
@@ -417,10 +433,14 @@ int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int C
  * 2 bf16 [B,Cout,HW].  epilogue / noise / bias / rgb_w / rgb_part / n_row_blocks as cips3d_modconv1x1_torgb (row blocks of 64).
  * cips3d_planes_supported: Cin % 64 == 0, Cout % 64 == 0. */
 int cips3d_planes_supported(int Cin, int Cout, int64_t HW);
-/* x_amax [B][CIPS3D_AMAX_FLOATS] (cips3d_absmax) -> planes of x * 2^-e, e -> exp_out[b]; both NULL: e = 0.  C % 8 == 0 */
-int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, const float* x_amax, int32_t* exp_out, void* stream);
+/* x_amax [B][CIPS3D_AMAX_FLOATS] (cips3d_absmax) -> planes of x * 2^-e with one e per sample, written to every pixel block's
+ * entry of exp_out [B][blocks]; both NULL: e = 0.  pmax_out (optional, C % 16 == 0): the sample's maximum in every entry of the
+ * tensor's patch maxima [B][ceil(HW/64)][C/16].  C % 8 == 0 */
+int cips3d_to_planes(const float* x, void* planes, int B, int C, int64_t HW, const float* x_amax, int32_t* exp_out,
+                     float* pmax_out, void* stream);
 int cips3d_from_planes(const void* planes, float* x, int B, int C, int64_t HW, const int32_t* exp, void* stream);
-/* rg: x_exp (input planes), x_amax + lconst (-> the exponent of a planes output, written to out_exp), out_amax */
+/* rg: x_exp / x_exp_const (input planes); for a planes output x_pmax / x_max_const + lconst (-> its exponents, written to out_exp)
+ * and out_pmax; out_amax (fp32 / bf16 output only: raised to max |out| per sample) */
 int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, void* out, int out_format, int B, int Cin, int Cout,
                              int64_t HW, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
                              const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks, const cips3d_range* rg,
@@ -483,7 +503,8 @@ typedef struct cips3d_dec_layer {
   const float* fir;        /* 4x4 FIR (blur.kernel / upsample.kernel) for kinds 1 and 3 */
   /* range workspace rows of this layer (cips3d_range; StyledConvs of a plan whose decoder runs split-fp16, else NULL) */
   float* amax;             /* [B][CIPS3D_AMAX_FLOATS] max |output| (kind 1: of the low-resolution GEMM result y_lo) */
-  int32_t* aexp;           /* [B] exponent of a planes output */
+  int32_t* aexp;           /* [B][ceil(H*W / CIPS3D_PLANES_EXP_BLOCK)] exponents of a planes output */
+  float* pmax;             /* [B][ceil(H*W / 64)][Cout / 16] patch maxima of a planes output */
   float* lconst;           /* [B][4] written by the modulate table */
 } cips3d_dec_layer;
 
@@ -517,8 +538,9 @@ typedef struct cips3d_generator_plan {
   /* range workspace (NULL: the decoder does not run split-fp16): zeroed by every forward before its first use */
   float* range_ws;               /* range_ws_words 32-bit words holding every layer's amax / aexp / lconst rows */
   int64_t range_ws_words;
-  float* feat_amax;              /* [B][CIPS3D_AMAX_FLOATS] of the NeRF feature map (inside range_ws) */
-  int32_t* feat_exp;             /* [B] */
+  float* feat_amax;              /* [B][CIPS3D_AMAX_FLOATS] of the NeRF feature map when it takes the fp32 -> planes conversion pass */
+  int32_t* feat_exp;             /* [B][blocks] exponents written by that pass */
+  float* feat_pmax;              /* [B][ceil(S*S/64)][hidden/16] patch maxima written by that pass */
   float* tmp_amax;               /* [B][CIPS3D_AMAX_FLOATS] scratch for tensors no producer tracked */
 } cips3d_generator_plan;
 

@@ -113,7 +113,7 @@ def test_planes_roundtrip_and_chain_gemm():
     mx = x.abs().amax(dim=(1, 2, 3), keepdim=True)
     assert bool(((back - x).abs() <= 2.5e-7 * x.abs() + mx * 2.0 ** -39).all())
     # planes layout: channel 8 cb + e of pixel n lives at [b, cb, plane, n, e]
-    e = p.cips3d_exp.to(torch.float32).view(B, 1, 1, 1)
+    e = p.cips3d_exp[:, 0].to(torch.float32).view(B, 1, 1, 1)       # (one exponent per sample, written to every pixel block)
     hi = (x * torch.exp2(-e)).to(torch.float16)
     assert torch.equal(p[:, :, 0].permute(0, 1, 3, 2).reshape(B, C, HW), hi.reshape(B, C, HW))
     raw = hip.to_planes(x, ranged=False)                 # e = 0: the halves of x itself
