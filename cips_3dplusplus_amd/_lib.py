@@ -38,7 +38,8 @@ class Range(C.Structure):
     """cips3d_range: range tracking of the split-fp16 modes (include/cips3d_hip.h)."""
     _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("x_exp_const", C.c_int32), ("x_max_const", C.c_float),
                 ("x_pmax", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
-                ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p), ("out_pmax", C.c_void_p)]
+                ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p), ("out_pmax", C.c_void_p),
+                ("next_gain", C.c_float), ("pad2_", C.c_int32)]
 
 
 AMAX_SLOTS, AMAX_STRIDE = 8, 64                 # CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE (re-read from the library by load())

@@ -1004,6 +1004,10 @@ struct FusedArgs {
   // range tracking (split mode; cips3d_range): amax of y_lo, the constants of conv1 / conv2; max |y_next| recorded (out2 is
   // not tracked: 64 registers is all the C = 32 stage has -- a split GEMM that reads a stored out2 measures it, cips3d_absmax)
   const float* x_amax; const float* lconst1; const float* lconst2; float* next_amax;
+  // next_gain > 0: next_amax does not receive the measured max|y_next| (a workgroup reduction + one atomic per workgroup:
+  // 4 us at the 4096 workgroups of the C = 64 stage) but its BOUND next_gain * U2 (next_gain: sqrt(C) for a demodulated next
+  // up-conv), written once -- good enough for a consumer that is the last stage of the decoder (cips3d_range)
+  float next_gain;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
@@ -1047,7 +1051,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   constexpr int BPT = BK * NBLK / NT;            // blocks per thread per stage
   static_assert((BK * NBLK) % NT == 0 && BPT >= 1, "block split");
   __shared__ __attribute__((aligned(16))) float sB[NBUF * BK * BN];
-  __shared__ __attribute__((aligned(16))) float s_nz1[BN];
+  __shared__ __attribute__((aligned(16))) float s_nz1[BN + 8];     // + the stage's scale factors (wave 0 -> everyone)
   // (the last stage has no chained GEMM: its B tile is dead when the ToRGB partials are exchanged, so they take its place --
   // 3 KB of LDS less per workgroup, which with <= 64 VGPRs admits an eighth workgroup per CU)
   __shared__ __attribute__((aligned(16))) float s_red_own[NEXT ? WGM * 3 * BN : 4];
@@ -1183,6 +1187,42 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   patch_load(0);
   if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
 
+  // Range of the split operands (cips3d_range, common.h).  act1 is split as act1 2^-e1, e1 from the bound
+  // U1 = c1 max|y_lo| + c0 (conv1's constants: FIR gain, noise, bias); conv2's accumulators come back with 2^-8 2^e1.  In the
+  // chained form out2 is split as out2 2^-e2, U2 = c1' U1 + c0' (conv2's constants), and y_next comes back with 2^-8 2^e2.
+  // Both powers of two ride on the sqrt(2) of the activations: no instruction per value.  Wave 0 makes them -- ONE vector load
+  // for the amax slots (lane = slot), issued here with the tile's first loads and waited for with them at the barrier below;
+  // as scalar loads in front of the first patch_store their latency was exposed: +2.9 us at C = 32 -- and leaves them behind
+  // the noise tile for everyone.
+#ifndef CIPS3D_FUSED_AB
+#define CIPS3D_FUSED_AB 0      // timing-only ablations: 1 no scale loads, 2 no y_next record, 3 neither
+#endif
+  if constexpr (SPLIT) {
+    if (a.x_amax && wave == 0 && !(CIPS3D_FUSED_AB & 1)) {
+      const float t = lane < CIPS3D_AMAX_SLOTS ? a.x_amax[b * CIPS3D_AMAX_FLOATS + lane * CIPS3D_AMAX_STRIDE] : 0.f;
+      const float* l1 = a.lconst1 + b * 4;            // (uniform addresses: scalar loads)
+      const float c10 = l1[0], c11 = l1[1];
+      float c20 = 0.f, c21 = 0.f;
+      if (NEXT) {
+        const float* l2 = a.lconst2 + b * 4;
+        c20 = l2[0];
+        c21 = fmaxf(l2[1], 1.41421356237309515f * l2[2]);
+      }
+      const float m_in = cips3d_wave_max_uniform(t);
+      const float u1 = fmaf(c11, m_in, c10);
+      const int e1 = cips3d_split_exp(u1);
+      f32x4 sc = {1.41421356237309515f * cips3d_pow2(-e1), kSplitInv * cips3d_pow2(e1), 1.41421356237309515f, 1.f};
+      if (NEXT) {
+        const float u2 = fmaf(c21, u1, c20);
+        const int e2 = cips3d_split_exp(u2);
+        sc[2] = 1.41421356237309515f * cips3d_pow2(-e2);
+        sc[3] = cips3d_pow2(e2);
+        // the bound of |y_next| instead of its measured maximum (see FusedArgs::next_gain): slot 0, once per sample
+        if (a.next_amax && a.next_gain > 0.f && blockIdx.x == 0 && lane == 0) a.next_amax[b * CIPS3D_AMAX_FLOATS] = a.next_gain * u2 * 1.000001f;
+      }
+      if (lane == 0) *reinterpret_cast<f32x4*>(s_nz1 + BN) = sc;
+    }
+  }
   // noise of the first conv for this tile (scaled), ToRGB weights
   if (tid < BN / 4) {
     const int r = tid / (TW / 4), x4 = tid % (TW / 4);
@@ -1206,23 +1246,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   FSTAMP(0);        // operand requests, noise staged, first barrier
-  // Range of the split operands (cips3d_range, common.h).  act1 is split as act1 2^-e1, e1 from the bound
-  // U1 = c1 max|y_lo| + c0 (conv1's constants: FIR gain, noise, bias); conv2's accumulators come back with 2^-8 2^e1.  In the
-  // chained form out2 is split as out2 2^-e2, U2 = c1' U1 + c0' (conv2's constants), and y_next comes back with 2^-8 2^e2.
-  // Both powers of two ride on the sqrt(2) of the activations: no instruction per value.
-  if constexpr (SPLIT) {
-    if (a.x_amax) {
-      const float m_in = cips3d_amax_load(a.x_amax + b * CIPS3D_AMAX_FLOATS);
-      const float* l1 = a.lconst1 + b * 4;            // (uniform address: scalar loads)
-      const float u1 = fmaf(l1[1], m_in, l1[0]);
-      const int e1 = cips3d_split_exp(u1);
-      kact1 = cips3d_uniform(1.41421356237309515f * cips3d_pow2(-e1));
-      k2in = cips3d_uniform(kSplitInv * cips3d_pow2(e1));
+  if constexpr (SPLIT) {      // the scale factors wave 0 left behind the noise tile (below), now wave-uniform registers
+    if (a.x_amax && !(CIPS3D_FUSED_AB & 1)) {
+      const f32x4 sc = *reinterpret_cast<const f32x4*>(s_nz1 + BN);
+      kact1 = cips3d_uniform(sc[0]);
+      k2in = cips3d_uniform(sc[1]);
       if (NEXT) {
-        const float* l2 = a.lconst2 + b * 4;
-        const int e2 = cips3d_split_exp(fmaf(fmaxf(l2[1], 1.41421356237309515f * l2[2]), u1, l2[0]));
-        kact2 = cips3d_uniform(1.41421356237309515f * cips3d_pow2(-e2));
-        kback2 = cips3d_uniform(cips3d_pow2(e2));
+        kact2 = cips3d_uniform(sc[2]);
+        kback2 = cips3d_uniform(sc[3]);
         kyn = cips3d_uniform(kSplitInv * kback2);
       }
     }
@@ -1429,7 +1460,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         else *reinterpret_cast<f32x4*>(yn + r * HWo) = yv;
       }
     }
-    if (a.next_amax) {     // the workgroup's largest |y_next| raises one slot of the sample's amax array; s_nz1 is dead (K loop over)
+    if (a.next_amax && !(a.next_gain > 0.f) && !(CIPS3D_FUSED_AB & 2)) {     // the workgroup's largest |y_next| raises one slot of the sample's amax array; s_nz1 is dead (K loop over)
       static_assert(!NEXT || 4 * WGM * WGN <= BN, "the reduction words fit the noise tile");
       const float m = cips3d_workgroup_max(mxn, s_nz1, wave, lane, WGM * WGN);
       if (tid == 0) cips3d_amax_raise_if(a.next_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.x);
@@ -1533,7 +1564,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         else *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = yv;
       }
   }
-  if (NEXT && !XCHG && a.next_amax) {     // (only wave row 0 stored: the other rows bring 0)
+  if (NEXT && !XCHG && a.next_amax && !(a.next_gain > 0.f) && !(CIPS3D_FUSED_AB & 2)) {     // (only wave row 0 stored: the other rows bring 0)
     const float m = cips3d_workgroup_max(mxn, s_nz1, wave, lane, WGM * WGN);
     if (tid == 0) cips3d_amax_raise_if(a.next_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.x);
   }
@@ -1776,7 +1807,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
               wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W,
               (skip_up & CIPS3D_GEMM_SPLIT) ? 3 : (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next,
               y_next, rg ? rg->x_amax : nullptr, rg ? rg->lconst : nullptr, rg ? rg->lconst2 : nullptr,
-              rg ? rg->next_amax : nullptr};
+              rg ? rg->next_amax : nullptr, rg ? rg->next_gain : 0.f};
   // split mode with range tracking: the bound of act1 needs conv1's constants, the chained form conv2's as well
   if ((skip_up & CIPS3D_GEMM_SPLIT) && rg && rg->x_amax && (!rg->lconst || (wm_next && !rg->lconst2))) return CIPS3D_E_BADARG;
   if ((skip_up & CIPS3D_Y_BF16) && !(skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;   // bf16 storage implies bf16 operands

@@ -241,6 +241,12 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         if (stage_ranged) {
           srg.x_amax = L.amax; srg.lconst = L.lconst; srg.lconst2 = L2.lconst;
           srg.next_amax = chain ? LN->amax : nullptr;
+          // The stage that feeds the LAST up-sampling stage publishes the bound of |y_next| instead of measuring it: that
+          // consumer splits once more (act1) and nothing after it, so ~2^8 of slack is harmless there, and the measurement is
+          // dearest exactly here (one reduction + atomic per workgroup, 4096 workgroups at C = 64: 4 us).  A non-demodulated
+          // next up-conv has no sqrt(C) row bound: measured then.
+          const bool ln_last = chain && li + 6 >= P.n_dec_layers;
+          srg.next_gain = (ln_last && (LN->flags & 64)) ? sqrtf((float)L.Cout) : 0.f;
         }
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
                                       L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split, rgb, chain ? LN->wm : nullptr,

@@ -261,7 +261,7 @@ class ForwardPlan:
                                                               info["W"], info["noise_index"])
             L.flags = ((1 if info.get("chained") else 0) | (2 if info.get("split") else 0) | (4 if info.get("planes_in") else 0) |
                        (8 if info.get("planes_out") else 0) | (16 if info.get("split16") else 0) |
-                       (32 if info.get("p16") else 0))
+                       (32 if info.get("p16") else 0) | (64 if conv.demodulate else 0))
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)

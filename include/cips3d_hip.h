@@ -261,6 +261,10 @@ typedef struct cips3d_range {
   int32_t* out_exp;        /* planes output: receives the exponents this launch chose, [B][blocks]                  */
   float* next_amax;        /* [B][CIPS3D_AMAX_FLOATS] or NULL: raised to max |y_next| (fused stage with wm_next)                 */
   float* out_pmax;         /* planes output: receives its patch maxima [B][ceil(HW/64)][Cout/16]                    */
+  float next_gain;         /* fused stage, > 0: next_amax receives the BOUND next_gain * U2 of |y_next| (U2: the stage's bound of
+                              |out2|; next_gain = sqrt(C) for a demodulated next up-conv) in slot 0 instead of the measured
+                              maximum -- no workgroup reduction, no atomics; for a consumer that is the decoder's last stage */
+  int32_t pad2_;
 } cips3d_range;
 /* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
 int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
@@ -495,7 +499,8 @@ typedef struct cips3d_dec_layer {
                               bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode;
                               bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes);
                               bit 5 (with bit 2 / 3): the planes are bf16 planes16 and wm is CIPS3D_MOD_BF16-packed (cips3d_modconv1x1_planes16);
-                              bit 4: wm is CIPS3D_MOD_SPLIT16-packed (conv2 / chained up-conv of a fused stage run in CIPS3D_GEMM_SPLIT mode) */
+                              bit 4: wm is CIPS3D_MOD_SPLIT16-packed (conv2 / chained up-conv of a fused stage run in CIPS3D_GEMM_SPLIT mode);
+                              bit 6: the conv is demodulated (its rows have unit norm: the sqrt(Cin) gain of the range bounds) */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */
