@@ -44,11 +44,17 @@
 // stored bf16 activation exactly the operand the next layer's GEMM would have rounded to, so nothing changes numerically
 // against the fp32-stored form of the mode; the folded ToRGB still reads the unrounded fp32 registers.
 //
-// Build note: this file is compiled with -fno-slp-vectorize (build.py).  With SLP on, hipcc pairs the ToRGB fold's channel-1 /
-// channel-2 accumulations into v_pk_fma_f32 chains; in the bf16 kernel (two workgroups per CU) the LOW lane of those chains
-// (channel 2) then came out wrong for isolated 16-pixel column tiles, differently from run to run (tools: 300-600 of 393k
-// partial sums per launch at batch 4; never with one workgroup per CU, never with scalar FMAs; the LDS exchange and the
-// operand loads were ruled out one by one).  Scalar FMAs cost nothing measurable here.
+// Build note (round 3).  With SLP vectorisation hipcc pairs the ToRGB fold's channel-1 / channel-2 accumulations into
+// v_pk_fma_f32 chains (operands picked with op_sel / op_sel_hi broadcasts out of v_mov-assembled register pairs).  In the bf16
+// kernel -- two workgroups per CU -- the partial sums of that form then differ from run to run: tools/fold_repeat.py, batch 4,
+// 59 of 59 repeats differ from the first (up to 1840 of 393k sums; always channel 2, the low half of the pair, for isolated
+// 16-pixel column tiles); never in the split-fp16 kernel (one workgroup per CU), never with one FMA per product.  The ISA of
+// the failing build shows nothing illegal around the chains (operands complete behind `s_waitcnt vmcnt(0) lgkmcnt(0)`, plain
+// VALU -> VALU dependencies), the LDS exchange and the operand loads were ruled out one by one in round 2: it behaves like a
+// packed-fp32 problem of the part under that occupancy, not like a race in this code.  The fold therefore spells its FMAs
+// out (asm v_fmac_f32 in the epilogue: 0 of 59 repeats differ, with or without SLP), so correctness does not hang on a
+// compiler flag; build.py still compiles this file with -fno-slp-vectorize (no other packed-fp32 arithmetic in the planes
+// kernels either; no measurable cost), and tests/test_gpu_bf16_storage.py repeats the folds bit for bit.
 #include <stdlib.h>
 #include "common.h"
 
@@ -353,7 +359,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) prgb[ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[ch][c]);
+          for (int r = 0; r < 4; ++r)
+            // one v_fmac_f32 per product, written out: nothing can pair the channel-1 / channel-2 accumulations into
+            // v_pk_fma_f32 (see the build note in the header of this file; VALU results feed VALU here: no hazard state to keep)
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[ch][c]) : "v"(wrgb[i][ch][r]), "v"(v[r]));
       }
       if (npx[c] < HW) {
         if (a.out_fmt == 1) {

@@ -261,3 +261,73 @@ def test_config3_forward_is_deterministic():
                 assert torch.equal(G(**kw)["rgb"], ref), prec
     finally:
         G.set_decoder_precision("fp32")
+
+
+@pytest.mark.parametrize("kind", ["planes16", "planes", "gemm_torgb", "fused_stage"])
+def test_torgb_folds_repeat_bit_for_bit(kind):
+    """The folded ToRGB partial sums (csrc/chain.hip both kernels, cips3d_modconv1x1_torgb, the fused up-sampling stage) at batch 4
+    -- two and more workgroups per CU -- are the same bits on every run.  (With hipcc's SLP pairing of the fold's accumulations
+    into v_pk_fma_f32 the planes16 kernel's sums differed on EVERY repeat: chain.hip's build note.  tools/fold_repeat.py is the
+    longer form of this test.)"""
+    import ctypes as C
+    B, Cc, H = 4, 512, 64
+    HW = H * H
+    lib = _lib.load()
+    x = cu(weights.det_normal("rp.x", (B, Cc, H, H), 2.0, 1))
+    scale = 1.0 / math.sqrt(Cc)
+    Wt = cu(weights.det_normal("rp.W", (1, Cc, Cc, 1, 1), 1.0, 3))
+    s = cu(1.0 + weights.det_uniform("rp.s", (B, Cc), 0.4, 4))
+    bias = cu(weights.det_uniform("rp.b", (Cc,), 0.3, 5))
+    nw = torch.full((1,), 0.2, device=DEV)
+    nz = cu(weights.det_normal("rp.n", (1, 1, H, H), 1.0, 6))
+    Wr = cu(weights.det_normal("rp.Wr", (1, 3, Cc, 1, 1), 1.0, 7))
+    wr = hip.modulate_weights(Wr, cu(1.0 + weights.det_uniform("rp.sr", (B, Cc), 0.3, 8)), Cc, B, 3, Cc, 1, 1.0 / math.sqrt(Cc), False, False)
+    if kind == "planes16":
+        p = hip.to_planes16(x)
+        wm = hip.modulate_weights(Wt, s, Cc, B, Cc, Cc, 1, scale, True, True, bf16=True)
+
+        def run():
+            part = torch.full((Cc // 64, B, 3, HW), float("nan"), device=DEV)
+            hip.modconv1x1_planes16(p, wm, Cc, HW, "planes16", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr, rgb_part=part)
+            return part
+    elif kind == "planes":
+        p = hip.to_planes(x)
+        wm = hip.modulate_weights(Wt, s, Cc, B, Cc, Cc, 1, scale, True, True, split=True)
+
+        def run():
+            part = torch.full((Cc // 64, B, 3, HW), float("nan"), device=DEV)
+            hip.modconv1x1_planes(p, wm, Cc, HW, "planes", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr, rgb_part=part)
+            return part
+    elif kind == "gemm_torgb":
+        wm = hip.modulate_weights(Wt, s, Cc, B, Cc, Cc, 1, scale, True, True)
+
+        def run():
+            part = torch.full((Cc // 64, B, 3, HW), float("nan"), device=DEV)
+            out = torch.empty(B, Cc, H, H, device=DEV)
+            nblk = C.c_int(0)
+            _lib.check(lib.cips3d_modconv1x1_torgb(x.data_ptr(), wm.data_ptr(), out.data_ptr(), B, Cc, Cc, HW, 1 | hip.GEMM_BF16, nz.data_ptr(), 0,
+                                                   nw.data_ptr(), bias.data_ptr(), wr.data_ptr(), part.data_ptr(), C.byref(nblk), None,
+                                                   hip.stream_ptr()), "cips3d_modconv1x1_torgb")
+            return part
+    else:
+        Cs, Hs = 64, 128
+        y = cu(weights.det_normal("rp.y", (B, Cs, Hs, Hs), 1.0, 9))
+        k1 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+        fir = cu(k1.outer(k1) / 16.0)
+        n1 = cu(weights.det_normal("rp.n1", (1, 1, 2 * Hs, 2 * Hs), 1.0, 2))
+        n2 = cu(weights.det_normal("rp.n2", (1, 1, 2 * Hs, 2 * Hs), 1.0, 3))
+        b1, b2 = cu(weights.det_uniform("rp.b1", (Cs,), 0.2, 4)), cu(weights.det_uniform("rp.b2", (Cs,), 0.2, 5))
+        W2 = cu(weights.det_normal("rp.W2", (1, Cs, Cs, 1, 1), 1.0, 6))
+        s2 = cu(1.0 + weights.det_uniform("rp.s2", (B, Cs), 0.3, 7))
+        wm2 = hip.modulate_weights(W2, s2, Cs, B, Cs, Cs, 1, 1.0 / math.sqrt(Cs), True, True)
+        Wr2 = cu(weights.det_normal("rp.Wr2", (1, 3, Cs, 1, 1), 1.0, 8))
+        wr2 = hip.modulate_weights(Wr2, s2, Cs, B, 3, Cs, 1, 1.0 / math.sqrt(Cs), False, False)
+        brgb = cu(weights.det_uniform("rp.brgb", (3,), 0.1, 8))
+        skip = cu(weights.det_normal("rp.skip", (B, 3, Hs, Hs), 1.0, 9))
+
+        def run():
+            return hip.fused_up_conv(y, fir, n1, nw, b1, wm2, n2, nw, b2, wr2, brgb, skip, skip_up=True, want_out2=False, bf16=True)[1]
+    first = run().clone()
+    assert bool(torch.isfinite(first).all())
+    for _ in range(12):
+        assert torch.equal(run(), first)
