@@ -105,6 +105,7 @@ _SIGS = {
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, c_f32, C.c_void_p]),
     "cips3d_absmax": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
     "cips3d_amax_layout": (c_int, [C.POINTER(c_int), C.POINTER(c_int)]),
+    "cips3d_split_words": (c_int, [c_f32p, c_f32, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
     "cips3d_range_consts": (c_int, [c_f32p, c_int, c_f32p, c_f32, c_f32p, c_f32, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_modconv1x1_supported": (c_int, [c_int, c_int, c_i64]),
     "cips3d_modconv1x1": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, c_f32p, c_i64, c_f32p,

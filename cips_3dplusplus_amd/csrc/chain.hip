@@ -367,14 +367,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       if (npx[c] < HW) {
         if (a.out_fmt == 1) {
           // planes: channels obase + 4 q + r live in channel block (obase >> 3) + (q >> 1), elements 4 (q & 1) + r
-          h4 hi, lo;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            _Float16 h_, l_;
-            cips3d_split16(v[r], h_, l_);
-            hi[r] = h_;
-            lo[r] = l_;
-          }
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          unsigned h0, l0, h1, l1;
+          cips3d_split_pair(v[0], v[1], h0, l0);
+          cips3d_split_pair(v[2], v[3], h1, l1);
+          const h4 hi = __builtin_bit_cast(h4, u32x2_t{h0, h1}), lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
           _Float16* dst = reinterpret_cast<_Float16*>(a.out) +
                           ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
           *reinterpret_cast<h4*>(dst) = hi;

@@ -148,6 +148,33 @@ __device__ static inline void cips3d_split16(float x, _Float16& hi, _Float16& lo
   lo = (_Float16)(x - (float)hi);
 }
 
+// The same split in two instructions per value.  v_fma_mix{lo,hi}_f16 evaluate fma(a, b, c) on a free mix of fp32 and fp16
+// sources and round ONCE to fp16 into the low / high half of the destination:
+//   cips3d_split_word(t, k)   {hi | lo << 16} with hi = fp16(t k), lo = fp16(t k - hi) of the EXACT product t k -- the
+//                             multiplication by a scale (a power of two of the range tracking, the sqrt(2) of an activation)
+//                             rides along, and the pair represents t k itself, not its fp32 rounding, to 22 bits.  This is
+//                             the word format of the fused up-sampling stages' LDS hand-off.
+//   cips3d_split_pair(a, b)   [hi_a | hi_b << 16] and [lo_a | lo_b << 16]: one v_cvt_pk_f16_f32 + two mixes for two values,
+//                             the register format of the MFMA fragments (chain.hip, nerf.hip).
+// (cips3d_split16's form costs cvt, cvt back, sub, cvt and a pack per value.  Inline asm: VALU results feeding VALU, no
+// hazard state to keep; the consumers -- LDS writes, MFMA fragments -- see ordinary compiler-tracked registers.)
+__device__ static inline unsigned cips3d_split_word(float t, float k) {      // k wave-uniform
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0\n\tv_fma_mixhi_f16 %0, %1, %2, -%0 op_sel_hi:[0,0,1]" : "=&v"(d) : "v"(t), "s"(k));
+  return d;
+}
+__device__ static inline unsigned cips3d_split_word(float t) {
+  unsigned d;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, 0\n\tv_fma_mixhi_f16 %0, %1, 1.0, -%0 op_sel_hi:[0,0,1]" : "=&v"(d) : "v"(t));
+  return d;
+}
+__device__ static inline void cips3d_split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+      "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+      : "=&v"(hi), "=&v"(lo) : "v"(a), "v"(b));
+}
+
 // ---- Range tracking of the decoder's split-fp16 operands (include/cips3d_hip.h: cips3d_range).
 // fp16 has 5 exponent bits: an unscaled pair (hi, lo) overflows at |x| >= 65520 and loses fp32's relative accuracy below
 // |x| ~ 2^-3 (lo turns subnormal; the pair's absolute floor is 2^-25).  The reference's fp32 convolution

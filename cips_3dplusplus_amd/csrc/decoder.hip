@@ -33,11 +33,9 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 // the fp32 fragment they replace), scaled by 2^8.
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float pack_split(float x) {
-  _Float16 hi, lo;
-  cips3d_split16(x, hi, lo);
-  return __builtin_bit_cast(float, h2{hi, lo});
-}
+__device__ __forceinline__ float pack_split(float x) { return __uint_as_float(cips3d_split_word(x)); }
+// ... of the exact product x * k (k wave-uniform): the activation's sqrt(2) 2^-e rides on the split, two instructions in all
+__device__ __forceinline__ float pack_split(float x, float k) { return __uint_as_float(cips3d_split_word(x, k)); }
 // four packed words (fragment elements 0..3) -> the hi fragment and the lo fragment
 __device__ __forceinline__ void unpack_frag(float p0, float p1, float p2, float p3, h4& hi, h4& lo) {
   typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -47,14 +45,12 @@ __device__ __forceinline__ void unpack_frag(float p0, float p1, float p2, float 
 }
 // split four fp32 values (fragment elements 0..3) in registers
 __device__ __forceinline__ void split_frag(float v0, float v1, float v2, float v3, h4& hi, h4& lo) {
-  const float v[4] = {v0, v1, v2, v3};
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    _Float16 a, b;
-    cips3d_split16(v[e], a, b);
-    hi[e] = a;
-    lo[e] = b;
-  }
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  unsigned h0, l0, h1, l1;
+  cips3d_split_pair(v0, v1, h0, l0);
+  cips3d_split_pair(v2, v3, h1, l1);
+  hi = __builtin_bit_cast(h4, u32x2_t{h0, h1});
+  lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
 }
 // the three products of one 16x16x16 block: A fragment word = {hi x4 | lo x4}
 __device__ __forceinline__ f32x4 split_mfma16(f32x4 afrag, h4 bh, h4 bl, f32x4 c) {
@@ -82,13 +78,12 @@ __device__ __forceinline__ f32x4 fused_mfma(float a, float b, f32x4 c) { return 
 // the LDS read; the epilogue undoes the scale exactly.
 constexpr float kSplitScale = 256.f, kSplitInv = 1.f / 256.f;
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  unsigned h[4], l[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    _Float16 a, b;
-    cips3d_split16(v[j], a, b);
-    hi[j] = a;
-    lo[j] = b;
-  }
+  for (int p = 0; p < 4; ++p) cips3d_split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
+  hi = __builtin_bit_cast(h8, u32x4_t{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(h8, u32x4_t{l[0], l[1], l[2], l[3]});
 }
 
 // bf16 compute mode of the GEMMs (BASELINE config 3: decoder in bf16 with fp32 accumulate).  Storage and data movement
@@ -1174,10 +1169,13 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * TW + qx * 4);
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs) * kact1;
-        if constexpr (SPLIT) {          // split once here; every wave row reads the packed halves
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs);
+        if constexpr (SPLIT) {          // split once here (with the activation's gain and range scale: cips3d_split_word);
+#pragma unroll                          // every wave row reads the packed halves
+          for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c], kact1);
+        } else {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c]);
+          for (int c = 0; c < 4; ++c) v[c] *= kact1;
         }
         *reinterpret_cast<f32x4*>(dst + ch * BN + (2 * by + py) * TW + qx * 4) = v;
       }
@@ -1646,6 +1644,24 @@ extern "C" int cips3d_modulate_table(const cips3d_modulate_desc* table_dev, int 
   if (B == 0) return 0;
   hipLaunchKernelGGL(modulate_table_kernel, dim3((unsigned)ceil_div(total_rows, 4), (unsigned)B), dim3(256), 0,
                      as_stream(stream), table_dev, n_desc, total_rows, noise_bound);
+  return cips3d_launch_status();
+}
+
+__global__ void __launch_bounds__(256) split_words_kernel(const float* __restrict__ x, float k, unsigned* __restrict__ words,
+                                                          unsigned* __restrict__ pairs, int64_t n) {
+  const float ku = cips3d_uniform(k);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n / 2; i += (int64_t)gridDim.x * 256) {
+    words[2 * i] = cips3d_split_word(x[2 * i], ku);
+    words[2 * i + 1] = cips3d_split_word(x[2 * i + 1] * k);
+    cips3d_split_pair(x[2 * i], x[2 * i + 1], pairs[2 * i], pairs[2 * i + 1]);
+  }
+}
+
+extern "C" int cips3d_split_words(const float* x, float k, uint32_t* words, uint32_t* pairs, int64_t n, void* stream) {
+  if (!x || !words || !pairs || n <= 0 || (n & 1)) return CIPS3D_E_BADARG;
+  int64_t blocks = ceil_div<int64_t>(n / 2, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(split_words_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, k, words, pairs, n);
   return cips3d_launch_status();
 }
 

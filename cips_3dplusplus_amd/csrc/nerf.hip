@@ -704,14 +704,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         if (P.features_planes) {
           // split-fp16 planes [b][H/8][hi|lo][R][8]: channels 4 cq .. 4 cq + 3 = elements 4 (cq & 1) .. of channel block cq >> 1
           typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-          h4 hi, lo;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            _Float16 a_, b_;
-            split2(acc[e] * 16384.f, a_, b_);      // 2^-CIPS3D_FEATURES_EXP: |feature| <= 1 (cips3d_range)
-            hi[e] = a_;
-            lo[e] = b_;
-          }
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          unsigned h0, l0, h1, l1;                   // 2^-CIPS3D_FEATURES_EXP: |feature| <= 1 (cips3d_range)
+          cips3d_split_pair(acc[0] * 16384.f, acc[1] * 16384.f, h0, l0);
+          cips3d_split_pair(acc[2] * 16384.f, acc[3] * 16384.f, h1, l1);
+          const h4 hi = __builtin_bit_cast(h4, u32x2_t{h0, h1}), lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
           _Float16* o = reinterpret_cast<_Float16*>(P.o_features) +
                         ((((int64_t)b * (H / 8) + (cq >> 1)) * 2) * R + gray) * 8 + 4 * (cq & 1);
           *reinterpret_cast<h4*>(o) = hi;

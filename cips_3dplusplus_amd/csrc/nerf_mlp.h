@@ -107,14 +107,14 @@ __device__ __forceinline__ void split2(float x, _Float16& hi, _Float16& lo) {
   cips3d_split16(x, hi, lo);
 }
 // eight fp32 values (units 4q..4q+3 of tile 2m, then of tile 2m+1) -> the hi / lo B fragments of k-block m
+// (cips3d_split_pair: one conversion and two v_fma_mix per two values instead of four instructions and a pack per value)
 __device__ __forceinline__ void split8(const float (&v)[8], h8& hi, h8& lo) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  unsigned h[4], l[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    _Float16 a, b;
-    split2(v[j], a, b);
-    hi[j] = a;
-    lo[j] = b;
-  }
+  for (int p = 0; p < 4; ++p) cips3d_split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
+  hi = __builtin_bit_cast(h8, u32x4_t{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(h8, u32x4_t{l[0], l[1], l[2], l[3]});
 }
 
 

@@ -268,6 +268,10 @@ typedef struct cips3d_range {
 } cips3d_range;
 /* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
 int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
+/* Test hook for the split itself (n even): words[i] = {hi | lo << 16} of x[i] * k -- even i through the fused form (the exact
+ * product t k is split), odd i through the plain form on the fp32 product -- and, per pair (x[2j], x[2j+1]),
+ * pairs[2j] = [hi_0 | hi_1 << 16], pairs[2j+1] = [lo_0 | lo_1 << 16] of the values themselves. */
+int cips3d_split_words(const float* x, float k, uint32_t* words, uint32_t* pairs, int64_t n, void* stream);
 /* CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE as the library was built (a binding sizes its amax arrays from these) */
 int cips3d_amax_layout(int* slots, int* stride);
 /* lconst[b] = {c0, c1, 0, 0} from a layer's parameters (device pointers; noise_w / bias / fir may be NULL):

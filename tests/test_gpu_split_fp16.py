@@ -283,3 +283,44 @@ def test_split_and_bf16_weight_fragments_are_the_plain_matrix_rearranged(Cout, C
     bf = hip.modulate_weights(W, s, Cin, B, Cout, Cin, 1, scale, demod, True, bf16=True)
     got16 = bf.view(torch.bfloat16)[: B * Cout * Cin].view(B, Cout // 16, Cin // 32, 4, 16, 8)
     assert torch.equal(got16, frag.to(torch.bfloat16))
+
+
+def test_the_two_instruction_split_is_the_split():
+    """cips3d_split_word / cips3d_split_pair (v_fma_mix{lo,hi}_f16, csrc/common.h): hi = fp16(x), lo = fp16(x - hi), round to
+    nearest even, fp16 subnormals kept; the scaled form splits the EXACT product t k (one rounding, not two).  (Compared as
+    values: fma(-0, 1, +0) is +0 where a conversion keeps -0 -- the one bit pattern that can differ.)"""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    mags = torch.tensor([1e-9, 1e-7, 6e-5, 1e-3, 0.3, 1.0, 37.0, 2049.0, 3.0e4])
+    x = torch.cat([torch.randn(40000, generator=g)[:, None] * mags[None, :], torch.tensor([[0.0, -0.0, 65504.0, -65504.0, 2.0 ** -24, 2.0 ** -25,
+                                                                                           1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -12, -5.5]])]).reshape(-1)
+    x = x[x.abs() < 65519.0]
+    x = x[: x.numel() // 2 * 2].contiguous()
+    for k in (1.0, 1.41421356237309515 * 2.0 ** -3, 0.7853981):
+        kk = float(torch.tensor(k, dtype=torch.float32))
+        xs = x if k == 1.0 else x[(x * kk).abs() < 65000.0]
+        xs = xs[: xs.numel() // 2 * 2].contiguous()
+        xd = cu(xs)
+        words = torch.empty(xs.numel(), dtype=torch.int32, device=DEV)
+        pairs = torch.empty(xs.numel(), dtype=torch.int32, device=DEV)
+        _lib.check(lib.cips3d_split_words(xd.data_ptr(), kk, words.data_ptr(), pairs.data_ptr(), xs.numel(), hip.stream_ptr()), "split_words")
+        w16 = words.cpu().view(torch.float16).view(-1, 2)            # [hi, lo] per value
+        import numpy as np
+        r16 = lambda d: torch.from_numpy(d.numpy().astype(np.float16))   # noqa: E731  (numpy rounds a double to half ONCE; torch goes through float)
+        p64 = xs.double() * kk                                        # exact
+        hi_exact = r16(p64)
+        lo_exact = r16(p64 - hi_exact.double())
+        p32 = (xs * kk)                                               # the fp32 product, then the plain split
+        hi_plain = r16(p32.double())
+        lo_plain = r16(p32.double() - hi_plain.double())
+        even = torch.arange(xs.numel()) % 2 == 0
+        assert torch.equal(w16[even, 0].float(), hi_exact[even].float())
+        assert torch.equal(w16[even, 1].float(), lo_exact[even].float())
+        assert torch.equal(w16[~even, 0].float(), hi_plain[~even].float())
+        assert torch.equal(w16[~even, 1].float(), lo_plain[~even].float())
+        if k == 1.0:
+            pr = pairs.cpu().view(torch.float16).view(-1, 2, 2)      # [pair][hi|lo][element]
+            xe = xs.view(-1, 2)
+            hi = r16(xe.double())
+            lo = r16(xe.double() - hi.double())
+            assert torch.equal(pr[:, 0].float(), hi.float()) and torch.equal(pr[:, 1].float(), lo.float())
