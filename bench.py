@@ -34,7 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DTYPE_NAMES = {"fp32": "f32 (NeRF point MLP and decoder GEMMs: fp32-equivalent split-fp16 MFMA products -- three exact fp16 products per "
-                       "fp32 product, fp32 accumulate, fp32 storage)",
+                       "fp32 product, fp32 accumulate, fp32 storage; operands range-tracked: per-tensor power-of-two scales)",
+               "fp32_exact": "f32 (decoder GEMMs on the fp32 matrix instruction v_mfma_f32_16x16x4_f32; NeRF point MLP split-fp16)",
                "bf16": "bf16 decoder GEMM operands (f32 accumulate, f32 storage), f32 NeRF",
                "bf16_storage": "bf16 decoder GEMM operands + bf16 storage of the up-sampling stages' activations "
                                "(f32 accumulate), f32 NeRF"}
@@ -43,7 +44,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* d
 MFMA_F16_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 SPLIT_PRODUCTS = 3                         # fp16 products the render kernel issues per fp32 product (w_hi x_hi + w_hi x_lo + w_lo x_hi)
 EVENT_STRIDE = 8                           # HIP events around the dominant kernel on every 8th step (a record drains the queue)
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_nerf_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_nerf_traffic.json")     # {"entries": [{depth, n_samples, batch, traffic_bytes_per_launch}]}
+PREROLL_MAX = 10                           # untimed regions until two consecutive ones agree within 1 % (clocks / caches settled)
 
 
 def nerf_flops_per_point(H, D):
@@ -190,6 +192,23 @@ class ForwardWorkload:
         from cips_3dplusplus_amd import hip
         for _ in range(warmup):
             self.step()
+        # pre-roll: --warmup steps do not reach steady clocks (round 2's driver-form repeats fell monotonically by 8 %): run
+        # whole untimed regions until two consecutive ones agree within 1 %, then time
+        self.preroll = []
+        for _ in range(PREROLL_MAX):
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.barrier()
+            dt = time.perf_counter() - t0
+            if self.world > 1:
+                t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+                dt = float(t)
+            self.preroll.append(dt)
+            if len(self.preroll) >= 2 and abs(self.preroll[-1] - self.preroll[-2]) <= 0.01 * self.preroll[-1]:
+                break
         # Short regions (the driver's --steps 20) time ONE launch per region, the one in the middle: every record drains the
         # queue (~6-10 us), and three of them in a 7 ms window are 0.4 % of it; long regions keep one launch in eight.
         stride = EVENT_STRIDE if steps >= 64 else max(1, steps)
@@ -215,10 +234,12 @@ class ForwardWorkload:
                 dt = float(t)
             elapsed.append(dt)
         med = statistics.median(elapsed)
-        kern_ms = sum(s.elapsed_time(t) for s, t in events) / len(events) if events else float("nan")
+        kern_ms = sum(s.elapsed_time(t) for s, t in events) / len(events) if events else None
         return med, elapsed, kern_ms, len(events)
 
     def roofline(self, kern_ms, n_events):
+        if not kern_ms:                              # no kernel events were taken (--no-kernel-events): nothing to price
+            return None
         H = self.cfg["renderer_cfg"]["hidden_dim"]
         flops = self.B * 64 * 64 * self.n_samples * nerf_flops_per_point(H, self.depth)
         achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -227,9 +248,11 @@ class ForwardWorkload:
         # configuration, not measured in this run.
         traffic, src = None, None
         tp = os.path.join(ROOT, TRAFFIC_FILE)
-        if self.depth == 2 and self.n_samples == 24 and self.B == 1 and os.path.exists(tp):
-            traffic = json.load(open(tp)).get("traffic_bytes_per_launch")
-            src = f"replayed from {TRAFFIC_FILE} (separate rocprofv3 --pmc passes of this command)"
+        if os.path.exists(tp):
+            for ent in json.load(open(tp)).get("entries", []):
+                if (ent.get("depth"), ent.get("n_samples"), ent.get("batch"), ent.get("img")) == (self.depth, self.n_samples, self.B, 64):
+                    traffic = ent.get("traffic_bytes_per_launch")
+                    src = f"replayed from {TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
         # The point-MLP GEMMs run as fp32-equivalent SPLIT-fp16 products on v_mfma_f32_16x16x32_f16 (csrc/nerf.hip): every
         # algorithmic fp32 multiply-add costs three fp16 ones, so the matrix-core ceiling for ALGORITHMIC flops is the fp16
         # dense peak / 3.  `achieved` counts algorithmic flops, as before; the fp32 matrix instruction's own peak
@@ -316,7 +339,7 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (N=64, config 3, config 5)")
     ap.add_argument("--no-kernel-events", action="store_true", help="A/B: no HIP events around the dominant kernel (roofline = null)")
     ap.add_argument("--deterministic", action="store_true", help="perturb off + fixed noise buffers (demo semantics)")
-    ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "bf16", "bf16_storage"],
+    ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "fp32_exact", "bf16", "bf16_storage"],
                     help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32); "
                          "bf16_storage = additionally the up-sampling stages' pre-FIR activations live in HBM as bf16")
     ap.add_argument("--dump-gathered", default=None, help="rank 0 saves the last step's gathered uint8 frames (torch.save)")
@@ -331,14 +354,18 @@ def main():
     if a.gpus != world:
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} "
                          f"(or without a launcher: bench.py starts its own ranks)")
-    if not torch.cuda.is_available():
+    # Nothing below touches a GPU before the rank has bound ITS device and joined the process group: counting devices does
+    # not initialise HIP on this image, and a rank that initialised device 0 first would hold a context there for nothing.
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # CIPS3D_DIST_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (ranks then share
     # devices round-robin); the driver's runs use the default: nccl (= RCCL), one GPU per rank.
     backend = os.environ.get("CIPS3D_DIST_BACKEND", "nccl")
-    n_dev = torch.cuda.device_count()
     if backend != "nccl":
         local_rank %= max(1, n_dev)
+    if world > 1 and torch.cuda.is_initialized():
+        raise SystemExit("bench.py: the GPU was initialised before the rank bound its device (a bug in this file)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -372,6 +399,7 @@ def main():
             "dtype": DTYPE_NAMES[a.decoder_precision],
             "data": "synthetic",
             "repeats": a.repeats, "ms_per_step_repeats": [e / a.steps * 1e3 for e in elapsed],
+            "preroll_ms_per_step": [e / a.steps * 1e3 for e in wl.preroll],
             "config": {"workload": wl.name(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
             "roofline": wl.roofline(kern_ms, n_ev),
@@ -389,17 +417,25 @@ def main():
             del wl
             torch.cuda.empty_cache()
             for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
+                            ("headline workload with the decoder GEMMs on the fp32 matrix instruction (fp32_exact) instead of the "
+                             "default split-fp16 products", dict(n_samples=24, batch=1, precision="fp32_exact")),
+                            ("BASELINE config 2: FFHQ 256^2, D = 2, single view", dict(n_samples=24, batch=1, precision="fp32", res=256)),
+                            ("BASELINE config 2 with the deep renderer: FFHQ 256^2, D = 8", dict(n_samples=24, batch=1, precision="fp32",
+                                                                                               res=256, depth=8)),
+                            ("BASELINE config 1 on the HIP path: FFHQ 64x64 output (no up-sampling), D = 8, N = 24, single view (its CPU "
+                             "figure: profiles/r01_config1_cpu_vs_gpu.json)", dict(n_samples=24, batch=1, precision="fp32", res=64, depth=8)),
                             ("BASELINE config 3: 1024^2, batch 4, bf16 decoder GEMM operands (fp32 storage: the faster of the two bf16 "
                              "modes on this build)", dict(n_samples=24, batch=4, precision="bf16")),
                             ("BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
                              "(HBM bytes of those stages halved; slower: the stages are VALU-bound)",
                              dict(n_samples=24, batch=4, precision="bf16_storage"))):
-                w2 = ForwardWorkload(dev, 0, 1, 1024, 2, kw["n_samples"], kw["batch"], kw["precision"], False)
+                w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False)
                 steps2 = max(10, a.steps // 2)
                 m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
                 also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
                              "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
                              "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
+                             "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
                              "dtype": DTYPE_NAMES[kw["precision"]],
                              "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2)})
                 del w2
@@ -412,7 +448,7 @@ def main():
             from cips_3dplusplus_amd import configs
             line["cpu_baseline"] = cpu_baseline(configs.ffhq_G_cfg(a.res, a.depth),
                                                 {"N_samples": a.n_samples, "perturb": True, "static_viewdirs": False}, B)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line, allow_nan=False), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

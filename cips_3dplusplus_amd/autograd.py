@@ -75,8 +75,12 @@ class ModulateFn(Function):
         return dW, ds, None, None, None
 
 
-def _split_ok(k):
-    """Split-fp16 GEMM mode for a forward GEMM (activation operand) whose contraction length is k (hip.SPLIT_BACKWARD: knob)."""
+def _split_ok(k, m=None):
+    """Split-fp16 GEMM mode for a forward GEMM (activation operand) whose contraction length is k (hip.SPLIT_BACKWARD: knob).
+    m: the StyledConv the GEMM belongs to -- the differentiable route follows the module's precision like the inference route
+    (Decoder.set_precision: "fp32" = split products, "fp32_exact" / "bf16*" = the fp32 matrix instruction here)."""
+    if m is not None and (not getattr(m, "split", True) or getattr(m, "bf16", False)):
+        return False
     return hip.SPLIT_BACKWARD and k % 32 == 0
 
 
@@ -84,11 +88,11 @@ class Conv1x1Fn(Function):
     """Per-sample GEMM y[b] = wm[b] x[b] (x [B,Cin,H,W]); backward = the same GEMM on wm^T + the pixel-contraction GEMM."""
 
     @staticmethod
-    def forward(ctx, x, wm, packed=None, packed_t=None):
+    def forward(ctx, x, wm, packed=None, packed_t=None, split=None):
         x = _c(x)
         wm = _c(wm)
         Cout = wm.shape[1]
-        sp = _split_ok(wm.shape[2])          # `packed` (from modulate_all) is split-packed under the same condition
+        sp = _split_ok(wm.shape[2]) if split is None else bool(split)   # `packed` (from modulate_all) is split-packed alike
         y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), Cout, epilogue=0, split=sp)
         ctx.save_for_backward(x, wm)
         ctx.packed_t = packed_t              # fragments of wm^T from the same table launch (else packed in the backward)
@@ -104,7 +108,7 @@ class Conv1x1Fn(Function):
             dx = hip.modconv1x1(dy, pt, wm.shape[2], epilogue=0)
         if ctx.needs_input_grad[1]:
             dwm = hip.gemm_wgrad(dy, x)
-        return dx, dwm, None, None
+        return dx, dwm, None, None, None
 
 
 class Conv1x1ActFn(Function):
@@ -112,10 +116,10 @@ class Conv1x1ActFn(Function):
     (cips3d_modconv1x1, epilogue 1); backward = NoiseBiasActFn's followed by Conv1x1Fn's."""
 
     @staticmethod
-    def forward(ctx, x, wm, packed, noise, noise_w, bias, packed_t=None):
+    def forward(ctx, x, wm, packed, noise, noise_w, bias, packed_t=None, split=None):
         x, wm, noise = _c(x), _c(wm), _c(noise)
         ctx.packed_t = packed_t
-        sp = _split_ok(wm.shape[2])
+        sp = _split_ok(wm.shape[2]) if split is None else bool(split)
         y = hip.modconv1x1(x, packed if packed is not None else hip.pack_weights(wm, split=sp), wm.shape[1], epilogue=1,
                            noise=noise, noise_w=noise_w, bias=bias, split=sp)
         ctx.save_for_backward(x, wm, y, noise, noise_w)
@@ -129,7 +133,7 @@ class Conv1x1ActFn(Function):
         pt = ctx.packed_t if ctx.packed_t is not None else (hip.pack_weights(wm, transpose=True) if n_x else None)
         dx = hip.modconv1x1(dpre, pt, wm.shape[2], epilogue=0) if n_x else None
         dwm = hip.gemm_wgrad(dpre, x) if n_wm else None
-        return dx, dwm, None, dnoise, dnw, db, None
+        return dx, dwm, None, dnoise, dnw, db, None, None
 
 
 class NoiseBiasActFn(Function):
@@ -239,7 +243,8 @@ def modulate_all(dec, s_list):
     from .decoder import StyledConv
     seq = dec._mod_layers()
     B, dev = s_list[0].shape[0], s_list[0].device
-    key = (B, dec.conv1.conv.modulation.weight.data_ptr())
+    key = (B, dec.conv1.conv.modulation.weight.data_ptr(), bool(getattr(dec, "split", True)), bool(getattr(dec, "bf16", False)),
+           hip.SPLIT_BACKWARD)
     ent = getattr(dec, "_grad_mod_table", None)
     if ent is None or ent[0] != key:
         sizes = [m.conv.in_channel for m, _ in seq]
@@ -261,7 +266,7 @@ def modulate_all(dec, s_list):
                 d.s_stride = cin
                 d.Cout, d.Cin, d.ksq = conv.out_channel, conv.in_channel, 1
                 d.flags = ((hip.MOD_DEMODULATE if conv.demodulate else 0) | (hip.MOD_PACKED if want_packed else 0) |
-                           (hip.MOD_SPLIT if (want_packed == 1 and _split_ok(conv.in_channel)) else 0) |
+                           (hip.MOD_SPLIT if (want_packed == 1 and _split_ok(conv.in_channel, m)) else 0) |
                            (hip.MOD_TRANSPOSE if want_packed == 2 else 0))
                 d.scale = conv.scale
                 d.row_begin = rows
@@ -309,8 +314,8 @@ def styled_conv(sc, x, style, noise, s=None, pre=None):
     if not conv.upsample:
         if noise is None:
             noise = torch.randn(x.shape[0], 1, x.shape[2], x.shape[3], device=x.device)
-        return Conv1x1ActFn.apply(x, wm, packed, noise, sc.noise.weight, sc.activate.bias, packed_t)
-    y = Conv1x1Fn.apply(x, wm, packed, packed_t)
+        return Conv1x1ActFn.apply(x, wm, packed, noise, sc.noise.weight, sc.activate.bias, packed_t, _split_ok(conv.in_channel, sc))
+    y = Conv1x1Fn.apply(x, wm, packed, packed_t, _split_ok(conv.in_channel, sc))
     y = op.upfirdn2d(y, conv.blur.kernel, up=2, pad=(2, 1))
     if noise is None:
         noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], device=y.device)

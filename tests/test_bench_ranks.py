@@ -66,3 +66,31 @@ def test_two_rank_bench_step_gathers_the_single_rank_frames(tmp_path):
         assert torch.equal(frames[rank:rank + 1], exp), f"rank {rank}'s gathered frame differs from its single-rank render"
         del wl
     assert not torch.equal(frames[0], frames[1])
+
+
+@pytest.mark.gpu
+def test_the_drivers_eight_rank_command_runs_end_to_end():
+    """The exact command form the driver uses for the 8-GPU leg -- `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8 --steps K --warmup W` -- on this box: with
+    fewer than eight devices the ranks share them and the exchange runs over gloo (the line says so), so every rank's render,
+    the uint8 conversion, the asynchronous gather to rank 0, the barrier / max-over-ranks timing and the one JSON line have
+    run once in the eight-rank shape.  No rank may have initialised the GPU before binding its device (bench.py asserts)."""
+    env = _env(MASTER_PORT="")
+    env.pop("MASTER_PORT")
+    n_dev = torch.cuda.device_count()
+    if n_dev < 8:
+        env["CIPS3D_DIST_BACKEND"] = "gloo"
+    port = str(29800 + os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", port, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--repeats", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["physical_gpus"] == n_dev
+    assert line["dist_backend"].startswith("nccl" if n_dev >= 8 else "gloo")
+    assert line["config"]["parallelism"] == "views x8" and line["value"] > 0 and line["ms_per_step"] > 0
+    assert line["roofline"] is None or line["roofline"]["frac"] > 0
+    assert "also" not in line and "cpu_baseline" not in line            # rank-0-at-N=1-only legs

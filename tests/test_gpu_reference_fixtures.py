@@ -142,7 +142,8 @@ def _psnr(a, b):
 def test_config3_at_stated_size():
     """BASELINE config 3 as stated: FFHQ 1024^2 full generator, batch 4, bf16 decoder (both forms: operands only, and operands +
     bf16 storage of the up-sampling stages' activations, the form bench.py reports).  Bounds: PSNR of the bf16-decoder
-    image against the exact fp32 image of the same inputs > 35 dB (measured ~60 dB), the fp32 NeRF outputs unchanged, and
+    image against the exact fp32 image of the same inputs >= 55 dB (measured ~60 dB: a 20 dB regression cannot pass), the fp32 NeRF
+    outputs unchanged, and
     batch independence: every view of the batch-4 call equals the batch-1 call on that view's inputs up to summation
     order (the ray-chunk count of the render kernel depends on the batch): 1e-4 of the range in fp32 mode, > 50 dB in
     bf16 mode (a last-bit change of a feature can flip a bf16 rounding)."""
@@ -164,13 +165,13 @@ def test_config3_at_stated_size():
     psnr = _psnr(r16["rgb"], rgb32)
     print(f"config 3 (1024^2, B=4, bf16 decoder) vs fp32: PSNR {psnr:.1f} dB, max-abs {maxdiff(r16['rgb'], rgb32):.3e} "
           f"on range {float(rgb32.abs().max()):.2f}")
-    assert psnr > 35.0 and not torch.equal(r16["rgb"], rgb32)
+    assert psnr >= 55.0 and not torch.equal(r16["rgb"], rgb32)
     assert torch.equal(r16["thumb_rgb"], thumb32)                        # the renderer stays fp32
     G.set_decoder_precision("bf16_storage")
     r16s = G(zs=zs, **kw)
     psnr_s = _psnr(r16s["rgb"], rgb32)
     print(f"config 3 with bf16 storage of the up-sampling stages: PSNR {psnr_s:.1f} dB, max-abs {maxdiff(r16s['rgb'], rgb32):.3e}")
-    assert psnr_s > 35.0 and bool(torch.isfinite(r16s["rgb"]).all()) and torch.equal(r16s["thumb_rgb"], thumb32)
+    assert psnr_s >= 55.0 and bool(torch.isfinite(r16s["rgb"]).all()) and torch.equal(r16s["thumb_rgb"], thumb32)
     assert not torch.equal(r16s["rgb"], r16["rgb"])
     rng = float(rgb32.abs().max())
     for prec, full in (("bf16", r16["rgb"]), ("bf16_storage", r16s["rgb"]), ("fp32", rgb32)):
@@ -269,3 +270,33 @@ def test_headline_forward_is_deterministic_and_batch_independent():
         one = run(slice(i, i + 1))
         assert maxdiff(one["rgb"].cpu(), both["rgb"][i:i + 1].cpu()) < 2e-5 * float(both["rgb"].abs().max()), i
         assert maxdiff(one["thumb_rgb"].cpu(), both["thumb_rgb"][i:i + 1].cpu()) < 1e-6, i
+
+
+def test_config1_at_stated_shape():
+    """BASELINE config 1 on the HIP path at its stated shape: FFHQ generator with a 64x64 output (upsample_list = [], the
+    `test__rendering_time` CPU case), D = 8 renderer layers, 64x64 rays x 24 samples, one view, against the oracle on the same
+    inputs -- with fixed and with jittered sample depths.  This is the configuration whose planes run ends in a different
+    place: nine ToRGBs at 64^2, one more than a fold holds (test_planes_run_ends_in_fp32_when_nothing_up_samples walks the
+    plan; here the numbers are held to the path's parity bar, 1e-3 max-abs, and to what is measured)."""
+    cfg = configs.ffhq_G_cfg(64, 8)
+    G = pkg.build_generator(cfg, DEV, seed=1)
+    zs, nb, _ = weights.synth_inputs(cfg, seed=9)
+    loc = torch.tensor([[0.25, -0.1]])
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=cu(loc))
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    u = weights.det_unit_uniform("c1.u", (1, 64, 64, 1), 5)
+    for perturb in (False, True):
+        ncfg = dict(N_samples=24, perturb=perturb, static_viewdirs=False)
+        r = G(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=[cu(b) for b in nb], nerf_cfg=ncfg,
+              perturb_u=cu(u) if perturb else None, return_xyz=True)
+        assert r["rgb"].shape == (1, 3, 64, 64) and r["thumb_rgb"].shape == (1, 3, 64, 64)
+        plan = list(G._plans.values())[0].plan
+        assert plan.nerf.depth == 8 and plan.nerf.n_samples == 24 and plan.nerf.img_size == 64
+        ref = O.generator_forward(sd, cfg, zs, e.cpu(), f.cpu(), 64, n.cpu(), fa.cpu(), ncfg, nb, perturb_u=u if perturb else None,
+                                  return_xyz=True)
+        for key, bar in (("rgb", 3e-4), ("thumb_rgb", 5e-5), ("mask", 5e-5), ("xyz", 5e-5)):
+            if key not in ref or key not in r:
+                continue
+            d = maxdiff(r[key].cpu(), ref[key])
+            print(f"config 1 (64^2 output, D=8, N=24, perturb={perturb}) {key}: max-abs {d:.2e} on range {float(ref[key].abs().max()):.2f}")
+            assert d < 1e-3 and d < bar * max(1.0, float(ref[key].abs().max())), key
