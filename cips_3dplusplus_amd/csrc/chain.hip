@@ -655,6 +655,10 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
   dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
   static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)
+  // (Round 3, measured and not kept: 128 x 128 tiles -- 2/3 of the operand bytes per flop through the L2 -> LDS path, 256
+  // workgroups -- 16.3 us per 512 -> 512 layer against 12.2: twice the MFMAs and fragment reads per wave at the same one
+  // workgroup per CU; 32 x 128 tiles / four waves for the 512 -> 256 exit, whose 64 x 128 grid covers half the CUs: 10.4 against
+  // 10.0 us.)
   if (cfg == 1) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 3>), grid, dim3(512), 0, as_stream(stream), a);
   else if (cfg == 2) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 32, 4>), grid, dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), a);
