@@ -143,18 +143,25 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #pragma unroll
     for (int j = 0; j < PW; ++j) {
       const int piece = j * NW + wave;
+      // (saddr form of the LDS-DMA: a uniform base advanced on the scalar unit + a 32-bit lane offset, both made opaque so that
+      // instruction selection sees base + zext(offset) -- with per-lane 64-bit pointers every piece first needed a
+      // v_lshl_add_u64 into the register pair the previous piece was still issuing from)
       if (piece < A_PIECES) {
         const int ot_l = piece / KQ, kq_l = piece % KQ;
-        const float* src = ab + ((((m0 >> 4) + ot_l) * ((K >> 5) * NP) + (k0 >> 5) * NP + kq_l) * 256 + lane * 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        const char* ub = reinterpret_cast<const char*>(ab + ((((m0 >> 4) + ot_l) * ((K >> 5) * NP) + (k0 >> 5) * NP + kq_l) * 256));
+        unsigned vo = lane * 16;
+        asm volatile("" : "+s"(ub), "+v"(vo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + vo),
                                          (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
       } else {
         const int pb = piece - A_PIECES;
         const int row = pb / (BN / 64), chunk = pb % (BN / 64);     // row = (channel block of the stage) * NP + plane
         int n = n0 + chunk * 64 + lane;
         if (n > HW - 1) n = HW - 1;                                  // clamp: those columns are never stored
-        const _Float16* src = xb + (((int64_t)((k0 >> 3) * NP + row) * HW + n) * 8);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        const char* ub = reinterpret_cast<const char*>(xb + ((int64_t)((k0 >> 3) * NP + row) * HW) * 8);
+        unsigned vo = (unsigned)n * 16u;
+        asm volatile("" : "+s"(ub), "+v"(vo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + vo),
                                          (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
       }
     }

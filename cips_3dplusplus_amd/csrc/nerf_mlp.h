@@ -24,8 +24,16 @@ __device__ __forceinline__ void stage_slab(const float* __restrict__ gsrc, float
   for (int j = 0; j < PER_WAVE; ++j) {
     const int piece = j * WAVES + wave;
     if (PIECES % WAVES == 0 || piece < PIECES) {
+      // uniform base (SGPR pair, advanced on the scalar unit) + a 32-bit lane offset: the saddr form of the instruction.  With
+      // a per-lane 64-bit pointer every piece needed a v_lshl_add_u64 into the same register pair first, and a wave's eight
+      // DMA issues of a step ran one behind the other's address arithmetic
+      const char* ub = reinterpret_cast<const char*>(gsrc + piece * 256);
+      unsigned vo = lane * 16;
+      // (both opaque: the optimiser otherwise re-associates the lane offset into the base, or hoists its zero extension out
+      // of the block, where instruction selection no longer sees the base + zext(offset) shape the saddr form needs)
+      asm volatile("" : "+s"(ub), "+v"(vo));
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+          (const __attribute__((address_space(1))) void*)(ub + vo),
           (__attribute__((address_space(3))) void*)(lds_dst + piece * 256), 16, 0, 0);
     }
   }
