@@ -36,6 +36,8 @@ def main(paths):
     for p in paths:
         for k, v in load(p).items():
             e = out.setdefault(k, {"kernel": k})
+            e.setdefault("avg_us_under_pmc", round(mean(v["_dur"]) / 1e3, 1))
+            e.setdefault("launches", len(v["_dur"]))
             if "GRBM_GUI_ACTIVE" in v:
                 cyc = mean(v["GRBM_GUI_ACTIVE"]) / 8
                 e["launches"] = len(v["GRBM_GUI_ACTIVE"])
