@@ -59,7 +59,7 @@ class NerfParams(C.Structure):
                 ("part", C.c_void_p), ("sdf", C.c_void_p),
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
-                ("features_planes", C.c_int32), ("pad_", C.c_int32),
+                ("features_planes", C.c_int32), ("raw_density", C.c_int32),
                 ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p)]
 
 
@@ -145,6 +145,7 @@ _SIGS = {
                                   c_i64, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_rays_in_world": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_z_vals": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
+    "cips3d_z_vals_stratified": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
     "cips3d_ray_points": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_volume_integration": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int,
                                           c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -437,6 +437,8 @@ class NerfRenderFn(Function):
     def forward(ctx, renderer, cam_poses, focals, near, far, film, perturb_u, img_size, n_samples, static_viewdirs):
         # With the fused backward available the forward keeps what it needs (accumulator stash, per-point sdf / rgb logits):
         # the backward then does not run the forward again (hip.STASH_IN_FORWARD = 0: it does, and nothing is held meanwhile).
+        if not renderer.with_sdf:        # fail here, not in backward: both backward kernels differentiate the sdf branch only
+            raise NotImplementedError("with_sdf=False (raw density, nerf_utils.py:288-297) is forward-only on the HIP path")
         fwd = None
         if hip.FUSED_NERF_BACKWARD and hip.STASH_IN_FORWARD and hip.nerf_backward_fused_supported(
                 renderer.hidden_dim, renderer.N_layers_renderer, img_size, n_samples):

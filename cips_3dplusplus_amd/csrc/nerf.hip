@@ -480,7 +480,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
-  const float sig_beta = P.sigmoid_beta[0];
+  const bool raw_density = P.raw_density != 0;
+  const float sig_beta = raw_density ? 1.f : P.sigmoid_beta[0];
 
   // ---- ray setup (nerf_utils.py:38-66)
   const float nearv = P.near_[b], farv = P.far_[b];
@@ -619,7 +620,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 
     // ---- compositing weight of this sample (nerf_utils.py:264-307); known before the view layer
     const float delta = (sk < N - 1 ? zsample(sk + 1) - z : 1e10f) * dnorm;
-    const float sigma = sigmoidf_acc(-sdf / sig_beta) / sig_beta;
+    const float sigma = raw_density ? (sdf > 20.f ? sdf : log1pf(expf(sdf)))      // with_sdf = False (nerf_utils.py:288-297)
+                                    : sigmoidf_acc(-sdf / sig_beta) / sig_beta;
     const float alpha = 1.f - expf(-sigma * delta);
     const float w = live ? alpha * T : 0.f;
     if (live) T *= (1.f - alpha) + 1e-10f;
@@ -942,7 +944,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
     return CIPS3D_E_BADARG;
   const int fuse = cips3d_nerf_fuses_finish(p);
   if (!P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
-      !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || !P.sigmoid_beta || (!P.part && !fuse))
+      !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || (!P.sigmoid_beta && !P.raw_density) || (!P.part && !fuse))
     return CIPS3D_E_BADARG;
   if (P.x_pts ? (!P.x_rays_d || !P.x_viewdirs || !P.x_z_vals || P.n_rays <= 0) : (!P.cam_poses || !P.focals || P.n_rays != 0))
     return CIPS3D_E_BADARG;
@@ -950,6 +952,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
       P.n_chunks > P.n_samples)
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
+  if (P.stash && P.raw_density) return CIPS3D_E_UNSUPP;      // the backward kernels differentiate the sdf branch only
   if (P.B == 0) return 0;
   NerfArgs a;
   a.p = P;

@@ -59,6 +59,28 @@ __global__ void __launch_bounds__(256) z_vals_kernel(const float* __restrict__ n
   z[i] = u ? z0 + (zbase(k + 1) - z0) * u[br] : z0;
 }
 
+// the classic NeRF stratified branch (offset_sampling = False, nerf_utils.py:98-117): t = linspace(0, 1, N) (symmetric
+// evaluation around the midpoint, as torch), one uniform PER SAMPLE u [B,R,N] inside its own interval between the midpoints
+__global__ void __launch_bounds__(256) z_vals_stratified_kernel(const float* __restrict__ near_, const float* __restrict__ far_,
+                                                                const float* __restrict__ u, int B, int R, int N,
+                                                                float* __restrict__ z) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)B * R * N) return;
+  const int k = (int)(i % N);
+  const int b = (int)(i / N / R);
+  const float nearv = near_[b], farv = far_[b];
+  const float t_step = N > 1 ? 1.f / (float)(N - 1) : 0.f;
+  auto zbase = [&](int kk) -> float {
+    const float t = (kk < N / 2 || N == 1) ? t_step * (float)kk : 1.f - t_step * (float)(N - 1 - kk);   // linspace(0, 1, 1) = [0]
+    return nearv * (1.f - t) + farv * t;
+  };
+  const float z0 = zbase(k);
+  if (!u) { z[i] = z0; return; }
+  const float lower = k > 0 ? 0.5f * (z0 + zbase(k - 1)) : z0;
+  const float upper = k < N - 1 ? 0.5f * (zbase(k + 1) + z0) : z0;
+  z[i] = lower + (upper - lower) * u[i];
+}
+
 // thread per point; pts / pts_n [B,R,N,3]
 __global__ void __launch_bounds__(256) points_kernel(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                      const float* __restrict__ z, const float* __restrict__ near_,
@@ -175,6 +197,15 @@ extern "C" int cips3d_z_vals(const float* near_, const float* far_, const float*
   if (B == 0) return 0;
   hipLaunchKernelGGL(z_vals_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * R * N, 256)), dim3(256), 0, as_stream(stream),
                      near_, far_, perturb_u, B, R, N, z);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_z_vals_stratified(const float* near_, const float* far_, const float* perturb_t, int B, int R, int N,
+                                        float* z, void* stream) {
+  if (!near_ || !far_ || !z || B < 0 || R <= 0 || N <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(z_vals_stratified_kernel, dim3((unsigned)ceil_div<int64_t>((int64_t)B * R * N, 256)), dim3(256), 0,
+                     as_stream(stream), near_, far_, perturb_t, B, R, N, z);
   return cips3d_launch_status();
 }
 

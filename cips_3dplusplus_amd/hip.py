@@ -205,6 +205,7 @@ def _nerf_params(kw):
     for f in ("x_pts", "x_rays_d", "x_viewdirs", "x_z_vals"):          # explicit-geometry mode
         setattr(p, f, dev_ptr(kw.get(f), f, True))
     p.n_rays = int(kw.get("n_rays", 0))
+    p.raw_density = int(bool(kw.get("raw_density", False)))            # with_sdf = False (forward only)
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))
     return p
@@ -263,11 +264,18 @@ def rays_in_world(cam_poses, focals, img_size, static_viewdirs=False):
     return o, d, v
 
 
-def z_vals(near, far, B, R, N, perturb_u=None):
+def z_vals(near, far, B, R, N, perturb_u=None, stratified=False):
+    """offset sampling (perturb_u: one uniform per ray, [B,R]) or, stratified=True, the classic stratified branch (perturb_u:
+    one uniform per sample, [B,R,N])."""
     lib = _lib.load()
     z = torch.empty(B, R, N, device=near.device)
-    u = None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous()
     nr, fr = near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous()   # converted copies live until the launch
+    if stratified:
+        u = None if perturb_u is None else perturb_u.float().reshape(B, R, N).contiguous()
+        check(lib.cips3d_z_vals_stratified(dev_ptr(nr, "near"), dev_ptr(fr, "far"), dev_ptr(u, "u", True), B, R, N, dev_ptr(z),
+                                           stream_ptr()), "cips3d_z_vals_stratified")
+        return z
+    u = None if perturb_u is None else perturb_u.float().reshape(B, R).contiguous()
     check(lib.cips3d_z_vals(dev_ptr(nr, "near"), dev_ptr(fr, "far"),
                             dev_ptr(u, "u", True), B, R, N, dev_ptr(z), stream_ptr()), "cips3d_z_vals")
     return z

@@ -29,11 +29,15 @@ class Render(object):
     @staticmethod
     @torch.no_grad()
     def get_z_vals(near, far, rays_d, N_samples, perturb=True, offset_sampling=True, perturb_u=None):
-        """nerf_utils.py:69-121 -> (b, h, w, N_samples).  Only the offset-sampling branch is on the generator path; the
-        classic stratified branch is used by `mlp_init_pass` (training) alone."""
-        if not offset_sampling:
-            raise NotImplementedError("stratified (non-offset) sampling is training-only (mlp_init_pass)")
+        """nerf_utils.py:69-121 -> (b, h, w, N_samples).  The offset-sampling branch is the generator path's (one uniform per
+        ray, perturb_u [b,h,w,1]); the classic stratified branch (`mlp_init_pass`) draws one uniform per SAMPLE
+        (perturb_u [b,h,w,N_samples])."""
         b, h, w, _ = rays_d.shape
+        if not offset_sampling:
+            t = None
+            if perturb:
+                t = perturb_u if perturb_u is not None else torch.rand(b, h, w, N_samples, device=rays_d.device)
+            return hip.z_vals(near, far, b, h * w, N_samples, perturb_u=t, stratified=True).view(b, h, w, N_samples)
         u = None
         if perturb:
             u = perturb_u if perturb_u is not None else torch.rand(b, h, w, 1, device=rays_d.device)

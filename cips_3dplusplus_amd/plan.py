@@ -294,6 +294,7 @@ class ForwardPlan:
         n.w_sigma, n.w_rgb = dev_ptr(net.sigma_linear.weight), dev_ptr(net.rgb_linear.weight)
         n.b_sigma, n.b_rgb = dev_ptr(net.sigma_linear.bias), dev_ptr(net.rgb_linear.bias)
         n.sigmoid_beta = dev_ptr(ren.sigmoid_beta)
+        n.raw_density = int(not ren.with_sdf)
         n.B, n.img_size, n.n_samples, n.hidden, n.depth = B, img_size, N_samples, H, D
         n.static_viewdirs, n.n_chunks = int(self.static), n_chunks
         n.part = part.data_ptr()
@@ -336,7 +337,7 @@ class ForwardPlan:
         ren = G.renderer
         return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key(),
                 bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)),
-                bool(getattr(G.decoder, "split", False)))
+                bool(getattr(G.decoder, "split", False)), bool(ren.with_sdf))
 
     def _noise_bound(self, noise_bufs, fresh_noise):
         """Upper bound of |noise| over the call (cips3d_forward_io.noise_bound; the bound constants of a ranged plan): known

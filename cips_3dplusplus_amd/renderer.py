@@ -101,8 +101,8 @@ class VolumeFeatureRenderer(nn.Module):
     def __init__(self, N_layers_renderer, input_dim, hidden_dim, style_dim, view_dim, with_sdf, output_features,
                  **kwargs):
         super().__init__()
-        if input_dim != 3 or view_dim != 3 or not with_sdf:
-            raise NotImplementedError("the HIP renderer implements input_dim=3, view_dim=3, with_sdf=True")
+        if input_dim != 3 or view_dim != 3:
+            raise NotImplementedError("the HIP renderer implements input_dim=3, view_dim=3")
         self.N_layers_renderer = N_layers_renderer
         self.input_dim, self.hidden_dim, self.style_dim, self.view_dim = input_dim, hidden_dim, style_dim, view_dim
         self.with_sdf, self.output_features = with_sdf, output_features
@@ -180,6 +180,8 @@ class VolumeFeatureRenderer(nn.Module):
         else:                       # FiLM table computed by the caller (differentiable path: autograd.film_table)
             film = film.detach().float().contiguous()
         if stash is not None:       # differentiable forward: hip.nerf_forward_stash buffers, filled for the fused backward
+            if not self.with_sdf:
+                raise NotImplementedError("with_sdf=False (raw density, nerf_utils.py:288-297) is forward-only on the HIP path")
             n_chunks = stash["n_chunks"]
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)
@@ -193,6 +195,7 @@ class VolumeFeatureRenderer(nn.Module):
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=img_size, n_samples=N_samples, hidden=H, depth=D,
                         static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf,
+                        raw_density=not self.with_sdf,
                         stash=None if stash is None else stash["stash"], bwd_sdf=None if stash is None else stash["sdf"],
                         bwd_crgb=None if stash is None else stash["crgb"])
         if sdf is not None:
@@ -236,6 +239,6 @@ class VolumeFeatureRenderer(nn.Module):
                         layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=1, n_samples=N, hidden=H, depth=D, static_viewdirs=0, n_chunks=n_chunks,
-                        sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R)
+                        sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R, raw_density=not self.with_sdf)
         to_rays = lambda t: t.view(B, t.shape[1], R).transpose(1, 2).reshape(*lead, t.shape[1]).contiguous()
         return to_rays(thumb), to_rays(features), sdf.view(*lead, N, 1), to_rays(mask), to_rays(xyz), None

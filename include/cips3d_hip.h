@@ -193,7 +193,10 @@ typedef struct cips3d_nerf_params {
    * pixel block has the exponent CIPS3D_FEATURES_EXP (cips3d_range.x_exp_const; a feature is a convex combination of sines,
    * |f| <= 1) */
   int32_t features_planes;
-  int32_t pad_;
+  /* != 0: with_sdf = False (cips3d/nerf_utils.py:288-297, noise-free): the sigma head's output is a raw density,
+   * alpha = 1 - exp(-softplus(raw) * delta) (torch's softplus: the identity above 20); sigmoid_beta is then not read.
+   * Forward only: the differentiable forward (stash / bwd_*) refuses it */
+  int32_t raw_density;
   /* Differentiable forward (camera-driven mode only; all three or none): the render kernel additionally writes what
    * cips3d_nerf_bwd_fused needs, so that the backward does not recompute the forward -- per MFMA layer the fp32 accumulators
    * (`stash`: cips3d_nerf_bwd_fused_stash_floats(B, img_size, n_samples, hidden, depth, n_chunks) floats, the layout of that
@@ -600,6 +603,11 @@ int cips3d_rays_in_world(const float* cam_poses, const float* focals, int img_si
                          float* rays_o, float* rays_d, float* viewdirs, void* stream);
 /* Render.get_z_vals, offset-sampling branch (:69-121): z [B,R,N]; perturb_u [B,R] per-ray uniform or NULL */
 int cips3d_z_vals(const float* near_, const float* far_, const float* perturb_u, int B, int R, int N, float* z, void* stream);
+/* the classic stratified branch of Render.get_z_vals (offset_sampling = False, cips3d/nerf_utils.py:98-117; `mlp_init_pass`):
+ * t = linspace(0, 1, N); perturb_t [B,R,N] (one uniform per SAMPLE, drawn inside the interval between the neighbouring
+ * midpoints) or NULL (perturb = False) */
+int cips3d_z_vals_stratified(const float* near_, const float* far_, const float* perturb_t, int B, int R, int N, float* z,
+                             void* stream);
 /* Render.get_points (+ Render.normalize_points when pts_normalized != NULL) (:124-170): [B,R,N,3]; either output may be NULL */
 int cips3d_ray_points(const float* rays_o, const float* rays_d, const float* z, const float* near_, const float* far_, int B,
                       int R, int N, float* pts, float* pts_normalized, void* stream);

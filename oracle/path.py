@@ -91,6 +91,24 @@ def z_vals(near, far, B, H, W, N, perturb_u=None):
     return z
 
 
+def z_vals_stratified(near, far, B, H, W, N, perturb_t=None):
+    """cips3d/nerf_utils.py:69-121, classic stratified branch (offset_sampling=False; :98-117).
+
+    perturb_t: None (perturb=False) or the injected per-sample uniform (B,H,W,N).
+    """
+    dt = near.dtype
+    near = near.view(B, 1, 1, 1).expand(B, H, W, 1)
+    far = far.view(B, 1, 1, 1).expand(B, H, W, 1)
+    t = torch.linspace(0.0, 1.0, N, dtype=dt).view(1, 1, 1, N)
+    z = near * (1.0 - t) + far * t
+    if perturb_t is not None:
+        mids = 0.5 * (z[..., 1:] + z[..., :-1])
+        upper = torch.cat([mids, z[..., -1:]], dim=-1)
+        lower = torch.cat([z[..., :1], mids], dim=-1)
+        z = lower + (upper - lower) * perturb_t
+    return z
+
+
 def ray_points(rays_o, rays_d, z):
     """cips3d/nerf_utils.py:136-170."""
     return rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
@@ -153,12 +171,13 @@ def volume_integration(rgb, sdf, feat, z, rays_d, pts, sigmoid_beta, with_sdf=Tr
     return rgb_map, feature_map, xyz, mask
 
 
-def renderer_forward(sd, prefix, pts, rays_d, viewdirs, z, near, far, styles, D):
-    """cips3d/volume_renderer.py:192-303 (no ray chunking: chunking does not change values)."""
+def renderer_forward(sd, prefix, pts, rays_d, viewdirs, z, near, far, styles, D, with_sdf=True):
+    """cips3d/volume_renderer.py:192-303 (no ray chunking: chunking does not change values); with_sdf=False: the sigma
+    head's output is a raw density (nerf_utils.py:288-297)."""
     pts_n = normalize_points(pts, near, far)
     rgb, sdf, feat = siren_points(sd, prefix + ".network", pts_n, viewdirs, styles, D)
     rgb_map, feature_map, xyz, mask = volume_integration(
-        rgb, sdf, feat, z, rays_d, pts, sd[prefix + ".sigmoid_beta"])
+        rgb, sdf, feat, z, rays_d, pts, sd[prefix + ".sigmoid_beta"], with_sdf=with_sdf)
     return rgb_map, feature_map, sdf, mask, xyz
 
 
@@ -357,7 +376,7 @@ def generator_forward(sd, cfg, zs, cam_poses, focals, img_size, near, far, nerf_
     R = S * S
     thumb, feat, sdf, mask, xyz = renderer_forward(
         sd, "renderer", pts.reshape(B, R, N, 3), rays_d.reshape(B, R, 3), viewdirs.reshape(B, R, 3),
-        z.reshape(B, R, N), near, far, style_render, D)
+        z.reshape(B, R, N), near, far, style_render, D, with_sdf=cfg["renderer_cfg"].get("with_sdf", True))
     to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S).contiguous()
     features = to_img(feat)
     rgb = decoder_forward(sd, cfg, features, style_decoder, noise_bufs, bf16_gemm=bool(bf16_decoder),

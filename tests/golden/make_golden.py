@@ -88,6 +88,23 @@ def g_rays():
     save("rays", **out)
 
 
+def g_rays_stratified():
+    """the classic stratified branch of Render.get_z_vals (offset_sampling=False: `mlp_init_pass`)"""
+    out = {"_src": "cips3d/nerf_utils.py:69-121 (offset_sampling=False branch :98-117)"}
+    locs = torch.tensor([[0.25, -0.1], [-0.5, 0.12]])
+    e, f, n, fa, _ = ref_nerf.Camera.generate_camera_params(
+        img_size=8, device="cpu", locations=locs, fov_ang=6, dist_radius=0.12)
+    out.update(near=n, far=fa)
+    _, d, _ = ref_nerf.Render.get_rays_in_world(f, 8, e)
+    for N in (1, 5, 24):
+        out[f"zs_{N}"] = ref_nerf.Render.get_z_vals(n, fa, d, N, perturb=False, offset_sampling=False)
+        torch.manual_seed(200 + N)
+        out[f"zsp_{N}"] = ref_nerf.Render.get_z_vals(n, fa, d, N, perturb=True, offset_sampling=False)
+        torch.manual_seed(200 + N)
+        out[f"t_{N}"] = torch.rand(2, 8, 8, N)
+    save("rays_stratified", **out)
+
+
 # ---------------------------------------------------------------- 3. FiLM-SIREN + compositing
 def g_siren():
     out = {"_src": "cips3d/volume_renderer.py:15-160; cips3d/nerf_utils.py:230-338"}
@@ -131,6 +148,35 @@ def g_siren():
         rm, fm, xz, mk, _ = ref_nerf.Render.volume_integration(rgb=rgb, features=feat, z_vals=z, rays_d=rays_d, pts=pts, **kw)
         br.update({f"{tag}_rgb_map": rm, f"{tag}_feature_map": fm, f"{tag}_xyz": xz, f"{tag}_mask": mk})
     save("vi_branches", **br)
+
+
+def g_renderer_raw():
+    """VolumeFeatureRenderer(with_sdf=False).forward on explicit sample points: the sigma head's output is a raw density
+    (softplus).  Three sigma-head biases: the seeded one, 20 (the raw values straddle softplus's threshold), -4 (thin medium)."""
+    out = {"_src": "cips3d/volume_renderer.py:163-303 with with_sdf=False; cips3d/nerf_utils.py:288-297"}
+    torch.manual_seed(31)
+    W, D = 32, 2
+    ren = ref_vr.VolumeFeatureRenderer(N_layers_renderer=D, input_dim=3, hidden_dim=W, style_dim=W, view_dim=3, with_sdf=False,
+                                       output_features=True)
+    out.update({"sd." + k: v.clone() for k, v in ren.state_dict().items()})
+    B, R, N = 2, 24, 8
+    near, far = torch.full((B, 1, 1), 0.88), torch.full((B, 1, 1), 1.12)
+    rays_d = torch.nn.functional.normalize(torch.randn(B, R, 3) * 0.2 + torch.tensor([0.0, 0.0, -1.0]), dim=-1) * 1.1
+    viewdirs = torch.nn.functional.normalize(rays_d, dim=-1)
+    rays_o = torch.tensor([0.0, 0.0, 1.0]).expand(B, R, 3) + 0.05 * torch.randn(B, R, 3)
+    z = ref_nerf.Render.get_z_vals(near, far, rays_d.view(B, R, 1, 3), N, perturb=True).view(B, R, N)
+    pts = rays_o.unsqueeze(-2) + rays_d.unsqueeze(-2) * z.unsqueeze(-1)
+    styles = torch.randn(B, D + 1, W) * 0.5
+    out.update(pts=pts, rays_d=rays_d, viewdirs=viewdirs, z=z, near=near, far=far, styles=styles)
+    for tag, bias in (("seeded", None), ("b20", 20.0), ("bm4", -4.0)):
+        if bias is not None:
+            ren.network.sigma_linear.bias.fill_(bias)
+        out[f"{tag}_bias"] = ren.network.sigma_linear.bias.clone()
+        rgb_map, fmap, raw, mask, xyz, _ = ren(pts.clone(), rays_d, viewdirs, z, near, far, styles=styles)
+        out.update({f"{tag}_rgb_map": rgb_map, f"{tag}_feature_map": fmap, f"{tag}_raw": raw, f"{tag}_mask": mask,
+                    f"{tag}_xyz": xyz})
+    assert float((out["b20_raw"] > 20).float().mean()) not in (0.0, 1.0)          # both sides of the threshold
+    save("renderer_raw", **out)
 
 
 # ---------------------------------------------------------------- 4/5. ops
@@ -454,7 +500,7 @@ if __name__ == "__main__":
     ap.add_argument("--full", action="store_true")
     ap.add_argument("--only", default=None)
     a = ap.parse_args()
-    jobs = dict(camera=g_camera, rays=g_rays, siren=g_siren, ops=g_ops, modconv=g_modconv,
+    jobs = dict(camera=g_camera, rays=g_rays, rays_stratified=g_rays_stratified, siren=g_siren, renderer_raw=g_renderer_raw, ops=g_ops, modconv=g_modconv,
                 tiny_generator=g_tiny_generator, ckpt_tiny=g_ckpt_tiny, backward=g_backward)
     if a.full:
         jobs["full_size"] = g_full

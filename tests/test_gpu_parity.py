@@ -794,6 +794,36 @@ def test_generator_shape_sweep_vs_oracle(hidden, D, S, N, B, static, perturb, tr
         assert maxdiff(r[k].cpu(), ref[k]) < 2e-4 * max(1.0, float(ref[k].abs().max())), k
 
 
+@pytest.mark.parametrize("hidden,D,S,N", [(32, 2, 8, 6), (256, 2, 16, 24)])
+def test_generator_with_raw_density_vs_oracle(hidden, D, S, N):
+    """renderer_cfg.with_sdf = False through the whole generator (the one-call plan and the per-op path): the sigma head is a
+    raw density (nerf_utils.py:288-297).  The image must also differ from the sdf reading of the same weights."""
+    cfg = configs.tiny_G_cfg(hidden, D, 1) if hidden < 256 else configs.ffhq_G_cfg(256, D)
+    cfg["renderer_cfg"] = dict(cfg["renderer_cfg"], with_sdf=False)
+    G = pkg.build_generator(cfg, DEV, seed=11)
+    assert G.renderer.with_sdf is False
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    B = 2
+    zs = [torch.randn(B, cfg["mapping_renderer_cfg"]["z_dim"], generator=g),
+          torch.randn(B, cfg["mapping_decoder_cfg"]["style_dim"], generator=g)]
+    locs = torch.tensor([[0.4, 0.1], [-0.3, -0.15]])
+    nb = [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(S, "cpu")]
+    ncfg = dict(N_samples=N, perturb=False, static_viewdirs=False)
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=cu(locs), fov_ang=12, dist_radius=0.12)
+    cam = O.camera_params(locs, S, 12, 0.12)
+    ref = O.generator_forward(sd, cfg, zs, cam[0], cam[1], S, cam[2], cam[3], ncfg, nb, return_sdf=True, return_xyz=True)
+    kw = dict(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=S, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+              nerf_cfg=ncfg, return_sdf=True, return_xyz=True)
+    r = G(**kw)
+    for k in ("rgb", "thumb_rgb", "sdf", "xyz", "mask", "depth"):
+        assert r[k].shape == ref[k].shape, k
+        assert maxdiff(r[k].cpu(), ref[k]) < 2e-4 * max(1.0, float(ref[k].abs().max())), k
+    G.renderer.with_sdf = True                   # part of the plan's key: the one-call plan is re-made
+    other = G(**kw)
+    assert maxdiff(other["thumb_rgb"].cpu(), ref["thumb_rgb"]) > 1e-3
+
+
 def test_full_size_properties():
     """Size-independent properties at the BASELINE size (1024^2, D=2, N=24), where the oracle is too slow to run inside the
     GPU suite: batch elements are independent (B=2 == two B=1 calls to fp32 round-off), repeat runs are bitwise identical,

@@ -42,6 +42,27 @@ def test_rays_fixture_on_hip(golden):
     assert maxdiff(Render.normalize_points(pts, near, far).cpu(), fx["pts_n_6"]) < 2e-5
 
 
+def test_stratified_samples_fixture_on_hip(golden):
+    """Render.get_z_vals(offset_sampling=False) -- the classic stratified branch `mlp_init_pass` uses (nerf_utils.py:98-117) --
+    on the HIP path against the reference's fixture, with and without the per-sample jitter."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    fx = golden("rays_stratified")
+    near, far = cu(fx["near"]), cu(fx["far"])
+    d = torch.zeros(2, 8, 8, 3, device=DEV)
+    for N in (1, 5, 24):
+        z = Render.get_z_vals(near, far, d, N, perturb=False, offset_sampling=False)
+        assert z.shape == fx[f"zs_{N}"].shape and maxdiff(z.cpu(), fx[f"zs_{N}"]) < 2e-6
+        zp = Render.get_z_vals(near, far, d, N, perturb=True, offset_sampling=False, perturb_u=cu(fx[f"t_{N}"]))
+        assert maxdiff(zp.cpu(), fx[f"zsp_{N}"]) < 2e-6
+        zr = Render.get_z_vals(near, far, d, N, perturb=True, offset_sampling=False)          # own draw: inside the strata
+        if N > 1:
+            base = fx[f"zs_{N}"]
+            mids = 0.5 * (base[..., 1:] + base[..., :-1])
+            lo = torch.cat([base[..., :1], mids], -1)
+            hi = torch.cat([mids, base[..., -1:]], -1)
+            assert bool(((zr.cpu() >= lo - 1e-6) & (zr.cpu() <= hi + 1e-6)).all())
+
+
 def _siren_renderer(fx):
     ren = pkg.VolumeFeatureRenderer(N_layers_renderer=2, input_dim=3, hidden_dim=32, style_dim=32, view_dim=3,
                                     with_sdf=True, output_features=True)
@@ -88,6 +109,37 @@ def test_volume_integration_unused_branches_on_hip(golden, tag, with_sdf, fb):
         ref = fx[f"{tag}_{k}"]
         assert a.shape == ref.shape, k
         assert maxdiff(a.cpu(), ref) < 2e-5 * max(1.0, float(ref.abs().max())), k
+
+
+@pytest.mark.parametrize("tag", ["seeded", "b20", "bm4"])
+def test_renderer_with_raw_density_fixture_on_hip(golden, tag):
+    """VolumeFeatureRenderer(with_sdf=False): the fused render kernel's raw-density branch (alpha = 1 - exp(-softplus(raw) *
+    delta), nerf_utils.py:288-297) against the reference's own outputs, through the reference entry (explicit sample points).
+    `b20` has raw values on both sides of softplus's threshold.  The differentiable path refuses the branch loudly."""
+    fx = golden("renderer_raw")
+    ren = pkg.VolumeFeatureRenderer(N_layers_renderer=2, input_dim=3, hidden_dim=32, style_dim=32, view_dim=3, with_sdf=False,
+                                    output_features=True)
+    sd = fx.sub("sd.")
+    sd["network.sigma_linear.bias"] = fx[f"{tag}_bias"]
+    ren.load_state_dict(sd, strict=True)
+    ren = ren.to(DEV).requires_grad_(False)
+    out = ren(cu(fx["pts"]), cu(fx["rays_d"]), cu(fx["viewdirs"]), cu(fx["z"]), cu(fx["near"]), cu(fx["far"]),
+              styles=cu(fx["styles"]))
+    for a, k in zip(out[:5], ("rgb_map", "feature_map", "raw", "mask", "xyz")):
+        ref = fx[f"{tag}_{k}"]
+        assert a.shape == ref.shape, k
+        assert maxdiff(a.cpu(), ref) < 3e-5 * max(1.0, float(ref.abs().max())), k
+    # the sdf interpretation of the same numbers gives a different image: the flag is what is tested
+    ren.with_sdf = True
+    other = ren(cu(fx["pts"]), cu(fx["rays_d"]), cu(fx["viewdirs"]), cu(fx["z"]), cu(fx["near"]), cu(fx["far"]),
+                styles=cu(fx["styles"]))
+    assert maxdiff(other[0].cpu(), fx[f"{tag}_rgb_map"]) > 1e-3
+    ren.with_sdf = False
+    from cips_3dplusplus_amd import autograd as ag
+    cam = O.camera_params(torch.tensor([[0.3, 0.1], [-0.6, -0.1]]), 8, 6, 0.12)
+    film = torch.zeros(2, 3, 2, 32, device=DEV)
+    with pytest.raises(NotImplementedError, match="forward-only"):
+        ag.NerfRenderFn.apply(ren, cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), film, None, 8, 6, False)
 
 
 @pytest.mark.parametrize("hidden,D", [(32, 2), (256, 2)])

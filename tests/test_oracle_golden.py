@@ -36,6 +36,14 @@ def test_frontal_camera_constants():
     assert maxdiff(e[0], torch.tensor([[1.0, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1]])) < 1e-7
 
 
+def test_stratified_samples(golden):
+    """the classic stratified branch of get_z_vals (offset_sampling=False) against the reference's fixture"""
+    fx = golden("rays_stratified")
+    for N in (1, 5, 24):
+        assert maxdiff(O.z_vals_stratified(fx["near"], fx["far"], 2, 8, 8, N), fx[f"zs_{N}"]) < TOL
+        assert maxdiff(O.z_vals_stratified(fx["near"], fx["far"], 2, 8, 8, N, fx[f"t_{N}"]), fx[f"zsp_{N}"]) < TOL
+
+
 def test_rays_and_samples(golden):
     fx = golden("rays")
     for static in (0, 1):
@@ -83,6 +91,20 @@ def test_volume_integration_unused_branches(golden, tag, with_sdf, fb):
                                              fx["pts"], fx["beta"], with_sdf=with_sdf, force_background=fb)
     for a, k in ((rm, "rgb_map"), (fm, "feature_map"), (xyz, "xyz"), (mask, "mask")):
         assert maxdiff(a, fx[f"{tag}_{k}"]) < TOL, k
+
+
+@pytest.mark.parametrize("tag", ["seeded", "b20", "bm4"])
+def test_renderer_with_raw_density(golden, tag):
+    """VolumeFeatureRenderer(with_sdf=False).forward (volume_renderer.py:192-303 + nerf_utils.py:288-297) on explicit sample
+    points, against the reference's outputs (tests/golden/renderer_raw.npz); `b20` straddles softplus's threshold."""
+    fx = golden("renderer_raw")
+    sd = {"renderer." + k: v for k, v in fx.sub("sd.").items()}
+    sd["renderer.network.sigma_linear.bias"] = fx[f"{tag}_bias"]
+    rm, fm, raw, mask, xyz = O.renderer_forward(sd, "renderer", fx["pts"], fx["rays_d"], fx["viewdirs"], fx["z"], fx["near"],
+                                                fx["far"], fx["styles"], 2, with_sdf=False)
+    assert maxdiff(raw, fx[f"{tag}_raw"]) < 2e-5
+    for a, k in ((rm, "rgb_map"), (fm, "feature_map"), (xyz, "xyz"), (mask, "mask")):
+        assert a.shape == fx[f"{tag}_{k}"].shape and maxdiff(a, fx[f"{tag}_{k}"]) < 2e-5, k
 
 
 def test_ops(golden):
