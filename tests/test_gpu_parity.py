@@ -805,8 +805,7 @@ def test_generator_with_raw_density_vs_oracle(hidden, D, S, N):
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
     g = torch.Generator().manual_seed(5)
     B = 2
-    zs = [torch.randn(B, cfg["mapping_renderer_cfg"]["z_dim"], generator=g),
-          torch.randn(B, cfg["mapping_decoder_cfg"]["style_dim"], generator=g)]
+    zs = [torch.randn(B, G.z_dim, generator=g), torch.randn(B, G.z_dim, generator=g)]
     locs = torch.tensor([[0.4, 0.1], [-0.3, -0.15]])
     nb = [torch.randn(*b.shape, generator=g) for b in G.create_noise_bufs(S, "cpu")]
     ncfg = dict(N_samples=N, perturb=False, static_viewdirs=False)
