@@ -157,6 +157,7 @@ _SIGS = {
                                     c_f32p, c_i64, C.c_void_p]),
     "cips3d_pack_weights": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_gemm_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_gemm_wgrad_split": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_torgb_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
@@ -184,7 +185,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 15           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 16           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

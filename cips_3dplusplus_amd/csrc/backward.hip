@@ -222,6 +222,146 @@ __global__ void __launch_bounds__(256) gemm_wgrad_kernel(const float* __restrict
         unsafeAtomicAdd(dwm + ((int64_t)b * M + m0 + 16 * i + 4 * q + t) * K + k0 + 16 * j + r, acc[i][j][t]);
 }
 
+// The same contraction on split-fp16 products (v_mfma_f32_16x16x32_f16, three per fp32 product; decoder.hip explains the
+// arithmetic).  Gradients have no natural scale, so both operands are split as v * 2^-e with the power of two that puts the
+// tensor's MEASURED maximum (amax slots of the producing kernel, cips3d_range) into [2^14, 2^15); the accumulators go back
+// through 2^(e_dy + e_x), exactly.
+// Dataflow (the direct-from-global form of gemm_wgrad_kernel moves every operand row once per WAVE: 536 MB per 512 x 512 x
+// 4096-pixel layer through the CU's L2 port, 66 us whatever the instruction): a workgroup of 2 x 2 waves owns a
+// (32 TM) x (32 TN) output tile and walks its pixel chunk in steps of 32.  Per step every thread fetches (TM + TN) float4 of
+// the NEXT step's rows into registers, the waves run the 3 TM TN MFMAs of the CURRENT step on fragments read from LDS, then
+// the fetched values are split ONCE (two instructions per value) and written as fp16 hi / lo planes into the other LDS
+// buffer: each value crosses the L2 port once per workgroup and is converted once.  LDS rows are 32 pixels = 64 bytes of
+// fp16, padded to 80: the 16 rows a fragment read touches then fall into 16 different bank groups.
+template <int TM, int TN, int WGM, int WGN>
+__global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          float* __restrict__ dwm, int M, int K, int64_t P, int64_t chunk,
+                                                          const float* __restrict__ dy_amax, const float* __restrict__ x_amax,
+                                                          int blocks, int n_chunks, int xcd_groups) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int BM = 16 * TM * WGM, BN = 16 * TN * WGN, ROWS = BM + BN;
+  constexpr int NV = ROWS * 8 / NT;             // float4 per thread and step
+  static_assert(ROWS * 8 % NT == 0, "whole float4s per thread");
+  constexpr int RS = 40;                        // LDS row stride in halfs (80 bytes)
+  __shared__ __attribute__((aligned(16))) _Float16 lds[2][2][ROWS * RS];      // [buffer][hi | lo][row][pixel]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  // Workgroup -> (output tile, pixel chunk, sample).  The tiles of one (chunk, sample) group read the same operand rows:
+  // with the dispatcher's round-robin of consecutive workgroups over the 8 XCDs, group g = id % 8 (+ 8 per pass) puts a whole
+  // group on ONE XCD, whose L2 then serves every re-read of the group's rows (the operands together do not fit any L2: left
+  // to the linear order, the re-reads come from the Infinity Cache at half the rate -- measured 33 vs 2x us).  Placement
+  // only: any mapping computes the same sums.
+  int blk, grp;
+  if (xcd_groups) {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    grp = xcd + 8 * (i / blocks);
+    blk = i % blocks;
+  } else {
+    blk = blockIdx.x % blocks;
+    grp = blockIdx.x / blocks;
+  }
+  const int kblocks = ceil_div(K, BN);
+  const int mb = blk / kblocks, kb = blk % kblocks;
+  const int m0 = mb * BM, k0 = kb * BN;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int b = grp / n_chunks;
+  int ea = 0, eb = 0;
+  if (dy_amax) ea = cips3d_split_exp(cips3d_amax_load(dy_amax + b * CIPS3D_AMAX_FLOATS));
+  if (x_amax) eb = cips3d_split_exp(cips3d_amax_load(x_amax + b * CIPS3D_AMAX_FLOATS));
+  const float ka = cips3d_uniform(cips3d_pow2(-ea)), kbs = cips3d_uniform(cips3d_pow2(-eb));
+  const int64_t p_begin = (int64_t)(grp % n_chunks) * chunk;
+  const int64_t p_end = p_begin + chunk < P ? p_begin + chunk : P;            // P % 32 == 0, chunk % 32 == 0
+  // staging: float4 f = tid + NT v covers row f / 8 (A rows first, then B rows), pixels 4 (f % 8) .. +3; rows past the
+  // matrix are clamped (loaded twice, never stored)
+  const float* src[NV];
+  float ksc[NV];
+  int dst[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int f = tid + NT * v, row = f >> 3, c4 = f & 7;
+    const bool isa = row < BM;
+    const int gr = isa ? min(m0 + row, M - 1) : min(k0 + row - BM, K - 1);
+    src[v] = (isa ? dy + ((int64_t)b * M + gr) * P : x + ((int64_t)b * K + gr) * P) + 4 * c4;
+    ksc[v] = isa ? ka : kbs;
+    dst[v] = row * RS + 4 * c4;
+  }
+  // register ring of fetched steps: the fetch of step s + D is issued when step s starts.  Measured at 512 x 512 x 4096 x 2
+  // (timing ablations): fetch + fragment reads + barriers alone 15.9 us (201 MB at 12.6 TB/s), + conversion 5.7, + MFMA 3.5,
+  // + atomics 5: the phases of a step do not overlap (every wave of the CU is in the same phase between two barriers; starting
+  // the second wave of each SIMD with the conversion instead changed nothing, more chunks cost more in atomics than they hide)
+  constexpr int D = 4;
+  f32x4 raw[D][NV];
+  auto fetch = [&](int slot, int64_t p) {
+    if (p < p_end) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) raw[slot][v] = *reinterpret_cast<const f32x4*>(src[v] + p);
+    }
+  };
+  auto stash = [&](int slot, int buf) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      unsigned h0, l0, h1, l1;
+      cips3d_split_pair(raw[slot][v][0] * ksc[v], raw[slot][v][1] * ksc[v], h0, l0);
+      cips3d_split_pair(raw[slot][v][2] * ksc[v], raw[slot][v][3] * ksc[v], h1, l1);
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      *reinterpret_cast<u32x2_t*>(&lds[buf][0][dst[v]]) = u32x2_t{h0, h1};
+      *reinterpret_cast<u32x2_t*>(&lds[buf][1][dst[v]]) = u32x2_t{l0, l1};
+    }
+  };
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < D; ++d) fetch(d, p_begin + 32 * d);
+  stash(0, 0);
+  __syncthreads();
+  const int arow = (wm * 16 * TM + r) * RS + 8 * q, brow = (BM + wn * 16 * TN + r) * RS + 8 * q;
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += 32 * D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int64_t p = p0 + 32 * d;
+      if (p >= p_end) break;
+      const int buf = d & 1;                        // D is even: the buffer parity of a step is the parity of its slot
+      fetch(d, p + 32 * D);                         // slot d was stashed during the previous step
+      cips3d_h8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][0][arow + 16 * i * RS]);
+        al[i] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][1][arow + 16 * i * RS]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][0][brow + 16 * j * RS]);
+        bl[j] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][1][brow + 16 * j * RS]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      if (p + 32 < p_end) stash((d + 1) % D, buf ^ 1);
+      __syncthreads();
+    }
+  }
+  // D layout: register t of lane (r, q) = C[4q + t][r]; two exact multiplications (2^(ea + eb) alone may not be a float)
+  const float oa = cips3d_pow2(ea), ob = cips3d_pow2(eb);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int m = m0 + wm * 16 * TM + 16 * i + 4 * q + t, k = k0 + wn * 16 * TN + 16 * j + r;
+        if (m < M && k < K) unsafeAtomicAdd(dwm + ((int64_t)b * M + m) * K + k, (acc[i][j][t] * oa) * ob);
+      }
+}
+
 // ------------------------------------------------------------------------------------------------ noise + bias + leaky-ReLU
 // y = lrelu(x + nw noise + bias_c) sqrt2  =>  dx = dy sqrt2 (y > 0 ? 1 : 0.2);  dbias_c = sum_{b,p} dx.
 // grid (pixel blocks, C, B): one block reduces its 1024 pixels of one channel.
@@ -458,6 +598,41 @@ extern "C" int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, in
   n_chunks = ceil_div<int64_t>(P, chunk);
   hipLaunchKernelGGL(gemm_wgrad_kernel, dim3((unsigned)blocks, (unsigned)n_chunks, (unsigned)B), dim3(256), 0, st, dy, x, dwm,
                      M, K, P, chunk);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_gemm_wgrad_split(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P,
+                                       const float* dy_amax, const float* x_amax, int accumulate, void* stream) {
+  if (!dy || !x || !dwm || B < 0 || M <= 0 || K <= 0 || P <= 0) return CIPS3D_E_BADARG;
+  if (M % 32 || K % 32 || P % 32) return CIPS3D_E_UNSUPP;
+  if ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(x)) & 15) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipStream_t st = as_stream(stream);
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(dwm, 0, sizeof(float) * (size_t)B * M * K, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  // workgroup tile: 128 x 64 (eight waves, two per SIMD: one converts while the other multiplies) where the matrix is that
+  // large -- the L2-port bytes go with 1 / BM + 1 / BN -- else 64 x 64 / 32 x 32 (four waves)
+  const int big = (M >= 128 && K >= 64) ? 2 : ((M >= 64 && K >= 64) ? 1 : 0);
+  const int BM = big == 2 ? 128 : (big == 1 ? 64 : 32), BN = big ? 64 : 32;
+  const int blocks = ceil_div(M, BM) * ceil_div(K, BN);
+  // pixel chunks: one to two workgroups per CU -- every chunk costs M K atomic adds per sample (1.3 TB/s chip-wide,
+  // MI355X_MICROARCH.md) -- and >= 256 pixels each
+  const int wgs = 256;
+  int64_t n_chunks = ceil_div<int64_t>(wgs, (int64_t)blocks * B);
+  const int64_t max_chunks = ceil_div<int64_t>(P, 256);
+  if (n_chunks > max_chunks) n_chunks = max_chunks;
+  if (n_chunks < 1) n_chunks = 1;
+  int64_t chunk = ceil_div<int64_t>(ceil_div<int64_t>(P, n_chunks), 32) * 32;
+  n_chunks = ceil_div<int64_t>(P, chunk);
+  const int groups = (int)n_chunks * B;
+  const int xg = (groups % 8 == 0) ? 1 : 0;
+  const dim3 grid((unsigned)(blocks * groups));
+  const int nc = (int)n_chunks;
+  if (big == 2) hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 4, 2>), grid, dim3(512), 0, st, dy, x, dwm, M, K, P, chunk, dy_amax, x_amax, blocks, nc, xg);
+  else if (big == 1) hipLaunchKernelGGL((wgrad_split_kernel<2, 2, 2, 2>), grid, dim3(256), 0, st, dy, x, dwm, M, K, P, chunk, dy_amax, x_amax, blocks, nc, xg);
+  else hipLaunchKernelGGL((wgrad_split_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, dy, x, dwm, M, K, P, chunk, dy_amax, x_amax, blocks, nc, xg);
   return cips3d_launch_status();
 }
 

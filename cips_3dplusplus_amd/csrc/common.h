@@ -175,6 +175,17 @@ __device__ static inline void cips3d_split_pair(float a, float b, unsigned& hi, 
       : "=&v"(hi), "=&v"(lo) : "v"(a), "v"(b));
 }
 
+// eight values -> the hi / lo fragments of v_mfma_f32_16x16x32_f16 (element j = value j)
+typedef _Float16 cips3d_h8 __attribute__((ext_vector_type(8)));
+__device__ static inline void cips3d_split8(const float (&v)[8], cips3d_h8& hi, cips3d_h8& lo) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  unsigned h[4], l[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) cips3d_split_pair(v[2 * p], v[2 * p + 1], h[p], l[p]);
+  hi = __builtin_bit_cast(cips3d_h8, u32x4_t{h[0], h[1], h[2], h[3]});
+  lo = __builtin_bit_cast(cips3d_h8, u32x4_t{l[0], l[1], l[2], l[3]});
+}
+
 // ---- Range tracking of the decoder's split-fp16 operands (include/cips3d_hip.h: cips3d_range).
 // fp16 has 5 exponent bits: an unscaled pair (hi, lo) overflows at |x| >= 65520 and loses fp32's relative accuracy below
 // |x| ~ 2^-3 (lo turns subnormal; the pair's absolute floor is 2^-25).  The reference's fp32 convolution

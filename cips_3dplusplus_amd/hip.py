@@ -830,6 +830,20 @@ def gemm_wgrad(dy, x):
     return dwm
 
 
+def gemm_wgrad_split(dy, x, dy_amax=None, x_amax=None, out=None):
+    """gemm_wgrad on split-fp16 products; dy_amax / x_amax: per-sample amax slot arrays (new_amax / absmax) or None.
+    out: accumulate into this [B,M,K] tensor instead of returning a fresh one."""
+    lib = _lib.load()
+    B, M = dy.shape[:2]
+    K = x.shape[1]
+    P = dy[0, 0].numel()
+    dwm = out if out is not None else torch.empty(B, M, K, device=dy.device)
+    check(lib.cips3d_gemm_wgrad_split(dev_ptr(dy, "dy"), dev_ptr(x, "x"), dev_ptr(dwm), B, M, K, P, dev_ptr(dy_amax, "dy_amax", True),
+                                      dev_ptr(x_amax, "x_amax", True), 1 if out is not None else 0, stream_ptr()),
+          "cips3d_gemm_wgrad_split")
+    return dwm
+
+
 def noise_bias_act_bwd(dy, y, noise, noise_w, need_dnoise=False, need_dnw=True, need_db=True):
     lib = _lib.load()
     B, Cc = y.shape[:2]

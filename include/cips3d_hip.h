@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 15  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 16  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -662,6 +662,13 @@ int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int
  * M, K multiples of 32, P multiple of 4, 16-byte aligned pointers.  Pixel chunks are summed with fp32 atomics, so the
  * last bits depend on the execution order (as cuDNN's default weight-gradient algorithms do). */
 int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P, void* stream);
+/* The same contraction on split-fp16 products (three fp16 MFMA products per fp32 product).  dy_amax / x_amax: the measured
+ * per-sample maxima of the operands ([B][CIPS3D_AMAX_FLOATS] slot arrays as cips3d_range uses them, or NULL: unscaled split,
+ * for tests on O(1) data); each operand is split as v * 2^-e with max|v| 2^-e in [2^14, 2^15) and the sums are scaled back
+ * exactly, so gradients of any magnitude keep fp32-level accuracy.  accumulate != 0: dwm is added to (the caller zeroed it).
+ * M % 32 == K % 32 == P % 32 == 0, 16-byte aligned operands, else CIPS3D_E_UNSUPP. */
+int cips3d_gemm_wgrad_split(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P, const float* dy_amax,
+                            const float* x_amax, int accumulate, void* stream);
 
 /* Backward of cips3d_noise_bias_act / the epilogue of StyledConv (models/model_v3.py:327-341; op/fused_act.py:20-84):
  * y = lrelu(x + noise_w*noise + bias_c)*sqrt2.  dx [B,C,HW] (may alias dy), dnoise [1 or B][HW] (layout of `noise`),
