@@ -42,6 +42,12 @@ class Range(C.Structure):
                 ("next_gain", C.c_float), ("pad2_", C.c_int32)]
 
 
+class ActBwd(C.Structure):
+    """cips3d_actbwd: operands of the activation-backward epilogue (include/cips3d_hip.h)."""
+    _fields_ = [("y", C.c_void_p), ("rgb_w", C.c_void_p), ("drgb", C.c_void_p), ("d_bias", C.c_void_p),
+                ("d_noise_w", C.c_void_p), ("d_rgb_w", C.c_void_p)]
+
+
 AMAX_SLOTS, AMAX_STRIDE = 8, 64                 # CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE (re-read from the library by load())
 AMAX_FLOATS = AMAX_SLOTS * AMAX_STRIDE          # floats per (tensor, sample) of an amax array
 FEATURES_EXP = -14
@@ -157,6 +163,8 @@ _SIGS = {
                                     c_f32p, c_i64, C.c_void_p]),
     "cips3d_pack_weights": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_gemm_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
+    "cips3d_modconv1x1_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, C.c_void_p, c_f32p, c_i64,
+                                         C.c_void_p, C.c_void_p]),
     "cips3d_gemm_wgrad_split": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_int, c_int, c_i64, C.c_void_p]),

@@ -234,6 +234,14 @@ __device__ static inline float cips3d_row16_max(float v) {
   u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true));
   return __uint_as_float(u);
 }
+// sum over the 16 lanes of a DPP row, in every lane of the row (the butterfly of cips3d_row16_max)
+__device__ static inline float cips3d_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
+  return v;
+}
 __device__ static inline float cips3d_readlanes4_max(float v) {          // max of lanes 0, 16, 32, 48 (wave-uniform), v >= 0
   const unsigned a = max((unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0), (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
   const unsigned b = max((unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32), (unsigned)__builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));

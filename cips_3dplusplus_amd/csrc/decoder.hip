@@ -324,6 +324,8 @@ struct GemmArgs {
   // range tracking (cips3d_range): split mode splits x * 2^-e, e from the measured maximum of x; any mode records max |out|
   const float* x_amax;      // [B][CIPS3D_AMAX_FLOATS] or NULL (e = 0)
   float* out_amax;          // [B][CIPS3D_AMAX_FLOATS] or NULL
+  // activation-backward epilogue (ACTBWD instantiations, cips3d_modconv1x1_actbwd): see cips3d_actbwd in the public header
+  cips3d_actbwd ab;
 };
 
 // s_waitcnt immediate that waits until at most n vector-memory operations of this wave are outstanding
@@ -331,7 +333,12 @@ struct GemmArgs {
 __device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
 
 // MODE: 0 exact fp32 MFMA, 1 bf16 operands (CIPS3D_GEMM_BF16), 2 split-fp16 (CIPS3D_GEMM_SPLIT; A pre-split by the modulate kernel)
-template <int WM, int WGM, int WGN, int BK, int NS, int MODE = 0>
+// ACTBWD: the data-gradient GEMM of the one-call decoder backward.  Its result is the gradient w.r.t. the OUTPUT of the
+// previous StyledConv; the epilogue turns it into the gradient w.r.t. that layer's pre-activation -- adds the contribution of
+// the ToRGB that read the same tensor (a rank-3 update), applies the leaky-ReLU derivative from the stored output's sign --
+// and reduces the bias / noise-weight / ToRGB-weight gradients of its rows (backward.hip: act_bwd_kernel + torgb_bwd_kernel,
+// which read and wrote the whole tensor once more each).
+template <int WM, int WGM, int WGN, int BK, int NS, int MODE = 0, bool ACTBWD = false>
 __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) {
   constexpr bool BF16 = MODE == 1;
   constexpr bool SPLIT = MODE == 2;
@@ -412,6 +419,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   f32x4 bias4[WM];
   f32x4 wrgb[WM][3];
   float nw = 0.f;
+  f32x4 aby[ACTBWD ? WM : 1][4], abg[3];                     // ACTBWD: the stored output's rows, the ToRGB gradient's pixels
   // With a 2-slot ring the first wait of the loop is vmcnt(0) anyway, so the operand loads go out right AFTER the first
   // stage's DMA (one exposed round trip less per launch).  Deeper rings count their waits in DMA pieces only: there the
   // operands are retired before the prologue.
@@ -426,6 +434,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       for (int i = 0; i < WM; ++i)
         bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
     }
+    if constexpr (ACTBWD) {
+      const bool ok = ncol < HW;
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+      nz4 = (a.ab.d_noise_w && ok) ? *reinterpret_cast<const f32x4*>(a.noise + (int64_t)b * a.noise_bstride + ncol) : z4;
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+        abg[ch] = (a.ab.drgb && ok) ? *reinterpret_cast<const f32x4*>(a.ab.drgb + ((int64_t)b * 3 + ch) * HW + ncol) : z4;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          aby[i][r] = ok ? *reinterpret_cast<const f32x4*>(a.ab.y + ((int64_t)b * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q + r) * HW + ncol) : z4;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          wrgb[i][ch] = a.ab.drgb ? *reinterpret_cast<const f32x4*>(a.ab.rgb_w + ((int64_t)b * 3 + ch) * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q) : z4;
+      }
+    }
     if (a.rgb_part) {        // the folded ToRGB's weights of this lane's rows (an epilogue-time load would be an exposed round trip)
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -437,7 +462,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
   if (!OPS_AFTER_PROLOGUE) {
     load_ops();
     // retire them now so that the counted waits below see DMA pieces only
-    if (a.epilogue == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.epilogue == 1 || ACTBWD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 
   f32x4 acc[WM][4];
@@ -544,9 +569,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
 
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4*q + r][pixel ncol + c]
   const bool col_ok = ncol < HW;
-  if (!col_ok && !a.rgb_part && !a.out_amax) return;
+  if (!ACTBWD && !col_ok && !a.rgb_part && !a.out_amax) return;
   float* ob = a.out + (int64_t)b * a.Cout * HW + ncol;
   float mx = 0.f;
+  float rs[ACTBWD ? WM : 1][4][5];             // ACTBWD row sums of this lane's 4 pixels: bias, noise weight, ToRGB weight x 3
   float prgb[3][4];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch)
@@ -565,6 +591,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       if (a.epilogue == 1) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
+      }
+      if constexpr (ACTBWD) {
+        const f32x4 yv = aby[i][r];
+        float sb = 0.f, sn = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float g = v[c];
+          g = fmaf(wrgb[i][0][r], abg[0][c], g);
+          g = fmaf(wrgb[i][1][r], abg[1][c], g);
+          g = fmaf(wrgb[i][2][r], abg[2][c], g);
+          g *= yv[c] > 0.f ? 1.41421356237309515f : 0.2f * 1.41421356237309515f;
+          if (!col_ok) g = 0.f;                      // (clamped columns past the image)
+          v[c] = g;
+          sb += g;
+          sn = fmaf(g, nz4[c], sn);
+          s0 = fmaf(abg[0][c], yv[c], s0); s1 = fmaf(abg[1][c], yv[c], s1); s2 = fmaf(abg[2][c], yv[c], s2);
+        }
+        rs[i][r][0] = sb; rs[i][r][1] = sn; rs[i][r][2] = s0; rs[i][r][3] = s1; rs[i][r][4] = s2;
       }
       if (col_ok) {
         mx = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), mx);
@@ -588,6 +632,31 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
     // words live in the ring slot the last K stage did not use (a __shared__ array of their own would move the ring)
     const float m = cips3d_workgroup_max(mx, lds + (nstage % NS) * STAGE, wave, lane, NW);
     if (tid == 0) cips3d_amax_raise_if(a.out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
+  }
+  if constexpr (ACTBWD) {
+    // row sums: over the 16 lanes of a DPP row (the 64 pixels of this wave), over the WGN wave columns through LDS, then
+    // ONE atomic per (row, quantity) and workgroup, issued as contiguous wave-wide instructions
+    __syncthreads();                                  // (every wave is past its last fragment read: the ring is free)
+    float* s_rs = lds;                                // [5][WGN][BM]
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          const float t = cips3d_row16_sum(rs[i][r][k]);
+          if (jn == 0) s_rs[(k * WGN + wn_i) * BM + (wm_i * WM + i) * 16 + 4 * q + r] = t;
+        }
+    __syncthreads();
+    for (int idx = tid; idx < 5 * BM; idx += 64 * NW) {
+      const int k = idx / BM, row = idx % BM;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < WGN; ++w) t += s_rs[(k * WGN + w) * BM + row];
+      float* dst = k == 0 ? a.ab.d_bias : (k == 1 ? a.ab.d_noise_w : (a.ab.d_rgb_w ? a.ab.d_rgb_w + ((int64_t)b * 3 + (k - 2)) * a.Cout : nullptr));
+      if (dst) unsafeAtomicAdd(dst + m0 + row, t);
+    }
+    return;
   }
   if (!a.rgb_part) return;
   // ---- ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows through
@@ -620,6 +689,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
     }
     *reinterpret_cast<f32x4*>(a.rgb_part + ((int64_t)blockIdx.y * a.B + b) * 3 * HW + (q * HW + ncol)) = v;
   }
+}
+
+template <int WM, int WGM, int WGN, int BK, int NS>
+int launch_gemm_actbwd(const GemmArgs& a, hipStream_t st) {
+  constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
+  dim3 grid((unsigned)ceil_div<int64_t>(a.HW, BN), (unsigned)(a.Cout / BM), (unsigned)a.B);
+  if (a.bf16 == 2) hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, 2, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((modconv1x1_kernel<WM, WGM, WGN, BK, NS, 0, true>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  return cips3d_launch_status();
 }
 
 template <int WM, int WGM, int WGN, int BK, int NS>
@@ -1729,7 +1807,7 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   GemmArgs a{x, wm, out, B, Cin, Cout, HW, epilogue, noise, noise_bstride, noise_w, bias, bf16, out_bf16, rgb_w, rgb_part,
-             rg ? rg->x_amax : nullptr, rg ? rg->out_amax : nullptr};
+             rg ? rg->x_amax : nullptr, rg ? rg->out_amax : nullptr, cips3d_actbwd{}};
   hipStream_t st = as_stream(stream);
   static const int dbg_cfg = getenv("CIPS3D_GEMM_CFG") ? atoi(getenv("CIPS3D_GEMM_CFG")) : 0;   // tuning knob (tools/)
   if (dbg_cfg && !rgb_part && Cout % 128 == 0) {      // (the ToRGB fold needs the default tiling: gemm_block_rows)
@@ -1762,6 +1840,27 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
   if (Cout == 128) return launch_gemm<1, 8, 1, 32, 4>(a, st);                     // all 128 rows: x read once
   if (Cout == 64) return launch_gemm<1, 4, 2, 32, 4>(a, st);                      // 64 x 128
   return launch_gemm<1, 2, 2, 32, 4>(a, st);                                      // 32 x 128 (any Cout % 32 == 0)
+}
+
+extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float* dpre, int B, int Cin, int Cout, int64_t HW,
+                                        int flags, const cips3d_actbwd* ab, const float* noise, int64_t noise_bstride,
+                                        const cips3d_range* rg, void* stream) {
+  if (!g || !wm_t || !dpre || !ab || !ab->y || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (flags & ~CIPS3D_GEMM_SPLIT) return CIPS3D_E_BADARG;
+  if ((ab->drgb == nullptr) != (ab->rgb_w == nullptr) || (ab->d_rgb_w && !ab->drgb)) return CIPS3D_E_BADARG;
+  if (ab->d_noise_w && !noise) return CIPS3D_E_BADARG;
+  if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  GemmArgs a{g, wm_t, dpre, B, Cin, Cout, HW, 0, noise, noise_bstride, nullptr, nullptr, (flags & CIPS3D_GEMM_SPLIT) ? 2 : 0, 0,
+             nullptr, nullptr, rg ? rg->x_amax : nullptr, rg ? rg->out_amax : nullptr, *ab};
+  hipStream_t st = as_stream(stream);
+  if (Cout >= 256 && Cout % 64 == 0) {
+    if (Cin % 64 == 0) return launch_gemm_actbwd<1, 4, 2, 64, 2>(a, st);
+    return launch_gemm_actbwd<1, 4, 2, 32, 2>(a, st);
+  }
+  if (Cout == 128) return launch_gemm_actbwd<1, 8, 1, 32, 4>(a, st);
+  if (Cout == 64) return launch_gemm_actbwd<1, 4, 2, 32, 4>(a, st);
+  return launch_gemm_actbwd<1, 2, 2, 32, 4>(a, st);
 }
 
 extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,

@@ -830,6 +830,27 @@ def gemm_wgrad(dy, x):
     return dwm
 
 
+def modconv1x1_actbwd(g, wm_t_packed, y, noise=None, rgb_w=None, drgb=None, split=False, g_amax=None, d_bias=None,
+                      d_noise_w=None, d_rgb_w=None, track=True):
+    """The data-gradient GEMM with the previous layer's activation backward as its epilogue (cips3d_modconv1x1_actbwd):
+    g [B,Cin,H,W], wm_t_packed = pack of wm^T [B,Cout,Cin], y [B,Cout,H,W] the previous layer's stored output -> dpre
+    [B,Cout,H,W]; the given accumulators (zeroed by the caller) are added to.  Returns (dpre, amax array of dpre or None)."""
+    lib = _lib.load()
+    B, Cin, H, W = g.shape
+    Cout = y.shape[1]
+    out = torch.empty_like(y)
+    out_amax = new_amax(B, g.device) if track else None
+    rg, _keep = _range(x_amax=g_amax if split else None, out_amax=out_amax)
+    ab = _lib.ActBwd()
+    ab.y, ab.rgb_w, ab.drgb = dev_ptr(y, "y"), dev_ptr(rgb_w, "rgb_w", True), dev_ptr(drgb, "drgb", True)
+    ab.d_bias, ab.d_noise_w, ab.d_rgb_w = dev_ptr(d_bias, "d_bias", True), dev_ptr(d_noise_w, "d_noise_w", True), dev_ptr(d_rgb_w, "d_rgb_w", True)
+    nb = H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    check(lib.cips3d_modconv1x1_actbwd(dev_ptr(g, "g"), dev_ptr(wm_t_packed, "wm_t"), dev_ptr(out), B, Cin, Cout, H * W,
+                                       GEMM_SPLIT if split else 0, C.byref(ab), dev_ptr(noise, "noise", True), nb, C.byref(rg),
+                                       stream_ptr()), "cips3d_modconv1x1_actbwd")
+    return out, out_amax
+
+
 def gemm_wgrad_split(dy, x, dy_amax=None, x_amax=None, out=None):
     """gemm_wgrad on split-fp16 products; dy_amax / x_amax: per-sample amax slot arrays (new_amax / absmax) or None.
     out: accumulate into this [B,M,K] tensor instead of returning a fresh one."""

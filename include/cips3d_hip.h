@@ -662,6 +662,33 @@ int cips3d_pack_weights(const float* wm, float* packed, int B, int M, int K, int
  * M, K multiples of 32, P multiple of 4, 16-byte aligned pointers.  Pixel chunks are summed with fp32 atomics, so the
  * last bits depend on the execution order (as cuDNN's default weight-gradient algorithms do). */
 int cips3d_gemm_wgrad(const float* dy, const float* x, float* dwm, int B, int M, int K, int64_t P, void* stream);
+/* ---- one-call decoder backward: the data-gradient GEMM with the previous layer's activation backward as its epilogue.
+ * The reference gets all of this from autograd over `StyledConv.forward` / `ToRGB.forward` (models/model_v3.py:444-482).
+ *
+ * g [B,Cin,HW] = gradient w.r.t. the pre-activation of StyledConv l (at the resolution of its GEMM), wm_t = its modulated
+ * weights packed TRANSPOSED (cips3d_modulate_table with CIPS3D_MOD_TRANSPOSE, + CIPS3D_MOD_SPLIT16 for flags =
+ * CIPS3D_GEMM_SPLIT): the product wm^T g [B,Cout,HW] is the gradient w.r.t. layer l's input = the output y of StyledConv
+ * l-1 (Cout here = that layer's channel count).  The epilogue makes it the gradient w.r.t. layer l-1's pre-activation:
+ *   dpre = (wm^T g + sum_c rgb_w[b][c][o] drgb[b][c][p]) * (y > 0 ? sqrt2 : 0.2 sqrt2)
+ * and adds, with one fp32 atomic per row and workgroup,
+ *   d_bias[o]      += sum_{b,p} dpre                     (FusedLeakyReLU bias, fused_act.py:20-84)
+ *   d_noise_w[o]   += sum_{b,p} dpre * noise[b][p]       (per-channel partials of NoiseInjection.weight's gradient; the
+ *                                                         caller sums the Cout partials)
+ *   d_rgb_w[b][c][o] += sum_p drgb[b][c][p] * y[b][o][p] (the modulated ToRGB weights' gradient)
+ * The accumulators must be zeroed by the caller.  rg->x_amax scales the split of g (CIPS3D_GEMM_SPLIT), rg->out_amax
+ * records max|dpre| per sample (the next GEMM's and the weight-gradient GEMM's operand scale). */
+typedef struct cips3d_actbwd {
+  const float* y;        /* [B,Cout,HW] stored output of layer l-1 (only its sign is used) */
+  const float* rgb_w;    /* [B,3,Cout] plain modulated weights of the ToRGB that read y, or NULL (both or neither with drgb) */
+  const float* drgb;     /* [B,3,HW] gradient w.r.t. that ToRGB's output */
+  float* d_bias;         /* [Cout] or NULL */
+  float* d_noise_w;      /* [Cout] or NULL (needs `noise`) */
+  float* d_rgb_w;        /* [B,3,Cout] or NULL */
+} cips3d_actbwd;
+int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float* dpre, int B, int Cin, int Cout, int64_t HW, int flags,
+                             const cips3d_actbwd* ab, const float* noise, int64_t noise_bstride, const cips3d_range* rg,
+                             void* stream);
+
 /* The same contraction on split-fp16 products (three fp16 MFMA products per fp32 product).  dy_amax / x_amax: the measured
  * per-sample maxima of the operands ([B][CIPS3D_AMAX_FLOATS] slot arrays as cips3d_range uses them, or NULL: unscaled split,
  * for tests on O(1) data); each operand is split as v * 2^-e with max|v| 2^-e in [2^14, 2^15) and the sums are scaled back
