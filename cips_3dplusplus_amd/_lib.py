@@ -165,6 +165,14 @@ _SIGS = {
     "cips3d_gemm_wgrad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_modconv1x1_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, C.c_void_p, c_f32p, c_i64,
                                          C.c_void_p, C.c_void_p]),
+    "cips3d_act_tail_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
+                                    c_int, c_i64, C.c_void_p]),
+    "cips3d_up2_fir_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_modulate_table_bwd": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_decoder_grad_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cips3d_decoder_grad_backward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cips3d_sizeof_grad_plan": (c_int, []),
+    "cips3d_sizeof_grad_io": (c_int, []),
     "cips3d_gemm_wgrad_split": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_int, c_int, c_i64, C.c_void_p]),

@@ -20,6 +20,9 @@ def _c(t):
 
 # the decoder's 26 style modulations go through one table launch (and a two-launch table backward); 0 = one op per layer
 STYLE_TABLE = os.environ.get("CIPS3D_STYLE_TABLE", "1") != "0"
+# Decoder.forward under autograd as ONE node with a one-call backward (decoder_grad.py); 0 = one node per op (A/B knob, and the
+# route for what the one-call plan does not cover)
+ONE_CALL_DECODER = os.environ.get("CIPS3D_ONE_CALL_DECODER", "1") != "0"
 
 
 class LinearFn(Function):
@@ -337,6 +340,12 @@ def decoder_forward(dec, features, styles, noise=None):
     """Decoder.forward (models/model_v3.py:592-637) with gradients."""
     if dec.kernel_size != 1:
         raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
+    if ONE_CALL_DECODER and noise is not None:
+        # the whole decoder as one autograd node (csrc/decoder_grad.hip); None when the plan does not cover this call
+        from . import decoder_grad
+        rgb = decoder_grad.decoder_forward(dec, features, styles, list(noise))
+        if rgb is not None:
+            return rgb
     if noise is None:
         noise = [None] * dec.num_layers
     # all 26 style modulations from one table launch (forward and backward); S maps module -> its s

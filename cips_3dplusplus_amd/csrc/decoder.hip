@@ -201,6 +201,15 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
                       ((q << 4) | (o & 15)) * 8;
       blk[el] = hi;
       blk[4 + el] = lo;
+    } else if ((packed & 16) && (packed & 64)) {     // split-fp16 fragments of wm^T (ksq == 1): row = input channel, k = output unit
+      const int i = e;
+      const int j = o & 7, q = (o >> 3) & 3;
+      const float sv = v * kSplitScale;
+      _Float16 hi, lo;
+      cips3d_split16(sv, hi, lo);
+      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 5) + (o >> 5)) * 1024);
+      blk[((q << 4) | (i & 15)) * 8 + j] = hi;
+      blk[512 + ((q << 4) | (i & 15)) * 8 + j] = lo;
     } else if (packed & 16) {     // split-fp16 fragments (ksq == 1)
       const int i = e;
       const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;      // natural k order: k = 8 q + j

@@ -306,8 +306,9 @@ int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, flo
  * CIPS3D_GEMM_SPLIT mode (16-channel k-groups, v_mfma_f32_16x16x16_f16): the element <-> channel map of the fp32 layout, each
  * lane's 16 bytes = {fp16 hi x 4 | fp16 lo x 4} of 2^8 wm */
 #define CIPS3D_MOD_SPLIT16    32
-/* with CIPS3D_MOD_PACKED and ksq == 1 (fp32 fragments only): the packed form of wm^T ([Cin x Cout]: the A operand of the
- * data-gradient GEMM dx = wm^T dy) instead of wm's -- what cips3d_pack_weights(transpose = 1) makes from the plain matrix */
+/* with CIPS3D_MOD_PACKED and ksq == 1: the packed form of wm^T ([Cin x Cout]: the A operand of the data-gradient GEMM
+ * dx = wm^T dy) instead of wm's -- what cips3d_pack_weights(transpose = 1) makes from the plain matrix; fp32 fragments, or
+ * with CIPS3D_MOD_SPLIT (Cout % 32 == 0) the split-fp16 ones (cips3d_pack_weights(transpose = 3)) */
 #define CIPS3D_MOD_TRANSPOSE  64
 /* with CIPS3D_MOD_PACKED and ksq == 1 (Cin % 32 == 0): bf16 A fragments (bf16(wm), round to nearest even, unscaled) for
  * cips3d_modconv1x1_planes16 -- the bf16 decoder mode's form of CIPS3D_MOD_SPLIT */
@@ -688,6 +689,97 @@ typedef struct cips3d_actbwd {
 int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float* dpre, int B, int Cin, int Cout, int64_t HW, int flags,
                              const cips3d_actbwd* ab, const float* noise, int64_t noise_bstride, const cips3d_range* rg,
                              void* stream);
+
+/* Activation backward without a GEMM in front of it (the LAST StyledConv: its output is read by the last ToRGB only):
+ * dpre = (g_in + rgb_w^T drgb) * lrelu'(y), same reductions as cips3d_actbwd; g_in may be NULL.  out_amax: amax row or NULL. */
+int cips3d_act_tail_bwd(const float* g_in, const float* y, const float* rgb_w, const float* drgb, const float* noise,
+                        int64_t noise_bstride, float* dpre, float* d_bias, float* d_noise_w, float* d_rgb_w, float* out_amax,
+                        int B, int C, int64_t HW, void* stream);
+/* Transpose of the 2x FIR up-sampler (upfirdn2d up = 2, pad = (2, 1), 4 x 4 taps; op/upfirdn2d.py:20-143 reaches it through
+ * upfirdn2d with swapped factors): g_hi [B,C,2H,2W] -> g_lo [B,C,H,W]; out_amax: per-sample amax rows of g_lo or NULL. */
+int cips3d_up2_fir_bwd(const float* g_hi, const float* fir, float* g_lo, float* out_amax, int B, int C, int H, int W,
+                       void* stream);
+/* Modulation backward (models/model_v3.py:267-278, k = 1) of a table of layers in ONE launch: cips3d_modulate_bwd's
+ * arithmetic; dW is stored, ds is ADDED to (the caller zeroes it).  Cin <= 512, B <= 4, n_desc <= 64. */
+typedef struct cips3d_modbwd_desc {
+  const float* d_wm;     /* [B, Cout, Cin] gradient of the modulated weights */
+  const float* W;        /* [Cout, Cin] */
+  const float* s;        /* row b at s + b * s_stride */
+  float* dW;             /* [Cout, Cin] or NULL */
+  float* ds;             /* row b at ds + b * ds_stride, or NULL */
+  int64_t s_stride, ds_stride;
+  int32_t Cout, Cin;
+  float scale;
+  int32_t demodulate;
+  int32_t row_begin;     /* exclusive prefix sum of ceil(Cout / 32) (workgroups) over the table */
+  int32_t pad_;
+} cips3d_modbwd_desc;
+int cips3d_modulate_table_bwd(const cips3d_modbwd_desc* table_dev, int n_desc, int total_blocks, int B, void* stream);
+
+/* The decoder as ONE differentiable node (csrc/decoder_grad.hip): Decoder.forward with every StyledConv output kept, and the
+ * whole backward -- gradients of the features, the W+ styles and every decoder parameter -- in one call each.
+ * models/model_v3.py:592-637 under `loss.backward()` (models/projector_v10.py:1203-1209).  kernel_size 1. */
+#define CIPS3D_GRAD_MAX_LAYERS 48
+typedef struct cips3d_grad_layer {
+  int32_t kind;            /* 0 StyledConv, 1 StyledConv with up-sampling, 2 ToRGB, 3 ToRGB whose skip is up-sampled first */
+  int32_t Cin, Cout;
+  int32_t H, W;            /* resolution of the layer's input */
+  int32_t noise_index;     /* StyledConv: entry of io->noise; -1 otherwise */
+  int32_t flags;           /* bit 0: split-fp16 GEMMs (wm / wm_t packed with CIPS3D_MOD_SPLIT16) */
+  int32_t pad_;
+  const float* bias;       /* FusedLeakyReLU bias [Cout] / ToRGB bias [3] */
+  const float* noise_w;    /* [1] (StyledConv) */
+  const float* fir;        /* [4,4] (kinds 1, 3) */
+  const float* wm;         /* StyledConv: packed modulated weights; ToRGB: plain [B,3,Cin] (both written by mod_table) */
+  const float* wm_t;       /* StyledConv: the packed transpose */
+  float* y;                /* StyledConv: the stored output [B,Cout,Ho,Wo] */
+  float* y_amax;           /* amax rows of y      (inside plan->amax_base .. + amax_bytes) */
+  float* g_amax;           /* amax rows of the gradient w.r.t. this layer's pre-activation (same region) */
+  float* glo_amax;         /* kind 1: amax rows of that gradient after the FIR transpose (same region) */
+  float* d_wm;             /* [B,Cout,Cin] gradient of the modulated weights      (inside plan->zero_base .. + zero_bytes) */
+  float* d_bias;           /* [Cout] / [3]                                         (same region) */
+  float* d_nw_part;        /* StyledConv: row of plan->nw_parts                    (same region) */
+} cips3d_grad_layer;
+
+typedef struct cips3d_decoder_grad_plan {
+  int32_t B, n_layers, style_dim, pad_;
+  const cips3d_linear_desc* style_table;      /* style -> s of every layer (cips3d_linear_table) */
+  int32_t style_n, style_rows;
+  const cips3d_modulate_desc* mod_table;      /* s -> wm in every form the layers name */
+  int32_t mod_n, mod_rows;
+  const cips3d_modbwd_desc* modbwd_table;
+  int32_t modbwd_n, modbwd_blocks;
+  const int64_t* style_w_offsets;             /* cips3d_linear_table_bwd's w_offsets */
+  const float* styles;                        /* [B, n_latent, style_dim]: the style table's input (filled by the caller) */
+  const float* s_all;                         /* the style table's output base */
+  const float* ds_all;                        /* its gradient, same layout (zero region; the modbwd table adds to it) */
+  float* d_styles;                            /* [B, n_latent, style_dim] or NULL (zero region) */
+  float* d_style_W; float* d_style_b;         /* flat gradients of the style heads or NULL */
+  float* amax_base; int64_t amax_bytes;       /* every amax row of the step: zeroed by the forward call */
+  float* zero_base; int64_t zero_bytes;       /* every accumulator of the backward: zeroed by the backward call */
+  float* feat_amax;                           /* amax rows of the features (amax region) */
+  float* y_lo;                                /* low-resolution GEMM result of an up-sampling layer (largest one) */
+  float* g[2];                                /* two gradient buffers of the largest activation */
+  float* g_lo;                                /* FIR-transposed gradient of an up-sampling layer (largest one) */
+  float* drgb_lo[4];                          /* gradient images of the skip chain below the output resolution */
+  float* rgb[2];                              /* intermediate rgb images */
+  const float* nw_parts; int32_t nw_stride, pad2_;    /* [n StyledConvs][nw_stride] per-channel noise-weight partials */
+  float* d_noise_w;                           /* [n StyledConvs] or NULL */
+  cips3d_grad_layer layers[CIPS3D_GRAD_MAX_LAYERS];
+} cips3d_decoder_grad_plan;
+
+typedef struct cips3d_decoder_grad_io {
+  const float* features;     /* [B, Cin0, H0, W0] */
+  const float* noise[CIPS3D_GRAD_MAX_LAYERS];
+  int64_t noise_bstride[CIPS3D_GRAD_MAX_LAYERS];
+  float* rgb;                /* forward: [B,3,Hf,Wf] */
+  const float* d_rgb;        /* backward: gradient of rgb */
+  float* d_features;         /* backward: [B, Cin0, H0, W0] or NULL */
+} cips3d_decoder_grad_io;
+int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan, const cips3d_decoder_grad_io* io, void* stream);
+int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan, const cips3d_decoder_grad_io* io, void* stream);
+int cips3d_sizeof_grad_plan(void);
+int cips3d_sizeof_grad_io(void);
 
 /* The same contraction on split-fp16 products (three fp16 MFMA products per fp32 product).  dy_amax / x_amax: the measured
  * per-sample maxima of the operands ([B][CIPS3D_AMAX_FLOATS] slot arrays as cips3d_range uses them, or NULL: unscaled split,

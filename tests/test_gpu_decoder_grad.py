@@ -72,3 +72,72 @@ def test_dgrad_with_activation_backward_epilogue(B, Cin, Cout, S, split, rgb, pe
     if rgb:
         wref = torch.einsum("bchw,bohw->bco", D(drgb), D(y))
         assert _rel(d_rgb_w, wref) < 2e-5
+
+
+def _decoder_case(cfg_fn, res, S0, B, seed):
+    from cips_3dplusplus_amd import configs
+    cfg = cfg_fn()
+    G = pkg.build_generator(cfg, DEV, seed=seed)
+    dec = G.decoder
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    with torch.no_grad():
+        for p in dec.parameters():                      # noise weights / biases start at zero: make every gradient path live
+            if p.abs().max() == 0:
+                p.copy_(0.1 * torch.randn(p.shape, device=DEV, generator=g))
+    feats = torch.randn(B, cfg["decoder_cfg"]["in_channel"], S0, S0, device=DEV, generator=g) * 0.5
+    styles = torch.randn(B, dec.n_latent, dec.style_dim, device=DEV, generator=g)
+    noise = [torch.randn(*b.shape, device=DEV, generator=g) for b in G.create_noise_bufs(S0, DEV)]
+    return dec, feats, styles, noise
+
+
+def _grads(dec, feats, styles, noise, one_call, target):
+    from cips_3dplusplus_amd import autograd as AG
+    from cips_3dplusplus_amd import decoder_grad
+    AG.ONE_CALL_DECODER = one_call
+    params = decoder_grad.parameters_of(dec)
+    for p in dec.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    f, s = feats.clone().requires_grad_(True), styles.clone().requires_grad_(True)
+    rgb = AG.decoder_forward(dec, f, s, noise)
+    loss = ((rgb - target) ** 2).mean() * 3.0
+    loss.backward()
+    AG.ONE_CALL_DECODER = True
+    return rgb.detach(), f.grad, s.grad, [p.grad for p in params]
+
+
+@pytest.mark.parametrize("name,res,S0,B", [("tiny", 32, 8, 2), ("tiny", 32, 16, 3), ("config5", 256, 64, 2), ("r1024", 1024, 64, 1)])
+def test_one_call_decoder_matches_the_per_op_route(name, res, S0, B):
+    """Decoder.forward + backward as one node (csrc/decoder_grad.hip) against the chain of per-op nodes (autograd.py, itself
+    pinned to the reference's gradients by tests/golden/backward.npz and config5.npz): image, feature / style gradients and
+    every parameter gradient.  The two routes share no backward kernel except the style-table one."""
+    from cips_3dplusplus_amd import configs
+    if name == "tiny":
+        cfg_fn = lambda: configs.tiny_G_cfg(32, 2, 1)           # noqa: E731
+    else:
+        cfg_fn = lambda: configs.ffhq_G_cfg(res, 2)             # noqa: E731
+    dec, feats, styles, noise = _decoder_case(cfg_fn, res, S0, B, seed=5)
+    from cips_3dplusplus_amd import decoder_grad
+    assert decoder_grad.plan_for(dec, B, S0, S0, feats.device) is not None, "the one-call plan must cover this decoder"
+    with torch.no_grad():
+        from cips_3dplusplus_amd import autograd as AG
+        shape = AG.decoder_forward(dec, feats, styles, noise).shape
+    target = torch.randn(*shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))
+    ref = _grads(dec, feats, styles, noise, False, target)
+    one = _grads(dec, feats, styles, noise, True, target)
+    assert _rel(one[0], ref[0].double().cpu()) < 2e-5
+    names = ["d_features", "d_styles"]
+    for tag, a, b in zip(names, one[1:3], ref[1:3]):
+        assert a is not None and _rel(a, b.double().cpu()) < 5e-4, tag
+    pnames = [n for n, _ in dec.named_parameters()]
+    by_id = {id(p): n for n, p in dec.named_parameters()}
+    for p, a, b in zip(decoder_grad.parameters_of(dec), one[3], ref[3]):
+        assert a is not None and b is not None, by_id[id(p)]
+        assert a.shape == p.shape, by_id[id(p)]
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        assert err <= 1e-3 * scale + 1e-9, (by_id[id(p)], err, scale)
+    # nothing the node returned aliases the plan: a second backward must not change the first one's gradients
+    keep = [g.clone() for g in one[3]]
+    _grads(dec, feats, styles * 0.5, noise, True, target)
+    assert all(torch.equal(a, b) for a, b in zip(keep, one[3]))
