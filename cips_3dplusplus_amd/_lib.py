@@ -45,7 +45,8 @@ class Range(C.Structure):
 class ActBwd(C.Structure):
     """cips3d_actbwd: operands of the activation-backward epilogue (include/cips3d_hip.h)."""
     _fields_ = [("y", C.c_void_p), ("rgb_w", C.c_void_p), ("drgb", C.c_void_p), ("d_bias", C.c_void_p),
-                ("d_noise_w", C.c_void_p), ("d_rgb_w", C.c_void_p)]
+                ("d_noise_w", C.c_void_p), ("d_rgb_w", C.c_void_p),
+                ("slots", C.c_int32), ("slot_stride", C.c_int32), ("rgb_slot_stride", C.c_int32), ("pad_", C.c_int32)]
 
 
 AMAX_SLOTS, AMAX_STRIDE = 8, 64                 # CIPS3D_AMAX_SLOTS / CIPS3D_AMAX_STRIDE (re-read from the library by load())
@@ -166,7 +167,8 @@ _SIGS = {
     "cips3d_modconv1x1_actbwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_int, C.c_void_p, c_f32p, c_i64,
                                          C.c_void_p, C.c_void_p]),
     "cips3d_act_tail_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_int,
-                                    c_int, c_i64, C.c_void_p]),
+                                    c_int, c_i64, c_int, c_int, c_int, C.c_void_p]),
+    "cips3d_slot_reduce": (c_int, [C.c_void_p, c_int, c_int, C.c_void_p]),
     "cips3d_up2_fir_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_modulate_table_bwd": (c_int, [C.c_void_p, c_int, c_int, c_int, C.c_void_p]),
     "cips3d_decoder_grad_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

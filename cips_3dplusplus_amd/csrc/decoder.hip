@@ -662,8 +662,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) 
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < WGN; ++w) t += s_rs[(k * WGN + w) * BM + row];
+      const int slot = a.ab.slots > 1 ? (int)(blockIdx.x & (a.ab.slots - 1)) : 0;
       float* dst = k == 0 ? a.ab.d_bias : (k == 1 ? a.ab.d_noise_w : (a.ab.d_rgb_w ? a.ab.d_rgb_w + ((int64_t)b * 3 + (k - 2)) * a.Cout : nullptr));
-      if (dst) unsafeAtomicAdd(dst + m0 + row, t);
+      if (dst) unsafeAtomicAdd(dst + (int64_t)slot * (k < 2 ? a.ab.slot_stride : a.ab.rgb_slot_stride) + m0 + row, t);
     }
     return;
   }
@@ -1858,6 +1859,8 @@ extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float
   if (flags & ~CIPS3D_GEMM_SPLIT) return CIPS3D_E_BADARG;
   if ((ab->drgb == nullptr) != (ab->rgb_w == nullptr) || (ab->d_rgb_w && !ab->drgb)) return CIPS3D_E_BADARG;
   if (ab->d_noise_w && !noise) return CIPS3D_E_BADARG;
+  if (ab->slots > 1 && ((ab->slots & (ab->slots - 1)) || ab->slot_stride < Cout || (ab->d_rgb_w && ab->rgb_slot_stride < B * 3 * Cout)))
+    return CIPS3D_E_BADARG;
   if (!cips3d_modconv1x1_supported(Cin, Cout, HW)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   GemmArgs a{g, wm_t, dpre, B, Cin, Cout, HW, 0, noise, noise_bstride, nullptr, nullptr, (flags & CIPS3D_GEMM_SPLIT) ? 2 : 0, 0,

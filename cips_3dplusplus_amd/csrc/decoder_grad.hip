@@ -39,9 +39,14 @@ __global__ void __launch_bounds__(256) act_tail_kernel(const float* __restrict__
                                                        const float* __restrict__ noise, int64_t noise_bstride,
                                                        float* __restrict__ dpre, float* __restrict__ d_bias,
                                                        float* __restrict__ d_nw, float* __restrict__ d_rgb_w,
-                                                       float* __restrict__ out_amax, int C, int64_t HW) {
+                                                       float* __restrict__ out_amax, int C, int64_t HW, int slots,
+                                                       int slot_stride, int rgb_slot_stride) {
   __shared__ float sh[16];
   const int c = blockIdx.y, b = blockIdx.z;
+  const int slot = slots > 1 ? (int)(blockIdx.x & (slots - 1)) : 0;     // (cips3d_actbwd: one cache line per slot and row block)
+  if (d_bias) d_bias += (int64_t)slot * slot_stride;
+  if (d_nw) d_nw += (int64_t)slot * slot_stride;
+  if (d_rgb_w) d_rgb_w += (int64_t)slot * rgb_slot_stride;
   const int64_t base = ((int64_t)b * C + c) * HW;
   const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   float sb = 0.f, sn = 0.f, s0 = 0.f, s1 = 0.f, s2 = 0.f, mx = 0.f;
@@ -159,6 +164,18 @@ __global__ void __launch_bounds__(256) rgb_bias_kernel(RgbBiasArgs a) {
     for (int i = 0; i < a.n_dst; ++i) unsafeAtomicAdd(a.dst[i] + ch, acc);
 }
 
+// dst[i] = sum of the slot copies (cips3d_slot_reduce)
+__global__ void __launch_bounds__(256) slot_reduce_kernel(const cips3d_slot_job* __restrict__ table, int n_jobs) {
+  const int lane = threadIdx.x & 63;
+  const int ji = owner_desc(table, n_jobs, (int)blockIdx.x, lane);
+  const cips3d_slot_job j = table[ji];
+  const int i = ((int)blockIdx.x - j.row_begin) * 256 + threadIdx.x;
+  if (i >= j.n) return;
+  float acc = 0.f;
+  for (int s_ = 0; s_ < j.slots; ++s_) acc += j.src[(int64_t)s_ * j.stride + i];
+  j.dst[i] = acc;
+}
+
 // d NoiseInjection.weight of every StyledConv = sum over its per-channel partials: block l sums row l of [n][stride]
 __global__ void __launch_bounds__(256) row_sums_kernel(const float* __restrict__ parts, int stride, float* __restrict__ out) {
   __shared__ float sh[4];
@@ -261,13 +278,22 @@ extern "C" int cips3d_modulate_table_bwd(const cips3d_modbwd_desc* table_dev, in
 
 extern "C" int cips3d_act_tail_bwd(const float* g_in, const float* y, const float* rgb_w, const float* drgb, const float* noise,
                                    int64_t noise_bstride, float* dpre, float* d_bias, float* d_noise_w, float* d_rgb_w,
-                                   float* out_amax, int B, int C, int64_t HW, void* stream) {
+                                   float* out_amax, int B, int C, int64_t HW, int slots, int slot_stride, int rgb_slot_stride,
+                                   void* stream) {
   if (!y || !dpre || B < 0 || C <= 0 || HW <= 0) return CIPS3D_E_BADARG;
+  if (slots > 1 && ((slots & (slots - 1)) || slot_stride < C || (d_rgb_w && rgb_slot_stride < B * 3 * C))) return CIPS3D_E_BADARG;
   if ((rgb_w == nullptr) != (drgb == nullptr) || (d_rgb_w && !drgb) || (d_noise_w && !noise)) return CIPS3D_E_BADARG;
   if (HW % 4) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   hipLaunchKernelGGL(act_tail_kernel, dim3((unsigned)ceil_div<int64_t>(HW, 1024), (unsigned)C, (unsigned)B), dim3(256), 0,
-                     as_stream(stream), g_in, y, rgb_w, drgb, noise, noise_bstride, dpre, d_bias, d_noise_w, d_rgb_w, out_amax, C, HW);
+                     as_stream(stream), g_in, y, rgb_w, drgb, noise, noise_bstride, dpre, d_bias, d_noise_w, d_rgb_w, out_amax, C, HW, slots,
+                     slot_stride, rgb_slot_stride);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_slot_reduce(const cips3d_slot_job* table_dev, int n_jobs, int total_blocks, void* stream) {
+  if (!table_dev || n_jobs <= 0 || n_jobs > 64 || total_blocks <= 0) return CIPS3D_E_BADARG;
+  hipLaunchKernelGGL(slot_reduce_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), table_dev, n_jobs);
   return cips3d_launch_status();
 }
 
@@ -417,7 +443,7 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
     const float* nz; int64_t nbs;
     noise_of(L, nz, nbs);
     TRY(cips3d_act_tail_bwd(nullptr, L.y, T.wm, drgb_of[ti], nz, nbs, P.g[gi], L.d_bias, L.d_nw_part, T.d_wm, L.g_amax, B,
-                            L.Cout, (int64_t)L.H * L.W * up * up, stream));
+                            L.Cout, (int64_t)L.H * L.W * up * up, L.slots, L.slot_stride, T.rgb_slot_stride, stream));
   }
   for (int ci = n_conv - 1; ci >= 0; --ci) {
     const int li = conv_idx[ci];
@@ -455,6 +481,8 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
       if (ti >= 0) { ab.rgb_w = P.layers[ti].wm; ab.drgb = drgb_of[ti]; ab.d_rgb_w = P.layers[ti].d_wm; }
       ab.d_bias = Lp.d_bias;
       ab.d_noise_w = Lp.d_nw_part;
+      ab.slots = Lp.slots; ab.slot_stride = Lp.slot_stride;
+      ab.rgb_slot_stride = ti >= 0 ? P.layers[ti].rgb_slot_stride : 0;
       const float* nz; int64_t nbs;
       noise_of(Lp, nz, nbs);
       const int go = gi ^ 1;
@@ -465,6 +493,7 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
   }
 
   // ---- parameters: modulation backward of every layer, the style heads, the scalar noise weights
+  if (P.slot_table) TRY(cips3d_slot_reduce(P.slot_table, P.slot_n, P.slot_blocks, stream));
   TRY(cips3d_modulate_table_bwd(P.modbwd_table, P.modbwd_n, P.modbwd_blocks, B, stream));
   if (P.d_styles || P.d_style_W)
     TRY(cips3d_linear_table_bwd(P.style_table, P.style_n, P.style_rows, P.style_dim, B, P.s_all, P.ds_all, P.styles, P.d_styles,

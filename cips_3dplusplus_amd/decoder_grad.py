@@ -29,7 +29,13 @@ class GradLayer(C.Structure):
                 ("noise_index", C.c_int32), ("flags", C.c_int32), ("pad_", C.c_int32),
                 ("bias", C.c_void_p), ("noise_w", C.c_void_p), ("fir", C.c_void_p), ("wm", C.c_void_p), ("wm_t", C.c_void_p),
                 ("y", C.c_void_p), ("y_amax", C.c_void_p), ("g_amax", C.c_void_p), ("glo_amax", C.c_void_p),
-                ("d_wm", C.c_void_p), ("d_bias", C.c_void_p), ("d_nw_part", C.c_void_p)]
+                ("d_wm", C.c_void_p), ("d_bias", C.c_void_p), ("d_nw_part", C.c_void_p),
+                ("slots", C.c_int32), ("slot_stride", C.c_int32), ("rgb_slot_stride", C.c_int32), ("pad2_", C.c_int32)]
+
+
+class SlotJob(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("n", C.c_int32), ("slots", C.c_int32), ("stride", C.c_int32),
+                ("row_begin", C.c_int32)]
 
 
 class DecoderGradPlan(C.Structure):
@@ -42,7 +48,8 @@ class DecoderGradPlan(C.Structure):
                 ("amax_base", C.c_void_p), ("amax_bytes", C.c_int64), ("zero_base", C.c_void_p), ("zero_bytes", C.c_int64),
                 ("feat_amax", C.c_void_p), ("y_lo", C.c_void_p), ("g", C.c_void_p * 2), ("g_lo", C.c_void_p),
                 ("drgb_lo", C.c_void_p * 4), ("rgb", C.c_void_p * 2),
-                ("nw_parts", C.c_void_p), ("nw_stride", C.c_int32), ("pad2_", C.c_int32), ("d_noise_w", C.c_void_p),
+                ("nw_parts", C.c_void_p), ("nw_stride", C.c_int32), ("pad2_", C.c_int32),
+                ("slot_table", C.c_void_p), ("slot_n", C.c_int32), ("slot_blocks", C.c_int32), ("d_noise_w", C.c_void_p),
                 ("layers", GradLayer * MAX_LAYERS)]
 
 
@@ -108,6 +115,20 @@ class GradPlan:
             raise Unsupported("a decoder starts with a StyledConv and ends with a ToRGB")
         self.info, self.n_conv = info, n_conv
         self.out_hw = (H, W)
+        # Slotted accumulators (cips3d_actbwd): the kernel that makes the gradient w.r.t. a StyledConv's pre-activation runs one
+        # workgroup per 64 (128 output rows) or 128 pixels (the tail kernel: 1024) and sample; at most ~128 of them add into one copy
+        pad32 = lambda n: (n + 31) // 32 * 32                       # noqa: E731
+        convs = [i for i in info if i["kind"] < 2]
+        for k, i in enumerate(convs):
+            px = 1024 if k == len(convs) - 1 else (64 if i["Cout"] == 128 else 128)
+            wgs = (i["Ho"] * i["Wo"] + px - 1) // px * B
+            S = 1
+            while S < 16 and wgs > 128 * S:
+                S *= 2
+            i["S"], i["cpad"] = S, pad32(i["Cout"])
+        for k, i in enumerate(info):
+            if i["kind"] >= 2:
+                i["S"], i["cpad"] = info[k - 1]["S"], pad32(B * 3 * i["Cin"])
 
         # ---- workspace layout (floats)
         off = [0]
@@ -126,10 +147,11 @@ class GradPlan:
         amax1 = take(0)
         zero0 = take(0)
         for i in info:
-            i["o_d_wm"] = take(B * i["Cout"] * i["Cin"])
+            i["o_d_wm"] = take(B * i["Cout"] * i["Cin"]) if i["kind"] < 2 else take(i["S"] * i["cpad"])
+            i["o_d_bias_part"] = take(i["S"] * i["cpad"]) if (i["kind"] < 2 and i["S"] > 1) else None
         tot_cin = sum(i["Cin"] for i in info)
         o_ds_all = take(B * tot_cin)
-        self.nw_stride = max(i["Cout"] for i in info if i["kind"] < 2)
+        self.nw_stride = max(i["S"] * i["cpad"] for i in info if i["kind"] < 2)
         o_nw_parts = take(n_conv * self.nw_stride)
         out0 = take(0)                                     # ---- from here: what the backward returns (cloned once per step)
         for i in info:
@@ -208,6 +230,18 @@ class GradPlan:
         if len(mdescs) > 64 or len(bdescs) > 64:
             raise Unsupported("more than 64 table entries")
         self._mod_tab = _upload((_lib.ModulateDesc * len(mdescs))(*mdescs), device)
+        jobs, jblocks = [], 0
+        for i in info:
+            if i["S"] > 1:
+                j = SlotJob()
+                if i["kind"] < 2:
+                    j.src, j.dst, j.n = P(i["o_d_bias_part"]), P(i["o_d_bias"]), i["Cout"]
+                else:
+                    j.src, j.dst, j.n = P(i["o_d_wm"]), P(i["o_d_wm"]), B * 3 * i["Cin"]
+                j.slots, j.stride, j.row_begin = i["S"], i["cpad"], jblocks
+                jblocks += (j.n + 255) // 256
+                jobs.append(j)
+        self._slot_tab = _upload((SlotJob * len(jobs))(*jobs), device) if jobs else None
         self._modbwd_tab = _upload((ModBwdDesc * len(bdescs))(*bdescs), device)
 
         # ---- the plan struct
@@ -227,10 +261,19 @@ class GradPlan:
             p.drgb_lo[k] = P(o)
         p.rgb[0], p.rgb[1] = P(o_rgb[0]), P(o_rgb[1])
         p.nw_parts, p.nw_stride, p.d_noise_w = P(o_nw_parts), self.nw_stride, P(o_d_noise_w)
+        if self._slot_tab is not None:
+            p.slot_table, p.slot_n, p.slot_blocks = self._slot_tab.data_ptr(), len(jobs), jblocks
         for k, i in enumerate(info):
             L, m = p.layers[k], i["m"]
             L.kind, L.Cin, L.Cout, L.H, L.W = i["kind"], i["Cin"], i["Cout"], i["H"], i["W"]
             L.wm, L.d_wm, L.d_bias = P(i["o_wm"]), P(i["o_d_wm"]), P(i["o_d_bias"])
+            L.slots = i["S"]
+            if i["kind"] < 2:
+                L.slot_stride = i["cpad"]
+                if i["S"] > 1:
+                    L.d_bias = P(i["o_d_bias_part"])            # the copies; cips3d_slot_reduce writes their sum to o_d_bias
+            else:
+                L.rgb_slot_stride = i["cpad"]
             if i["kind"] < 2:
                 L.noise_index, L.flags = i["conv_i"], 1 if i["split"] else 0
                 L.bias, L.noise_w = m.activate.bias.data_ptr(), m.noise.weight.data_ptr()

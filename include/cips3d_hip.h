@@ -685,6 +685,11 @@ typedef struct cips3d_actbwd {
   float* d_bias;         /* [Cout] or NULL */
   float* d_noise_w;      /* [Cout] or NULL (needs `noise`) */
   float* d_rgb_w;        /* [B,3,Cout] or NULL */
+  /* Slotted accumulators.  The L2 executes atomics per cache line and instruction: at 256^2 a row's accumulator line would
+   * take one add from each of ~2000 workgroups, ~50 ns apiece (measured: 108 us for a 40 us GEMM).  With slots = S (a power
+   * of two, 0 / 1 = none) workgroup w adds into copy w % S: d_bias / d_noise_w copy s at + s * slot_stride floats, d_rgb_w
+   * copy s at + s * rgb_slot_stride floats; the caller sums the copies (cips3d_slot_reduce). */
+  int32_t slots, slot_stride, rgb_slot_stride, pad_;
 } cips3d_actbwd;
 int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float* dpre, int B, int Cin, int Cout, int64_t HW, int flags,
                              const cips3d_actbwd* ab, const float* noise, int64_t noise_bstride, const cips3d_range* rg,
@@ -694,7 +699,14 @@ int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float* dpre, int
  * dpre = (g_in + rgb_w^T drgb) * lrelu'(y), same reductions as cips3d_actbwd; g_in may be NULL.  out_amax: amax row or NULL. */
 int cips3d_act_tail_bwd(const float* g_in, const float* y, const float* rgb_w, const float* drgb, const float* noise,
                         int64_t noise_bstride, float* dpre, float* d_bias, float* d_noise_w, float* d_rgb_w, float* out_amax,
-                        int B, int C, int64_t HW, void* stream);
+                        int B, int C, int64_t HW, int slots, int slot_stride, int rgb_slot_stride, void* stream);
+/* dst[i] = sum_{s < S} src[s * stride + i] for a table of jobs in one launch (dst may be src: copy 0 then holds the sum) */
+typedef struct cips3d_slot_job {
+  const float* src; float* dst;
+  int32_t n, slots, stride;
+  int32_t row_begin;     /* exclusive prefix sum of ceil(n / 256) (workgroups) over the table */
+} cips3d_slot_job;
+int cips3d_slot_reduce(const cips3d_slot_job* table_dev, int n_jobs, int total_blocks, void* stream);
 /* Transpose of the 2x FIR up-sampler (upfirdn2d up = 2, pad = (2, 1), 4 x 4 taps; op/upfirdn2d.py:20-143 reaches it through
  * upfirdn2d with swapped factors): g_hi [B,C,2H,2W] -> g_lo [B,C,H,W]; out_amax: per-sample amax rows of g_lo or NULL. */
 int cips3d_up2_fir_bwd(const float* g_hi, const float* fir, float* g_lo, float* out_amax, int B, int C, int H, int W,
@@ -739,6 +751,9 @@ typedef struct cips3d_grad_layer {
   float* d_wm;             /* [B,Cout,Cin] gradient of the modulated weights      (inside plan->zero_base .. + zero_bytes) */
   float* d_bias;           /* [Cout] / [3]                                         (same region) */
   float* d_nw_part;        /* StyledConv: row of plan->nw_parts                    (same region) */
+  /* slotted accumulators (cips3d_actbwd): copies of d_bias / d_nw_part at + s * slot_stride, of d_wm (ToRGB: the
+   * accumulators of the epilogue that reads this ToRGB's input) at + s * rgb_slot_stride; slots <= 1: none */
+  int32_t slots, slot_stride, rgb_slot_stride, pad2_;
 } cips3d_grad_layer;
 
 typedef struct cips3d_decoder_grad_plan {
@@ -763,7 +778,9 @@ typedef struct cips3d_decoder_grad_plan {
   float* g_lo;                                /* FIR-transposed gradient of an up-sampling layer (largest one) */
   float* drgb_lo[4];                          /* gradient images of the skip chain below the output resolution */
   float* rgb[2];                              /* intermediate rgb images */
-  const float* nw_parts; int32_t nw_stride, pad2_;    /* [n StyledConvs][nw_stride] per-channel noise-weight partials */
+  const float* nw_parts; int32_t nw_stride, pad2_;    /* [n StyledConvs][nw_stride] noise-weight partials (all slots of a row) */
+  const cips3d_slot_job* slot_table;          /* sums the slot copies of d_bias / ToRGB d_wm before they are used, or NULL */
+  int32_t slot_n, slot_blocks;
   float* d_noise_w;                           /* [n StyledConvs] or NULL */
   cips3d_grad_layer layers[CIPS3D_GRAD_MAX_LAYERS];
 } cips3d_decoder_grad_plan;
