@@ -186,7 +186,8 @@ _SIGS = {
     "cips3d_nerf_bwd_heads": (c_int, [c_f32p, c_f32p, c_int, c_int, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, C.c_void_p]),
     "cips3d_nerf_bwd_dot": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, C.c_void_p]),
     "cips3d_nerf_bwd_composite": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                          c_f32p, C.c_void_p]),
+                                          c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_row_dots": (c_int, [c_f32p, c_f32p, c_int, c_i64, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_nerf_bwd_film_grad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_nerf_bwd_camera": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -436,6 +436,20 @@ def film_table(renderer, styles):
     return torch.stack(rows, 1)
 
 
+def nerf_named_parameters(renderer):
+    """(name, parameter) of the renderer's own weights NerfRenderFn differentiates, in the order it takes them: layer weights
+    and biases, the two heads, sigmoid_beta -- everything of VolumeFeatureRenderer except the gamma / beta heads (film_table)."""
+    net = renderer.network
+    out = []
+    for l, layer in enumerate(net.pts_linears):
+        out += [(f"pts_linears.{l}.weight", layer.weight), (f"pts_linears.{l}.bias", layer.bias)]
+    out += [("views_linears.weight", net.views_linears.weight), ("views_linears.bias", net.views_linears.bias),
+            ("rgb_linear.weight", net.rgb_linear.weight), ("rgb_linear.bias", net.rgb_linear.bias),
+            ("sigma_linear.weight", net.sigma_linear.weight), ("sigma_linear.bias", net.sigma_linear.bias),
+            ("sigmoid_beta", renderer.sigmoid_beta)]
+    return out
+
+
 class NerfRenderFn(Function):
     """VolumeFeatureRenderer.render with gradients w.r.t. the camera pose and the FiLM table.  Forward = the fused kernel;
     backward = the fused recompute + backward kernels of csrc/nerf_bwd_fused.hip (the materialised sequence of
@@ -443,13 +457,18 @@ class NerfRenderFn(Function):
     (`optim_render_params: false` in the released inversion recipes, train_cips3d_compcars_v10.yaml:585)."""
 
     @staticmethod
-    def forward(ctx, renderer, cam_poses, focals, near, far, film, perturb_u, img_size, n_samples, static_viewdirs):
+    def forward(ctx, renderer, cam_poses, focals, near, far, film, perturb_u, img_size, n_samples, static_viewdirs, *params):
+        """params: nerf_parameters(renderer) when the renderer's own weights are optimised (`optim_render_params`,
+        models/projector_v10.py:848-872; the gamma / beta heads go through film_table) -- the backward then takes the
+        materialised route, which keeps every layer's activations and can contract them with the gradients."""
         # With the fused backward available the forward keeps what it needs (accumulator stash, per-point sdf / rgb logits):
         # the backward then does not run the forward again (hip.STASH_IN_FORWARD = 0: it does, and nothing is held meanwhile).
         if not renderer.with_sdf:        # fail here, not in backward: both backward kernels differentiate the sdf branch only
             raise NotImplementedError("with_sdf=False (raw density, nerf_utils.py:288-297) is forward-only on the HIP path")
+        ctx.n_params = len(params)
+        ctx.want_params = any(p.requires_grad for p in params)
         fwd = None
-        if hip.FUSED_NERF_BACKWARD and hip.STASH_IN_FORWARD and hip.nerf_backward_fused_supported(
+        if not ctx.want_params and hip.FUSED_NERF_BACKWARD and hip.STASH_IN_FORWARD and hip.nerf_backward_fused_supported(
                 renderer.hidden_dim, renderer.N_layers_renderer, img_size, n_samples):
             fwd = hip.nerf_forward_stash(cam_poses.shape[0], img_size, n_samples, renderer.hidden_dim,
                                          renderer.N_layers_renderer, cam_poses.device)
@@ -474,6 +493,14 @@ class NerfRenderFn(Function):
             dfeat = torch.zeros(B, H, img_size, img_size, device=cam_poses.device)
         if dthumb is None:
             dthumb = torch.zeros(B, 3, img_size, img_size, device=cam_poses.device)
+        if ctx.want_params:
+            dfilm, dcam, pg = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
+                                                layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float(),
+                                                need_params=True)
+            names = [n for n, _ in nerf_named_parameters(r)]
+            grads = tuple(pg[n].reshape(p.shape) if ctx.needs_input_grad[10 + i] else None
+                          for i, (n, (_, p)) in enumerate(zip(names, nerf_named_parameters(r))))
+            return (None, dcam, None, None, None, dfilm, None, None, None, None) + grads
         if hip.FUSED_NERF_BACKWARD and hip.nerf_backward_fused_supported(H, r.N_layers_renderer, img_size, n_samples):
             packed, _ = r._derived_buffers()
             dfilm, dcam = hip.nerf_backward_fused(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u,
@@ -483,4 +510,4 @@ class NerfRenderFn(Function):
         else:
             dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
                                             layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())
-        return None, dcam, None, None, None, dfilm, None, None, None, None
+        return (None, dcam, None, None, None, dfilm, None, None, None, None) + (None,) * ctx.n_params

@@ -208,7 +208,8 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
                                                         const float* __restrict__ dthumb,
                                                         const float* __restrict__ sigmoid_beta, float* __restrict__ w,
                                                         float* __restrict__ Tbuf, float* __restrict__ dsdf,
-                                                        float* __restrict__ dcrgb, float* __restrict__ ddnorm) {
+                                                        float* __restrict__ dcrgb, float* __restrict__ ddnorm,
+                                                        float* __restrict__ dbeta_ray) {
   const int b = blockIdx.y;
   const int R = G.img_size * G.img_size;
   const int ray = blockIdx.x * 256 + threadIdx.x;
@@ -235,6 +236,7 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
   float* dcp = dcrgb + (int64_t)b * 3 * P + ray;
   float S = 0.f;      // sum_{j>k} w_j G_j
   float dn = 0.f;     // d loss / d |rays_d|  (delta_k = dz_k * |rays_d|)
+  float dbt = 0.f;    // d loss / d sigmoid_beta of this ray: sigma = s / beta, s = sigmoid(-sdf / beta)
   for (int k = N - 1; k >= 0; --k) {
     const int64_t o = (int64_t)k * R;
     const float dz = (k < N - 1 ? r.z(k + 1) - r.z(k) : 1e10f);
@@ -251,11 +253,42 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
     const float dsigma = dalpha * delta * e;
     dn = fmaf(dalpha * sigma * e, dz, dn);
     dsdf[(int64_t)b * P + ray + o] = dsigma * (-sg * (1.f - sg) / (beta * beta));
+    dbt = fmaf(dsigma, (sg * (1.f - sg) * sp[o] / beta - sg) / (beta * beta), dbt);
     dcp[o] = 2.f * wk * d0 * s0 * (1.f - s0);
     dcp[P + o] = 2.f * wk * d1 * s1 * (1.f - s1);
     dcp[2 * P + o] = 2.f * wk * d2 * s2 * (1.f - s2);
   }
   ddnorm[(int64_t)b * R + ray] = dn;
+  if (dbeta_ray) dbeta_ray[(int64_t)b * R + ray] = dbt;
+}
+
+// ---------------------------------------------------------------------------------------------- row dots (renderer-weight gradients)
+// out[row][c] += sum_{b,p} a[b][row][p] * x[b][c][p mod Px]  (c < nx <= 3),   out[row][3] += sum_{b,p} a[b][row][p]
+// The narrow weight gradients of the point MLP: the first layer (x = normalised points), the view-direction columns of the
+// view layer (x = per-ray directions, Px = R), the rgb / sigma heads (rows = features, x = d logits) and every bias.
+// grid (ceil(P / 1024), rows, B); one atomic per (row, column) and workgroup.
+__global__ void __launch_bounds__(256) row_dots_kernel(const float* __restrict__ a, const float* __restrict__ x, int nx,
+                                                       int64_t Px, float* __restrict__ out, int rows, int64_t P) {
+  __shared__ float sh[4];
+  const int row = blockIdx.y, b = blockIdx.z;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p0 < P) {
+    const float4 v = *reinterpret_cast<const float4*>(a + ((int64_t)b * rows + row) * P + p0);
+    acc[3] = (v.x + v.y) + (v.z + v.w);
+    for (int c = 0; c < nx; ++c) {
+      const float4 t = *reinterpret_cast<const float4*>(x + ((int64_t)b * nx + c) * Px + p0 % Px);   // Px % 4 == 0
+      acc[c] = fmaf(v.w, t.w, fmaf(v.z, t.z, fmaf(v.y, t.y, v.x * t.x)));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float t = wave_sum(acc[c]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0 && (c == 3 || c < nx)) unsafeAtomicAdd(out + row * 4 + c, (sh[0] + sh[1]) + (sh[2] + sh[3]));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- FiLM backward
@@ -473,13 +506,23 @@ extern "C" int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H
 
 extern "C" int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* G, const float* sdf, const float* crgb, const float* g,
                                          const float* dthumb, const float* sigmoid_beta, float* w, float* T_scratch,
-                                         float* dsdf, float* dcrgb, float* ddnorm, void* stream) {
+                                         float* dsdf, float* dcrgb, float* ddnorm, float* dbeta_ray, void* stream) {
   if (!geom_ok(G) || !sdf || !crgb || !g || !dthumb || !sigmoid_beta || !w || !T_scratch || !dsdf || !dcrgb || !ddnorm)
     return CIPS3D_E_BADARG;
   if (G->B == 0) return 0;
   const int R = G->img_size * G->img_size;
   hipLaunchKernelGGL(composite_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, as_stream(stream), *G, sdf,
-                     crgb, g, dthumb, sigmoid_beta, w, T_scratch, dsdf, dcrgb, ddnorm);
+                     crgb, g, dthumb, sigmoid_beta, w, T_scratch, dsdf, dcrgb, ddnorm, dbeta_ray);
+  return cips3d_launch_status();
+}
+
+extern "C" int cips3d_nerf_bwd_row_dots(const float* a, const float* x, int nx, int64_t Px, float* out, int B, int rows,
+                                        int64_t P, void* stream) {
+  if (!a || !out || B < 0 || rows <= 0 || P <= 0 || nx < 0 || nx > 3 || (nx > 0 && (!x || Px <= 0))) return CIPS3D_E_BADARG;
+  if (P % 4 || (nx > 0 && (Px % 4 || P % Px))) return CIPS3D_E_UNSUPP;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(row_dots_kernel, dim3((unsigned)ceil_div<int64_t>(P, 1024), (unsigned)rows, (unsigned)B), dim3(256), 0,
+                     as_stream(stream), a, x, nx, nx > 0 ? Px : 4, out, rows, P);
   return cips3d_launch_status();
 }
 

@@ -891,7 +891,7 @@ int launch_fused(const FusedArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((nerf_stash_kernel<NT, TPS>), dim3(wgs), dim3(WAVES * 64), lds_a, st, a);
   if (int rc = cips3d_launch_status()) return rc;
   if (int rc = cips3d_nerf_bwd_composite(&G, a.sdf, a.crgb, a.g, P.d_thumb, P.sigmoid_beta, a.wts, a.Tb, a.dsdf, a.dcrgb,
-                                         a.ddnorm, st))
+                                         a.ddnorm, nullptr, st))
     return rc;
   hipLaunchKernelGGL((nerf_bwd_kernel<NT, TPS>), dim3(wgs), dim3(WAVES * 64), lds_b, st, a);
   return cips3d_launch_status();

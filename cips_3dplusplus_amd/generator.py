@@ -231,16 +231,19 @@ class Generator(nn.Module):
             if torch.is_grad_enabled():
                 ins = [cam_poses, style_render, style_decoder] + list(noise_bufs or [])
                 differentiable = (any(torch.is_tensor(t) and t.requires_grad for t in ins)
-                                  or any(p.requires_grad for p in self.decoder.parameters()))
+                                  or any(p.requires_grad for p in self.decoder.parameters())
+                                  or any(p.requires_grad for p in self.renderer.parameters()))
         if differentiable:
             if not torch.is_grad_enabled():
                 raise RuntimeError("differentiable=True under torch.no_grad()")
-            frozen = [n for mod in ("renderer", "style", "style_decoder")
+            # the renderer's weights may be optimised (`optim_render_params`, projector_v10.py:848-872, 968); the two mapping
+            # networks may not: the inversion loop never runs them (it optimises W+ directly)
+            frozen = [n for mod in ("style", "style_decoder")
                       for n, p in getattr(self, mod).named_parameters(prefix=mod) if p.requires_grad]
             if frozen:
                 raise NotImplementedError(
-                    f"{len(frozen)} renderer / mapping-network parameters require grad (first: {frozen[0]}): their gradients "
-                    "are not implemented (the released inversion recipes keep them constant); call "
+                    f"{len(frozen)} mapping-network parameters require grad (first: {frozen[0]}): their gradients "
+                    "are not implemented (the inversion recipes optimise W+ styles, not the mapping networks); call "
                     "`G.requires_grad_(False); G.decoder.requires_grad_(True)` as projector_v10.py does, or run under "
                     "torch.no_grad()")
             return self._forward_grad(**kw)
@@ -275,9 +278,12 @@ class Generator(nn.Module):
 
         static = bool(nerf_cfg.get("static_viewdirs", False))
         film = AG.film_table(self.renderer, style_render)
+        rparams = [p for _, p in AG.nerf_named_parameters(self.renderer)]
+        if not any(p.requires_grad for p in rparams):
+            rparams = []
         features, thumb, xyz, mask = AG.NerfRenderFn.apply(
             self.renderer, cam_poses.float(), per_view(focals), per_view(near), per_view(far), film,
-            None if perturb_u is None else perturb_u.detach(), img_size, N, static)
+            None if perturb_u is None else perturb_u.detach(), img_size, N, static, *rparams)
         if self.renderer_detach if renderer_detach is None else renderer_detach:
             features = features.detach()                                    # model_v3.py:1016-1017
         rgb = AG.decoder_forward(self.decoder, features, style_decoder, noise_bufs)

@@ -914,8 +914,11 @@ def camera_params_bwd(locations, dextr, up=None):
 
 
 def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, film, layer_bias, img_size, n_samples,
-                  static_viewdirs, d_features, d_thumb):
-    """The materialised NeRF backward (see csrc/nerf_bwd.hip): returns (dfilm [B,L,2,H], dcam [B,3,4]).
+                  static_viewdirs, d_features, d_thumb, need_params=False):
+    """The materialised NeRF backward (see csrc/nerf_bwd.hip): returns (dfilm [B,L,2,H], dcam [B,3,4]) -- and, with
+    need_params (`optim_render_params`, models/projector_v10.py:848-872), a dict of the gradients of the renderer's own
+    weights: pts_linears.{l}.weight / .bias, views_linears.weight / .bias, rgb_linear.*, sigma_linear.*, sigmoid_beta
+    (the gamma / beta heads get theirs from the FiLM table's backward).
 
     net = SirenGenerator (weights), film [B,L,2,H], layer_bias [L,H]; d_features [B,H,S,S], d_thumb [B,3,S,S]."""
     lib = _lib.load()
@@ -980,9 +983,38 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
 
     # ---- compositing backward
     wts, Tb, dsdf, dcrgb, ddnorm = new(B, P), new(B, P), new(B, P), new(B, 3, P), new(B, R)
+    dbeta_ray = new(B, R) if need_params else None
     check(lib.cips3d_nerf_bwd_composite(gp, dev_ptr(sdf), dev_ptr(crgb), dev_ptr(g), dev_ptr(dth), dev_ptr(sigmoid_beta),
-                                        dev_ptr(wts), dev_ptr(Tb), dev_ptr(dsdf), dev_ptr(dcrgb), dev_ptr(ddnorm), st),
-          "cips3d_nerf_bwd_composite")
+                                        dev_ptr(wts), dev_ptr(Tb), dev_ptr(dsdf), dev_ptr(dcrgb), dev_ptr(ddnorm),
+                                        dev_ptr(dbeta_ray, "dbeta_ray", True), st), "cips3d_nerf_bwd_composite")
+
+    # ---- gradients of the renderer's own weights (optional): the wide blocks W_l [H,H] on the split-fp16 weight-gradient
+    # GEMM (contraction over the points), everything narrow -- biases, the first layer, the view-direction columns, the heads
+    # -- as row dots
+    pg = {}
+
+    def row_dots(a, rows, Pa, x=None, nx=0, Px=0):
+        out = torch.zeros(rows, 4, device=dev)
+        check(lib.cips3d_nerf_bwd_row_dots(dev_ptr(a), dev_ptr(x, "x", True), nx, Px, dev_ptr(out), B, rows, Pa, st),
+              "cips3d_nerf_bwd_row_dots")
+        return out
+
+    def wide(dp, h):                 # sum_b dp[b] h[b]^T
+        if H % 32 or P % 32:
+            return gemm_wgrad(dp, h).sum(0)
+        acc = torch.zeros(1, H, H, device=dev)
+        am = absmax(dp)
+        for b in range(B):
+            gemm_wgrad_split(dp[b:b + 1], h[b:b + 1], am[b:b + 1], sine_amax[:1], out=acc)
+        return acc[0]
+
+    if need_params:
+        t = row_dots(f, H, P, dcrgb, 3, P)
+        pg["rgb_linear.weight"] = t[:, :3].t().contiguous()
+        pg["rgb_linear.bias"] = row_dots(dcrgb, 3, P)[:, 3].contiguous()
+        pg["sigma_linear.weight"] = row_dots(h_last, H, P, dsdf, 1, P)[:, :1].t().contiguous()
+        pg["sigma_linear.bias"] = row_dots(dsdf, 1, P)[:, 3].contiguous()
+        pg["sigmoid_beta"] = row_dots(dbeta_ray, 1, R)[:, 3].contiguous()
 
     # ---- MLP backward
     dfilm = torch.zeros(B, L, 2, H, device=dev)
@@ -994,6 +1026,10 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
     dvd_pt = new(B, 3, P)
     check(lib.cips3d_nerf_bwd_heads(dev_ptr(dpre), w_view.data_ptr() + 4 * H, 1, H + 3, None, 3, B, H, P, dev_ptr(dvd_pt), st),
           "cips3d_nerf_bwd_heads")
+    if need_params:                                        # the view layer: [h_{D-1} | view direction] -> H
+        t = row_dots(dpre, H, P, viewdirs, 3, R)
+        pg["views_linears.weight"] = torch.cat([wide(dpre, hh[D - 1]), t[:, :3]], 1)
+        pg["views_linears.bias"] = t[:, 3].contiguous()
     for l in range(D, 0, -1):
         dh = gemm(dpre, packed_t[l - 1])                  # gradient w.r.t. h_{l-1}
         first = l == D                                     # h_{D-1} also feeds the sigma head
@@ -1001,13 +1037,23 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
                                             dev_ptr(net.sigma_linear.weight) if first else None,
                                             dev_ptr(dsdf) if first else None, None, None, None, None, dfilm_l(l - 1), B, H, R,
                                             P, st), "cips3d_nerf_bwd_film_grad")
-        dpre = dh
+        dpre = dh                                          # now d(pre_{l-1})
+        if need_params:
+            if l - 1 >= 1:
+                pg[f"pts_linears.{l - 1}.weight"] = wide(dpre, hh[l - 2])
+                pg[f"pts_linears.{l - 1}.bias"] = row_dots(dpre, H, P)[:, 3].contiguous()
+            else:
+                t = row_dots(dpre, H, P, ptsn, 3, P)
+                pg["pts_linears.0.weight"] = t[:, :3].contiguous()
+                pg["pts_linears.0.bias"] = t[:, 3].contiguous()
     dptsn = new(B, 3, P)
     check(lib.cips3d_nerf_bwd_heads(dev_ptr(dpre), dev_ptr(w_first), 1, 3, None, 3, B, H, P, dev_ptr(dptsn), st),
           "cips3d_nerf_bwd_heads")
     dcam = new(B, 3, 4)
     check(lib.cips3d_nerf_bwd_camera(gp, dev_ptr(dptsn), dev_ptr(dvd_pt), dev_ptr(ddnorm), dev_ptr(dcam), st),
           "cips3d_nerf_bwd_camera")
+    if need_params:
+        return dfilm, dcam, pg
     return dfilm, dcam
 
 

@@ -88,12 +88,14 @@ class FlipProjector:
             groups.append({"params": [azim, elev], "lr": lr_cam, "initial_lr": lr_cam, "betas": (0.9, 0.999)})
         return azim, elev, _adam(groups) if groups else None
 
-    def _render_optimizer(self, G, mean_r, optim_render_w, lr_render_w, bs):
+    def _render_optimizer(self, G, mean_r, optim_render_w, lr_render_w, bs, optim_render_params=False):
         w = mean_r.detach().reshape(1, 1, -1).repeat(bs, G.N_layers_renderer + 1, 1).contiguous()
         groups = []
         if optim_render_w:
             w = nn.Parameter(w)
             groups.append({"params": [w], "lr": lr_render_w, "initial_lr": lr_render_w, "betas": (0.9, 0.999)})
+        if optim_render_params:                          # projector_v10.py:866-872 (lr fixed at 1e-4 there)
+            groups.append({"params": list(G.renderer.parameters()), "lr": 0.0001, "initial_lr": 0.0001, "betas": (0.9, 0.999)})
         return w, _adam(groups) if groups else None
 
     def _decoder_optimizer(self, G, mean_d, optim_decoder_w, optim_decoder_params, optim_noise_bufs, zero_noise_bufs,
@@ -128,17 +130,19 @@ class FlipProjector:
         return r["rgb"], r["thumb_rgb"], r["mask"]
 
     def project_wplus(self, cam_cfg, nerf_cfg, loss_fn, N_steps_pose=200, N_steps_app=0, optim_cam=True, optim_render_w=True,
-                      optim_decoder_w=True, optim_decoder_params=True, optim_noise_bufs=False, zero_noise_bufs=True,
+                      optim_render_params=False, optim_decoder_w=True, optim_decoder_params=True, optim_noise_bufs=False, zero_noise_bufs=True,
                       bs_cam=2, bs_render=1, bs_decoder=2, lr_cam=0.02, lr_render_w=0.001, lr_decoder_w=0.01,
                       lr_decoder_params=0.005, lr_noise=0.001, truncation_psi=1.0, flip_w_decoder_every=10,
                       azim_init=(0.0, 0.0), w_avg_samples=10000, regularize_noise_weight=1e5, on_step=None):
         """Returns the dict `checkpoint.save_inversion` writes (azim, elev, W+ styles, state dicts, noise)."""
         G = copy.deepcopy(self.G).eval().requires_grad_(False).to(self.device)
+        if optim_render_params:                              # projector_v10.py:967-968
+            G.renderer.requires_grad_(True)
         G.decoder.requires_grad_(True)
         with torch.no_grad():
             mean_r, mean_d = G.get_mean_latent(w_avg_samples, self.device)
         azim, elev, opt_cam = self._cam_optimizer(optim_cam, lr_cam, list(azim_init), bs_cam)
-        w_render, opt_render = self._render_optimizer(G, mean_r, optim_render_w, lr_render_w, bs_render)
+        w_render, opt_render = self._render_optimizer(G, mean_r, optim_render_w, lr_render_w, bs_render, optim_render_params)
         w_decoder, noise_bufs, opt_dec = self._decoder_optimizer(
             G, mean_d, optim_decoder_w, optim_decoder_params, optim_noise_bufs, zero_noise_bufs, lr_decoder_w,
             lr_decoder_params, lr_noise, bs_decoder, cam_cfg["img_size"])

@@ -849,7 +849,12 @@ int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H, int R, in
  * sample spacing); T_scratch [B,P]. */
 int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* geom, const float* sdf, const float* crgb, const float* g,
                               const float* dthumb, const float* sigmoid_beta, float* w, float* T_scratch, float* dsdf,
-                              float* dcrgb, float* ddnorm, void* stream);
+                              float* dcrgb, float* ddnorm, float* dbeta_ray, void* stream);
+/* (dbeta_ray [B,R] or NULL: per-ray d loss / d sigmoid_beta, for `optim_render_params`, models/projector_v10.py:848-872)
+ * out[row][c] += sum_{b,p} a[b][row][p] * x[b][c][p mod Px] (c < nx <= 3), out[row][3] += sum_{b,p} a[b][row][p]; a [B,rows,P],
+ * x [B,nx,Px], out [rows,4] zeroed by the caller: the narrow weight gradients and the biases of the point MLP. */
+int cips3d_nerf_bwd_row_dots(const float* a, const float* x, int nx, int64_t Px, float* out, int B, int rows, int64_t P,
+                             void* stream);
 /* FiLM-sine backward, in place on buf [B,H,P]:
  *   mode 0: buf = dh (+ w_sigma[c]*dsdf[p] when w_sigma != NULL)            -> buf = d(pre)
  *   mode 1: upstream = weights[p]*dF[c][ray] + sum_r w_rgb[r][c]*dcrgb[r][p] -> buf = d(pre)   (buf's old content unused)

@@ -235,6 +235,68 @@ def test_nerf_render_bwd_vs_oracle(D, static, perturb, N, S):
     close(cg.grad, cr.grad, 3e-4, "dcam_poses")
 
 
+@pytest.mark.parametrize("D,static,perturb,N,S", [(2, False, False, 8, 8), (3, True, True, 8, 12)])
+def test_renderer_weight_gradients_vs_oracle(D, static, perturb, N, S):
+    """`optim_render_params` (projector_v10.py:848-872, 968): gradients of EVERY renderer parameter -- layer weights and biases,
+    the view layer's direction columns, the rgb / sigma heads, sigmoid_beta (NerfRenderFn, materialised backward) and the
+    gamma / beta heads (film_table) -- against torch autograd through the CPU oracle on the same inputs."""
+    cfg = configs.tiny_G_cfg(32, D, 1)
+    G = pkg.build_generator(cfg, DEV, seed=4)
+    g = torch.Generator().manual_seed(D + N)
+    with torch.no_grad():
+        for p in G.renderer.parameters():                  # a zero bias hides a wrong bias gradient
+            if p.abs().max() == 0:
+                p.copy_(0.05 * torch.randn(p.shape, generator=g))
+    sd = {k: leaf(v.detach().cpu()) if k.startswith("renderer.") else v.detach().cpu() for k, v in G.state_dict().items()}
+    B, R, H = 2, S * S, 32
+    locs = torch.tensor([[0.25, 0.1], [-0.4, -0.05]])
+    cam = O.camera_params(locs, S, 6, 0.12)
+    styles = 0.5 * torch.randn(B, D + 1, 32, generator=g)
+    u = torch.rand(B, S, S, 1, generator=g) if perturb else None
+    tF, tT = torch.randn(B, H, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
+    rays_o, rays_d, viewdirs = O.rays_in_world(cam[1], S, cam[0], static)
+    z = O.z_vals(cam[2], cam[3], B, S, S, N, u)
+    pts = O.ray_points(rays_o, rays_d, z)
+    thumb, feat, sdf, mask, xyz = O.renderer_forward(sd, "renderer", pts.reshape(B, R, N, 3), rays_d.reshape(B, R, 3),
+                                                     viewdirs.reshape(B, R, 3), z.reshape(B, R, N), cam[2], cam[3], styles, D)
+    to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S)
+    ((to_img(feat) * tF).sum() + 3.0 * (to_img(thumb) * tT).sum()).backward()
+    # HIP
+    G.requires_grad_(False)
+    G.renderer.requires_grad_(True)
+    film = AG.film_table(G.renderer, cu(styles))
+    rp = [p for _, p in AG.nerf_named_parameters(G.renderer)]
+    f_g, t_g, _, _ = AG.NerfRenderFn.apply(G.renderer, cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), film,
+                                           None if u is None else cu(u), S, N, static, *rp)
+    close(f_g, to_img(feat).detach(), 1e-4, "features")
+    ((f_g * cu(tF)).sum() + 3.0 * (t_g * cu(tT)).sum()).backward()
+    n = 0
+    for name, p in G.renderer.named_parameters():
+        ref = sd["renderer." + name].grad
+        assert ref is not None and p.grad is not None, name
+        close(p.grad, ref, 5e-4, name)
+        n += 1
+    assert n == 5 + 6 * (D + 1)
+
+
+def test_generator_optimises_renderer_parameters():
+    """Generator.forward accepts renderer parameters that require gradients (it raised before) and the projector's
+    `optim_render_params` switch moves them."""
+    from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=2)
+    g = torch.Generator(device=DEV).manual_seed(0)
+    t_rgb = torch.randn(2, 3, 32, 32, device=DEV, generator=g).clamp(-1, 1)
+    t_thumb = torch.randn(2, 3, 8, 8, device=DEV, generator=g).clamp(-1, 1)
+    before = {k: v.detach().clone() for k, v in G.renderer.state_dict().items()}
+    out = FlipProjector(G, DEV).project_wplus({"img_size": 8, "fov_ang": 6, "dist_radius": 0.12},
+                                             {"N_samples": 6, "perturb": False, "static_viewdirs": True},
+                                             surrogate_loss(t_rgb, t_thumb), N_steps_pose=6, N_steps_app=0, w_avg_samples=64,
+                                             optim_render_params=True)
+    moved = [k for k, v in out["render_state_dict"].items() if not torch.equal(v, before[k])]
+    assert len(moved) == len(before), sorted(set(before) - set(moved))
+    assert all(bool(torch.isfinite(v).all()) for v in out["render_state_dict"].values())
+
+
 @pytest.mark.parametrize("tag,D,static", [("h32_d2", 2, True), ("h32_d3", 3, False)])
 def test_generator_backward_golden(golden, tag, D, static):
     """One inversion-like step: loss and every gradient vs the imported reference (tests/golden/backward.npz)."""
@@ -271,7 +333,7 @@ def test_generator_backward_golden(golden, tag, D, static):
 
 def test_path_selection_by_grad_requirements():
     """Plain inference (frozen handle, or torch.no_grad()) runs the fused no-graph path; decoder parameters that require
-    grad select the differentiable path even when no input does; renderer parameters that require grad raise."""
+    grad select the differentiable path even when no input does; so do renderer parameters; mapping-network parameters raise."""
     from cips_3dplusplus_amd.camera import Camera
     G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=1)
     assert not any(p.requires_grad for p in G.parameters())
@@ -290,8 +352,13 @@ def test_path_selection_by_grad_requirements():
     close(r1["rgb"], r["rgb"].cpu(), 1e-5, "rgb on the two paths")
     r1["rgb"].square().mean().backward()
     assert G.decoder.conv1.conv.weight.grad is not None and float(G.decoder.conv1.conv.weight.grad.abs().max()) > 0
-    G.renderer.requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="renderer"):
+    G.renderer.requires_grad_(True)                     # optim_render_params: the renderer's weights get gradients too
+    r2 = G(**kw)
+    (r2["rgb"].square().mean() + r2["thumb_rgb"].square().mean()).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in G.renderer.parameters())
+    assert float(G.renderer.network.pts_linears[0].weight.grad.abs().max()) > 0
+    G.style.requires_grad_(True)                        # the mapping networks stay constants
+    with pytest.raises(NotImplementedError, match="mapping-network"):
         G(**kw)
     with torch.no_grad():
         G(**kw)                                          # inference is unaffected
