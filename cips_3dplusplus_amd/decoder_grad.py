@@ -290,7 +290,8 @@ class GradPlan:
 
     @staticmethod
     def weights_key(dec):
-        return tuple(p.data_ptr() for p in parameters_of(dec)) + tuple(bool(getattr(m, "split", True)) for m, _ in dec._mod_layers())
+        return tuple(p.data_ptr() for p in parameters_of(dec)) + \
+            tuple((bool(getattr(m, "split", True)), bool(getattr(m, "bf16", False))) for m, _ in dec._mod_layers())
 
     def _io(self, features, noise):
         io = DecoderGradIO()

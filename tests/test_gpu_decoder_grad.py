@@ -74,11 +74,12 @@ def test_dgrad_with_activation_backward_epilogue(B, Cin, Cout, S, split, rgb, pe
         assert _rel(d_rgb_w, wref) < 2e-5
 
 
-def _decoder_case(cfg_fn, res, S0, B, seed):
+def _decoder_case(cfg_fn, res, S0, B, seed, precision="fp32", per_sample_noise=False):
     from cips_3dplusplus_amd import configs
     cfg = cfg_fn()
     G = pkg.build_generator(cfg, DEV, seed=seed)
     dec = G.decoder
+    dec.set_precision(precision)
     g = torch.Generator(device=DEV).manual_seed(seed)
     with torch.no_grad():
         for p in dec.parameters():                      # noise weights / biases start at zero: make every gradient path live
@@ -86,7 +87,7 @@ def _decoder_case(cfg_fn, res, S0, B, seed):
                 p.copy_(0.1 * torch.randn(p.shape, device=DEV, generator=g))
     feats = torch.randn(B, cfg["decoder_cfg"]["in_channel"], S0, S0, device=DEV, generator=g) * 0.5
     styles = torch.randn(B, dec.n_latent, dec.style_dim, device=DEV, generator=g)
-    noise = [torch.randn(*b.shape, device=DEV, generator=g) for b in G.create_noise_bufs(S0, DEV)]
+    noise = [torch.randn(B if per_sample_noise else 1, *b.shape[1:], device=DEV, generator=g) for b in G.create_noise_bufs(S0, DEV)]
     return dec, feats, styles, noise
 
 
@@ -141,3 +142,23 @@ def test_one_call_decoder_matches_the_per_op_route(name, res, S0, B):
     keep = [g.clone() for g in one[3]]
     _grads(dec, feats, styles * 0.5, noise, True, target)
     assert all(torch.equal(a, b) for a, b in zip(keep, one[3]))
+
+
+@pytest.mark.parametrize("precision,per_sample_noise,B", [("fp32_exact", False, 2), ("fp32", True, 2), ("fp32_exact", True, 4)])
+def test_one_call_decoder_other_modes(precision, per_sample_noise, B):
+    """The one-call node on the fp32 matrix instruction (`fp32_exact`: fp32 GEMMs and the fp32 weight-gradient kernel), with
+    per-sample noise maps, at batch 4 -- against the per-op route; the bf16 modes and batches above 4 are handed to that route."""
+    from cips_3dplusplus_amd import configs, decoder_grad
+    dec, feats, styles, noise = _decoder_case(lambda: configs.tiny_G_cfg(32, 2, 1), 32, 8, B, seed=9, precision=precision,
+                                              per_sample_noise=per_sample_noise)
+    assert decoder_grad.plan_for(dec, B, 8, 8, feats.device) is not None
+    target = torch.randn(B, 3, 32, 32, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    ref = _grads(dec, feats, styles, noise, False, target)
+    one = _grads(dec, feats, styles, noise, True, target)
+    assert _rel(one[0], ref[0].double().cpu()) < 2e-5
+    for a, b in list(zip(one[1:3], ref[1:3])) + list(zip(one[3], ref[3])):
+        assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9
+    dec.set_precision("bf16")
+    assert decoder_grad.plan_for(dec, B, 8, 8, feats.device) is None            # key changed: re-planned, refused
+    dec.set_precision("fp32")
+    assert decoder_grad.plan_for(dec, 5, 8, 8, feats.device) is None
