@@ -8,6 +8,7 @@ buffers that require gradients, batches above 4).  The plan (device pointers int
 is built once per (batch, input size) and re-made when a parameter is re-allocated.
 """
 import ctypes as C
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -342,8 +343,13 @@ class GradPlan:
         return d_features, v(self.o_d_styles, self.B, dec.n_latent, sd), grads
 
 
+# plans live beside the modules, not inside them: copy.deepcopy(G) (the projector's first step) must neither copy raw device
+# pointers of the original's parameters nor trip over ctypes structures
+_PLANS = weakref.WeakKeyDictionary()
+
+
 def plan_for(dec, B, H0, W0, device):
-    plans = dec.__dict__.setdefault("_grad_plans", {})
+    plans = _PLANS.setdefault(dec, {})
     key = (B, H0, W0, str(device))
     ent = plans.get(key)
     if ent is None or (ent is not False and ent.key != GradPlan.weights_key(dec)):

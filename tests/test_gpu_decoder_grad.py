@@ -158,6 +158,10 @@ def test_one_call_decoder_other_modes(precision, per_sample_noise, B):
     assert _rel(one[0], ref[0].double().cpu()) < 2e-5
     for a, b in list(zip(one[1:3], ref[1:3])) + list(zip(one[3], ref[3])):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9
+    import copy
+    twin = copy.deepcopy(dec)                      # (the projector's first step) the copy plans for its own parameters
+    two = _grads(twin, feats, styles, noise, True, target)
+    assert torch.equal(two[0], one[0]) and decoder_grad.plan_for(twin, B, 8, 8, feats.device) is not decoder_grad.plan_for(dec, B, 8, 8, feats.device)
     dec.set_precision("bf16")
     assert decoder_grad.plan_for(dec, B, 8, 8, feats.device) is None            # key changed: re-planned, refused
     dec.set_precision("fp32")
