@@ -370,12 +370,18 @@ class DecoderFn(Function):
         features = features.contiguous().float()
         rgb = plan.forward(features, styles.contiguous().float(), noise)
         ctx.plan, ctx.n_noise, ctx.n_params = plan, n_noise, len(rest) - n_noise
+        plan.generation = ctx.generation = getattr(plan, "generation", 0) + 1      # the kept activations belong to THIS forward
         ctx.save_for_backward(features, *noise)
         return rgb
 
     @staticmethod
     def backward(ctx, d_rgb):
         features, *noise = ctx.saved_tensors
+        if ctx.generation != ctx.plan.generation:
+            raise RuntimeError(
+                "DecoderFn.backward: the decoder ran forward again (same batch and size) before this graph's backward -- the "
+                "one-call plan keeps ONE forward's activations.  Run backward before the next forward, or set "
+                "CIPS3D_ONE_CALL_DECODER=0 (one autograd node per op, every graph keeps its own tensors)")
         d_features, d_styles, grads = ctx.plan.backward(features, noise, d_rgb.contiguous().float(),
                                                         need_features=ctx.needs_input_grad[2])
         need = ctx.needs_input_grad[5 + ctx.n_noise:]

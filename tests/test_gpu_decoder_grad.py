@@ -158,6 +158,14 @@ def test_one_call_decoder_other_modes(precision, per_sample_noise, B):
     assert _rel(one[0], ref[0].double().cpu()) < 2e-5
     for a, b in list(zip(one[1:3], ref[1:3])) + list(zip(one[3], ref[3])):
         assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-9
+    # two graphs alive at once: the plan keeps ONE forward's activations -- the older graph's backward fails loudly
+    from cips_3dplusplus_amd import autograd as AG
+    s1 = styles.clone().requires_grad_(True)
+    r1 = AG.decoder_forward(dec, feats, s1, noise)
+    r2 = AG.decoder_forward(dec, feats, styles.clone().requires_grad_(True), noise)
+    with pytest.raises(RuntimeError, match="ran forward again"):
+        r1.sum().backward()
+    r2.sum().backward()
     import copy
     twin = copy.deepcopy(dec)                      # (the projector's first step) the copy plans for its own parameters
     two = _grads(twin, feats, styles, noise, True, target)
