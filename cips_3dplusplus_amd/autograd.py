@@ -53,27 +53,25 @@ def linear(x, W, bias=None, w_scale=1.0, b_scale=1.0, lrelu=False, act_gain=1.0,
 
 
 class ModulateFn(Function):
-    """ModulatedConv2d weight modulation (k = 1): W [1,Cout,Cin,1,1], s [B,Cin] -> wm [B,Cout,Cin]."""
+    """ModulatedConv2d weight modulation: W [1,Cout,Cin,k,k], s [B,Cin] -> wm [B,Cout,Cin] (k = 1) or [B,Cout,Cin,k,k]."""
 
     @staticmethod
     def forward(ctx, W, s, scale, demodulate, pre=None):
         """pre: this layer's wm when every layer was modulated by one table launch (modulate_all); the node then only
         records the dependency."""
         _, Cout, Cin, kh, kw = W.shape
-        if kh * kw != 1:
-            raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
         s = _c(s)
         if pre is None:
-            pre = hip.modulate_weights(W, s, s.shape[1], s.shape[0], Cout, Cin, 1, scale, demodulate, packed=False)
+            pre = hip.modulate_weights(W, s, s.shape[1], s.shape[0], Cout, Cin, kh * kw, scale, demodulate, packed=False)
         ctx.save_for_backward(W, s)
-        ctx.cfg = (Cout, Cin, scale, demodulate)
-        return pre.view(s.shape[0], Cout, Cin)
+        ctx.cfg = (Cout, Cin, kh * kw, scale, demodulate)
+        return pre.view(s.shape[0], Cout, Cin) if kh * kw == 1 else pre.view(s.shape[0], Cout, Cin, kh, kw)
 
     @staticmethod
     def backward(ctx, dwm):
         W, s = ctx.saved_tensors
-        Cout, Cin, scale, demodulate = ctx.cfg
-        dW, ds = hip.modulate_bwd(dwm.contiguous().clone(), W, s, Cout, Cin, 1, scale, demodulate,
+        Cout, Cin, ksq, scale, demodulate = ctx.cfg
+        dW, ds = hip.modulate_bwd(dwm.contiguous().clone(), W, s, Cout, Cin, ksq, scale, demodulate,
                                   need_dW=ctx.needs_input_grad[0])
         return dW, ds, None, None, None
 
@@ -112,6 +110,53 @@ class Conv1x1Fn(Function):
         if ctx.needs_input_grad[1]:
             dwm = hip.gemm_wgrad(dy, x)
         return dx, dwm, None, None, None
+
+
+class ConvKxKFn(Function):
+    """k x k modulated convolution (models/model_v3.py:280-312): cross-correlation with padding k // 2, or -- `up` -- the
+    stride-2 transposed convolution of the up-sampling branch (the blur that follows is op.upfirdn2d).  wm [B,Cout,Cin,k,k].
+    Forward = cips3d_modconv_kxk.  Backward = ONE data-gradient GEMM and k^2 weight-gradient GEMMs on the 1x1 kernels: the k^2
+    shifted (strided, for `up`) views of the output gradient are stacked along the channels, so that
+        dx = [W_tap^T]_taps . [dy_tap]_taps                (cips3d_modconv1x1, contraction over k^2 Cout)
+        dwm[..., tap] = dy_tap x^T  (up) / dy x_tap^T       (cips3d_gemm_wgrad, contraction over the pixels)
+    -- the shifts are copies (pad / slice), every multiply-add runs in a HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, x, wm, up):
+        x, wm = _c(x), _c(wm)
+        B, Cout, Cin, k, _ = wm.shape
+        if Cout % 32 or Cin % 32 or (x.shape[2] * x.shape[3]) % 4:
+            raise NotImplementedError("k x k backward needs channel counts that are multiples of 32 and H * W % 4 == 0")
+        ctx.save_for_backward(x, wm)
+        ctx.up = bool(up)
+        return hip.modconv_kxk(x, wm, Cout, k, transpose2=bool(up))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wm = ctx.saved_tensors
+        dy = _c(dy)
+        B, Cout, Cin, k, _ = wm.shape
+        H, W = x.shape[2:]
+        taps = [(ky, kx) for ky in range(k) for kx in range(k)]
+        pad = k // 2
+        if ctx.up:        # y[o][2y + ky][2x + kx] += x[i][y][x] w[o][i][ky][kx]
+            dys = [dy[:, :, ky:ky + 2 * H:2, kx:kx + 2 * W:2].contiguous() for ky, kx in taps]
+        else:             # y[o][Y][X] = sum x[i][Y + ky - pad][X + kx - pad] w[o][i][ky][kx]
+            dyp = torch.nn.functional.pad(dy, (pad, pad, pad, pad))
+            dys = [dyp[:, :, 2 * pad - ky:2 * pad - ky + H, 2 * pad - kx:2 * pad - kx + W].contiguous() for ky, kx in taps]
+        dx = dwm = None
+        if ctx.needs_input_grad[0]:
+            stacked = torch.cat(dys, 1)                                                   # [B, k^2 Cout, H, W]
+            w_all = wm.permute(0, 2, 3, 4, 1).reshape(B, Cin, k * k * Cout).contiguous()    # [B, Cin, (tap, o)]
+            dx = hip.modconv1x1(stacked, hip.pack_weights(w_all), Cin, epilogue=0)
+        if ctx.needs_input_grad[1]:
+            if ctx.up:
+                parts = [hip.gemm_wgrad(d, x) for d in dys]
+            else:
+                xp = torch.nn.functional.pad(x, (pad, pad, pad, pad))
+                parts = [hip.gemm_wgrad(dy, xp[:, :, ky:ky + H, kx:kx + W].contiguous()) for ky, kx in taps]
+            dwm = torch.stack(parts, -1).view(B, Cout, Cin, k, k)
+        return dx, dwm, None
 
 
 class Conv1x1ActFn(Function):
@@ -311,6 +356,14 @@ def styled_conv(sc, x, style, noise, s=None, pre=None):
     mod = conv.modulation
     if s is None:
         s = linear(style, mod.weight, mod.bias, w_scale=mod.scale, b_scale=mod.lr_mul)
+    if conv.kernel_size != 1:              # k x k: modulate -> ConvKxKFn [-> blur] -> noise + bias + activation
+        wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate, None)
+        y = ConvKxKFn.apply(x, wm, bool(conv.upsample))
+        if conv.upsample:
+            y = op.upfirdn2d(y, conv.blur.kernel, pad=conv.blur.pad)
+        if noise is None:
+            noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], device=y.device)
+        return NoiseBiasActFn.apply(y, noise, sc.noise.weight, sc.activate.bias)
     wm = ModulateFn.apply(conv.weight, s, conv.scale, conv.demodulate, pre[0] if pre else None)
     packed = pre[1] if (pre and x.shape[2] * x.shape[3] % 4 == 0) else None
     packed_t = pre[2] if (pre and packed is not None and len(pre) > 2) else None
@@ -338,9 +391,7 @@ def to_rgb(tr, x, style, skip, s=None, pre=None):
 
 def decoder_forward(dec, features, styles, noise=None):
     """Decoder.forward (models/model_v3.py:592-637) with gradients."""
-    if dec.kernel_size != 1:
-        raise NotImplementedError("backward is implemented for kernel_size = 1 (every released config)")
-    if ONE_CALL_DECODER and noise is not None:
+    if ONE_CALL_DECODER and noise is not None and dec.kernel_size == 1:
         # the whole decoder as one autograd node (csrc/decoder_grad.hip); None when the plan does not cover this call
         from . import decoder_grad
         rgb = decoder_grad.decoder_forward(dec, features, styles, list(noise))
@@ -354,7 +405,8 @@ def decoder_forward(dec, features, styles, noise=None):
     if STYLE_TABLE and dec.style_dim % 4 == 0:
         s_list = decoder_styles(dec, styles)
         S = {id(m): sl for (m, _), sl in zip(seq, s_list)}
-        if all(m.conv.in_channel % 32 == 0 and m.conv.out_channel % 32 == 0 for m, _ in seq if hasattr(m, "noise")):
+        if dec.kernel_size == 1 and all(m.conv.in_channel % 32 == 0 and m.conv.out_channel % 32 == 0
+                                        for m, _ in seq if hasattr(m, "noise")):
             M = modulate_all(dec, s_list)
     out = styled_conv(dec.conv1, features, styles[:, 0], noise[0], S.get(id(dec.conv1)), M.get(id(dec.conv1)))
     skip = to_rgb(dec.to_rgb1, out, styles[:, 1], None, S.get(id(dec.to_rgb1)), M.get(id(dec.to_rgb1)))

@@ -121,6 +121,73 @@ def test_styled_conv_bwd_vs_oracle(cin, cout, hw, up, B, per_sample_noise):
         close(p.grad, sd["m." + name].grad, what=name)
 
 
+@pytest.mark.parametrize("cin,cout,hw,up,B", [(32, 64, 8, False, 2), (64, 32, 8, True, 2), (32, 32, 12, True, 1), (96, 64, 6, False, 3)])
+def test_styled_conv_3x3_bwd_vs_oracle(cin, cout, hw, up, B):
+    """kernel_size = 3 under autograd (it raised before): the plain branch and the stride-2 transposed + blur branch of
+    ModulatedConv2d (models/model_v3.py:280-312) with noise, bias and activation, every gradient against torch autograd through
+    the CPU oracle."""
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(cin + cout + hw + up)
+    sc = dec.StyledConv(cin, cout, 3, 64, upsample=up)
+    sc.noise.weight.data.fill_(0.3)
+    sc.activate.bias.data = torch.randn(cout) * 0.2
+    sd = {"m." + k: leaf(v) if v.is_floating_point() and "kernel" not in k else v.clone() for k, v in sc.state_dict().items()}
+    x, st = torch.randn(B, cin, hw, hw), torch.randn(B, 64)
+    ho = 2 * hw if up else hw
+    nz = torch.randn(1, 1, ho, ho)
+    dy = torch.randn(B, cout, ho, ho)
+    xr, sr, nr = leaf(x), leaf(st), leaf(nz)
+    ref = O.styled_conv(sd, "m", xr, sr, nr, upsample=up)
+    ref.backward(dy)
+    sc = sc.to(DEV)
+    xg, sg, ng = leaf(cu(x)), leaf(cu(st)), leaf(cu(nz))
+    y = AG.styled_conv(sc, xg, sg, ng)
+    close(y, ref.detach(), 3e-5, "y")
+    y.backward(cu(dy))
+    close(xg.grad, xr.grad, what="dx"); close(sg.grad, sr.grad, what="dstyle"); close(ng.grad, nr.grad, what="dnoise")
+    for name, p in sc.named_parameters():
+        if name == "bias":
+            assert p.grad is None
+            continue
+        close(p.grad, sd["m." + name].grad, what=name)
+
+
+def test_decoder_3x3_bwd_vs_oracle():
+    """Decoder.forward with decoder_cfg.kernel_size = 3 under autograd: image and the gradients of features, styles and every
+    parameter against the oracle."""
+    cfg = configs.tiny_G_cfg(32, 2, 3)
+    G = pkg.build_generator(cfg, DEV, seed=6)
+    for sc in [G.decoder.conv1] + list(G.decoder.convs):
+        sc.noise.weight.data.fill_(0.2)
+    sd = {k: (leaf(v.cpu()) if v.is_floating_point() and "kernel" not in k else v.cpu().clone())
+          for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    B, S = 2, 8
+    feat = torch.randn(B, 32, S, S, generator=g)
+    styles = torch.randn(B, G.decoder.n_latent, 32, generator=g)
+    noise = [torch.randn(*b.shape, generator=g) for b in G.decoder.create_noise_bufs(S, "cpu")]
+    fr, sr = leaf(feat), leaf(styles)
+    ref = O.decoder_forward(sd, cfg, fr, sr, noise)
+    tgt = torch.randn(ref.shape, generator=g)
+    ((ref - tgt) ** 2).mean().backward()
+    fg, sg = leaf(cu(feat)), leaf(cu(styles))
+    for p in G.decoder.parameters():
+        p.requires_grad_(True)
+    out = AG.decoder_forward(G.decoder, fg, sg, [cu(n) for n in noise])
+    close(out, ref.detach(), 1e-4, "rgb")
+    ((out - cu(tgt)) ** 2).mean().backward()
+    close(fg.grad, fr.grad, 5e-4, "dfeatures"); close(sg.grad, sr.grad, 5e-4, "dstyles")
+    n = 0
+    for name, p in G.decoder.named_parameters():
+        ref_g = sd["decoder." + name].grad
+        if ref_g is None:
+            assert p.grad is None, name
+            continue
+        close(p.grad, ref_g, 5e-4, name)
+        n += 1
+    assert n >= 30
+
+
 @pytest.mark.parametrize("up", [False, True])
 def test_to_rgb_bwd_vs_oracle(up):
     import cips_3dplusplus_amd.decoder as dec
