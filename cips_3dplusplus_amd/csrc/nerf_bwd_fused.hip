@@ -644,14 +644,16 @@ __device__ __forceinline__ void bwd_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
     const int o_base = sl * (TPS * 16) + q4o;
     // operands of the epilogue, requested before the matrix block so that they arrive under it
-    f32x4 st[TPS], wsg[TPS], wx[TPS], wy[TPS], wz[TPS];
+    // (register diet: the sigma-head weights and the first layer's three weight rows are needed by ONE of the D layers each --
+    // they are fetched where they are used, one o-tile at a time, instead of living through the matrix block: the 64 registers
+    // they took were what the kernel spilled)
+    f32x4 st[TPS];
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
-      st[tt] = wsg[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      st[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #ifndef CIPS3D_BWD_NO_STASH     // (timing-only ablation)
       if (!first) st[tt] = *reinterpret_cast<const f32x4*>(stash_l + ((sl * TPS + tt) * 64 + lane) * 4);
 #endif
-      if (sigma) wsg[tt] = *reinterpret_cast<const f32x4*>(tables + 6 * H + o_base + tt * 16);
     }
     f32x4 acc[TPS];
 #pragma unroll
@@ -662,11 +664,11 @@ __device__ __forceinline__ void bwd_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)
 #pragma unroll
       for (int tt = 0; tt < TPS; ++tt) {
         const int o4 = o_base + tt * 16;
-        wx[tt] = *reinterpret_cast<const f32x4*>(tables + o4);
-        wy[tt] = *reinterpret_cast<const f32x4*>(tables + H + o4);
-        wz[tt] = *reinterpret_cast<const f32x4*>(tables + 2 * H + o4);
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(tables + o4);
+        const f32x4 wy = *reinterpret_cast<const f32x4*>(tables + H + o4);
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(tables + 2 * H + o4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) st[tt][i] = fmaf(wz[tt][i], nz, fmaf(wy[tt][i], ny, wx[tt][i] * nx));
+        for (int i = 0; i < 4; ++i) st[tt][i] = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
       }
     }
     float q1[TPS], q2[TPS], yv[R];
@@ -675,11 +677,13 @@ __device__ __forceinline__ void bwd_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)
       const int o4 = o_base + tt * 16;
       const f32x4 g4 = *reinterpret_cast<const f32x4*>(film_l + o4);
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(film_l + H + o4);
+      f32x4 wsg = {0.f, 0.f, 0.f, 0.f};
+      if (sigma) wsg = *reinterpret_cast<const f32x4*>(tables + 6 * H + o4);
       float e1[4], e2[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float av = st[tt][i];
-        const float u = fmaf(wsg[tt][i], dsdf, acc[tt][i] * uscale);
+        const float u = fmaf(wsg[i], dsdf, acc[tt][i] * uscale);
         const float uc = u * cips3d_cos(fmaf(g4[i], av, c4[i]));
         e1[i] = uc * av;
         e2[i] = uc;
@@ -690,13 +694,18 @@ __device__ __forceinline__ void bwd_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)
     }
     if (first) {
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt)
+      for (int tt = 0; tt < TPS; ++tt) {
+        const int o4 = o_base + tt * 16;
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(tables + o4);
+        const f32x4 wy = *reinterpret_cast<const f32x4*>(tables + H + o4);
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(tables + 2 * H + o4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          dp[0] = fmaf(wx[tt][i], yv[tt * 4 + i], dp[0]);
-          dp[1] = fmaf(wy[tt][i], yv[tt * 4 + i], dp[1]);
-          dp[2] = fmaf(wz[tt][i], yv[tt * 4 + i], dp[2]);
+          dp[0] = fmaf(wx[i], yv[tt * 4 + i], dp[0]);
+          dp[1] = fmaf(wy[i], yv[tt * 4 + i], dp[1]);
+          dp[2] = fmaf(wz[i], yv[tt * 4 + i], dp[2]);
         }
+      }
     }
     accumulate_sums<TPS>(q1, q2, sum_l, H, sl * (TPS * 16), lane);
     // (the sink pass would otherwise move the epilogue below the step barrier, undoing the stagger)
