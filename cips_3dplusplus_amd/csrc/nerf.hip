@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   }
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
-  const bool raw_density = P.raw_density != 0;
+  const bool raw_density = __builtin_amdgcn_readfirstlane(P.raw_density) != 0;
   const float sig_beta = raw_density ? 1.f : P.sigmoid_beta[0];
 
   // ---- ray setup (nerf_utils.py:38-66)
@@ -620,8 +620,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
 
     // ---- compositing weight of this sample (nerf_utils.py:264-307); known before the view layer
     const float delta = (sk < N - 1 ? zsample(sk + 1) - z : 1e10f) * dnorm;
-    const float sigma = raw_density ? (sdf > 20.f ? sdf : log1pf(expf(sdf)))      // with_sdf = False (nerf_utils.py:288-297)
-                                    : sigmoidf_acc(-sdf / sig_beta) / sig_beta;
+    float sigma;
+    if (raw_density) {        // with_sdf = False (nerf_utils.py:288-297): softplus of the raw density.  A real (uniform) branch and
+      // the hardware exp / log: the library forms held enough temporaries here to spill four registers of the default path
+      sigma = sdf > 20.f ? sdf : __logf(1.f + __expf(sdf));
+    } else {
+      sigma = sigmoidf_acc(-sdf / sig_beta) / sig_beta;
+    }
     const float alpha = 1.f - expf(-sigma * delta);
     const float w = live ? alpha * T : 0.f;
     if (live) T *= (1.f - alpha) + 1e-10f;
