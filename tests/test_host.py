@@ -97,3 +97,49 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             txt = open(os.path.join(pkg_dir, fn)).read()
             assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+@pytest.mark.parametrize("res,D,B,S0", [(256, 6, 2, 64), (1024, 2, 1, 64)])
+def test_decoder_grad_plan_layout(res, D, B, S0, monkeypatch):
+    """Host side of the one-call decoder backward (decoder_grad.GradPlan) without a GPU: the python structs have the library's
+    sizes, the workspace regions (amax rows | accumulators zeroed per backward | outputs cloned per backward | per-forward
+    tensors) are ordered and disjoint, every pointer the plan hands to C lies inside its region, slot counts are powers of two
+    and the slot-reduce table covers every slotted accumulator."""
+    import ctypes as C
+    from cips_3dplusplus_amd import decoder_grad as dg
+    from cips_3dplusplus_amd.decoder import Decoder
+    from cips_3dplusplus_amd import hip
+    # (layout only, nothing is launched: the binding's CUDA-tensor guard is lifted for the table builder)
+    monkeypatch.setattr(hip, "dev_ptr", lambda t, name="", optional=False, **kw: None if t is None else t.data_ptr())
+    lib = _lib.load()
+    assert lib.cips3d_sizeof_grad_plan() == C.sizeof(dg.DecoderGradPlan) and lib.cips3d_sizeof_grad_io() == C.sizeof(dg.DecoderGradIO)
+    cfg = configs.ffhq_G_cfg(res, D)
+    dec = Decoder(style_dim=cfg["mapping_decoder_cfg"]["style_dim"], **cfg["decoder_cfg"])
+    plan = dg.GradPlan(dec, B, S0, S0, "cpu")
+    p, ws = plan.plan, plan.ws
+    base, end = ws.data_ptr(), ws.data_ptr() + 4 * ws.numel()
+    a0, a1 = p.amax_base, p.amax_base + p.amax_bytes
+    z0, z1 = p.zero_base, p.zero_base + p.zero_bytes
+    o0, o1 = base + 4 * plan.out_range[0], base + 4 * plan.out_range[1]
+    assert base <= a0 < a1 <= z0 < z1 <= end and z0 < o0 < z1 <= o1 <= end      # the zeroed outputs open the output block
+    n_conv = 0
+    for k in range(p.n_layers):
+        L, i = p.layers[k], plan.info[k]
+        assert (L.kind, L.Cin, L.Cout, L.H, L.W) == (i["kind"], i["Cin"], i["Cout"], i["H"], i["W"])
+        assert z0 <= L.d_wm < z1 and base <= L.wm < end
+        S = L.slots
+        assert S >= 1 and S & (S - 1) == 0 and S <= 16
+        if L.kind < 2:
+            n_conv += 1
+            assert a0 <= L.y_amax < a1 and a0 <= L.g_amax < a1 and (L.kind == 0 or a0 <= L.glo_amax < a1)
+            assert z0 <= L.d_bias < z1 and z0 <= L.d_nw_part < z1 and o1 <= L.y < end and o1 <= L.wm_t < end
+            assert L.slot_stride >= L.Cout and L.slot_stride % 32 == 0 and S * L.slot_stride <= p.nw_stride
+        else:
+            assert L.rgb_slot_stride >= B * 3 * L.Cin and L.slots == p.layers[k - 1].slots
+            assert o0 <= L.d_bias < z1                                              # ToRGB bias gradient: zeroed, returned
+    assert n_conv == plan.n_conv == dec.num_layers
+    slotted = sum(1 for k in range(p.n_layers) if p.layers[k].slots > 1)
+    assert p.slot_n == slotted and (slotted == 0) == (not p.slot_table)
+    assert len(dg.parameters_of(dec)) == 3 * p.n_layers + 2 * n_conv + (p.n_layers - n_conv)
+    # at 256^2 and above the row accumulators are slotted (one cache line per slot: L2 atomics serialise per line)
+    assert any(p.layers[k].slots > 1 for k in range(p.n_layers))
