@@ -467,6 +467,50 @@ def test_flip_inversion_loop_reduces_loss():
     assert all(torch.equal(a, b) for a, b in zip(G.renderer.state_dict().values(), out["render_state_dict"].values()))
 
 
+def test_pose_phase_trajectory_matches_the_oracle_loop():
+    """Eight steps of the pose phase (projector_v10.py:915-1216: camera angles + NeRF W+ under Adam with the ramped learning rate,
+    decoder at lr 0) on the HIP path -- one-call decoder node, fused NeRF backward, fused Adam -- against the same loop written
+    with torch autograd over the CPU oracle and torch's default Adam: the loss and the camera angles of every step."""
+    from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss, cur_lr
+    cfg = configs.tiny_G_cfg(32, 2, 1)
+    G = pkg.build_generator(cfg, DEV, seed=13)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    g = torch.Generator().manual_seed(4)
+    mr, md = 0.3 * torch.randn(1, 32, generator=g), 0.3 * torch.randn(1, 32, generator=g)
+    t_rgb, t_thumb = torch.randn(2, 3, 32, 32, generator=g).clamp(-1, 1), torch.randn(2, 3, 8, 8, generator=g).clamp(-1, 1)
+    N, lr_cam, lr_w, az0 = 8, 0.02, 0.01, (0.3, -0.2)
+    ncfg = {"N_samples": 6, "perturb": False, "static_viewdirs": True}
+    G.get_mean_latent = lambda n, dev: (cu(mr), cu(md))        # (the projector draws its means on the device otherwise)
+    traj = []
+    FlipProjector(G, DEV).project_wplus({"img_size": 8, "fov_ang": 6, "dist_radius": 0.12}, ncfg,
+                                        surrogate_loss(cu(t_rgb), cu(t_thumb)), N_steps_pose=N, N_steps_app=0, lr_cam=lr_cam,
+                                        lr_render_w=lr_w, azim_init=az0, w_avg_samples=8,
+                                        on_step=lambda s_, l, a, e: traj.append((float(l.detach()), a.detach().cpu().clone(),
+                                                                                 e.detach().cpu().clone())))
+    # the same loop on the CPU oracle
+    azim = torch.tensor([[az0[0]], [az0[1]]], requires_grad=True)
+    elev = torch.zeros(2, 1, requires_grad=True)
+    w_r = mr.reshape(1, 1, -1).repeat(1, 3, 1).clone().requires_grad_(True)
+    w_d = md.reshape(1, 1, -1).repeat(2, G.decoder.n_latent, 1)
+    nb = [torch.zeros(*b.shape) for b in G.create_noise_bufs(8, "cpu")]
+    o_cam = torch.optim.Adam([{"params": [azim, elev], "lr": lr_cam, "betas": (0.9, 0.999)}])
+    o_w = torch.optim.Adam([{"params": [w_r], "lr": lr_w, "betas": (0.9, 0.999)}])
+    for step in range(N):
+        m = cur_lr(step, N)
+        o_cam.param_groups[0]["lr"], o_w.param_groups[0]["lr"] = lr_cam * m, lr_w * m
+        cam = O.camera_params(torch.cat([azim, elev], 1), 8, 6, 0.12)
+        r = O.generator_forward(sd, cfg, [None, None], cam[0], cam[1], 8, cam[2], cam[3], ncfg, nb, style_render=w_r.repeat(2, 1, 1),
+                                style_decoder=w_d)
+        loss = ((r["rgb"] - t_rgb) ** 2).mean() + 50.0 * ((r["thumb_rgb"] - t_thumb) ** 2).mean()
+        o_cam.zero_grad(); o_w.zero_grad()
+        loss.backward()
+        o_cam.step(); o_w.step()
+        l_hip, a_hip, e_hip = traj[step]
+        assert abs(l_hip - float(loss.detach())) < 2e-4 * abs(float(loss.detach())), (step, l_hip)
+        assert float((a_hip - azim.detach()).abs().max()) < 2e-4 and float((e_hip - elev.detach()).abs().max()) < 2e-4, step
+    assert len(traj) == N and abs(float(azim.detach()[0]) - az0[0]) > 1e-3            # the camera moved
+
+
 def test_modulate_transpose_packing_equals_pack_weights():
     """CIPS3D_MOD_TRANSPOSE: the modulate kernel writes the A fragments of wm^T directly -- bit for bit what
     cips3d_pack_weights(transpose = 1) makes from the plain modulated matrix (the data-gradient GEMM's operand)."""
