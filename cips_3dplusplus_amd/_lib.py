@@ -121,7 +121,7 @@ _SIGS = {
                                         c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_torgb_reduce": (c_int, [c_f32p, c_int, C.c_void_p, c_int, c_f32p, c_f32p, c_int, c_i64, C.c_void_p]),
     "cips3d_up2_fir_act": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_f32p, c_i64, c_f32p, c_f32p,
-                                   C.c_void_p]),
+                                   c_f32p, C.c_void_p]),
     "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_fused_up_conv_supported": (c_int, [c_int, c_int, c_int]),
     "cips3d_fused_up_conv": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
@@ -204,7 +204,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 16           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 17           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

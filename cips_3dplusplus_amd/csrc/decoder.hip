@@ -834,8 +834,11 @@ __device__ __forceinline__ void up2_block(const float* __restrict__ src, int H, 
 __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restrict__ y_lo, const float* __restrict__ fir,
                                                           float* __restrict__ out, int B, int C, int H, int W,
                                                           const float* __restrict__ noise, int64_t noise_bstride,
-                                                          const float* __restrict__ nwp, const float* __restrict__ bias) {
+                                                          const float* __restrict__ nwp, const float* __restrict__ bias,
+                                                          float* __restrict__ out_amax) {
   const float noise_w = (noise && nwp) ? nwp[0] : 0.f;
+  float mx = 0.f;      // out_amax: the largest |out| of the sample this thread is in (a grid-stride loop may cross samples)
+  int mx_b = -1;
   float kf[16];   // flipped taps: kf[ky][kx] = fir[3-ky][3-kx]
 #pragma unroll
   for (int i = 0; i < 16; ++i) kf[i] = fir[15 - i];
@@ -851,6 +854,11 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
     const int b = (int)(t / C);
     const float* src = y_lo + ((int64_t)b * C + c) * H * W;
     const float bs = bias[c];
+    if (out_amax && b != mx_b) {        // (rare: at most B - 1 times per thread)
+      if (mx_b >= 0) cips3d_amax_raise(out_amax + mx_b * CIPS3D_AMAX_FLOATS, mx, blockIdx.x);
+      mx = 0.f;
+      mx_b = b;
+    }
     float o[2][4];
     up2_block(src, H, W, iy, qx, kf, o);
     float* dst = out + (((int64_t)b * C + c) * 2 * H + 2 * iy) * OW + 4 * qx;
@@ -864,6 +872,17 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
       r.z = lrelu02((o[py][2] + noise_w * nz.z) + bs) * 1.41421356237309515f;
       r.w = lrelu02((o[py][3] + noise_w * nz.w) + bs) * 1.41421356237309515f;
       *reinterpret_cast<float4*>(dst + (int64_t)py * OW) = r;
+      mx = fmaxf(fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))), mx);
+    }
+  }
+  if (out_amax && mx_b >= 0) {
+    // one atomic per wave when all its lanes ended in the same sample (the rule), else one per lane
+    const int b0 = __builtin_amdgcn_readfirstlane(mx_b);
+    if (__all(mx_b == b0)) {
+      const float m = cips3d_wave_max_uniform(mx);
+      if ((threadIdx.x & 63) == 0) cips3d_amax_raise_if(out_amax + b0 * CIPS3D_AMAX_FLOATS, m, blockIdx.x * 4 + (threadIdx.x >> 6));
+    } else {
+      cips3d_amax_raise(out_amax + mx_b * CIPS3D_AMAX_FLOATS, mx, blockIdx.x);
     }
   }
 }
@@ -1877,7 +1896,7 @@ extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float
 
 extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
                                   const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
-                                  void* stream) {
+                                  float* out_amax, void* stream) {
   if (!y_lo || !fir || !out || !bias || B < 0 || C <= 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
   if (W % 2 != 0) return CIPS3D_E_UNSUPP;     // 16-byte output quads
   if (B == 0) return 0;
@@ -1885,7 +1904,7 @@ extern "C" int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* ou
   int64_t blocks = ceil_div<int64_t>(total, 256);
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(up2_fir_act_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), y_lo, fir, out, B,
-                     C, H, W, noise, noise_bstride, noise_w, bias);
+                     C, H, W, noise, noise_bstride, noise_w, bias, out_amax);
   return cips3d_launch_status();
 }
 

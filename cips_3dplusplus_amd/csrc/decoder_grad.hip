@@ -362,8 +362,7 @@ extern "C" int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan,
         if (!P.y_lo) return CIPS3D_E_BADARG;
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, hw, 0 | (split ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr,
                               nullptr, &rg, stream));
-        TRY(cips3d_up2_fir_act(P.y_lo, L.fir, L.y, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, stream));
-        TRY(cips3d_absmax(L.y, B, (int64_t)L.Cout * hw * 4, L.y_amax, stream));
+        TRY(cips3d_up2_fir_act(P.y_lo, L.fir, L.y, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, L.y_amax, stream));
       }
       x = L.y;
       x_amax = L.y_amax;

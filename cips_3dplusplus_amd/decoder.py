@@ -209,7 +209,7 @@ class StyledConv(nn.Module):
                 wm = conv.modulated_weight(style, packed=True, split=split)
             if conv.upsample:
                 y_lo = hip.modconv1x1(x, wm, conv.out_channel, epilogue=0, bf16=self.bf16, split=split)
-                return hip.up2_fir_act(y_lo, conv.blur.kernel, noise, nw, self.activate.bias)
+                return hip.up2_fir_act(y_lo, conv.blur.kernel, noise, nw, self.activate.bias, track=split)
             return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias,
                                   bf16=self.bf16, split=split)
         if conv.tiled3x3(H, W):

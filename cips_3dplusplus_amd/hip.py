@@ -485,15 +485,19 @@ def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=No
     return out
 
 
-def up2_fir_act(y_lo, fir, noise, noise_w, bias, out=None):
+def up2_fir_act(y_lo, fir, noise, noise_w, bias, out=None, track=False):
+    """track: the kernel records the output's amax array (cips3d_range) and leaves it attached to the result."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
     if out is None:
         out = torch.empty(B, Cc, 2 * H, 2 * W, device=y_lo.device, dtype=torch.float32)
     nb = 4 * H * W if (noise is not None and noise.shape[0] == B and B > 1) else 0
+    out_amax = new_amax(B, y_lo.device) if track else None
     check(lib.cips3d_up2_fir_act(dev_ptr(y_lo, "y_lo"), dev_ptr(fir, "fir"), dev_ptr(out), B, Cc, H, W,
-                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias"), stream_ptr()),
-          "cips3d_up2_fir_act")
+                                 dev_ptr(noise, "noise", True), nb, dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias"),
+                                 dev_ptr(out_amax, "out_amax", True), stream_ptr()), "cips3d_up2_fir_act")
+    if out_amax is not None:
+        tag_amax(out, out_amax)
     return out
 
 

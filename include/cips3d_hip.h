@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 16  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 17  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -388,10 +388,10 @@ int cips3d_torgb_reduce(const float* part, int n_slots, const float* const* bias
 /* 2x FIR up-sampling of a low-resolution conv result fused with the StyledConv epilogue:
  *   u   = upfirdn2d(y_lo, fir, up=2, pad=(2,1))      (fir = outer([1,3,3,1])/64*4, [4,4] device)
  *   out = lrelu(u + noise_w * noise + bias[c], 0.2) * sqrt(2)
- * y_lo [B,C,H,W] -> out [B,C,2H,2W]. */
+ * y_lo [B,C,H,W] -> out [B,C,2H,2W].  out_amax: per-sample amax rows of `out` (cips3d_range; raised, not zeroed) or NULL. */
 int cips3d_up2_fir_act(const float* y_lo, const float* fir, float* out, int B, int C, int H, int W,
                        const float* noise, int64_t noise_bstride, const float* noise_w, const float* bias,
-                       void* stream);
+                       float* out_amax, void* stream);
 
 /* StyledConv epilogue on its own (used after the k x k path):
  *   out = lrelu(x + noise_w * noise + bias[c], 0.2) * sqrt(2);  x/out [B,C,HW]. */

@@ -174,3 +174,20 @@ def test_one_call_decoder_other_modes(precision, per_sample_noise, B):
     assert decoder_grad.plan_for(dec, B, 8, 8, feats.device) is None            # key changed: re-planned, refused
     dec.set_precision("fp32")
     assert decoder_grad.plan_for(dec, 5, 8, 8, feats.device) is None
+
+
+@pytest.mark.parametrize("B,C,H,W,per_sample", [(2, 64, 16, 16, False), (3, 32, 8, 12, True), (1, 256, 64, 64, False)])
+def test_up2_fir_act_records_its_maximum(B, C, H, W, per_sample):
+    """cips3d_up2_fir_act(out_amax): the per-sample maximum of the up-sampled, activated tensor, recorded by the kernel that
+    writes it (grid-stride loop: a thread may cross samples) -- what cips3d_absmax would measure in a pass of its own."""
+    g = torch.Generator(device=DEV).manual_seed(B * C + H)
+    y_lo = torch.randn(B, C, H, W, device=DEV, generator=g) * torch.tensor([1.0, 30.0, 0.01][:B], device=DEV).view(B, 1, 1, 1)
+    fir = torch.tensor([1.0, 3.0, 3.0, 1.0], device=DEV)
+    fir = (fir[:, None] * fir[None, :] / 64.0 * 4.0).contiguous()
+    noise = torch.randn(B if per_sample else 1, 1, 2 * H, 2 * W, device=DEV, generator=g)
+    nw, bias = torch.tensor([0.3], device=DEV), torch.randn(C, device=DEV, generator=g) * 0.1
+    out = hip.up2_fir_act(y_lo, fir, noise, nw, bias, track=True)
+    ref = hip.up2_fir_act(y_lo, fir, noise, nw, bias)
+    assert torch.equal(out, ref)
+    got = hip.amax_value(hip.amax_of(out, measure=False))
+    assert torch.equal(got, ref.abs().amax(dim=(1, 2, 3)))
