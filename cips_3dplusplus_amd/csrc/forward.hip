@@ -343,8 +343,9 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         TRY(cips3d_modconv1x1(x, L.wm, P.y_lo, B, L.Cin, L.Cout, (int64_t)L.H * L.W,
                               0 | gemm_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
                               ranged ? &rg : nullptr, stream));
-        TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, nullptr, stream));
-        x_amax = nullptr;                // (the FIR's output is not tracked: its reader measures it)
+        float* fir_amax = (ranged && L.amax) ? L.amax : nullptr;      // (this route leaves the row unused: y_lo is not tracked here)
+        TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, fir_amax, stream));
+        x_amax = fir_amax;               // recorded by the FIR kernel itself (else its reader measures it)
         x_exp = nullptr;
       }
       x = out;
