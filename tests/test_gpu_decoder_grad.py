@@ -107,7 +107,8 @@ def _grads(dec, feats, styles, noise, one_call, target):
     return rgb.detach(), f.grad, s.grad, [p.grad for p in params]
 
 
-@pytest.mark.parametrize("name,res,S0,B", [("tiny", 32, 8, 2), ("tiny", 32, 16, 3), ("config5", 256, 64, 2), ("r1024", 1024, 64, 1)])
+@pytest.mark.parametrize("name,res,S0,B", [("tiny", 32, 8, 2), ("tiny", 32, 16, 3), ("config5", 256, 64, 2), ("r1024", 1024, 64, 1),
+                                           ("config1_no_upsampling", 64, 64, 2)])
 def test_one_call_decoder_matches_the_per_op_route(name, res, S0, B):
     """Decoder.forward + backward as one node (csrc/decoder_grad.hip) against the chain of per-op nodes (autograd.py, itself
     pinned to the reference's gradients by tests/golden/backward.npz and config5.npz): image, feature / style gradients and
