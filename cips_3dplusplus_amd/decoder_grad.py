@@ -252,7 +252,7 @@ class GradPlan:
         p.mod_table, p.mod_n, p.mod_rows = self._mod_tab.data_ptr(), len(mdescs), rows
         p.modbwd_table, p.modbwd_n, p.modbwd_blocks = self._modbwd_tab.data_ptr(), len(bdescs), blocks
         p.style_w_offsets = self._woffs.data_ptr()
-        p.styles, p.s_all, p.ds_all = P(o_styles), P(0), P(o_ds_all - o_s_all)     # bases: the table addresses out = ws + offset
+        p.styles, p.s_all, p.ds_all = P(o_styles), P(o_s_all), P(o_ds_all)       # (the table backward mirrors out -> dy by offset)
         p.d_styles, p.d_style_W, p.d_style_b = P(o_d_styles), P(info[0]["o_dmW"]), P(o_d_style_b)
         p.amax_base, p.amax_bytes = P(amax0), 4 * (amax1 - amax0)
         p.zero_base, p.zero_bytes = P(zero0), 4 * (zero1 - zero0)
