@@ -86,7 +86,9 @@ class GradPlan:
         seq = dec._mod_layers()
         if dec.kernel_size != 1 or len(seq) > MAX_LAYERS or B > 4 or dec.style_dim % 4:
             raise Unsupported("kernel_size != 1, too many layers, batch > 4 or style_dim % 4")
-        self.B, self.dev, self.dec = B, device, dec
+        # (no reference to `dec` itself: the plans live in a WeakKeyDictionary keyed by it, and a value that holds its key is never
+        # collected -- one ~0.6 GB workspace leaked per copy.deepcopy(G) of the projector)
+        self.B, self.dev, self.n_latent, self.style_dim = B, device, dec.n_latent, dec.style_dim
         self.key = self.weights_key(dec)
         AF = hip.amax_floats()
         sd = dec.style_dim
@@ -329,7 +331,7 @@ class GradPlan:
         o0, o1 = self.out_range
         out = self.ws[o0:o1].clone()
         v = lambda o, *shape: out[o - o0:o - o0 + int(torch.Size(shape).numel())].view(*shape)     # noqa: E731
-        dec, sd = self.dec, self.dec.style_dim
+        sd = self.style_dim
         grads = []
         for i in self.info:
             m = i["m"]
@@ -340,7 +342,7 @@ class GradPlan:
                 grads += [v(self.o_d_noise_w + i["conv_i"], 1), v(i["o_d_bias"], i["Cout"])]
             else:
                 grads.append(v(i["o_d_bias"], 1, 3, 1, 1))
-        return d_features, v(self.o_d_styles, self.B, dec.n_latent, sd), grads
+        return d_features, v(self.o_d_styles, self.B, self.n_latent, sd), grads
 
 
 # plans live beside the modules, not inside them: copy.deepcopy(G) (the projector's first step) must neither copy raw device

@@ -143,3 +143,14 @@ def test_decoder_grad_plan_layout(res, D, B, S0, monkeypatch):
     assert len(dg.parameters_of(dec)) == 3 * p.n_layers + 2 * n_conv + (p.n_layers - n_conv)
     # at 256^2 and above the row accumulators are slotted (one cache line per slot: L2 atomics serialise per line)
     assert any(p.layers[k].slots > 1 for k in range(p.n_layers))
+    # the plan cache is keyed weakly by the decoder and a plan does not keep its decoder alive: dropping the module drops
+    # the plan (and its workspace)
+    import gc
+    import weakref
+    n0 = len(dg._PLANS)
+    dg._PLANS.setdefault(dec, {})["k"] = plan
+    assert len(dg._PLANS) == n0 + 1
+    ws_ref = weakref.ref(plan.ws)
+    del dec, plan, p, ws
+    gc.collect()
+    assert len(dg._PLANS) == n0 and ws_ref() is None
