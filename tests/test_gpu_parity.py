@@ -865,6 +865,49 @@ def test_full_size_properties():
     assert maxdiff(rgb_ops, both["rgb"]) < 2e-4 * float(both["rgb"].abs().max())
 
 
+def test_config4_shape_n128_static_truncated():
+    """BASELINE config 4's per-view shape (the reference demo's: 1024^2, N = 128 samples, static view directions, truncation 0.5
+    with preset means, return_xyz -- render_video_web_v10.py:1806-1824): the NeRF half against the oracle on a strided subset
+    of the rays (explicit-points entry of the same fused kernel), and size-independent properties of the whole forward: the
+    fused render == Render.prepare_nerf_inputs + rays_forward, two batch elements independent, repeat bitwise."""
+    from cips_3dplusplus_amd.nerf_utils import Render
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=3)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    zs = [torch.randn(2, 256, device=DEV, generator=g), torch.randn(2, 256, device=DEV, generator=g)]
+    G.style_render_mean = 0.1 * torch.randn(1, 256, device=DEV, generator=g)
+    G.style_decoder_mean = 0.1 * torch.randn(1, 512, device=DEV, generator=g)
+    locs = torch.tensor([[0.77, 0.0], [-0.4, 0.0]], device=DEV)             # the yaw sweep's extreme and an inner frame
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=locs)
+    nb = G.create_noise_bufs(64, DEV)
+    ncfg = dict(N_samples=128, perturb=False, static_viewdirs=True)
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=nb, truncation=0.5, nerf_cfg=ncfg,
+              return_xyz=True, return_sdf=True)
+    both = {k: v.clone() for k, v in G(**kw).items() if v is not None}
+    again = G(**kw)
+    assert all(torch.equal(both[k], again[k]) for k in both)
+    assert both["sdf"].shape == (2, 64, 64, 128, 1) and both["rgb"].shape == (2, 3, 1024, 1024)
+    assert bool(torch.isfinite(both["rgb"]).all()) and float(both["thumb_rgb"].abs().max()) <= 1.0 + 1e-6
+    for b in range(2):
+        one = G(**{**kw, "zs": [z[b:b + 1] for z in zs], "cam_poses": e[b:b + 1], "focals": f[b:b + 1], "near": n[b:b + 1],
+                   "far": fa[b:b + 1]})
+        for k in both:
+            assert maxdiff(both[k][b:b + 1], one[k]) < 3e-5 * max(1.0, float(one[k].abs().max())), k
+    # the NeRF half against the oracle on every 37th ray (N = 128 makes the full grid slow on the CPU)
+    s_r, _ = G.mapping_networks(zs=zs, truncation=0.5, inject_index=None)
+    pts, rd, vd, zz = Render.prepare_nerf_inputs(f, 64, e, n, fa, N_samples=128, perturb=False, static_viewdirs=True)
+    idx = torch.arange(0, 4096, 37, device=DEV)
+    sub = lambda t: t.reshape(2, 4096, *t.shape[3:])[:, idx].contiguous()     # noqa: E731
+    out = G.renderer(sub(pts), sub(rd), sub(vd), sub(zz), n, fa, styles=s_r)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    ref = O.renderer_forward(sd, "renderer", sub(pts).cpu(), sub(rd).cpu(), sub(vd).cpu(), sub(zz).cpu(), n.cpu(), fa.cpu(),
+                             s_r.cpu(), 2)
+    for a, r, k in zip(out[:5], ref, ("rgb_map", "feature_map", "sdf", "mask", "xyz")):
+        assert maxdiff(a.cpu(), r) < 1e-4 * max(1.0, float(r.abs().max())), k
+    thumb = both["thumb_rgb"].reshape(2, 3, 4096)[:, :, idx].transpose(1, 2)
+    assert maxdiff(thumb.cpu(), ref[0]) < 1e-4                                # the camera-driven kernel == the explicit entry
+
+
 def test_generator_rays_forward_equals_fused_forward():
     """Generator.rays_forward on Render.prepare_nerf_inputs == the NeRF half of Generator.forward (the reference's own
     decomposition, model_v3.py:941-1003)."""
