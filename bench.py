@@ -427,6 +427,8 @@ def main():
                                                                                                res=256, depth=8)),
                             ("BASELINE config 1 on the HIP path: FFHQ 64x64 output (no up-sampling), D = 8, N = 24, single view (its CPU "
                              "figure: profiles/r01_config1_cpu_vs_gpu.json)", dict(n_samples=24, batch=1, precision="fp32", res=64, depth=8)),
+                            ("BASELINE config 4's per-view shape on one GPU: 1024^2 with N = 128 samples per ray (the reference demo's "
+                             "value; the 8-GPU leg of the metric shards whole views, `--gpus N`)", dict(n_samples=128, batch=1, precision="fp32")),
                             ("BASELINE config 3: 1024^2, batch 4, bf16 decoder GEMM operands (fp32 storage: the faster of the two bf16 "
                              "modes on this build)", dict(n_samples=24, batch=4, precision="bf16")),
                             ("BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
