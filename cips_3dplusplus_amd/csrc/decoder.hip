@@ -348,7 +348,9 @@ __device__ __forceinline__ constexpr int vmcnt_imm(int n) { return (n & 15) | ((
 // and reduces the bias / noise-weight / ToRGB-weight gradients of its rows (backward.hip: act_bwd_kernel + torgb_bwd_kernel,
 // which read and wrote the whole tensor once more each).
 template <int WM, int WGM, int WGN, int BK, int NS, int MODE = 0, bool ACTBWD = false>
-__global__ void __launch_bounds__(64 * WGM * WGN) modconv1x1_kernel(GemmArgs a) {
+// (the ACTBWD forms with a 2-slot ring -- short contractions, HBM-bound -- are compiled for two 8-wave workgroups per CU:
+// 128 VGPRs, a handful of spills outside the K loop)
+__global__ void __launch_bounds__(64 * WGM * WGN, (ACTBWD && NS == 2 && BK == 32 && WGM * WGN == 8) ? 4 : 1) modconv1x1_kernel(GemmArgs a) {
   constexpr bool BF16 = MODE == 1;
   constexpr bool SPLIT = MODE == 2;
   constexpr int NW = WGM * WGN;               // waves per workgroup: 8 = two per SIMD, so one wave's DMA issue,
@@ -1866,6 +1868,12 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
     if (bk == 64 && Cin % 64 == 0) return launch_gemm<1, 4, 2, 64, 2>(a, st);
     return launch_gemm<1, 4, 2, 32, 2>(a, st);
   }
+  static const int ns2 = getenv("CIPS3D_GEMM_NS2") ? atoi(getenv("CIPS3D_GEMM_NS2")) : 1;     // (see cips3d_modconv1x1_actbwd)
+  if (ns2 && Cin <= 128) {      // (same rows per workgroup as the 4-slot forms: the ToRGB fold's slot count does not change)
+    if (Cout == 128) return launch_gemm<1, 8, 1, 32, 2>(a, st);
+    if (Cout == 64) return launch_gemm<1, 4, 2, 32, 2>(a, st);
+    if (Cout < 256) return launch_gemm<1, 2, 2, 32, 2>(a, st);
+  }
   if (Cout == 128) return launch_gemm<1, 8, 1, 32, 4>(a, st);                     // all 128 rows: x read once
   if (Cout == 64) return launch_gemm<1, 4, 2, 32, 4>(a, st);                      // 64 x 128
   return launch_gemm<1, 2, 2, 32, 4>(a, st);                                      // 32 x 128 (any Cout % 32 == 0)
@@ -1888,6 +1896,15 @@ extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float
   if (Cout >= 256 && Cout % 64 == 0) {
     if (Cin % 64 == 0) return launch_gemm_actbwd<1, 4, 2, 64, 2>(a, st);
     return launch_gemm_actbwd<1, 4, 2, 32, 2>(a, st);
+  }
+  // Short contractions (K <= 128: the decoder's 128 / 64 / 32-channel layers at 256^2 and above) are HBM-bound streams with
+  // two to four K stages: a 2-slot ring (half the LDS) lets a second workgroup share the CU and cover the first one's
+  // epilogue loads and stores
+  static const int ns2 = getenv("CIPS3D_GEMM_NS2") ? atoi(getenv("CIPS3D_GEMM_NS2")) : 1;
+  if (ns2 && Cin <= 128) {
+    if (Cout == 128) return launch_gemm_actbwd<1, 8, 1, 32, 2>(a, st);
+    if (Cout == 64) return launch_gemm_actbwd<1, 4, 2, 32, 2>(a, st);
+    if (Cout < 256) return launch_gemm_actbwd<1, 2, 2, 32, 2>(a, st);
   }
   if (Cout == 128) return launch_gemm_actbwd<1, 8, 1, 32, 4>(a, st);
   if (Cout == 64) return launch_gemm_actbwd<1, 4, 2, 32, 4>(a, st);
