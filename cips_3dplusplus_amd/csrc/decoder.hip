@@ -1864,8 +1864,12 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
       if (small_cfg == 2) return launch_gemm<1, 4, 1, 32, 4>(a, st);    // 64 x 64, 4 waves
     }
     // 8 waves; 64-deep stages (half as many stage barriers: 705.9 -> 703.4 us per 1024^2 view, A/B on one box) when K allows
-    static const int bk = getenv("CIPS3D_GEMM_BK") ? atoi(getenv("CIPS3D_GEMM_BK")) : 64;       // tuning knob (tools/)
-    if (bk == 64 && Cin % 64 == 0) return launch_gemm<1, 4, 2, 64, 2>(a, st);
+    // ... for a grid of at most ONE workgroup per CU (the 64^2 layers of a single view: 256 tiles).  A larger grid (batch 2 and
+    // up: the inversion step) runs 32-deep stages in a 48 KB ring instead: two workgroups share a CU and one's prologue /
+    // epilogue -- a third of a launch, with the L2 port idle -- runs under the other's K loop (inversion step +3.4 %, same box)
+    static const int bk = getenv("CIPS3D_GEMM_BK") ? atoi(getenv("CIPS3D_GEMM_BK")) : 0;       // tuning knob (tools/): 32 | 64
+    const bool one_round = (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) <= 256;
+    if ((bk ? bk == 64 : one_round) && Cin % 64 == 0) return launch_gemm<1, 4, 2, 64, 2>(a, st);
     return launch_gemm<1, 4, 2, 32, 2>(a, st);
   }
   static const int ns2 = getenv("CIPS3D_GEMM_NS2") ? atoi(getenv("CIPS3D_GEMM_NS2")) : 1;     // (see cips3d_modconv1x1_actbwd)
@@ -1894,7 +1898,10 @@ extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float
              nullptr, nullptr, rg ? rg->x_amax : nullptr, rg ? rg->out_amax : nullptr, *ab};
   hipStream_t st = as_stream(stream);
   if (Cout >= 256 && Cout % 64 == 0) {
-    if (Cin % 64 == 0) return launch_gemm_actbwd<1, 4, 2, 64, 2>(a, st);
+    // (as cips3d_modconv1x1: 64-deep stages for a grid of at most one workgroup per CU, else the 48 KB ring and two per CU)
+    static const int bk = getenv("CIPS3D_GEMM_BK") ? atoi(getenv("CIPS3D_GEMM_BK")) : 0;       // tuning knob (tools/): 32 | 64
+    const bool one_round = (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) <= 256;
+    if ((bk ? bk == 64 : one_round) && Cin % 64 == 0) return launch_gemm_actbwd<1, 4, 2, 64, 2>(a, st);
     return launch_gemm_actbwd<1, 4, 2, 32, 2>(a, st);
   }
   // Short contractions (K <= 128: the decoder's 128 / 64 / 32-channel layers at 256^2 and above) are HBM-bound streams with
