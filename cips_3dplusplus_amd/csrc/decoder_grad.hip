@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) act_tail_kernel(const float* __restrict__
                                                        float* __restrict__ d_nw, float* __restrict__ d_rgb_w,
                                                        float* __restrict__ out_amax, int C, int64_t HW, int slots,
                                                        int slot_stride, int rgb_slot_stride) {
-  __shared__ float sh[16];
+  __shared__ float sh6[24];
   const int c = blockIdx.y, b = blockIdx.z;
   const int slot = slots > 1 ? (int)(blockIdx.x & (slots - 1)) : 0;     // (cips3d_actbwd: one cache line per slot and row block)
   if (d_bias) d_bias += (int64_t)slot * slot_stride;
@@ -79,24 +79,25 @@ __global__ void __launch_bounds__(256) act_tail_kernel(const float* __restrict__
       for (int e = 0; e < 4; ++e) sn = fmaf(g[e], nz[e], sn);
     }
   }
-  sb = block_sum_256(sb, sh);
-  if (threadIdx.x == 0 && d_bias) unsafeAtomicAdd(d_bias + c, sb);
-  if (d_nw) {
-    sn = block_sum_256(sn, sh);
-    if (threadIdx.x == 0) unsafeAtomicAdd(d_nw + c, sn);
+  // six block reductions through ONE barrier: wave sums / maximum first, one LDS word per (wave, quantity)
+  sb = wave_sum(sb); sn = wave_sum(sn); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  mx = wave_max(mx);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    float* w = sh6 + wave * 6;
+    w[0] = sb; w[1] = sn; w[2] = s0; w[3] = s1; w[4] = s2; w[5] = mx;
   }
-  if (d_rgb_w) {
-    s0 = block_sum_256(s0, sh); s1 = block_sum_256(s1, sh); s2 = block_sum_256(s2, sh);
-    if (threadIdx.x == 0) {
-      unsafeAtomicAdd(d_rgb_w + ((int64_t)b * 3 + 0) * C + c, s0);
-      unsafeAtomicAdd(d_rgb_w + ((int64_t)b * 3 + 1) * C + c, s1);
-      unsafeAtomicAdd(d_rgb_w + ((int64_t)b * 3 + 2) * C + c, s2);
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    const float t0 = sh6[k], t1 = sh6[6 + k], t2 = sh6[12 + k], t3 = sh6[18 + k];
+    if (k < 5) {
+      const float t = (t0 + t1) + (t2 + t3);
+      float* dst = k == 0 ? d_bias : (k == 1 ? d_nw : d_rgb_w);
+      if (dst) unsafeAtomicAdd(k < 2 ? dst + c : dst + ((int64_t)b * 3 + (k - 2)) * C + c, t);
+    } else if (out_amax) {
+      cips3d_amax_raise_if(out_amax + b * CIPS3D_AMAX_FLOATS, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), blockIdx.y * gridDim.x + blockIdx.x);
     }
-  }
-  if (out_amax) {
-    __syncthreads();
-    const float m = cips3d_workgroup_max(mx, sh, threadIdx.x >> 6, threadIdx.x & 63, 4);
-    if (threadIdx.x == 0) cips3d_amax_raise_if(out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
   }
 }
 

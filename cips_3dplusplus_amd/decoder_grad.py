@@ -123,8 +123,11 @@ class GradPlan:
         pad32 = lambda n: (n + 31) // 32 * 32                       # noqa: E731
         convs = [i for i in info if i["kind"] < 2]
         for k, i in enumerate(convs):
-            px = 1024 if k == len(convs) - 1 else (64 if i["Cout"] == 128 else 128)
+            last = k == len(convs) - 1
+            px = 1024 if last else (64 if i["Cout"] == 128 else 128)
             wgs = (i["Ho"] * i["Wo"] + px - 1) // px * B
+            if last:          # the tail kernel's workgroups own ONE channel each: 32 of them add into the same 128-byte line
+                wgs *= min(32, i["Cout"])
             S = 1
             while S < 16 and wgs > 128 * S:
                 S *= 2
