@@ -42,6 +42,11 @@ class Range(C.Structure):
                 ("next_gain", C.c_float), ("pad2_", C.c_int32)]
 
 
+class AdamEntry(C.Structure):
+    """cips3d_adam_entry (include/cips3d_hip.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
+
+
 class ActBwd(C.Structure):
     """cips3d_actbwd: operands of the activation-backward epilogue (include/cips3d_hip.h)."""
     _fields_ = [("y", C.c_void_p), ("rgb_w", C.c_void_p), ("drgb", C.c_void_p), ("d_bias", C.c_void_p),
@@ -175,6 +180,7 @@ _SIGS = {
     "cips3d_decoder_grad_backward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_grad_plan": (c_int, []),
     "cips3d_sizeof_grad_io": (c_int, []),
+    "cips3d_adam_step": (c_int, [C.c_void_p, c_int, C.c_float, C.c_float, C.c_float, C.c_float, c_int, C.c_void_p]),
     "cips3d_gemm_wgrad_split": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_int, c_int, c_i64, C.c_void_p]),
@@ -204,7 +210,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 17           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 18           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

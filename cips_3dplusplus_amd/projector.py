@@ -11,8 +11,8 @@ What is NOT here: the VGG perceptual features (`get_perceptual_fea`, pretrained 
 is a callable; the default is the surrogate of SURVEY 8d config 5 (MSE on `rgb` + `thumb_weight` x MSE on `thumb_rgb`
 against fixed targets).  Streamlit charts, videos and PSNR logging are out of scope.
 
-torch.optim.Adam is used as in the reference (host-side plumbing; the path's kernels are all in csrc/), in its fused form on
-the GPU (one launch per optimiser instead of ~10 multi-tensor launches; CIPS3D_FUSED_ADAM=0: torch's default).
+The three Adam optimisers of the reference run as `optim.HipAdam` (csrc/optim.hip: torch.optim.Adam's update rule, one
+bandwidth-bound launch per 48 tensors; CIPS3D_HIP_ADAM=0: torch.optim.Adam, fused where torch offers it).
 """
 import copy
 import math
@@ -25,7 +25,13 @@ from .camera import Camera
 
 
 def _adam(groups):
-    """torch.optim.Adam; fused=True where torch offers it for these parameters (same update rule, one launch per step)."""
+    """Adam over the given parameter groups: the HIP kernel (optim.HipAdam: torch.optim.Adam's update rule, one launch per 48
+    tensors) for CUDA parameters; CIPS3D_HIP_ADAM=0: torch.optim.Adam (fused=True where torch offers it, CIPS3D_FUSED_ADAM=0:
+    its default form)."""
+    on_gpu = all(p.is_cuda and p.dtype == torch.float32 for g in groups for p in g["params"])
+    if os.environ.get("CIPS3D_HIP_ADAM", "1") != "0" and on_gpu:
+        from .optim import HipAdam
+        return HipAdam(groups)
     if os.environ.get("CIPS3D_FUSED_ADAM", "1") != "0" and all(p.is_cuda for g in groups for p in g["params"]):
         try:
             return torch.optim.Adam(groups, fused=True)

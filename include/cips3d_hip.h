@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 17  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 18  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -727,6 +727,17 @@ typedef struct cips3d_modbwd_desc {
   int32_t pad_;
 } cips3d_modbwd_desc;
 int cips3d_modulate_table_bwd(const cips3d_modbwd_desc* table_dev, int n_desc, int total_blocks, int B, void* stream);
+
+/* Adam step over a list of parameter tensors in one launch per 48 tensors (csrc/optim.hip): the update rule of
+ * torch.optim.Adam (amsgrad off, no weight decay) that the reference's inversion loop runs three of per step
+ * (models/projector_v10.py:279-390, 1210-1216).  `entries` is a HOST array (copied into the kernel arguments); p / m / v are
+ * updated in place; step = the 1-based step count of these tensors (bias corrections). */
+typedef struct cips3d_adam_entry {
+  float* p; const float* g; float* m; float* v;
+  int64_t n;
+} cips3d_adam_entry;
+int cips3d_adam_step(const cips3d_adam_entry* entries, int n_entries, float lr, float beta1, float beta2, float eps, int step,
+                     void* stream);
 
 /* The decoder as ONE differentiable node (csrc/decoder_grad.hip): Decoder.forward with every StyledConv output kept, and the
  * whole backward -- gradients of the features, the W+ styles and every decoder parameter -- in one call each.
