@@ -306,7 +306,7 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
                                    f"(surrogate loss, random-init weights)"},
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
     from cips_3dplusplus_amd import autograd as AG
-    line["route"] = ("decoder = one autograd node (cips3d_decoder_grad_forward / _backward), fused NeRF backward, fused Adam"
+    line["route"] = ("decoder = one autograd node (cips3d_decoder_grad_forward / _backward), fused NeRF backward, HIP Adam (optim.HipAdam)"
                      if AG.ONE_CALL_DECODER else "decoder = one autograd node per op (CIPS3D_ONE_CALL_DECODER=0)")
     line["roofline"] = hip.inversion_roofline(G.renderer, B=2, n_samples=n_samples)
     return line

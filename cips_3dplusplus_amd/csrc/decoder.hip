@@ -877,14 +877,20 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
       mx = fmaxf(fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))), mx);
     }
   }
-  if (out_amax && mx_b >= 0) {
-    // one atomic per wave when all its lanes ended in the same sample (the rule), else one per lane
-    const int b0 = __builtin_amdgcn_readfirstlane(mx_b);
-    if (__all(mx_b == b0)) {
-      const float m = cips3d_wave_max_uniform(mx);
-      if ((threadIdx.x & 63) == 0) cips3d_amax_raise_if(out_amax + b0 * CIPS3D_AMAX_FLOATS, m, blockIdx.x * 4 + (threadIdx.x >> 6));
-    } else {
-      cips3d_amax_raise(out_amax + mx_b * CIPS3D_AMAX_FLOATS, mx, blockIdx.x);
+  if (out_amax) {
+    // One atomic per WORKGROUP, and only when it would raise the slot (the slot's current value is peeked first: 16 384
+    // workgroups raising 8 lines unconditionally cost more than the absmax pass this replaces).  Lanes that ended in another
+    // sample than the workgroup's first (a straddling workgroup: at most B - 1 of them) raise theirs directly.
+    __shared__ float s_mx[16];
+    __shared__ int s_b;
+    if (threadIdx.x == 0) s_b = mx_b;
+    __syncthreads();
+    const int b0 = s_b;
+    if (mx_b >= 0 && mx_b != b0) cips3d_amax_raise(out_amax + mx_b * CIPS3D_AMAX_FLOATS, mx, blockIdx.x);
+    const float m = cips3d_workgroup_max(mx_b == b0 ? mx : 0.f, s_mx, threadIdx.x >> 6, threadIdx.x & 63, 4);
+    if (threadIdx.x == 0 && b0 >= 0) {
+      float* slots = out_amax + b0 * CIPS3D_AMAX_FLOATS;
+      cips3d_amax_raise_if(slots, m, blockIdx.x, cips3d_amax_peek(slots, blockIdx.x));
     }
   }
 }

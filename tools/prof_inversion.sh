@@ -1,5 +1,5 @@
 # BASELINE config 5 (one flip-inversion step): unprofiled rate + kernel-trace summary of the one-call decoder route and of the
-# per-op route (CIPS3D_ONE_CALL_DECODER=0 CIPS3D_FUSED_ADAM=0: round 2's) on the SAME box, + the launch sequence of one step
+# per-op route (CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0: round 2's) on the SAME box, + the launch sequence of one step
 export TMPDIR=/tmp
 O=gpurun_out/inv; rm -rf $O; mkdir -p $O
 summ() {
@@ -15,11 +15,11 @@ for r in rows[:40]:
 PY
 }
 python3 tools/bench_inversion.py --steps 104 > $O/bench_one_call.json 2> $O/bench.err; cat $O/bench_one_call.json
-CIPS3D_ONE_CALL_DECODER=0 CIPS3D_FUSED_ADAM=0 python3 tools/bench_inversion.py --steps 104 > $O/bench_per_op.json 2>> $O/bench.err; cat $O/bench_per_op.json
+CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0 python3 tools/bench_inversion.py --steps 104 > $O/bench_per_op.json 2>> $O/bench.err; cat $O/bench_per_op.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/bench_inversion.py --steps 44 > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/inversion_kernel_stats.csv
 summ $O/inversion_kernel_stats.csv 44 > $O/inversion_summary.txt; head -30 $O/inversion_summary.txt
-export CIPS3D_ONE_CALL_DECODER=0 CIPS3D_FUSED_ADAM=0
+export CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -- python3 tools/bench_inversion.py --steps 44 > $O/kt0.log 2>&1
 unset CIPS3D_ONE_CALL_DECODER CIPS3D_FUSED_ADAM
 cp $(find $O/kt0 -name "*kernel_stats.csv" | head -1) $O/inversion_per_op_kernel_stats.csv
