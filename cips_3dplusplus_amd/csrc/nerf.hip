@@ -693,20 +693,28 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // (opaque: the output addresses derived from it were otherwise computed before the sample loop and kept in spilled
     // 64-bit registers across it -- 2.1 MB of scratch traffic per launch for nothing)
     asm volatile("" : "+v"(rr));
-    const int gray = g * RAYS + rr;
+    // With fewer chunks per ray (n_chunks = 4, 2, 1: batches of 2, 4, 8 and more) the workgroup holds 8 / n_chunks ray
+    // groups, wave w = chunk w % n_chunks of group w / n_chunks: the same combination per group, over n_chunks partials.
+    const int NC = P.n_chunks;
+    const int g0 = ((int)(task0 % a.tasks_per_view)) / NC;      // ray group of wave 0 (task0 is a multiple of 8)
+    for (int gi = 0; gi < WAVES / NC; ++gi) {
+    const int wb = gi * NC;                                     // first wave of this group
+    const int gray = (g0 + gi) * RAYS + rr;
     if (gray < R) {
       float Tp[WAVES];
       Tp[0] = 1.f;
 #pragma unroll
-      for (int cc = 1; cc < WAVES; ++cc) Tp[cc] = Tp[cc - 1] * xs[(cc - 1) * 8 * RAYS + 7 * RAYS + rr];
+      for (int cc = 1; cc < WAVES; ++cc) Tp[cc] = cc < NC ? Tp[cc - 1] * xs[(wb + cc - 1) * 8 * RAYS + 7 * RAYS + rr] : 0.f;
       // features: thread (ray rr, channel quad cq) for cq = tid >> 4 + 32 j
       for (int cq = tid >> 4; cq < H / 4; cq += WAVES * 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int cc = 0; cc < WAVES; ++cc) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(xf + (cc * RAYS + rr) * nerf_xf_pitch(H) + 4 * cq);
+          if (cc < NC) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xf + ((wb + cc) * RAYS + rr) * nerf_xf_pitch(H) + 4 * cq);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = fmaf(Tp[cc], v[e], acc[e]);
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(Tp[cc], v[e], acc[e]);
+          }
         }
         if (P.features_planes) {
           // split-fp16 planes [b][H/8][hi|lo][R][8]: channels 4 cq .. 4 cq + 3 = elements 4 (cq & 1) .. of channel block cq >> 1
@@ -730,7 +738,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       if (k < 7) {
         float acc = 0.f;
 #pragma unroll
-        for (int cc = 0; cc < WAVES; ++cc) acc = fmaf(Tp[cc], xs[cc * 8 * RAYS + k * RAYS + rr], acc);
+        for (int cc = 0; cc < WAVES; ++cc)
+          if (cc < NC) acc = fmaf(Tp[cc], xs[(wb + cc) * 8 * RAYS + k * RAYS + rr], acc);
         if (k < 3) {
           P.o_thumb[((int64_t)b * 3 + k) * R + gray] = -1.f + 2.f * acc;
         } else if (k < 6) {
@@ -740,14 +749,17 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
           float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
           for (int cc = 0; cc < WAVES; ++cc) {
-            sx = fmaf(Tp[cc], xs[cc * 8 * RAYS + 3 * RAYS + rr], sx);
-            sy = fmaf(Tp[cc], xs[cc * 8 * RAYS + 4 * RAYS + rr], sy);
-            sz = fmaf(Tp[cc], xs[cc * 8 * RAYS + 5 * RAYS + rr], sz);
+            if (cc < NC) {
+              sx = fmaf(Tp[cc], xs[(wb + cc) * 8 * RAYS + 3 * RAYS + rr], sx);
+              sy = fmaf(Tp[cc], xs[(wb + cc) * 8 * RAYS + 4 * RAYS + rr], sy);
+              sz = fmaf(Tp[cc], xs[(wb + cc) * 8 * RAYS + 5 * RAYS + rr], sz);
+            }
           }
           P.o_mask[((int64_t)b * 2 + 1) * R + gray] = -sqrtf((sx * sx + sy * sy) + sz * sz);
         }
       }
     }
+    }   // ray groups of the workgroup
     STAMP(6);   // fused finish
     STAMP_FLUSH();
     return;
@@ -929,14 +941,14 @@ extern "C" int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int 
   return (int64_t)n_chunks * B * (hidden + 8) * img_size * img_size;
 }
 
-// fused finish: needs the 8 chunk waves of a ray group in one workgroup, the tables large enough for the scalar exchange
+// fused finish: needs the chunk waves of a ray group in one workgroup (n_chunks divides 8), the tables large enough for the scalar exchange
 // and the partial exchange + tables within the 160 KB of LDS
 extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
   if (!p || !p->o_features || !p->o_thumb || !p->o_xyz || !p->o_mask) return 0;
   static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
   if (off) return 0;
   const int H = p->hidden, L = p->depth + 1;
-  if (p->n_chunks != WAVES || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
+  if (p->n_chunks < 1 || WAVES % p->n_chunks != 0 || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
   const int tables = L * 2 * H + 10 * H;
   if (tables < WAVES * 8 * RAYS) return 0;
   return sizeof(float) * ((size_t)nerf_ring_floats(H, H == 256 ? 4 : 2, true) + tables) <= 160 * 1024;

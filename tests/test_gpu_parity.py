@@ -185,10 +185,13 @@ def test_nerf_render_hidden256(D, N, img, B, chunks):
                       chunks=chunks, tol=2e-4)
 
 
-@pytest.mark.parametrize("hidden,D,img,N,B", [(256, 2, 10, 24, 1), (256, 8, 8, 9, 2), (64, 2, 9, 16, 2)])
-def test_nerf_in_kernel_chunk_combination_is_bit_identical(hidden, D, img, N, B, monkeypatch):
-    """With eight chunks the render kernel combines the partials itself (cips3d_nerf_fuses_finish); the result must equal
-    the `part` + cips3d_nerf_finish route bit for bit -- ragged ray groups (img^2 % 16 != 0), N not a multiple of 8."""
+@pytest.mark.parametrize("hidden,D,img,N,B,NC", [(256, 2, 10, 24, 1, 8), (256, 8, 8, 9, 2, 8), (64, 2, 9, 16, 2, 8),
+                                                 (256, 2, 10, 24, 2, 4), (256, 2, 9, 24, 4, 2), (64, 3, 11, 10, 3, 1),
+                                                 (64, 2, 6, 7, 2, 4)])
+def test_nerf_in_kernel_chunk_combination_is_bit_identical(hidden, D, img, N, B, NC, monkeypatch):
+    """When the chunk count divides the eight waves of a workgroup (8 at batch 1, 4 / 2 / 1 at batches 2 / 4 / 8+) the render
+    kernel combines the partials itself (cips3d_nerf_fuses_finish); the result must equal the `part` + cips3d_nerf_finish route
+    bit for bit -- ragged ray groups (img^2 % 16 != 0), N not a multiple of the chunk count, padded tasks."""
     cfg = configs.ffhq_G_cfg(256, D) if hidden == 256 else configs.tiny_G_cfg(hidden, D)
     G = pkg.build_generator(cfg, DEV, seed=5)
     g = torch.Generator().manual_seed(1)
@@ -203,16 +206,16 @@ def test_nerf_in_kernel_chunk_combination_is_bit_identical(hidden, D, img, N, B,
         return real(**kw)
 
     monkeypatch.setattr(hip, "nerf_render_maps", spy)
-    thumb, feat, _, mask, xyz = G.renderer.render(*cam, styles, img, N, perturb_u=u, n_chunks=8)
+    thumb, feat, _, mask, xyz = G.renderer.render(*cam, styles, img, N, perturb_u=u, n_chunks=NC)
     p = hip._nerf_params(seen)
     out = [torch.empty_like(t) for t in (feat, thumb, xyz, mask)]
     p.o_features, p.o_thumb, p.o_xyz, p.o_mask = (t.data_ptr() for t in out)
     from cips_3dplusplus_amd import _lib
     import ctypes
     assert _lib.load().cips3d_nerf_fuses_finish(ctypes.byref(p)) == 1
-    part = torch.empty(8, B, hidden + 8, img * img, device=DEV)
+    part = torch.empty(NC, B, hidden + 8, img * img, device=DEV)
     hip.nerf_render(**{**seen, "part": part})
-    f2, t2, x2, m2 = hip.nerf_finish(part, 8, B, img, hidden)
+    f2, t2, x2, m2 = hip.nerf_finish(part, NC, B, img, hidden)
     assert torch.equal(feat, f2) and torch.equal(thumb, t2) and torch.equal(xyz, x2) and torch.equal(mask, m2)
 
 
