@@ -49,6 +49,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <type_traits>
 #include "common.h"
 #include "nerf_mlp.h"
 
@@ -695,7 +696,11 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     asm volatile("" : "+v"(rr));
     // With fewer chunks per ray (n_chunks = 4, 2, 1: batches of 2, 4, 8 and more) the workgroup holds 8 / n_chunks ray
     // groups, wave w = chunk w % n_chunks of group w / n_chunks: the same combination per group, over n_chunks partials.
-    const int NC = P.n_chunks;
+    // The batch-1 case (8 chunks, one group) keeps its fully unrolled form: with the chunk count a run-time value the
+    // headline launch lost 1.1 us (same-box A/B).
+    auto combine = [&](auto nc_) {
+    constexpr int NCT = decltype(nc_)::value;
+    const int NC = NCT > 0 ? NCT : P.n_chunks;
     const int g0 = ((int)(task0 % a.tasks_per_view)) / NC;      // ray group of wave 0 (task0 is a multiple of 8)
     for (int gi = 0; gi < WAVES / NC; ++gi) {
     const int wb = gi * NC;                                     // first wave of this group
@@ -760,6 +765,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       }
     }
     }   // ray groups of the workgroup
+    };
+    if (P.n_chunks == WAVES) combine(std::integral_constant<int, WAVES>{});
+    else combine(std::integral_constant<int, 0>{});
     STAMP(6);   // fused finish
     STAMP_FLUSH();
     return;
