@@ -204,13 +204,14 @@ _SIGS = {
     "cips3d_nerf_pack_weights_t": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     "cips3d_nerf_bwd_fused": (c_int, [C.c_void_p, C.c_void_p]),
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cips3d_style_phase": (c_int, [C.c_void_p, C.c_void_p, c_int, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),
     "cips3d_sizeof_struct": (c_i64, [c_int]),
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 18           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 19           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -3,6 +3,8 @@
 // ~20 us each (more than the GPU time of most of them), issuing them from here costs a hipLaunchKernel
 // each, and the call can be captured into a hipGraph by the caller because nothing here allocates,
 // synchronises or touches anything but `stream`.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define TRY(expr)            \
@@ -28,28 +30,25 @@ extern "C" int64_t cips3d_sizeof_struct(int which) {
   }
 }
 
-extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io,
-                                        void* stream) {
-  if (!plan || !io) return CIPS3D_E_BADARG;
+int cips3d_style_phase_one_launch(const cips3d_linear_args* ar, int nr, const cips3d_linear_args* ad, int nd,
+                                  const cips3d_linear_desc* film, int film_n, int film_rows, const cips3d_linear_desc* mod,
+                                  int mod_n, int mod_rows, const float* styles_r, int sd_r, const float* styles_d, int sd_d,
+                                  void* xch, void* sync, int dim, const cips3d_rng_job* job, float* zero_ptr, int zero_n,
+                                  void* stream);
+
+extern "C" int cips3d_style_phase(const cips3d_generator_plan* plan, const cips3d_forward_io* io, int mode, void* stream) {
+  if (!plan || !io || mode < -1 || mode > 1) return CIPS3D_E_BADARG;
   const cips3d_generator_plan& P = *plan;
   const cips3d_forward_io& IO = *io;
-  if (P.B <= 0 || P.n_map_r > CIPS3D_MAX_MAP_LAYERS || P.n_map_d > CIPS3D_MAX_MAP_LAYERS ||
-      P.n_dec_layers > CIPS3D_MAX_DEC_LAYERS || P.n_dec_layers < 2)
-    return CIPS3D_E_BADARG;
-  if (!IO.cam_poses || !IO.focals || !IO.near_ || !IO.far_ || !IO.rgb || !IO.thumb || !IO.xyz || !IO.mask)
-    return CIPS3D_E_BADARG;
+  if (P.B <= 0 || P.n_map_r > CIPS3D_MAX_MAP_LAYERS || P.n_map_d > CIPS3D_MAX_MAP_LAYERS) return CIPS3D_E_BADARG;
   const int B = P.B;
   const int D = P.nerf.depth;
-  const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
-  // decoder_bf16 == 2: the low-resolution GEMM results of the fused up-sampling stages (y_lo / y_next) live in HBM as bf16
-  const int ybf_flag = P.decoder_bf16 == 2 ? CIPS3D_Y_BF16 : 0;
   const bool trunc = IO.mean_r && IO.mean_d && IO.trunc_psi < 1.f;
+  const bool ranged = P.range_ws != nullptr;
+  if (ranged && (P.range_ws_words <= 0 || P.range_ws_words > (1 << 30))) return CIPS3D_E_BADARG;
 
-  // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot.  The two chains
-  // are independent: their i-th layers share a launch (8 dependent ~4.5 us launches -> 5), and the FiLM heads of the
-  // (shorter) renderer chain ride on the decoder chain's next layer.
+  // ---- mapping networks (model_v3.py:1299-1418); the last layer broadcasts w to every style slot.
   cips3d_linear_args ar[CIPS3D_MAX_MAP_LAYERS], ad[CIPS3D_MAX_MAP_LAYERS];
-  bool film_done = false;
   const int nr = IO.z_r ? P.n_map_r : 0, nd = IO.z_d ? P.n_map_d : 0;
   {
     const float* x = IO.z_r;
@@ -76,19 +75,43 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                                  (last && trunc) ? IO.mean_d : nullptr, IO.trunc_psi, last ? P.n_latent : 1, P.style_dim_d};
       x = out; xs = P.style_dim_d;
     }
-    // fresh draws of this call: slices of one cips3d_rng_fill ride on the paired launches; none of those: a launch of its own
-    const bool want_rng = IO.rng_n_normal > 0 || IO.rng_n_uniform > 0;
-    if (IO.rng_n_normal < 0 || IO.rng_n_uniform < 0 || (IO.rng_n_normal > 0 && !IO.rng_normal) ||
-        (IO.rng_n_uniform > 0 && !IO.rng_uniform))
-      return CIPS3D_E_BADARG;
+  }
+  // fresh draws of this call: slices of one cips3d_rng_fill ride on the phase's launch(es); none of those: a launch of its own
+  const bool want_rng = IO.rng_n_normal > 0 || IO.rng_n_uniform > 0;
+  if (IO.rng_n_normal < 0 || IO.rng_n_uniform < 0 || (IO.rng_n_normal > 0 && !IO.rng_normal) ||
+      (IO.rng_n_uniform > 0 && !IO.rng_uniform))
+    return CIPS3D_E_BADARG;
+  const long long rng_threads = want_rng ? cips3d_rng_fill_threads(IO.rng_n_normal, IO.rng_n_uniform) : 0;
+  cips3d_rng_job whole{(unsigned)IO.rng_seed, (unsigned)(IO.rng_seed >> 32), (unsigned long long)IO.rng_base, IO.rng_normal,
+                       (long long)IO.rng_n_normal, IO.rng_uniform, (long long)IO.rng_n_uniform, 0, rng_threads};
+
+  // ---- ONE launch: resident workgroups, layer outputs handed over as tagged granules (linear.hip: style_phase_kernel).
+  // Opt-in: measured 9 us SLOWER per forward than the launches below (~14 dependent memory round trips of
+  // ~2.2 us inside the launch against six kernel boundaries).
+  bool one = mode == 1;
+  if (mode == -1) {
+    const char* e = getenv("CIPS3D_STYLE_PHASE");
+    one = e && e[0] == '1';
+  }
+  if (one) {
+    const int rc = cips3d_style_phase_one_launch(ar, nr, ad, nd, P.film_table, P.film_n, P.film_rows, P.mod_table, P.mod_n, P.mod_rows,
+                                                 P.styles_r, P.style_dim_r, P.styles_d, P.style_dim_d, P.style_xch, P.style_sync,
+                                                 P.style_xch_dim, want_rng ? &whole : nullptr, ranged ? P.range_ws : nullptr,
+                                                 ranged ? (int)P.range_ws_words : 0, stream);
+    if (rc != CIPS3D_E_UNSUPP || mode == 1) return rc;
+  }
+
+  // ---- launches.  The two chains are independent: their i-th layers share a launch (8 dependent ~4.5 us launches -> 5),
+  // and the FiLM heads of the (shorter) renderer chain ride on the decoder chain's next layer.
+  bool film_done = false;
+  {
     const int n_pair = nr < nd ? nr : nd;
-    const long long rng_threads = want_rng ? cips3d_rng_fill_threads(IO.rng_n_normal, IO.rng_n_uniform) : 0;
     if (want_rng && n_pair == 0)
       TRY(cips3d_rng_fill(IO.rng_seed, IO.rng_base, IO.rng_normal, IO.rng_n_normal, IO.rng_uniform, IO.rng_n_uniform, stream));
     for (int i = 0; i < (nr > nd ? nr : nd); ++i) {
       if (i < nr && i < nd) {
-        cips3d_rng_job job{(unsigned)IO.rng_seed, (unsigned)(IO.rng_seed >> 32), (unsigned long long)IO.rng_base, IO.rng_normal,
-                           (long long)IO.rng_n_normal, IO.rng_uniform, (long long)IO.rng_n_uniform, 0, 0};
+        cips3d_rng_job job = whole;
+        job.t1 = 0;
         if (want_rng) {      // slice i of n_pair, in whole blocks of 256 threads
           const long long per = ((rng_threads + n_pair - 1) / n_pair + 255) / 256 * 256;
           job.t0 = per * i < rng_threads ? per * i : rng_threads;
@@ -107,16 +130,36 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       }
     }
   }
-
-  // ---- style heads: FiLM gamma/beta of every SIREN layer; every decoder modulation; modulated weights
+  // ---- style heads: FiLM gamma/beta of every SIREN layer; every decoder modulation
   if (!film_done) TRY(cips3d_linear_table(P.film_table, P.film_n, P.film_rows, B, stream));
   // Range tracking of the split-fp16 decoder (cips3d_range): the workspace -- amax slots every producing epilogue raises with
-  // atomicMax, planes exponents, layer constants -- is zeroed by the launch of the modulation heads; the modulate table then
-  // writes every layer's constants with this call's bound of |noise| (6: cips3d_rng_fill's draws stay below 5.89).
-  const bool ranged = P.range_ws != nullptr;
-  if (ranged && (P.range_ws_words <= 0 || P.range_ws_words > (1 << 30) || !P.feat_amax || !P.feat_exp || !P.tmp_amax)) return CIPS3D_E_BADARG;
+  // atomicMax, planes exponents, layer constants -- is zeroed by the launch of the modulation heads.
   if (ranged) TRY(cips3d_linear_table_zero(P.mod_table, P.mod_n, P.mod_rows, B, P.range_ws, (int)P.range_ws_words, stream));
   else TRY(cips3d_linear_table(P.mod_table, P.mod_n, P.mod_rows, B, stream));
+  return 0;
+}
+
+extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io,
+                                        void* stream) {
+  if (!plan || !io) return CIPS3D_E_BADARG;
+  const cips3d_generator_plan& P = *plan;
+  const cips3d_forward_io& IO = *io;
+  if (P.B <= 0 || P.n_map_r > CIPS3D_MAX_MAP_LAYERS || P.n_map_d > CIPS3D_MAX_MAP_LAYERS ||
+      P.n_dec_layers > CIPS3D_MAX_DEC_LAYERS || P.n_dec_layers < 2)
+    return CIPS3D_E_BADARG;
+  if (!IO.cam_poses || !IO.focals || !IO.near_ || !IO.far_ || !IO.rgb || !IO.thumb || !IO.xyz || !IO.mask)
+    return CIPS3D_E_BADARG;
+  const int B = P.B;
+  const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
+  // decoder_bf16 == 2: the low-resolution GEMM results of the fused up-sampling stages (y_lo / y_next) live in HBM as bf16
+  const int ybf_flag = P.decoder_bf16 == 2 ? CIPS3D_Y_BF16 : 0;
+
+  // ---- mapping networks, FiLM heads, modulation heads, the call's draws (cips3d_style_phase); then the modulated weights:
+  // the modulate table also writes every layer's range constants with this call's bound of |noise| (6: cips3d_rng_fill's
+  // draws stay below 5.89).
+  const bool ranged = P.range_ws != nullptr;
+  if (ranged && (P.range_ws_words <= 0 || P.range_ws_words > (1 << 30) || !P.feat_amax || !P.feat_exp || !P.tmp_amax)) return CIPS3D_E_BADARG;
+  TRY(cips3d_style_phase(plan, io, -1, stream));
   TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, IO.noise_bound > 0.f ? IO.noise_bound : 6.f, stream));
 
   // ---- NeRF: rays -> samples -> FiLM-SIREN -> compositing

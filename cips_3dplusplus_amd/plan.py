@@ -38,7 +38,8 @@ class GeneratorPlan(C.Structure):
                 ("rgb_part", C.c_void_p),
                 ("rgb_part_slots", C.c_int64),
                 ("range_ws", C.c_void_p), ("range_ws_words", C.c_int64), ("feat_amax", C.c_void_p), ("feat_exp", C.c_void_p),
-                ("feat_pmax", C.c_void_p), ("tmp_amax", C.c_void_p)]
+                ("feat_pmax", C.c_void_p), ("tmp_amax", C.c_void_p),
+                ("style_xch", C.c_void_p), ("style_sync", C.c_void_p), ("style_xch_dim", C.c_int32), ("pad3_", C.c_int32)]
 
 
 class ForwardIO(C.Structure):
@@ -106,6 +107,11 @@ class ForwardPlan:
         lat = torch.empty(4, B, lat_w, device=dev)
         for i in range(4):
             p.lat[i] = lat[i].data_ptr()
+        # workspace of the one-launch style phase (cips3d_style_phase): tagged granules + the generation word
+        xdim = (max([lat_w] + [l.weight.shape[1] for l in map_d]) + 3) // 4 * 4
+        self.style_xch = torch.zeros(2 * MAX_MAP * B * xdim, dtype=torch.int64, device=dev)
+        self.style_sync = torch.zeros(64, dtype=torch.int32, device=dev)
+        p.style_xch, p.style_sync, p.style_xch_dim = self.style_xch.data_ptr(), self.style_sync.data_ptr(), xdim
 
         # ---- FiLM heads (renderer owns styles staging + film + table)
         styles_r, film, film_tab = ren._film_table(B, dev)
@@ -322,6 +328,26 @@ class ForwardPlan:
         self._keep += [lat, film, film_tab, mod_tab, s_buf, wm_buf, wm_tab_dev, packed, layer_bias, part, features, act,
                        y_lo, skip]
         self.noise_total = sum(s * s for s in self.noise_sizes)
+        self.film, self.s_buf, self.range_ws = film, s_buf, range_ws
+
+    def style_phase(self, z_r, z_d, mode=-1, trunc_psi=1.0, mean_r=None, mean_d=None, rng=None):
+        """cips3d_style_phase alone (tests, tools): the mapping networks and every style head of this plan for (z_r, z_d);
+        mode 0 = as launches, 1 = one launch, -1 = the forward's choice.  rng = (seed, base, normal, uniform): the draw that
+        rides on it.  Results land in styles_r / styles_d / film / s_buf of the plan."""
+        lib = _lib.load()
+        io = ForwardIO()
+        io.z_r, io.z_d = dev_ptr(z_r, "z_r"), dev_ptr(z_d, "z_d")
+        io.mean_r = dev_ptr(mean_r, "mean_r", allow_none=True)
+        io.mean_d = dev_ptr(mean_d, "mean_d", allow_none=True)
+        io.trunc_psi = float(trunc_psi)
+        if rng is not None:
+            seed, base, normal, uniform = rng
+            io.rng_seed, io.rng_base = seed, base
+            if normal is not None:
+                io.rng_normal, io.rng_n_normal = normal.data_ptr(), normal.numel()
+            if uniform is not None:
+                io.rng_uniform, io.rng_n_uniform = uniform.data_ptr(), uniform.numel()
+        _lib.check(lib.cips3d_style_phase(C.byref(self.plan), C.byref(io), int(mode), _lib.stream_ptr()), "cips3d_style_phase")
 
     def __deepcopy__(self, memo):
         """A copied generator owns new parameter storage: the copy of a plan is a tombstone whose key never matches,

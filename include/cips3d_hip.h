@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 18  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 19  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -555,6 +555,12 @@ typedef struct cips3d_generator_plan {
   int32_t* feat_exp;             /* [B][blocks] exponents written by that pass */
   float* feat_pmax;              /* [B][ceil(S*S/64)][hidden/16] patch maxima written by that pass */
   float* tmp_amax;               /* [B][CIPS3D_AMAX_FLOATS] scratch for tensors no producer tracked */
+  /* workspace of the one-launch style phase (cips3d_style_phase) or NULL (the phase then runs as launches): */
+  void* style_xch;               /* 2 * CIPS3D_MAX_MAP_LAYERS * B * style_xch_dim 8-byte {value, tag} granules, zeroed once */
+  void* style_sync;              /* 256 bytes, zeroed once: [0] generation of the last launch, [1] waits that gave up (stays 0),
+                                    [3..] diagnostics: 10 ns ticks from the start of workgroup 0 to its end / to each stage */
+  int32_t style_xch_dim;         /* >= every width of the two mapping networks, % 4 == 0 */
+  int32_t pad3_;
 } cips3d_generator_plan;
 
 typedef struct cips3d_forward_io {
@@ -587,6 +593,17 @@ typedef struct cips3d_forward_io {
 } cips3d_forward_io;
 
 int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io, void* stream);
+
+/* The part of cips3d_generator_forward in front of the modulated weights: Generator.mapping_networks (models/model_v3.py:
+ * 1299-1418) -> plan.styles_r / styles_d, the FiLM heads (cips3d/volume_renderer.py:66-67) and every
+ * ModulatedConv2d.modulation (models/model_v3.py:254,268) through the plan's tables, the call's fresh draws (io.rng_*) and the
+ * zeroing of the range workspace.  mode 0: a chain of dependent launches (two layers or a layer and a table per launch);
+ * mode 1: ONE launch of resident workgroups that hand each layer's outputs to each other through plan.style_xch
+ * (CIPS3D_E_UNSUPP when the plan has no such workspace, a chain is absent, B > 8 or a width exceeds style_xch_dim);
+ * mode -1: what cips3d_generator_forward does -- mode 0, or mode 1 (where supported) when the environment says
+ * CIPS3D_STYLE_PHASE=1: the one launch measured slower on MI355X.  Both modes give bit-identical
+ * results. */
+int cips3d_style_phase(const cips3d_generator_plan* plan, const cips3d_forward_io* io, int mode, void* stream);
 /* sizeof() of the two structs as the library sees them (layout check for foreign-language bindings) */
 int64_t cips3d_sizeof_plan(void);
 int64_t cips3d_sizeof_io(void);
