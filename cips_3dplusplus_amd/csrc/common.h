@@ -38,6 +38,24 @@ int cips3d_linear_and_table(const cips3d_linear_args& a, const cips3d_linear_des
 int cips3d_linear_table_zero(const cips3d_linear_desc* table_dev, int n_desc, int total_rows, int B, float* zero_ptr,
                              int zero_n, void* stream);
 
+// "This pointer is global memory."  A pointer that was itself loaded from memory (a descriptor table's fields) is generic
+// to the compiler: its loads and stores become flat_ instructions, which count on lgkmcnt as well as vmcnt and may return
+// out of order with respect to both -- every wait behind one is a wait for everything.  (Kernel-argument pointers are
+// known to be global already.)
+#ifdef CIPS3D_NO_GLOBAL_CAST      /* A/B knob: leave them generic */
+template <typename T> __device__ static inline const T* cips3d_g(const T* p) { return p; }
+template <typename T> __device__ static inline T* cips3d_g(T* p) { return p; }
+#else
+template <typename T>
+__device__ static inline const __attribute__((address_space(1))) T* cips3d_g(const T* p) {
+  return (const __attribute__((address_space(1))) T*)p;
+}
+template <typename T>
+__device__ static inline __attribute__((address_space(1))) T* cips3d_g(T* p) {
+  return (__attribute__((address_space(1))) T*)p;
+}
+#endif
+
 // floor division for possibly negative numerators (b > 0)
 __host__ __device__ static inline int floor_div_i(int a, int b) {
   int q = a / b;

@@ -149,11 +149,13 @@ __device__ __forceinline__ void layer_consts(const float* __restrict__ bias, int
   }
 }
 
-__device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb,
-                                             float* __restrict__ wm, int b, int o, int Cout, int Cin, int ksq,
+__device__ __forceinline__ void modulate_row(const float* __restrict__ W, const float* __restrict__ sb_,
+                                             float* __restrict__ wm_, int b, int o, int Cout, int Cin, int ksq,
                                              float scale, int demod, int packed, int lane, float* __restrict__ l1_out = nullptr) {
   const int len = Cin * ksq;
-  const float* w = W + (int64_t)o * len;
+  const auto* w = cips3d_g(W + (int64_t)o * len);       // (global, whatever the pointers' provenance: see cips3d_g)
+  const auto* sb = cips3d_g(sb_);
+  auto* wm = cips3d_g(wm_);
   // (A 16-byte-store form of the split / bf16 layouts -- 8 consecutive channels per lane, bit-identical output -- was built
   // and measured: modulate_table_kernel 10.9 us against 10.3 us.  The launch is a chain of dependent latencies (descriptor,
   // row, reduction, store), not store-bound; not kept.)
@@ -197,7 +199,7 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       const float sv = v * kSplitScale;
       _Float16 hi, lo;
       cips3d_split16(sv, hi, lo);
-      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 512) +
+      auto* blk = cips3d_g(reinterpret_cast<_Float16*>(wm_)) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 512) +
                       ((q << 4) | (o & 15)) * 8;
       blk[el] = hi;
       blk[4 + el] = lo;
@@ -207,7 +209,7 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       const float sv = v * kSplitScale;
       _Float16 hi, lo;
       cips3d_split16(sv, hi, lo);
-      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 5) + (o >> 5)) * 1024);
+      auto* blk = cips3d_g(reinterpret_cast<_Float16*>(wm_)) + ((((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 5) + (o >> 5)) * 1024);
       blk[((q << 4) | (i & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (i & 15)) * 8 + j] = lo;
     } else if (packed & 16) {     // split-fp16 fragments (ksq == 1)
@@ -216,14 +218,14 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       const float sv = v * kSplitScale;
       _Float16 hi, lo;
       cips3d_split16(sv, hi, lo);
-      _Float16* blk = reinterpret_cast<_Float16*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
+      auto* blk = cips3d_g(reinterpret_cast<_Float16*>(wm_)) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 1024);
       blk[((q << 4) | (o & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (o & 15)) * 8 + j] = lo;
     } else if (packed & 128) {    // bf16 fragments of v_mfma_f32_16x16x32_bf16 (ksq == 1): the split layout's positions, one plane
       const int i = e;
       const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;
       const __bf16 r = (__bf16)v;                                            // round to nearest even (the bf16 mode's operand rounding)
-      unsigned short* blk = reinterpret_cast<unsigned short*>(wm) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 512);
+      auto* blk = cips3d_g(reinterpret_cast<unsigned short*>(wm_)) + ((((int64_t)b * (Cout >> 4) + ot) * (Cin >> 5) + kb) * 512);
       blk[((q << 4) | (o & 15)) * 8 + j] = __builtin_bit_cast(unsigned short, r);
     } else if (packed & 64) {     // fragments of wm^T (ksq == 1): row = input channel, k = output unit (backward.hip:pack_kernel)
       const int i = e;

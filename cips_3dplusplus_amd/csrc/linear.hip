@@ -23,12 +23,13 @@ __device__ __forceinline__ void dot_rows(const float* __restrict__ w, const floa
   const bool vec = (in_dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && (x_stride % 4 == 0);
   if (vec) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
     for (int i = lane * 4; i < in_dim; i += 256) {
-      const float4 wv = *reinterpret_cast<const float4*>(w + i);
+      const v4 wv = *cips3d_g(reinterpret_cast<const v4*>(w + i));         // (global: see cips3d_g)
 #pragma unroll
       for (int j = 0; j < BT; ++j) {
         if (j < nb) {
-          const float4 xv = *reinterpret_cast<const float4*>(x + j * x_stride + i);
+          const v4 xv = *cips3d_g(reinterpret_cast<const v4*>(x + j * x_stride + i));
           acc[j] = fmaf(wv.x, xv.x, acc[j]);
           acc[j] = fmaf(wv.y, xv.y, acc[j]);
           acc[j] = fmaf(wv.z, xv.z, acc[j]);
@@ -38,10 +39,10 @@ __device__ __forceinline__ void dot_rows(const float* __restrict__ w, const floa
     }
   } else {
     for (int i = lane; i < in_dim; i += 64) {
-      const float wv = w[i];
+      const float wv = cips3d_g(w)[i];
 #pragma unroll
       for (int j = 0; j < BT; ++j)
-        if (j < nb) acc[j] = fmaf(wv, x[j * x_stride + i], acc[j]);
+        if (j < nb) acc[j] = fmaf(wv, cips3d_g(x)[j * x_stride + i], acc[j]);
     }
   }
 #pragma unroll
@@ -158,7 +159,7 @@ __device__ __forceinline__ void table_rows(const cips3d_linear_desc* __restrict_
   const cips3d_linear_desc d = table[lo];
   const int row = grow - d.row_begin;
   const float* w = d.W + (int64_t)row * d.in_dim;
-  const float b = d.bias ? d.bias[row] * d.b_scale : 0.f;
+  const float b = d.bias ? cips3d_g(d.bias)[row] * d.b_scale : 0.f;
   for (int b0 = 0; b0 < B; b0 += BT) {
     const int nb = min(BT, B - b0);
     float acc[BT];
@@ -168,7 +169,7 @@ __device__ __forceinline__ void table_rows(const cips3d_linear_desc* __restrict_
       for (int j = 0; j < BT; ++j) {
         if (j >= nb) break;
         const float y = fmaf(acc[j], d.w_scale, b);
-        d.out[(int64_t)(b0 + j) * d.out_stride + row] = fmaf(y, d.out_scale, d.out_shift);
+        cips3d_g(d.out)[(int64_t)(b0 + j) * d.out_stride + row] = fmaf(y, d.out_scale, d.out_shift);
       }
     }
   }
