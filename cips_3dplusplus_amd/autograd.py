@@ -515,8 +515,6 @@ class NerfRenderFn(Function):
         materialised route, which keeps every layer's activations and can contract them with the gradients."""
         # With the fused backward available the forward keeps what it needs (accumulator stash, per-point sdf / rgb logits):
         # the backward then does not run the forward again (hip.STASH_IN_FORWARD = 0: it does, and nothing is held meanwhile).
-        if not renderer.with_sdf:        # fail here, not in backward: both backward kernels differentiate the sdf branch only
-            raise NotImplementedError("with_sdf=False (raw density, nerf_utils.py:288-297) is forward-only on the HIP path")
         ctx.n_params = len(params)
         ctx.want_params = any(p.requires_grad for p in params)
         fwd = None
@@ -546,7 +544,7 @@ class NerfRenderFn(Function):
         if dthumb is None:
             dthumb = torch.zeros(B, 3, img_size, img_size, device=cam_poses.device)
         if ctx.want_params:
-            dfilm, dcam, pg = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
+            dfilm, dcam, pg = hip.nerf_backward(r.network, r.sigmoid_beta.detach() if r.with_sdf else None, cam_poses, focals, near, far, perturb_u, film,
                                                 layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float(),
                                                 need_params=True)
             names = [n for n, _ in nerf_named_parameters(r)]
@@ -555,11 +553,11 @@ class NerfRenderFn(Function):
             return (None, dcam, None, None, None, dfilm, None, None, None, None) + grads
         if hip.FUSED_NERF_BACKWARD and hip.nerf_backward_fused_supported(H, r.N_layers_renderer, img_size, n_samples):
             packed, _ = r._derived_buffers()
-            dfilm, dcam = hip.nerf_backward_fused(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u,
+            dfilm, dcam = hip.nerf_backward_fused(r.network, r.sigmoid_beta.detach() if r.with_sdf else None, cam_poses, focals, near, far, perturb_u,
                                                   film, layer_bias, packed, r._packed_transposed(), img_size, n_samples,
                                                   static, dfeat, dthumb, fwd=ctx.fwd)
             ctx.fwd = None
         else:
-            dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach(), cam_poses, focals, near, far, perturb_u, film,
+            dfilm, dcam = hip.nerf_backward(r.network, r.sigmoid_beta.detach() if r.with_sdf else None, cam_poses, focals, near, far, perturb_u, film,
                                             layer_bias, img_size, n_samples, static, dfeat.float(), dthumb.float())
         return (None, dcam, None, None, None, dfilm, None, None, None, None) + (None,) * ctx.n_params

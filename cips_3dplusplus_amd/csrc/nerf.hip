@@ -977,7 +977,6 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
       P.n_chunks > P.n_samples)
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
-  if (P.stash && P.raw_density) return CIPS3D_E_UNSUPP;      // the backward kernels differentiate the sdf branch only
   if (P.B == 0) return 0;
   NerfArgs a;
   a.p = P;

@@ -217,14 +217,18 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
   const int N = G.n_samples;
   const int64_t P = (int64_t)R * N;
   const RayGeom r = ray_geom(G, b, ray);
-  const float beta = sigmoid_beta[0];
+  // sigmoid_beta == NULL: with_sdf = False -- `sdf` holds the raw density v, sigma = softplus(v), d sigma / d v = sigmoid(v)
+  // (nerf_utils.py:288-297)
+  const bool raw = sigmoid_beta == nullptr;
+  const float beta = raw ? 1.f : sigmoid_beta[0];
   const float* sp = sdf + (int64_t)b * P + ray;
   float* wp = w + (int64_t)b * P + ray;
   float* tp = Tbuf + (int64_t)b * P + ray;
   float T = 1.f;
   for (int k = 0; k < N; ++k) {
     const float delta = (k < N - 1 ? r.z(k + 1) - r.z(k) : 1e10f) * r.dnorm;
-    const float sigma = sigmoid_acc(-sp[(int64_t)k * R] / beta) / beta;
+    const float v = sp[(int64_t)k * R];
+    const float sigma = raw ? (v > 20.f ? v : log1pf(expf(v))) : sigmoid_acc(-v / beta) / beta;
     const float alpha = 1.f - expf(-sigma * delta);
     tp[(int64_t)k * R] = T;
     wp[(int64_t)k * R] = alpha * T;
@@ -241,8 +245,8 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
     const int64_t o = (int64_t)k * R;
     const float dz = (k < N - 1 ? r.z(k + 1) - r.z(k) : 1e10f);
     const float delta = dz * r.dnorm;
-    const float sg = sigmoid_acc(-sp[o] / beta);
-    const float sigma = sg / beta;
+    const float sg = raw ? sigmoid_acc(sp[o]) : sigmoid_acc(-sp[o] / beta);
+    const float sigma = raw ? (sp[o] > 20.f ? sp[o] : log1pf(expf(sp[o]))) : sg / beta;
     const float e = expf(-sigma * delta);
     const float alpha = 1.f - e;
     const float Tk = tp[o], wk = wp[o];
@@ -252,8 +256,8 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
     S = fmaf(wk, Gk, S);
     const float dsigma = dalpha * delta * e;
     dn = fmaf(dalpha * sigma * e, dz, dn);
-    dsdf[(int64_t)b * P + ray + o] = dsigma * (-sg * (1.f - sg) / (beta * beta));
-    dbt = fmaf(dsigma, (sg * (1.f - sg) * sp[o] / beta - sg) / (beta * beta), dbt);
+    dsdf[(int64_t)b * P + ray + o] = raw ? dsigma * sg : dsigma * (-sg * (1.f - sg) / (beta * beta));
+    if (!raw) dbt = fmaf(dsigma, (sg * (1.f - sg) * sp[o] / beta - sg) / (beta * beta), dbt);
     dcp[o] = 2.f * wk * d0 * s0 * (1.f - s0);
     dcp[P + o] = 2.f * wk * d1 * s1 * (1.f - s1);
     dcp[2 * P + o] = 2.f * wk * d2 * s2 * (1.f - s2);
@@ -507,7 +511,7 @@ extern "C" int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H
 extern "C" int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* G, const float* sdf, const float* crgb, const float* g,
                                          const float* dthumb, const float* sigmoid_beta, float* w, float* T_scratch,
                                          float* dsdf, float* dcrgb, float* ddnorm, float* dbeta_ray, void* stream) {
-  if (!geom_ok(G) || !sdf || !crgb || !g || !dthumb || !sigmoid_beta || !w || !T_scratch || !dsdf || !dcrgb || !ddnorm)
+  if (!geom_ok(G) || !sdf || !crgb || !g || !dthumb || !w || !T_scratch || !dsdf || !dcrgb || !ddnorm)
     return CIPS3D_E_BADARG;
   if (G->B == 0) return 0;
   const int R = G->img_size * G->img_size;

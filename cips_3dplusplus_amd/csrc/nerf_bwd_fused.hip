@@ -952,7 +952,7 @@ extern "C" int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* pp, voi
   const cips3d_nerf_bwd_geom& G = P.geom;
   if (!G.cam_poses || !G.focals || !G.near_ || !G.far_ || G.B < 0 || G.img_size <= 0 || G.n_samples <= 0) return CIPS3D_E_BADARG;
   if (!P.w_first || !P.packed || !P.packed_t || !P.w_view || !P.film || !P.layer_bias || !P.w_sigma || !P.b_sigma || !P.w_rgb ||
-      !P.b_rgb || !P.sigmoid_beta || !P.d_features || !P.d_thumb || !P.stash || !P.scratch || !P.dfilm || !P.dcam)
+      !P.b_rgb || !P.d_features || !P.d_thumb || !P.stash || !P.scratch || !P.dfilm || !P.dcam)
     return CIPS3D_E_BADARG;
   if (P.n_chunks < 1 || P.n_chunks > G.n_samples) return CIPS3D_E_BADARG;
   if (!fused_shape_ok(P.hidden, P.depth, G.img_size, G.n_samples)) return CIPS3D_E_UNSUPP;

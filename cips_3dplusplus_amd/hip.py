@@ -205,7 +205,7 @@ def _nerf_params(kw):
     for f in ("x_pts", "x_rays_d", "x_viewdirs", "x_z_vals"):          # explicit-geometry mode
         setattr(p, f, dev_ptr(kw.get(f), f, True))
     p.n_rays = int(kw.get("n_rays", 0))
-    p.raw_density = int(bool(kw.get("raw_density", False)))            # with_sdf = False (forward only)
+    p.raw_density = int(bool(kw.get("raw_density", False)))            # with_sdf = False (backward: sigmoid_beta = None)
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))
     return p
@@ -988,7 +988,8 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
     # ---- compositing backward
     wts, Tb, dsdf, dcrgb, ddnorm = new(B, P), new(B, P), new(B, P), new(B, 3, P), new(B, R)
     dbeta_ray = new(B, R) if need_params else None
-    check(lib.cips3d_nerf_bwd_composite(gp, dev_ptr(sdf), dev_ptr(crgb), dev_ptr(g), dev_ptr(dth), dev_ptr(sigmoid_beta),
+    check(lib.cips3d_nerf_bwd_composite(gp, dev_ptr(sdf), dev_ptr(crgb), dev_ptr(g), dev_ptr(dth),
+                                        dev_ptr(sigmoid_beta, "sigmoid_beta", True),      # None: with_sdf = False
                                         dev_ptr(wts), dev_ptr(Tb), dev_ptr(dsdf), dev_ptr(dcrgb), dev_ptr(ddnorm),
                                         dev_ptr(dbeta_ray, "dbeta_ray", True), st), "cips3d_nerf_bwd_composite")
 
@@ -1018,7 +1019,7 @@ def nerf_backward(net, sigmoid_beta, cam_poses, focals, near, far, perturb_u, fi
         pg["rgb_linear.bias"] = row_dots(dcrgb, 3, P)[:, 3].contiguous()
         pg["sigma_linear.weight"] = row_dots(h_last, H, P, dsdf, 1, P)[:, :1].t().contiguous()
         pg["sigma_linear.bias"] = row_dots(dsdf, 1, P)[:, 3].contiguous()
-        pg["sigmoid_beta"] = row_dots(dbeta_ray, 1, R)[:, 3].contiguous()
+        pg["sigmoid_beta"] = row_dots(dbeta_ray, 1, R)[:, 3].contiguous() if sigmoid_beta is not None else torch.zeros(1, device=dev)
 
     # ---- MLP backward
     dfilm = torch.zeros(B, L, 2, H, device=dev)
@@ -1120,7 +1121,7 @@ def nerf_backward_fused(net, sigmoid_beta, cam_poses, focals, near, far, perturb
     p.w_view, p.film, p.layer_bias = dev_ptr(net.views_linears.weight), dev_ptr(keep[5]), dev_ptr(layer_bias)
     p.w_sigma, p.b_sigma = dev_ptr(net.sigma_linear.weight), dev_ptr(net.sigma_linear.bias)
     p.w_rgb, p.b_rgb = dev_ptr(net.rgb_linear.weight), dev_ptr(net.rgb_linear.bias)
-    p.sigmoid_beta = dev_ptr(sigmoid_beta)
+    p.sigmoid_beta = dev_ptr(sigmoid_beta, "sigmoid_beta", True)      # None: with_sdf = False (raw density)
     p.d_features, p.d_thumb = dev_ptr(keep[6]), dev_ptr(keep[7])
     p.stash, p.scratch, p.dfilm, p.dcam = dev_ptr(stash), dev_ptr(scratch), dev_ptr(dfilm), dev_ptr(dcam)
     p.hidden, p.depth, p.n_chunks = H, D, n_chunks

@@ -180,8 +180,6 @@ class VolumeFeatureRenderer(nn.Module):
         else:                       # FiLM table computed by the caller (differentiable path: autograd.film_table)
             film = film.detach().float().contiguous()
         if stash is not None:       # differentiable forward: hip.nerf_forward_stash buffers, filled for the fused backward
-            if not self.with_sdf:
-                raise NotImplementedError("with_sdf=False (raw density, nerf_utils.py:288-297) is forward-only on the HIP path")
             n_chunks = stash["n_chunks"]
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)

@@ -874,7 +874,8 @@ int cips3d_nerf_bwd_heads(const float* x, const float* Wm, int row_stride, int c
 int cips3d_nerf_bwd_dot(const float* dF, const float* f, int B, int H, int R, int64_t P, float* g, void* stream);
 /* volume integration forward + backward per ray: sdf [B,P], crgb [B,3,P] (rgb logits), g [B,P], dthumb [B,3,R]
  * -> w [B,P] (compositing weights), dsdf [B,P], dcrgb [B,3,P], ddnorm [B,R] (d loss / d |rays_d|, which scales the
- * sample spacing); T_scratch [B,P]. */
+ * sample spacing); T_scratch [B,P].  sigmoid_beta == NULL: with_sdf = False -- `sdf` is the raw density, sigma = softplus(sdf)
+ * (cips3d/nerf_utils.py:288-297); no dbeta_ray then. */
 int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* geom, const float* sdf, const float* crgb, const float* g,
                               const float* dthumb, const float* sigmoid_beta, float* w, float* T_scratch, float* dsdf,
                               float* dcrgb, float* ddnorm, float* dbeta_ray, void* stream);

@@ -346,6 +346,65 @@ def test_renderer_weight_gradients_vs_oracle(D, static, perturb, N, S):
     assert n == 5 + 6 * (D + 1)
 
 
+@pytest.mark.parametrize("hidden,S,N", [(32, 8, 6), (64, 16, 8)])
+def test_raw_density_renderer_bwd_vs_oracle(hidden, S, N):
+    """renderer_cfg.with_sdf = False (sigma = softplus of the head's output, cips3d/nerf_utils.py:288-297) under autograd:
+    camera / style gradients on the route NerfRenderFn picks for the shape (fused where it tiles), and every renderer
+    parameter's gradient on the materialised route, against torch autograd through the CPU oracle."""
+    D = 2
+    cfg = configs.tiny_G_cfg(hidden, D, 1)
+    cfg["renderer_cfg"] = dict(cfg["renderer_cfg"], with_sdf=False)
+    G = pkg.build_generator(cfg, DEV, seed=6)
+    assert G.renderer.with_sdf is False
+    g = torch.Generator().manual_seed(hidden + N)
+    with torch.no_grad():
+        for q in G.renderer.parameters():
+            if q.abs().max() == 0:
+                q.copy_(0.05 * torch.randn(q.shape, generator=g))
+    sd = {k: leaf(v.detach().cpu()) if k.startswith("renderer.") else v.detach().cpu() for k, v in G.state_dict().items()}
+    B, R, H = 2, S * S, hidden
+    locs = torch.tensor([[0.25, 0.1], [-0.4, -0.05]])
+    cam = O.camera_params(locs, S, 6, 0.12)
+    sdim = G.renderer.style_dim
+    styles = 0.5 * torch.randn(B, D + 1, sdim, generator=g)
+    u = torch.rand(B, S, S, 1, generator=g)
+    tF, tT = torch.randn(B, H, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
+    cr, sr = leaf(cam[0]), leaf(styles)
+    rays_o, rays_d, viewdirs = O.rays_in_world(cam[1], S, cr, False)
+    z = O.z_vals(cam[2], cam[3], B, S, S, N, u)
+    pts = O.ray_points(rays_o, rays_d, z)
+    thumb, feat, sdf, mask, xyz = O.renderer_forward(sd, "renderer", pts.reshape(B, R, N, 3), rays_d.reshape(B, R, 3),
+                                                     viewdirs.reshape(B, R, 3), z.reshape(B, R, N), cam[2], cam[3], sr, D,
+                                                     with_sdf=False)
+    to_img = lambda t: t.transpose(1, 2).reshape(B, t.shape[-1], S, S)
+    ((to_img(feat) * tF).sum() + 3.0 * (to_img(thumb) * tT).sum()).backward()
+    # camera / styles: the route of the shape
+    G.requires_grad_(False)
+    cg, sg = leaf(cu(cam[0])), leaf(cu(styles))
+    film = AG.film_table(G.renderer, sg)
+    f_g, t_g, _, _ = AG.NerfRenderFn.apply(G.renderer, cg, cu(cam[1]), cu(cam[2]), cu(cam[3]), film, cu(u), S, N, False)
+    close(f_g, to_img(feat).detach(), 1e-4, "features"); close(t_g, to_img(thumb).detach(), 1e-4, "thumb")
+    ((f_g * cu(tF)).sum() + 3.0 * (t_g * cu(tT)).sum()).backward()
+    close(sg.grad, sr.grad, 3e-4, "dstyles")
+    close(cg.grad, cr.grad, 3e-4, "dcam_poses")
+    # the renderer's own parameters: materialised route
+    G.renderer.requires_grad_(True)
+    film = AG.film_table(G.renderer, cu(styles))
+    rp = [q for _, q in AG.nerf_named_parameters(G.renderer)]
+    f_g, t_g, _, _ = AG.NerfRenderFn.apply(G.renderer, cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), film, cu(u), S, N, False, *rp)
+    ((f_g * cu(tF)).sum() + 3.0 * (t_g * cu(tT)).sum()).backward()
+    n = 0
+    for name, q in G.renderer.named_parameters():
+        ref = sd["renderer." + name].grad
+        if name == "sigmoid_beta":              # unused on this branch
+            assert ref is None and (q.grad is None or float(q.grad.abs().max()) == 0.0)
+            continue
+        assert ref is not None and q.grad is not None, name
+        close(q.grad, ref, 5e-4, name)
+        n += 1
+    assert n == 4 + 6 * (D + 1)
+
+
 def test_generator_optimises_renderer_parameters():
     """Generator.forward accepts renderer parameters that require gradients (it raised before) and the projector's
     `optim_render_params` switch moves them."""
