@@ -42,6 +42,13 @@ def test_argument_errors_do_not_launch():
     assert lib.cips3d_fused_bias_act(None, None, None, None, 16, 1, 1, 3, 0, 0.2, 1.0, None) == -1
     assert lib.cips3d_upfirdn2d(None, None, None, 1, 4, 4, 1, 4, 4, 1, 1, 1, 1, 0, 0, 0, 0, None) == -1
     assert lib.cips3d_nerf_render(None, None) == -1
+    assert lib.cips3d_generator_forward(None, None, None) == -1
+    assert lib.cips3d_style_phase(None, None, 1, None) == -1
+    import ctypes as C
+    from cips_3dplusplus_amd import plan as PL
+    p, io = PL.GeneratorPlan(), PL.ForwardIO()
+    assert lib.cips3d_style_phase(C.byref(p), C.byref(io), 7, None) == -1        # no such mode
+    assert lib.cips3d_style_phase(C.byref(p), C.byref(io), 1, None) == -1        # B = 0
     assert lib.cips3d_modconv1x1_supported(512, 512, 4096) == 1
     assert lib.cips3d_modconv1x1_supported(8, 12, 36) == 0
     assert lib.cips3d_nerf_suggest_chunks(1, 64, 24) == 8
