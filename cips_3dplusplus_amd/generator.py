@@ -202,9 +202,11 @@ class Generator(nn.Module):
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb)
+        # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
+        m2 = mask.transpose(0, 1).contiguous()
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
                 "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
-                "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
+                "mask": m2[0].unsqueeze(1), "depth": m2[1].unsqueeze(1)}
 
     # ---------------------------------------------------------------- forward
     def forward(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
