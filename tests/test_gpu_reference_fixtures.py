@@ -115,7 +115,8 @@ def test_volume_integration_unused_branches_on_hip(golden, tag, with_sdf, fb):
 def test_renderer_with_raw_density_fixture_on_hip(golden, tag):
     """VolumeFeatureRenderer(with_sdf=False): the fused render kernel's raw-density branch (alpha = 1 - exp(-softplus(raw) *
     delta), nerf_utils.py:288-297) against the reference's own outputs, through the reference entry (explicit sample points).
-    `b20` has raw values on both sides of softplus's threshold.  The differentiable path refuses the branch loudly."""
+    `b20` has raw values on both sides of softplus's threshold.  The differentiable path takes the branch as well (its
+    gradients: test_gpu_backward.py::test_raw_density_renderer_bwd_vs_oracle)."""
     fx = golden("renderer_raw")
     ren = pkg.VolumeFeatureRenderer(N_layers_renderer=2, input_dim=3, hidden_dim=32, style_dim=32, view_dim=3, with_sdf=False,
                                     output_features=True)
@@ -137,9 +138,10 @@ def test_renderer_with_raw_density_fixture_on_hip(golden, tag):
     ren.with_sdf = False
     from cips_3dplusplus_amd import autograd as ag
     cam = O.camera_params(torch.tensor([[0.3, 0.1], [-0.6, -0.1]]), 8, 6, 0.12)
-    film = torch.zeros(2, 3, 2, 32, device=DEV)
-    with pytest.raises(NotImplementedError, match="forward-only"):
-        ag.NerfRenderFn.apply(ren, cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), film, None, 8, 6, False)
+    film = torch.zeros(2, 3, 2, 32, device=DEV, requires_grad=True)
+    f, t, _, _ = ag.NerfRenderFn.apply(ren, cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), film, None, 8, 6, False)
+    (f.sum() + t.sum()).backward()
+    assert film.grad is not None and bool(torch.isfinite(film.grad).all())
 
 
 @pytest.mark.parametrize("hidden,D", [(32, 2), (256, 2)])
