@@ -21,7 +21,7 @@ cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/inversion_kernel_stats.c
 summ $O/inversion_kernel_stats.csv 44 > $O/inversion_summary.txt; head -30 $O/inversion_summary.txt
 export CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -- python3 tools/bench_inversion.py --steps 44 > $O/kt0.log 2>&1
-unset CIPS3D_ONE_CALL_DECODER CIPS3D_FUSED_ADAM
+unset CIPS3D_ONE_CALL_DECODER CIPS3D_FUSED_ADAM CIPS3D_HIP_ADAM
 cp $(find $O/kt0 -name "*kernel_stats.csv" | head -1) $O/inversion_per_op_kernel_stats.csv
 summ $O/inversion_per_op_kernel_stats.csv 44 > $O/inversion_per_op_summary.txt; head -3 $O/inversion_per_op_summary.txt
 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 tools/bench_inversion.py --steps 24 > $O/tr.log 2>&1
