@@ -205,13 +205,18 @@ _SIGS = {
     "cips3d_nerf_bwd_fused": (c_int, [C.c_void_p, C.c_void_p]),
     "cips3d_generator_forward": (c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_style_phase": (c_int, [C.c_void_p, C.c_void_p, c_int, C.c_void_p]),
+    "cips3d_sqdiff_pair_partials": (c_int, [C.c_int64, C.c_int64]),
+    "cips3d_sqdiff_pair": (c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_int64, C.c_float,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "cips3d_sqdiff_pair_bwd": (c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "cips3d_sizeof_plan": (c_i64, []),
     "cips3d_sizeof_io": (c_i64, []),
     "cips3d_sizeof_struct": (c_i64, [c_int]),
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 19           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 20           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

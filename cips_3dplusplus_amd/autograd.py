@@ -421,6 +421,30 @@ def decoder_forward(dec, features, styles, noise=None):
 
 
 # ------------------------------------------------------------------------------------------ camera + NeRF
+class SqDiffPairFn(Function):
+    """c0 sum (a0 - b0)^2 + c1 sum (a1 - b1)^2 (the inversion loss' two squared-difference terms, projector_v10.py:1173-1174;
+    c = weight / numel is F.mse_loss): two launches forward, one backward (the torch expression with its graph: ~23).
+    Differentiable with respect to a0 and a1; b0 / b1 are targets."""
+
+    @staticmethod
+    def forward(ctx, a0, b0, c0, a1, b1, c1):
+        a0, b0, a1, b1 = _c(a0), _c(b0), _c(a1), _c(b1)
+        ctx.save_for_backward(a0, b0, a1, b1)
+        ctx.c = (float(c0), float(c1))
+        return hip.sqdiff_pair(a0, b0, c0, a1, b1, c1)
+
+    @staticmethod
+    def backward(ctx, g):
+        a0, b0, a1, b1 = ctx.saved_tensors
+        d0, d1 = hip.sqdiff_pair_bwd(a0, b0, ctx.c[0], a1, b1, ctx.c[1], g.contiguous().float())
+        return d0, None, None, d1, None, None
+
+
+def weighted_mse_pair(a0, b0, w0, a1, b1, w1):
+    """w0 mse(a0, b0) + w1 mse(a1, b1) on the device in three launches per step (forward + backward)."""
+    return SqDiffPairFn.apply(a0, b0, w0 / a0.numel(), a1, b1, w1 / a1.numel())
+
+
 class CameraFn(Function):
     """Camera.generate_camera_params for given `locations` (azim, elev), differentiable w.r.t. them."""
 

@@ -295,8 +295,9 @@ class Generator(nn.Module):
                 sdf = self.renderer.render(cam_poses.detach(), per_view(focals), per_view(near), per_view(far), None, img_size,
                                            N, perturb_u=perturb_u, static_viewdirs=static, return_sdf=True,
                                            film=film.detach())[2]
+        m2 = mask.transpose(0, 1).contiguous()          # one copy for both maps (see _planned_forward)
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None, "sdf": sdf,
-                "xyz": xyz if return_xyz else None, "mask": mask[:, 0:1].contiguous(), "depth": mask[:, 1:2].contiguous()}
+                "xyz": xyz if return_xyz else None, "mask": m2[0].unsqueeze(1), "depth": m2[1].unsqueeze(1)}
 
     def _forward_infer(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
                        path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
@@ -348,6 +349,7 @@ class Generator(nn.Module):
             cam_poses, per_view(focals), per_view(near), per_view(far), style_render, img_size, N,
             perturb_u=perturb_u, static_viewdirs=nerf_cfg.get("static_viewdirs", False), return_sdf=return_sdf)
         rgb = self.decoder(features=features, styles=style_decoder, rgbd_in=None, noise=noise_bufs)
+        m2 = mask.transpose(0, 1).contiguous()
         return {
             "rgb": rgb,
             "thumb_rgb": thumb_rgb,
@@ -355,6 +357,6 @@ class Generator(nn.Module):
             "eikonal_term": None,
             "sdf": sdf if return_sdf else None,
             "xyz": xyz if return_xyz else None,
-            "mask": mask[:, 0:1].contiguous(),
-            "depth": mask[:, 1:2].contiguous(),
+            "mask": m2[0].unsqueeze(1),
+            "depth": m2[1].unsqueeze(1),
         }

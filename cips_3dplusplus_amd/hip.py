@@ -1175,3 +1175,27 @@ def inversion_roofline(renderer, B, n_samples, img_size=64, iters=10):
             "avg_launch_ms": ms, "flop_per_launch": flop,
             "stash_bytes_per_launch": 2.0 * 4 * P * D * H,
             "note": "stash written once and read once: at this time it moves at %.2f TB/s" % (2.0 * 4 * P * D * H / (ms * 1e-3) / 1e12)}
+
+
+def sqdiff_pair(a0, b0, c0, a1, b1, c1):
+    """loss = c0 sum (a0 - b0)^2 + c1 sum (a1 - b1)^2 as a device scalar (cips3d_sqdiff_pair: the two squared-difference terms
+    of the inversion loss, projector_v10.py:1173-1174), deterministic; a1 / b1 may be None."""
+    lib = _lib.load()
+    n0, n1 = a0.numel(), (a1.numel() if a1 is not None else 0)
+    partial = torch.empty(2 * int(lib.cips3d_sqdiff_pair_partials(n0, n1)), device=a0.device)
+    loss = torch.empty((), device=a0.device)
+    check(lib.cips3d_sqdiff_pair(dev_ptr(a0, "a0"), dev_ptr(b0, "b0"), n0, float(c0), dev_ptr(a1, "a1", True), dev_ptr(b1, "b1", True),
+                                 n1, float(c1), partial.data_ptr(), loss.data_ptr(), stream_ptr()), "cips3d_sqdiff_pair")
+    return loss
+
+
+def sqdiff_pair_bwd(a0, b0, c0, a1, b1, c1, gloss):
+    """(d loss / d a0, d loss / d a1) of sqdiff_pair for the incoming gradient `gloss` (a device scalar), one launch."""
+    lib = _lib.load()
+    n0, n1 = a0.numel(), (a1.numel() if a1 is not None else 0)
+    d0 = torch.empty_like(a0)
+    d1 = torch.empty_like(a1) if a1 is not None else None
+    check(lib.cips3d_sqdiff_pair_bwd(dev_ptr(a0, "a0"), dev_ptr(b0, "b0"), n0, float(c0), d0.data_ptr(), dev_ptr(a1, "a1", True),
+                                     dev_ptr(b1, "b1", True), n1, float(c1), dev_ptr(d1, "d1", True), dev_ptr(gloss, "gloss"),
+                                     stream_ptr()), "cips3d_sqdiff_pair_bwd")
+    return d0, d1

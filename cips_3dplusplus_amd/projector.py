@@ -73,8 +73,19 @@ def noise_regulariser(noise_bufs):
     return reg
 
 
+FUSED_LOSS = os.environ.get("CIPS3D_FUSED_LOSS", "1") != "0"      # 0: the torch expression (A/B knob)
+
+
 def surrogate_loss(target_rgb, target_thumb, rgb_weight=1.0, thumb_weight=50.0):
+    """rgb_weight mse(rgb, target) + thumb_weight mse(thumb, target_thumb): the structure of the reference's loss
+    (projector_v10.py:1173-1178) on the images themselves.  On the GPU it is one autograd node (autograd.SqDiffPairFn)."""
     def loss(rgb, thumb):
+        if (FUSED_LOSS and rgb.is_cuda and rgb.dtype == torch.float32 and thumb.dtype == torch.float32
+                and rgb.shape == target_rgb.shape and thumb.shape == target_thumb.shape
+                and not target_rgb.requires_grad and not target_thumb.requires_grad):
+            from . import autograd as AG
+            return AG.weighted_mse_pair(rgb, target_rgb.to(rgb.device, torch.float32), rgb_weight,
+                                        thumb, target_thumb.to(thumb.device, torch.float32), thumb_weight)
         return rgb_weight * ((rgb - target_rgb) ** 2).mean() + thumb_weight * ((thumb - target_thumb) ** 2).mean()
     return loss
 

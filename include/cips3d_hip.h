@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 19  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 20  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -755,6 +755,18 @@ typedef struct cips3d_adam_entry {
 } cips3d_adam_entry;
 int cips3d_adam_step(const cips3d_adam_entry* entries, int n_entries, float lr, float beta1, float beta2, float eps, int step,
                      void* stream);
+
+/* The two squared-difference terms of the inversion loss (models/projector_v10.py:1173-1174:
+ * `(target - synth).square().sum() * rgb_weight + (target_thumb - synth_thumb).square().sum() * thumb_weight`; with
+ * c_k = weight_k / n_k the F.mse_loss form of :1178):  loss[0] = c0 sum (a0 - b0)^2 + c1 sum (a1 - b1)^2, deterministic
+ * (per-workgroup partial sums, then their total in a fixed order: two launches).  partial: scratch of
+ * 2 * cips3d_sqdiff_pair_partials(n0, n1) floats.  _bwd: d_k = gloss[0] * 2 c_k (a_k - b_k), one launch; gloss = the
+ * loss' incoming gradient, a device scalar.  Either tensor may be empty (n = 0). */
+int cips3d_sqdiff_pair_partials(int64_t n0, int64_t n1);
+int cips3d_sqdiff_pair(const float* a0, const float* b0, int64_t n0, float c0, const float* a1, const float* b1, int64_t n1,
+                       float c1, float* partial, float* loss, void* stream);
+int cips3d_sqdiff_pair_bwd(const float* a0, const float* b0, int64_t n0, float c0, float* d0, const float* a1, const float* b1,
+                           int64_t n1, float c1, float* d1, const float* gloss, void* stream);
 
 /* The decoder as ONE differentiable node (csrc/decoder_grad.hip): Decoder.forward with every StyledConv output kept, and the
  * whole backward -- gradients of the features, the W+ styles and every decoder parameter -- in one call each.

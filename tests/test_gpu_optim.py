@@ -41,3 +41,48 @@ def test_hip_adam_tracks_torch_adam():
     opt.param_groups[0]["params"][0].grad = torch.ones(3)
     with pytest.raises(RuntimeError, match="fp32 CUDA"):
         opt.step()                                          # ... the step refuses CPU tensors (no CPU fallback)
+
+
+@pytest.mark.parametrize("n0,n1", [(2 * 3 * 256 * 256, 2 * 3 * 64 * 64), (1001, 7), (4099, 0)])
+def test_fused_squared_difference_pair_matches_torch(n0, n1):
+    """autograd.SqDiffPairFn (cips3d_sqdiff_pair / _bwd): the inversion loss' two squared-difference terms
+    (projector_v10.py:1173-1178) against the torch expression -- value, both gradients, bit-identical repeats."""
+    from cips_3dplusplus_amd import autograd as AG
+    g = torch.Generator().manual_seed(n0 + n1)
+    a0, b0 = torch.randn(n0, generator=g).cuda(), torch.randn(n0, generator=g).cuda()
+    a1 = torch.randn(n1, generator=g).cuda() if n1 else None
+    b1 = torch.randn(n1, generator=g).cuda() if n1 else None
+    c0, c1 = 1.0 / n0, (50.0 / n1 if n1 else 0.0)
+    x0 = a0.clone().requires_grad_(True)
+    x1 = a1.clone().requires_grad_(True) if n1 else None
+    ref = c0 * ((x0.double() - b0.double()) ** 2).sum()
+    if n1:
+        ref = ref + c1 * ((x1.double() - b1.double()) ** 2).sum()
+    (3.0 * ref).backward()
+    y0 = a0.clone().requires_grad_(True)
+    y1 = a1.clone().requires_grad_(True) if n1 else None
+    out = AG.SqDiffPairFn.apply(y0, b0, c0, y1, b1, c1)
+    assert out.shape == () and abs(float(out) - float(ref)) < 2e-6 * abs(float(ref))
+    (3.0 * out).backward()
+    assert float((y0.grad - x0.grad).abs().max()) <= 1e-6 * float(x0.grad.abs().max())
+    if n1:
+        assert float((y1.grad - x1.grad).abs().max()) <= 1e-6 * float(x1.grad.abs().max())
+    again = AG.SqDiffPairFn.apply(a0, b0, c0, a1, b1, c1)
+    assert torch.equal(again, out.detach())
+
+
+def test_surrogate_loss_takes_the_fused_node_on_the_gpu():
+    from cips_3dplusplus_amd.projector import surrogate_loss
+    g = torch.Generator().manual_seed(5)
+    t_rgb, t_th = torch.randn(2, 3, 32, 32, generator=g).cuda(), torch.randn(2, 3, 8, 8, generator=g).cuda()
+    rgb = torch.randn(2, 3, 32, 32, generator=g).cuda().requires_grad_(True)
+    th = torch.randn(2, 3, 8, 8, generator=g).cuda().requires_grad_(True)
+    loss = surrogate_loss(t_rgb, t_th)(rgb, th)
+    assert "SqDiffPairFn" in type(loss.grad_fn).__name__
+    ref = ((rgb.detach() - t_rgb) ** 2).mean() + 50.0 * ((th.detach() - t_th) ** 2).mean()
+    assert abs(float(loss) - float(ref)) < 1e-5 * float(ref)
+    loss.backward()
+    assert float((rgb.grad - 2 * (rgb.detach() - t_rgb) / rgb.numel()).abs().max()) < 1e-9
+    # CPU tensors (the oracle's loops) keep the torch expression
+    l2 = surrogate_loss(t_rgb.cpu(), t_th.cpu())(rgb.detach().cpu().requires_grad_(True), th.detach().cpu())
+    assert "SqDiffPairFn" not in type(l2.grad_fn).__name__
