@@ -14,6 +14,8 @@
 //                                 then ONE launch for the modulation backward of all layers, the style-table backward, and a
 //                                 tail launch for the scalar noise weights.
 // Gradient operands of the split-fp16 GEMMs are scaled by their measured maxima (amax slots, cips3d_range).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -345,6 +347,28 @@ extern "C" int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan,
   const float* x_amax = P.feat_amax;
   const float* skip = nullptr;
   int rgb_i = 0;
+  // ToRGB folding (as in cips3d_generator_forward): a non-up-sampling ToRGB that follows a StyledConv is computed from that
+  // conv's registers (partial sums per row block, cips3d_modconv1x1_torgb), and the slots of consecutive such layers are
+  // folded by ONE cips3d_torgb_reduce when their sum is first needed -- eight cips3d_torgb launches that re-read the
+  // activations become two reductions at CompCars 256^2.  The slots live in g[0] (a gradient buffer: idle in the forward;
+  // one layer's slots are < 3/32 of its activation).  CIPS3D_GRAD_TORGB_FOLD=0: one cips3d_torgb per layer (A/B knob).
+  static const bool fold_on = [] { const char* e = getenv("CIPS3D_GRAD_TORGB_FOLD"); return !(e && e[0] == '0'); }();
+  int64_t g_floats = 0;        // what g[0] certainly holds: the largest StyledConv output
+  for (int li = 0; li < P.n_layers; ++li)
+    if (P.layers[li].kind == 0) {
+      const int64_t n = (int64_t)B * P.layers[li].Cout * P.layers[li].H * P.layers[li].W;
+      if (n > g_floats) g_floats = n;
+    }
+  float* const part = P.g[0];
+  int fold_slots = 0, fold_nb = 0, fold_H = 0, fold_W = 0;
+  const float* fold_bias[CIPS3D_TORGB_FOLD_MAX];
+  auto fold_flush = [&](float* dst) -> int {
+    if (fold_slots == 0) return 0;
+    const int rc = cips3d_torgb_reduce(part, fold_slots, fold_bias, fold_nb, skip, dst, B, (int64_t)fold_H * fold_W, stream);
+    skip = dst;
+    fold_slots = fold_nb = 0;
+    return rc;
+  };
   for (int li = 0; li < P.n_layers; ++li) {
     const cips3d_grad_layer& L = P.layers[li];
     const int64_t hw = (int64_t)L.H * L.W;
@@ -355,7 +379,25 @@ extern "C" int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan,
       if (!nz) return CIPS3D_E_BADARG;
       cips3d_range rg{};
       rg.x_amax = x_amax;
-      if (L.kind == 0) {
+      if (L.kind == 1 && fold_slots) {          // resolution changes: the folded sum becomes the skip of the next stage
+        TRY(fold_flush(P.rgb[rgb_i]));
+        rgb_i ^= 1;
+      }
+      const cips3d_grad_layer* T = li + 1 < P.n_layers ? &P.layers[li + 1] : nullptr;
+      const bool fold = fold_on && L.kind == 0 && T && T->kind == 2 && T->Cin == L.Cout && T->H == L.H && T->W == L.W && hw % 4 == 0 &&
+                        fold_nb < CIPS3D_TORGB_FOLD_MAX && (fold_slots == 0 || (fold_H == L.H && fold_W == L.W)) &&
+                        ((int64_t)fold_slots + L.Cout / 16) * B * 3 * hw <= g_floats;
+      if (fold) {
+        int nblk = 0;
+        rg.out_amax = L.y_amax;
+        TRY(cips3d_modconv1x1_torgb(x, L.wm, L.y, B, L.Cin, L.Cout, hw, 1 | (split ? CIPS3D_GEMM_SPLIT : 0), nz, nbs, L.noise_w, L.bias,
+                                    T->wm, part + (int64_t)fold_slots * B * 3 * hw, &nblk, &rg, stream));
+        fold_slots += nblk;
+        fold_bias[fold_nb++] = T->bias;
+        fold_H = L.H; fold_W = L.W;
+        ++li;                                     // the ToRGB layer is done (its sum is pending in the slots)
+        if (li == P.n_layers - 1) TRY(fold_flush(IO.rgb));
+      } else if (L.kind == 0) {
         rg.out_amax = L.y_amax;
         TRY(cips3d_modconv1x1(x, L.wm, L.y, B, L.Cin, L.Cout, hw, 1 | (split ? CIPS3D_GEMM_SPLIT : 0), nz, nbs, L.noise_w, L.bias,
                               &rg, stream));
@@ -368,6 +410,10 @@ extern "C" int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan,
       x = L.y;
       x_amax = L.y_amax;
     } else {
+      if (fold_slots) {                           // a ToRGB that could not be folded: settle the pending sum first
+        TRY(fold_flush(P.rgb[rgb_i]));
+        rgb_i ^= 1;
+      }
       const bool last = li == P.n_layers - 1;
       float* out = last ? IO.rgb : P.rgb[rgb_i];
       // (x is the previous StyledConv's output, at this ToRGB's resolution H x W)
