@@ -453,11 +453,14 @@ class CameraFn(Function):
         extr, focal, near, far = hip.camera_params(locations, img_size, fov_ang, dist_radius, up=up)
         ctx.save_for_backward(locations.detach(), up)
         ctx.mark_non_differentiable(focal, near, far)
+        ctx.set_materialize_grads(False)        # (else the engine fills a zero gradient for each of focal / near / far)
         return extr, focal, near, far
 
     @staticmethod
     def backward(ctx, dextr, dfocal, dnear, dfar):
         locations, up = ctx.saved_tensors
+        if dextr is None:
+            return None, None, None, None, None
         return hip.camera_params_bwd(locations, dextr, up).to(locations.dtype), None, None, None, None
 
 
@@ -554,6 +557,7 @@ class NerfRenderFn(Function):
         ctx.cfg = (img_size, n_samples, static_viewdirs)
         ctx.save_for_backward(cam_poses.detach(), focals, near, far, film.detach(), perturb_u)
         ctx.mark_non_differentiable(mask, xyz)
+        ctx.set_materialize_grads(False)        # (else the engine fills zero gradients for xyz and mask; None is handled below)
         return features, thumb, xyz, mask
 
     @staticmethod

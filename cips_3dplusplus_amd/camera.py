@@ -41,8 +41,13 @@ class Camera(object):
     @staticmethod
     def generate_camera_params_v1(img_size, device, batch=1, locations=None, sweep=False, uniform=False,
                                   azim_range=0.3, elev_range=0.15, fov_ang=6, dist_radius=0.12, up=None):
-        azim, elev, _ = Camera._angles(batch, device, locations, sweep, uniform, azim_range, elev_range)
-        viewpoint = torch.cat([azim, elev], 1).float()
+        if locations is not None and locations.dim() == 2 and locations.shape[1] == 2:
+            # (azim, elev) given: they ARE the viewpoint -- no column selects and re-concatenation (seven launches of autograd
+            # plumbing per inversion step when `locations` carries gradients)
+            viewpoint = locations.float()
+        else:
+            azim, elev, _ = Camera._angles(batch, device, locations, sweep, uniform, azim_range, elev_range)
+            viewpoint = torch.cat([azim, elev], 1).float()
         n = viewpoint.shape[0]
         fov = fov_ang
         if torch.is_tensor(fov_ang) and fov_ang.numel() not in (1, n):
