@@ -122,40 +122,7 @@ extern "C" int cips3d_debug_read_clock(unsigned long long* out2) {
 }
 #endif
 
-// CIPS3D_FILM_REVOLUTIONS: the staged FiLM table carries gamma' / 2 pi and c / 2 pi, so that the epilogue's FMA yields the
-// sine argument in revolutions and v_sin_f32(fract(.)) takes it as it is -- one multiplication less per activation.  The extra
-// rounding (of gamma' / 2 pi, once per table entry) perturbs the argument by |x| 2^-24 relative, the size of an ulp of gamma.
-#ifndef CIPS3D_FILM_REVOLUTIONS
-#define CIPS3D_FILM_REVOLUTIONS 1
-#endif
-#if CIPS3D_FILM_REVOLUTIONS && !defined(CIPS3D_EXACT_SINE) && !defined(CIPS3D_REDUCED_SINE)
-#define FILM_UNIT 0.159154943091895336f
-#define FILM_SIN sin_revolutions
-#else
-#define FILM_UNIT 1.f
-#define FILM_SIN cips3d_sin
-#endif
-
 namespace {
-
-struct NerfArgs {
-  cips3d_nerf_params p;
-  int groups;          // ray groups of 16 per view
-  int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
-  int chunk;           // samples per chunk (uniform trip count)
-  int fuse_finish;     // the workgroup's eight chunk waves combine their partials in LDS and write the final maps
-  float t_end, t_step; // torch.linspace(0, 1 - 1/N, N): last value and step, computed on the host (kernel arguments are
-                       // re-readable scalars; computed in the kernel they ended up as spilled VGPR copies)
-};
-
-// LDS floats of the render kernel: slab ring (or the 8 x 16 x H partial exchange of the fused finish, whichever is
-// larger) + per-view tables (which double as the 8 x 8 x 16 scalar exchange once the last sample is done)
-// pitch of one ray's partial in the exchange: H + 4 floats, so that the 16 rays of a wave start 16 bytes apart in the bank
-// pattern (at pitch H every ray of a quarter hit the same banks: 8-way conflicts on the writes, 16-way on the combining reads)
-__host__ __device__ constexpr int nerf_xf_pitch(int H) { return H + 4; }
-__host__ __device__ constexpr int nerf_ring_floats(int H, int TPS, bool fuse) {
-  return (fuse && WAVES * RAYS * nerf_xf_pitch(H) > 2 * 16 * H * TPS) ? WAVES * RAYS * nerf_xf_pitch(H) : 2 * 16 * H * TPS;
-}
 
 // ------------------------------------------------------------------------------------------------
 // weight packing (split-fp16).  o-tile t = 16 output units; k-block m = 32 input units = one v_mfma_f32_16x16x32_f16.
@@ -955,6 +922,7 @@ extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
   if (!p || !p->o_features || !p->o_thumb || !p->o_xyz || !p->o_mask) return 0;
   static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
   if (off) return 0;
+  if (cips3d_nerf_pair_applies(p)) return 1;     // nerf_pair.hip only exists in the fused form, with its own chunking
   const int H = p->hidden, L = p->depth + 1;
   if (p->n_chunks < 1 || WAVES % p->n_chunks != 0 || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
   const int tables = L * 2 * H + 10 * H;
@@ -978,6 +946,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
   if (P.B == 0) return 0;
+  if (fuse && cips3d_nerf_pair_applies(p)) return cips3d_nerf_render_pair(p, stream);
   NerfArgs a;
   a.p = P;
   a.groups = ceil_div(P.n_rays > 0 ? P.n_rays : P.img_size * P.img_size, RAYS);
