@@ -44,7 +44,13 @@ MFMA_F32_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: v_mfma_f32_* d
 MFMA_F16_PEAK_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA peak
 SPLIT_PRODUCTS = 3                         # fp16 products the render kernel issues per fp32 product (w_hi x_hi + w_hi x_lo + w_lo x_hi)
 EVENT_STRIDE = 8                           # HIP events around the dominant kernel on every 8th step (a record drains the queue)
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_nerf_traffic.json")     # {"entries": [{depth, n_samples, batch, traffic_bytes_per_launch}]}
+# HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass with timing or
+# with each other): tools/profile_round.sh writes one summary per workload, stamped with the source hash of the library that ran.
+# An entry is replayed only while that hash equals the loaded library's (a kernel edit silently invalidated round 3's file).
+TRAFFIC_FILES = {"headline": os.path.join("profiles", "r04_pmc_all_kernels.json"),
+                 "n64": os.path.join("profiles", "r04_pmc_n64_traffic.json"),
+                 "b4_bf16": os.path.join("profiles", "r04_pmc_b4_traffic.json")}
+HBM_PEAK_TBS = 8.0                         # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
 PREROLL_MAX = 10                           # untimed regions until two consecutive ones agree within 1 % (clocks / caches settled)
 
 
@@ -237,22 +243,101 @@ class ForwardWorkload:
         kern_ms = sum(s.elapsed_time(t) for s, t in events) / len(events) if events else None
         return med, elapsed, kern_ms, len(events)
 
-    def roofline(self, kern_ms, n_events):
+    def traffic_table(self):
+        """{kernel-name prefix: (bytes per launch, source note)} of the committed PMC summary that matches this workload AND the
+        loaded library; ({}, reason) when there is none."""
+        from cips_3dplusplus_amd import build
+        key = None
+        if (self.res, self.depth, self.B) == (1024, 2, 1) and self.precision == "fp32":
+            key = {24: "headline", 64: "n64"}.get(self.n_samples)
+        elif (self.res, self.depth, self.B, self.n_samples) == (1024, 2, 4, 24) and self.precision == "bf16":
+            key = "b4_bf16"
+        if key is None:
+            return {}, "no PMC pass committed for this workload"
+        tp = os.path.join(ROOT, TRAFFIC_FILES[key])
+        if not os.path.exists(tp):
+            return {}, f"{TRAFFIC_FILES[key]} not present"
+        d = json.load(open(tp))
+        try:
+            with open(build.STAMP) as fh:
+                lib_hash = fh.read().strip()
+        except OSError:
+            lib_hash = None
+        if not d.get("lib_srchash") or d.get("lib_srchash") != lib_hash:
+            return {}, (f"{TRAFFIC_FILES[key]} was collected on library {str(d.get('lib_srchash'))[:12]}, this run loads "
+                        f"{str(lib_hash)[:12]}: not replayed")
+        out = {}
+        for e in d.get("kernels", []):
+            if "hbm_fetch_MB_x2" in e and "hbm_write_MB" in e:
+                out[e["kernel"]] = (e["hbm_fetch_MB_x2"] * 1e6 + e["hbm_write_MB"] * 1e6,
+                                    f"replayed from {TRAFFIC_FILES[key]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    f"this workload on this library build; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)")
+        return out, None
+
+    def decoder_kernels(self, n_calls=24):
+        """Per-kernel table of the decoder for `roofline.kernels`: launch-to-launch intervals of the one-call forward's own
+        timeline marks (cips3d_forward_io.ev_marks) over `n_calls` extra forwards OUTSIDE the timed region (a record between
+        dependent launches costs 1-2 us of queue drain, so the intervals are upper bounds of the kernel times; the rocprofv3
+        summary under profiles/ is the reference for them), medians per (kind, widths, resolution), priced against the bound
+        each kernel has."""
+        from cips_3dplusplus_amd import hip
+        per = {}
+        for _ in range(3):
+            self.step()
+        for _ in range(n_calls):
+            m = hip.DecoderMarks()
+            hip.DECODER_MARKS = m
+            self.step()
+            torch.cuda.synchronize()
+            for kind, ci, co, hh, us in m.intervals():
+                per.setdefault((kind, ci, co, hh), []).append(us)
+        traffic, why = self.traffic_table()
+        B, split = self.B, self.precision in ("fp32",)
+        mm_peak = (MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS) if split else (MFMA_F32_PEAK_TFLOPS if self.precision == "fp32_exact" else MFMA_F16_PEAK_TFLOPS)
+        rows = []
+        for (kind, ci, co, hh), v in sorted(per.items(), key=lambda kv: -statistics.median(kv[1]) * len(kv[1])):
+            us = statistics.median(v)
+            per_view = len(v) // n_calls
+            row = {"kind": kind, "c_in": ci, "c_out": co, "out_res": hh, "launches_per_step": per_view,
+                   "avg_launch_ms": us * 1e-3, "interval": "mark to mark (includes the event record's queue drain)"}
+            hw = hh * hh
+            if kind in ("planes_gemm", "gemm", "lowres_gemm"):
+                flops = 2.0 * B * ci * co * hw
+                row.update(kernel="chain_gemm_kernel" if kind == "planes_gemm" else "modconv1x1_kernel", bound="mfma",
+                           flop_per_launch=flops, achieved=flops / (us * 1e-6) / 1e12, peak=mm_peak, unit="TFLOP/s")
+            elif kind == "fused_stage":
+                C = ci
+                # bytes: low-res input + noise maps (two) + next stage's low-res output (or nothing) + rgb out + skip in; fp32
+                act_b = 2 if self.precision == "bf16_storage" else 4
+                byts = B * (C * (hw // 4) * act_b + co * hw * act_b + 3 * hw * 4 + 3 * (hw // 4) * 4) + 2 * hw * 4
+                flops = 2.0 * B * C * C * hw + 2.0 * B * C * co * hw
+                row.update(kernel=f"fused_up_conv_kernel<{C}, ...>", bound="hbm", algorithmic_bytes=byts, flop_per_launch=flops,
+                           achieved=byts / (us * 1e-6) / 1e12, peak=HBM_PEAK_TBS, unit="TB/s")
+            else:
+                row.update(kernel="torgb_reduce_kernel / torgb" if kind == "torgb" else kind, bound="latency")
+            if "achieved" in row:
+                row["frac"] = row["achieved"] / row["peak"]
+            for name, (tb, note) in traffic.items():
+                if row.get("kernel", "").split("<")[0] and name.startswith(row["kernel"].split("<")[0]) and \
+                        (kind != "fused_stage" or name.startswith(f"fused_up_conv_kernel<{ci},")):
+                    row["traffic"], row["traffic_source"] = tb, note
+                    break
+            else:
+                row["traffic"] = None
+            rows.append(row)
+        return rows, why
+
+    def roofline(self, kern_ms, n_events, kernels=False):
         if not kern_ms:                              # no kernel events were taken (--no-kernel-events): nothing to price
             return None
         H = self.cfg["renderer_cfg"]["hidden_dim"]
         flops = self.B * 64 * 64 * self.n_samples * nerf_flops_per_point(H, self.depth)
         achieved = flops / (kern_ms * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel come from a separate rocprofv3 --pmc pass (FETCH_SIZE and WRITE_SIZE
-        # cannot share a pass with timing): the committed summary of that pass is REPLAYED here for the matching
-        # configuration, not measured in this run.
-        traffic, src = None, None
-        tp = os.path.join(ROOT, TRAFFIC_FILE)
-        if os.path.exists(tp):
-            for ent in json.load(open(tp)).get("entries", []):
-                if (ent.get("depth"), ent.get("n_samples"), ent.get("batch"), ent.get("img")) == (self.depth, self.n_samples, self.B, 64):
-                    traffic = ent.get("traffic_bytes_per_launch")
-                    src = f"replayed from {TRAFFIC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload)"
+        table, why = self.traffic_table()
+        traffic, src = None, why
+        for name, (tb, note) in table.items():
+            if name.startswith("nerf_render"):
+                traffic, src = tb, note
         # The point-MLP GEMMs run as fp32-equivalent SPLIT-fp16 products on v_mfma_f32_16x16x32_f16 (csrc/nerf.hip): every
         # algorithmic fp32 multiply-add costs three fp16 ones, so the matrix-core ceiling for ALGORITHMIC flops is the fp16
         # dense peak / 3.  `achieved` counts algorithmic flops (SURVEY 8d), as before; the fp32 matrix instruction's own peak
@@ -266,7 +351,8 @@ class ForwardWorkload:
                 "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src,
                 "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
-                "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE)}
+                "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE),
+                **({"kernels": self.decoder_kernels()[0]} if kernels else {})}
 
 
 def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24):
@@ -310,6 +396,41 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
                      if AG.ONE_CALL_DECODER else "decoder = one autograd node per op (CIPS3D_ONE_CALL_DECODER=0)")
     line["roofline"] = hip.inversion_roofline(G.renderer, B=2, n_samples=n_samples)
     return line
+
+
+def multiview_workload(dev, repeats, n_frames=8, n_samples=128, res=1024):
+    """BASELINE config 4 with the demo's own semantics on ONE GPU: `multiview.sample_multi_view(view_mode="yaw", N_frames=8,
+    N_samples=128, truncation_ratio=0.5)` -- one z pair, ONE set of noise buffers, perturb=False, truncated styles with cached
+    means, return_xyz=True, uint8 frames (/root/reference/exp/cips3d/models/render_video_web_v10.py:1806-1826).  The multi-GPU
+    leg shards these frames over ranks (`--gpus N`); this entry is the per-GPU work of that loop."""
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs
+    from cips_3dplusplus_amd.multiview import sample_multi_view
+    G = pkg.build_generator(configs.ffhq_G_cfg(res, 2), dev, seed=0)
+    g = torch.Generator(device=dev).manual_seed(4)
+    zs = [torch.randn(1, 256, device=dev, generator=g), torch.randn(1, 256, device=dev, generator=g)]
+    cam_cfg = {"img_size": 64, "fov_ang": configs.FFHQ_CAM_CFG["fov_ang"], "dist_radius": configs.FFHQ_CAM_CFG["dist_radius"]}
+    ncfg = {"N_samples": n_samples, "perturb": False, "static_viewdirs": False}
+    nb = G.create_noise_bufs(64, dev)
+    run = lambda: sample_multi_view(G, cam_cfg, ncfg, zs, view_mode="yaw", N_frames=n_frames, truncation_ratio=0.5,   # noqa: E731
+                                    N_samples=n_samples, noise_bufs=nb)
+    for _ in range(2):                               # mean latents (10 000 samples, cached on G), plans, allocator
+        run()
+    torch.cuda.synchronize()
+    elapsed = []
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        for _ in range(3):
+            out = run()
+        torch.cuda.synchronize()
+        elapsed.append((time.perf_counter() - t0) / 3)
+    med = statistics.median(elapsed)
+    assert out["rgb"].dtype == torch.uint8 and out["rgb"].shape[0] == n_frames
+    return {"what": "BASELINE config 4, the demo loop's semantics on one GPU: sample_multi_view(yaw, 8 frames, N = 128, truncation 0.5, "
+                    "fixed noise buffers, perturb off, xyz returned, uint8 frames)",
+            "metric": "rendered views/s", "value": n_frames / med, "unit": "views/s", "ms_per_step": med / n_frames * 1e3,
+            "steps": 3 * n_frames, "repeats": repeats, "ms_per_step_repeats": [e / n_frames * 1e3 for e in elapsed], "dtype": DTYPE_NAMES["fp32"],
+            "config": {"workload": f"ffhq_r{res}_nerf64x64x{n_samples}_D2_B1 x {n_frames} frames (multiview.sample_multi_view)"}}
 
 
 def spawn_ranks(a):
@@ -405,13 +526,15 @@ def main():
             "preroll_ms_per_step": [e / a.steps * 1e3 for e in wl.preroll],
             "config": {"workload": wl.name(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
-            "roofline": wl.roofline(kern_ms, n_ev),
+            "roofline": wl.roofline(kern_ms, n_ev, kernels=(world == 1)),
         }
         if world == 1 and a.decoder_precision == "fp32":
             # the default arithmetic (split-fp16 products) against the fp32 matrix instruction on this run's own inputs
             line["fp32_equivalence"] = wl.fp32_equivalence()
         if world > 1:
-            line["rccl_ranks"] = torch.distributed.get_world_size()
+            # ranks that actually exchanged over RCCL: 0 when the gather ran over gloo (ranks sharing a device on a small box)
+            line["rccl_ranks"] = torch.distributed.get_world_size() if backend == "nccl" else 0
+            line["ranks"] = torch.distributed.get_world_size()
             line["dist_backend"] = backend + (" (RCCL)" if backend == "nccl" else " (ranks share devices: not an RCCL measurement)")
             line["physical_gpus"] = n_dev
         if world == 1 and not a.no_also and published_cfg:
@@ -442,9 +565,10 @@ def main():
                              "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
                              "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
                              "dtype": DTYPE_NAMES[kw["precision"]],
-                             "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2)})
+                             "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
                 del w2
                 torch.cuda.empty_cache()
+            also.append(multiview_workload(dev, min(a.repeats, 3)))
             inv = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3))
             inv["what"] = "BASELINE config 5: one flip-inversion step"
             also.append(inv)

@@ -216,7 +216,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 20           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 21           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -194,6 +194,17 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   }
 
   // ---- decoder (model_v3.py:592-637)
+  int n_marks = 0;
+  auto mark = [&](int kind, int Ci, int Co, int H) {          // timeline for bench.py (cips3d_forward_io.ev_marks)
+    if (!IO.ev_marks || n_marks >= IO.n_ev_marks) return;
+    hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_marks[n_marks]), as_stream(stream));
+    if (IO.ev_info) {
+      IO.ev_info[4 * n_marks] = kind; IO.ev_info[4 * n_marks + 1] = Ci; IO.ev_info[4 * n_marks + 2] = Co; IO.ev_info[4 * n_marks + 3] = H;
+    }
+    ++n_marks;
+    if (IO.ev_count) *IO.ev_count = n_marks;
+  };
+  mark(CIPS3D_MARK_START, 0, 0, 0);
   const float* x = P.features;
   // range rows of x (ranged plans).  fp32 x: the measured maximum of its values (x_amax; nullptr: no producer tracked this tensor
   // -- a split GEMM that reads it measures it first, amax_of).  Planes x: the exponents of its pixel blocks (x_exp; nullptr: the
@@ -220,6 +231,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   auto fold_flush = [&](float* dst) -> int {
     if (fold_slots == 0) return 0;
     const int rc = cips3d_torgb_reduce(P.rgb_part, fold_slots, fold_bias, fold_nb, skip, dst, B, (int64_t)fold_H * fold_W, stream);
+    mark(CIPS3D_MARK_TORGB, 0, 3, fold_H);
     skip = dst;
     fold_slots = fold_nb = 0;
     return rc;
@@ -267,6 +279,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                                   0 | gemm_flag | ybf_flag | ((L.flags & 2) ? CIPS3D_GEMM_SPLIT : 0), nullptr, 0, nullptr, nullptr,
                                   ranged ? &rg : nullptr, stream));
           }
+          mark(CIPS3D_MARK_LOWRES_GEMM, L.Cin, L.Cout, L.H);
         }
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
@@ -294,6 +307,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
                                       L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split, rgb, chain ? LN->wm : nullptr,
                                       chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stage_ranged ? &srg : nullptr, stream));
+        mark(CIPS3D_MARK_FUSED_STAGE, L.Cout, chain ? LN->Cout : 0, 2 * L.H);
         ylo_ready = chain;
         if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }
         x = out2;
@@ -337,6 +351,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           TRY(cips3d_modconv1x1_planes(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,
                                        fold ? T->wm : nullptr, fold ? P.rgb_part + (int64_t)fold_slots * B * 3 * hw : nullptr, &nblk,
                                        lr ? &rg : nullptr, stream));
+        mark(CIPS3D_MARK_PLANES_GEMM, L.Cin, L.Cout, L.H);
         x_amax = (lr && fmt != 1) ? L.amax : nullptr;
         x_exp = (lr && fmt == 1) ? L.aexp : nullptr;
         x_pmax = (lr && fmt == 1) ? rg.out_pmax : nullptr;
@@ -367,6 +382,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           int nblk = 0;
           TRY(cips3d_modconv1x1_torgb(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias, T->wm,
                                       P.rgb_part + (int64_t)fold_slots * B * 3 * hw, &nblk, ranged ? &rg : nullptr, stream));
+          mark(CIPS3D_MARK_GEMM, L.Cin, L.Cout, L.H);
           fold_slots += nblk;
           fold_bias[fold_nb++] = T->bias;
           fold_H = L.H; fold_W = L.W;
@@ -377,6 +393,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         }
         TRY(cips3d_modconv1x1(x, L.wm, out, B, L.Cin, L.Cout, hw, 1 | gemm_flag | split_flag, nz, nbs, L.noise_w, L.bias,
                               ranged ? &rg : nullptr, stream));
+        mark(CIPS3D_MARK_GEMM, L.Cin, L.Cout, L.H);
       } else {
         if (L.flags & 1) return CIPS3D_E_BADARG;   // chained packs only exist for stages that take the fused route above
         if (L.flags & 4) return CIPS3D_E_BADARG;   // planes reach an up-conv only on the fused route (the plan guarantees it)
@@ -388,6 +405,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
                               ranged ? &rg : nullptr, stream));
         float* fir_amax = (ranged && L.amax) ? L.amax : nullptr;      // (this route leaves the row unused: y_lo is not tracked here)
         TRY(cips3d_up2_fir_act(P.y_lo, L.fir, out, B, L.Cout, L.H, L.W, nz, nbs, L.noise_w, L.bias, fir_amax, stream));
+        mark(CIPS3D_MARK_OTHER, L.Cout, L.Cout, 2 * L.H);
         x_amax = fir_amax;               // recorded by the FIR kernel itself (else its reader measures it)
         x_exp = nullptr;
       }
@@ -400,6 +418,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       }
       float* out = last ? IO.rgb : P.skip[skip_i];
       TRY(cips3d_torgb(x, L.wm, L.bias, skip, L.kind == 3 ? 1 : 0, L.fir, out, B, L.Cin, L.H, L.W, stream));
+      mark(CIPS3D_MARK_TORGB, L.Cin, 3, L.kind == 3 ? 2 * L.H : L.H);
       skip = out;
       skip_i ^= 1;
     } else {

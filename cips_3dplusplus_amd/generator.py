@@ -191,6 +191,7 @@ class Generator(nn.Module):
             if truncation < 1:
                 mean_r = self.style_render_mean.reshape(-1).contiguous()
                 mean_d = self.style_decoder_mean.reshape(-1).contiguous()
+        marks, hip.DECODER_MARKS = hip.DECODER_MARKS, None
         events = None
         lst = hip.want_events("nerf_render")
         if lst is not None:
@@ -201,7 +202,8 @@ class Generator(nn.Module):
             z_r, z_d, cam_poses.float().contiguous(), focals.float().reshape(B).contiguous(),
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
-            float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb)
+            float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
+            marks=None if marks is None else marks.io_fields())
         # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
         m2 = mask.transpose(0, 1).contiguous()
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,

@@ -51,6 +51,39 @@ def want_events(name):
     return lst if k % st == KERNEL_EVENTS_PHASE % st else None
 
 
+class DecoderMarks:
+    """Timeline of the decoder launches of ONE cips3d_generator_forward call (cips3d_forward_io.ev_marks): hipEvent_t handles
+    the call records before / after each decoder launch, and what each launch was.  Measurement only (bench.py); set
+    `hip.DECODER_MARKS = DecoderMarks()` and the next Generator.forward fills it, then read `intervals()` after a
+    synchronise."""
+    KINDS = {0: "start", 1: "planes_gemm", 2: "gemm", 3: "lowres_gemm", 4: "fused_stage", 5: "torgb", 6: "other"}
+
+    def __init__(self, n=40):
+        self.events = [torch.cuda.Event(enable_timing=True) for _ in range(n)]
+        for e in self.events:
+            e.record()                                # materialise the hipEvent_t handles
+        self.handles = (C.c_void_p * n)(*[e.cuda_event for e in self.events])
+        self.info = (C.c_int32 * (4 * n))()
+        self.count = C.c_int32(0)
+        self.n = n
+
+    def io_fields(self):
+        return (C.addressof(self.handles), C.addressof(self.info), C.addressof(self.count), self.n)
+
+    def intervals(self):
+        """[(kind, C_in, C_out, H_out, microseconds)] for launch k = mark k-1 -> mark k (after torch.cuda.synchronize()).
+        fused_stage: C_in = the stage's width, C_out = the width of the next stage's low-resolution GEMM it also computes (0:
+        none)."""
+        out = []
+        for k in range(1, self.count.value):
+            out.append((self.KINDS.get(self.info[4 * k], "?"), self.info[4 * k + 1], self.info[4 * k + 2], self.info[4 * k + 3],
+                        self.events[k - 1].elapsed_time(self.events[k]) * 1e3))
+        return out
+
+
+DECODER_MARKS = None      # a DecoderMarks: filled by the next one-call forward, then reset to None
+
+
 def event_pair():
     if _EVENT_POOL:
         return _EVENT_POOL.pop()

@@ -52,7 +52,9 @@ class ForwardIO(C.Structure):
                 ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p),
                 ("rng_seed", C.c_uint64), ("rng_base", C.c_uint64), ("rng_normal", C.c_void_p), ("rng_n_normal", C.c_int64),
                 ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
-                ("noise_bound", C.c_float), ("pad2_", C.c_int32)]
+                ("noise_bound", C.c_float), ("pad2_", C.c_int32),
+                ("ev_marks", C.c_void_p), ("ev_info", C.c_void_p), ("ev_count", C.c_void_p), ("n_ev_marks", C.c_int32),
+                ("pad3_", C.c_int32)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -391,7 +393,7 @@ class ForwardPlan:
         return bound
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
-            events=None, fresh_perturb=False):
+            events=None, fresh_perturb=False, marks=None):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
         one cips3d_rng_fill launch when both are fresh."""
         lib = _lib.load()
@@ -454,6 +456,8 @@ class ForwardPlan:
         io.rgb, io.thumb, io.xyz, io.mask = rgb.data_ptr(), thumb.data_ptr(), xyz.data_ptr(), mask.data_ptr()
         if events is not None:
             io.ev_nerf_start, io.ev_nerf_stop = events
+        if marks is not None:        # decoder timeline (bench.py): (handle array, info array, count) of hip.DecoderMarks
+            io.ev_marks, io.ev_info, io.ev_count, io.n_ev_marks = marks
         _lib.check(lib.cips3d_generator_forward(C.byref(self.plan), C.byref(io), _lib.stream_ptr()),
                    "cips3d_generator_forward")
         if sdf is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 20  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 21  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -590,7 +590,21 @@ typedef struct cips3d_forward_io {
   float* rng_uniform; int64_t rng_n_uniform;
   float noise_bound;       /* upper bound of |noise[i][...]| over the call (0: the rng draw's own bound, 5.77, is used) */
   int32_t pad2_;
+  /* optional timeline of the decoder (measurement only; bench.py's roofline.kernels): ev_marks[0] is recorded right before
+   * the first decoder launch and ev_marks[k] right after the k-th decoder launch of the call (hipEvent_t handles, at most
+   * n_ev_marks of them; further launches are not marked); ev_info[4 k .. 4 k + 3] receives what launch k was:
+   * {CIPS3D_MARK_* kind, input channels, output channels, output height}.  *ev_count = marks recorded.  A record between two dependent
+   * launches costs ~1-2 us of queue drain: intervals are upper bounds of the kernel times. */
+  void** ev_marks; int32_t* ev_info; int32_t* ev_count; int32_t n_ev_marks; int32_t pad3_;
 } cips3d_forward_io;
+
+#define CIPS3D_MARK_START 0
+#define CIPS3D_MARK_PLANES_GEMM 1   /* a 1x1 StyledConv of the planes run (chain_gemm_kernel), epilogue + folded ToRGB included */
+#define CIPS3D_MARK_GEMM 2          /* cips3d_modconv1x1 / _torgb (fp32 activations in HBM) */
+#define CIPS3D_MARK_LOWRES_GEMM 3   /* the low-resolution GEMM of an up-sampling StyledConv as a launch of its own */
+#define CIPS3D_MARK_FUSED_STAGE 4   /* cips3d_fused_up_conv_next: FIR + act -> conv2 + act -> ToRGB + skip [-> next low-res GEMM] */
+#define CIPS3D_MARK_TORGB 5         /* cips3d_torgb / cips3d_torgb_reduce */
+#define CIPS3D_MARK_OTHER 6
 
 int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_forward_io* io, void* stream);
 

@@ -50,7 +50,8 @@ def test_two_rank_bench_step_gathers_the_single_rank_frames(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
+    rccl = 2 if torch.cuda.device_count() >= 2 else 0      # `rccl_ranks` counts ranks that exchanged over RCCL: none over gloo
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["rccl_ranks"] == rccl and line["scaling"] == "weak"
     assert line["config"]["parallelism"] == "views x2" and line["value"] > 0
     assert len(line["ms_per_step_repeats"]) == 2
     frames = torch.load(dump)
@@ -88,7 +89,8 @@ def test_the_drivers_eight_rank_command_runs_end_to_end():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 8 and line["rccl_ranks"] == 8 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["n_gpus"] == 8 and line["ranks"] == 8 and line["scaling"] == "weak" and line["steps"] == 2
+    assert line["rccl_ranks"] == (8 if n_dev >= 8 else 0)          # a gloo run must not claim RCCL ranks
     assert line["physical_gpus"] == n_dev
     assert line["dist_backend"].startswith("nccl" if n_dev >= 8 else "gloo")
     assert line["config"]["parallelism"] == "views x8" and line["value"] > 0 and line["ms_per_step"] > 0

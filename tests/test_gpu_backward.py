@@ -423,6 +423,51 @@ def test_generator_optimises_renderer_parameters():
     assert all(bool(torch.isfinite(v).all()) for v in out["render_state_dict"].values())
 
 
+def test_optimised_renderer_parameters_are_the_ones_the_forward_uses(monkeypatch):
+    """HipAdam writes parameters through raw pointers; the renderer's packed hidden weights and stacked biases are cached on
+    (data_ptr, _version).  Without a version bump every step after the first rendered with the INITIAL hidden weights and
+    biases while the backward recomputed with live ones.  (a) After K steps the live module must render exactly what a fresh
+    generator loaded from its state_dict renders; (b) the loss trajectory must be the one torch.optim.Adam produces
+    (CIPS3D_HIP_ADAM=0), which always bumped the versions."""
+    from cips_3dplusplus_amd.camera import Camera
+    from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss
+    g = torch.Generator(device=DEV).manual_seed(0)
+    t_rgb = torch.randn(2, 3, 32, 32, device=DEV, generator=g).clamp(-1, 1)
+    t_thumb = torch.randn(2, 3, 8, 8, device=DEV, generator=g).clamp(-1, 1)
+    cam_cfg = {"img_size": 8, "fov_ang": 6, "dist_radius": 0.12}
+    nerf_cfg = {"N_samples": 6, "perturb": False, "static_viewdirs": True}
+
+    def run(hip_adam):
+        monkeypatch.setenv("CIPS3D_HIP_ADAM", "1" if hip_adam else "0")
+        G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=2)
+        losses = []
+        loss_fn = surrogate_loss(t_rgb, t_thumb)
+
+        def logged(*a, **k):
+            v = loss_fn(*a, **k)
+            losses.append(float(v.detach() if torch.is_tensor(v) else v[0].detach()))
+            return v
+        FlipProjector(G, DEV).project_wplus(cam_cfg, nerf_cfg, logged, N_steps_pose=8, N_steps_app=0, w_avg_samples=64,
+                                            optim_render_params=True)
+        return G, losses
+
+    G_hip, l_hip = run(True)
+    G_ref, l_ref = run(False)
+    assert len(l_hip) == len(l_ref) == 8
+    for a, b in zip(l_hip, l_ref):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (l_hip, l_ref)
+    # the module after the optimisation against a fresh one built from its state_dict: same render, bit for bit
+    fresh = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, state_dict={k: v.detach().clone() for k, v in G_hip.state_dict().items()})
+    e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.tensor([[0.2, -0.1]], device=DEV), fov_ang=6, dist_radius=0.12)
+    styles = torch.randn(1, 3, G_hip.renderer.style_dim, device=DEV, generator=g)
+    with torch.no_grad():
+        a = G_hip.renderer.render(e, f, n, fa, styles, 8, 6)
+        b = fresh.renderer.render(e, f, n, fa, styles, 8, 6)
+    for x, y in zip(a, b):
+        if x is not None:
+            assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("tag,D,static", [("h32_d2", 2, True), ("h32_d3", 3, False)])
 def test_generator_backward_golden(golden, tag, D, static):
     """One inversion-like step: loss and every gradient vs the imported reference (tests/golden/backward.npz)."""
