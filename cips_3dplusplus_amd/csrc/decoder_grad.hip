@@ -532,7 +532,7 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
       const float* nz; int64_t nbs;
       noise_of(Lp, nz, nbs);
       const int go = gi ^ 1;
-      rg.out_amax = Lp.g_amax;              // (every gradient has an amax row of its own, zeroed with the rest up front)
+      rg.out_amax = Lp.g_amax;              // (every gradient has an amax row of its own, in the block this call zeroed up front)
       TRY(cips3d_modconv1x1_actbwd(g, L.wm_t, P.g[go], B, L.Cout, L.Cin, hw, split ? CIPS3D_GEMM_SPLIT : 0, &ab, nz, nbs, &rg, stream));
       gi = go;
     }

@@ -148,10 +148,16 @@ class GradPlan:
         self.o_feat_amax = take(B * AF)
         for i in info:
             if i["kind"] < 2:
-                i["o_y_amax"], i["o_g_amax"] = take(B * AF), take(B * AF)
-                i["o_glo_amax"] = take(B * AF) if i["kind"] == 1 else None
+                i["o_y_amax"] = take(B * AF)
         amax1 = take(0)
         zero0 = take(0)
+        # the gradients' maxima are raised by the BACKWARD's kernels: their rows belong to the block the backward zeroes (in the
+        # forward's block a second backward over a retained graph scaled its split-fp16 operands with the previous backward's
+        # maxima -- lo halves underflow when the new d_rgb is orders of magnitude smaller)
+        for i in info:
+            if i["kind"] < 2:
+                i["o_g_amax"] = take(B * AF)
+                i["o_glo_amax"] = take(B * AF) if i["kind"] == 1 else None
         for i in info:
             i["o_d_wm"] = take(B * i["Cout"] * i["Cin"]) if i["kind"] < 2 else take(i["S"] * i["cpad"])
             i["o_d_bias_part"] = take(i["S"] * i["cpad"]) if (i["kind"] < 2 and i["S"] > 1) else None

@@ -8,13 +8,39 @@ The autograd wiring follows op/fused_act.py:20-84 and op/upfirdn2d.py:20-143: th
 bias+leaky-ReLU is the same kernel in mode (act 3, grad 1) keyed on the saved OUTPUT, the backward
 of upfirdn2d is upfirdn2d with the flipped FIR and swapped up/down factors.
 
-Unlike the reference there is no pure-torch CPU branch: tensors must live on the GPU (see _lib).
+Device dispatch as in the reference (op/fused_act.py:105-116, op/upfirdn2d.py:147-150): a CPU tensor takes a pure-torch
+evaluation of the same formula (differentiable through torch's own autograd), a GPU tensor the HIP kernels.  This is the
+op-level API's own behaviour, not a fallback: a GPU tensor never takes the torch branch, a missing or stale HIP library still
+raises (see _lib), and nothing else in the package accepts CPU tensors (hip.py / Generator refuse them).
 """
 import torch
 from torch import nn
 from torch.autograd import Function
+from torch.nn import functional as F
 
 from . import _lib
+
+
+# ------------------------------------------------------------------------------------------ CPU tensors (torch ops)
+def _fused_leaky_relu_cpu(x, bias, negative_slope, scale):
+    """scale * leaky_relu(x + bias): the bias runs along dim 1."""
+    if bias is not None:
+        x = x + bias.reshape(1, -1, *([1] * (x.ndim - 2)))
+    return F.leaky_relu(x, negative_slope) * scale
+
+
+def _upfirdn2d_cpu(x, kernel, up, down, pad):
+    """zero-stuff by `up` (the sample first, up - 1 zeros after it), pad (negative = crop), true convolution
+    with `kernel`, keep every `down`-th sample.  x [N, C, H, W]; pad = (x0, x1, y0, y1)."""
+    (ux, uy), (dx, dy), (px0, px1, py0, py1) = up, down, pad
+    n, c, h, w = x.shape
+    z = x.reshape(n * c, 1, h, 1, w, 1)
+    z = F.pad(z, (0, ux - 1, 0, 0, 0, uy - 1)).reshape(n * c, 1, h * uy, w * ux)
+    z = F.pad(z, (max(px0, 0), max(px1, 0), max(py0, 0), max(py1, 0)))
+    z = z[:, :, max(-py0, 0): z.shape[2] - max(-py1, 0), max(-px0, 0): z.shape[3] - max(-px1, 0)]
+    k = torch.flip(kernel, [0, 1]).to(z.dtype).reshape(1, 1, *kernel.shape)     # conv2d correlates: flip for a convolution
+    z = F.conv2d(z, k)[:, :, ::dy, ::dx]
+    return z.reshape(n, c, z.shape[2], z.shape[3])
 
 
 # ------------------------------------------------------------------------------------------ raw calls
@@ -91,6 +117,8 @@ class _FusedLeakyReLU(Function):
 
 
 def fused_leaky_relu(input, bias=None, negative_slope=0.2, scale=2 ** 0.5):
+    if input.device.type == "cpu":
+        return _fused_leaky_relu_cpu(input, bias, negative_slope, scale)
     return _FusedLeakyReLU.apply(input, bias, negative_slope, scale)
 
 
@@ -153,4 +181,6 @@ class _UpFirDn2d(Function):
 
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    if input.device.type == "cpu":
+        return _upfirdn2d_cpu(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
     return _UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -380,16 +380,20 @@ class ForwardPlan:
         for nb in noise_bufs:
             if nb is None:
                 continue
-            key = (nb.data_ptr(), nb._version, nb.numel())
-            if key in cache:
+            # maps under optimisation (leaf tensors that require gradients: `optim_noise_bufs`) change between calls through
+            # whatever the optimiser does to their storage -- raw-pointer kernels included: measured every call, never cached
+            key = None if nb.requires_grad else (nb.data_ptr(), nb._version, nb.numel())
+            if key is not None and key in cache:
                 bound = max(bound, cache[key])
             else:
                 todo.append((key, hip.absmax(nb.detach().float().contiguous(), B=1)))
         for key, am in todo:        # (one synchronisation for all of them)
-            if len(cache) > 256:
-                cache.clear()
-            cache[key] = float(hip.amax_value(am)[0])
-            bound = max(bound, cache[key])
+            v = float(hip.amax_value(am)[0])
+            if key is not None:
+                if len(cache) > 256:
+                    cache.clear()
+                cache[key] = v
+            bound = max(bound, v)
         return bound
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,

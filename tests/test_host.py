@@ -91,10 +91,39 @@ def test_full_size_golden_weights_reproduce(golden):
 
 
 def test_product_path_refuses_cpu_tensors():
+    """Everything that launches a kernel refuses CPU tensors (no CPU fallback of the path) ..."""
+    from cips_3dplusplus_amd import _lib, op
     with pytest.raises(RuntimeError, match="CUDA"):
-        pkg.fused_leaky_relu(torch.randn(2, 4), torch.randn(4))
+        _lib.dev_ptr(torch.randn(2, 4), "x")
     with pytest.raises(RuntimeError, match="CUDA"):
-        pkg.upfirdn2d(torch.randn(1, 1, 4, 4), torch.ones(2, 2))
+        op.bias_act_raw(torch.randn(2, 4), torch.randn(4), None, 3, 0, 0.2, 1.0)
+    G = pkg.Generator(**configs.tiny_G_cfg(32, 2, 1))
+    with pytest.raises(RuntimeError, match="CUDA|GPU|HIP"):
+        G.renderer.render(torch.zeros(1, 3, 4), torch.ones(1, 1, 1), torch.ones(1, 1, 1), torch.ones(1, 1, 1),
+                          torch.zeros(1, 3, 32), 4, 2)
+
+
+def test_op_level_api_dispatches_cpu_tensors_to_torch_like_the_reference(golden):
+    """... except the two op-level entry points, whose CPU branch is part of the reference's API
+    (/root/reference/exp/op/fused_act.py:105-116, /root/reference/exp/op/upfirdn2d.py:147-150, 160-201): package-own torch ops,
+    checked against the reference-generated fixtures (tests/golden/ops.npz) and differentiable through torch's autograd."""
+    fx = golden("ops")
+    n = 0
+    for name in fx["ufd_names"]:
+        up, down, p0, p1 = [int(v) for v in fx[f"ufd_{name}_cfg"]]
+        y = pkg.upfirdn2d(fx[f"ufd_{name}_x"], fx[f"ufd_{name}_k"], up=up, down=down, pad=(p0, p1))
+        assert y.shape == fx[f"ufd_{name}_y"].shape, name
+        assert float((y - fx[f"ufd_{name}_y"]).abs().max()) < 1e-5, name
+        n += 1
+    for name in ("2d_g1", "2d_gs", "4d", "4d_nob", "3d"):
+        b = fx[f"flr_{name}_b"] if f"flr_{name}_b" in fx else None
+        y = pkg.fused_leaky_relu(fx[f"flr_{name}_x"], b, scale=float(fx[f"flr_{name}_scale"]))
+        assert float((y - fx[f"flr_{name}_y"]).abs().max()) < 1e-6, name
+        n += 1
+    assert n == 14
+    x = torch.randn(1, 2, 5, 5, requires_grad=True)
+    pkg.upfirdn2d(pkg.fused_leaky_relu(x, torch.zeros(2)), torch.ones(2, 2) / 4, up=2, pad=(1, 0)).sum().backward()
+    assert x.grad is not None and bool(torch.isfinite(x.grad).all())
 
 
 def test_product_never_imports_oracle():
@@ -138,7 +167,9 @@ def test_decoder_grad_plan_layout(res, D, B, S0, monkeypatch):
         assert S >= 1 and S & (S - 1) == 0 and S <= 16
         if L.kind < 2:
             n_conv += 1
-            assert a0 <= L.y_amax < a1 and a0 <= L.g_amax < a1 and (L.kind == 0 or a0 <= L.glo_amax < a1)
+            # the activations' maxima are the forward's (zeroed with the amax block), the gradients' the backward's (zeroed with
+            # its accumulators: a second backward over a retained graph must not see the previous one's maxima)
+            assert a0 <= L.y_amax < a1 and z0 <= L.g_amax < o0 and (L.kind == 0 or z0 <= L.glo_amax < o0)
             assert z0 <= L.d_bias < z1 and z0 <= L.d_nw_part < z1 and o1 <= L.y < end and o1 <= L.wm_t < end
             assert L.slot_stride >= L.Cout and L.slot_stride % 32 == 0 and S * L.slot_stride <= p.nw_stride
         else:
