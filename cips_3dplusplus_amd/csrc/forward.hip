@@ -205,6 +205,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
     if (IO.ev_count) *IO.ev_count = n_marks;
   };
   mark(CIPS3D_MARK_START, 0, 0, 0);
+  mark(CIPS3D_MARK_START, 0, 0, 0);     // (two records back to back: their distance is what a record itself costs)
   const float* x = P.features;
   // range rows of x (ranged plans).  fp32 x: the measured maximum of its values (x_amax; nullptr: no producer tracked this tensor
   // -- a split GEMM that reads it measures it first, amax_of).  Planes x: the exponents of its pixel blocks (x_exp; nullptr: the

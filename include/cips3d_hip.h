@@ -590,8 +590,9 @@ typedef struct cips3d_forward_io {
   float* rng_uniform; int64_t rng_n_uniform;
   float noise_bound;       /* upper bound of |noise[i][...]| over the call (0: the rng draw's own bound, 5.77, is used) */
   int32_t pad2_;
-  /* optional timeline of the decoder (measurement only; bench.py's roofline.kernels): ev_marks[0] is recorded right before
-   * the first decoder launch and ev_marks[k] right after the k-th decoder launch of the call (hipEvent_t handles, at most
+  /* optional timeline of the decoder (measurement only; bench.py's roofline.kernels): ev_marks[0] and ev_marks[1] are
+   * recorded back to back right before the first decoder launch (their distance calibrates what a record costs) and
+   * ev_marks[k + 1] right after the k-th decoder launch of the call (hipEvent_t handles, at most
    * n_ev_marks of them; further launches are not marked); ev_info[4 k .. 4 k + 3] receives what launch k was:
    * {CIPS3D_MARK_* kind, input channels, output channels, output height}.  *ev_count = marks recorded.  A record between two dependent
    * launches costs ~1-2 us of queue drain: intervals are upper bounds of the kernel times. */

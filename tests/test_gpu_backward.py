@@ -423,45 +423,57 @@ def test_generator_optimises_renderer_parameters():
     assert all(bool(torch.isfinite(v).all()) for v in out["render_state_dict"].values())
 
 
-def test_optimised_renderer_parameters_are_the_ones_the_forward_uses(monkeypatch):
+def test_optimised_renderer_parameters_are_the_ones_the_forward_uses():
     """HipAdam writes parameters through raw pointers; the renderer's packed hidden weights and stacked biases are cached on
     (data_ptr, _version).  Without a version bump every step after the first rendered with the INITIAL hidden weights and
-    biases while the backward recomputed with live ones.  (a) After K steps the live module must render exactly what a fresh
-    generator loaded from its state_dict renders; (b) the loss trajectory must be the one torch.optim.Adam produces
-    (CIPS3D_HIP_ADAM=0), which always bumped the versions."""
+    biases while the backward recomputed with live ones.  (a) every step must change the cache key and the cached buffers must
+    equal a fresh packing of the live weights; (b) after K steps of the projector (`optim_render_params`) the optimised module
+    must render exactly what a fresh generator loaded from its state_dict renders.  (A loss-trajectory comparison with
+    torch.optim.Adam is not a test: Adam's first steps are +-lr by the SIGN of each gradient, and the backward's fp32 atomics
+    reorder sums, so entries with noise-level gradients legitimately take different signs from run to run.)"""
     from cips_3dplusplus_amd.camera import Camera
+    from cips_3dplusplus_amd.optim import HipAdam
     from cips_3dplusplus_amd.projector import FlipProjector, surrogate_loss
     g = torch.Generator(device=DEV).manual_seed(0)
+    # (a) the optimiser alone
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=2)
+    ren = G.renderer
+    ren.requires_grad_(True)
+    opt = HipAdam(list(ren.parameters()), lr=1e-2)
+    packed0, bias0 = (t.clone() for t in ren._derived_buffers())
+    key0 = ren._weights_key()
+    for step in range(3):
+        for p in ren.parameters():
+            p.grad = torch.randn(p.shape, device=DEV, generator=g)
+        key_before = ren._weights_key()
+        opt.step()
+        assert ren._weights_key() != key_before, "a HipAdam step must bump the parameters' versions"
+        packed, bias = ren._derived_buffers()
+        net = ren.network
+        fresh_bias = torch.stack([l.bias for l in net.pts_linears] + [net.views_linears.bias]).detach()
+        fresh_packed = hip.nerf_pack_weights(torch.stack([l.weight for l in net.pts_linears[1:]]).detach().contiguous(),
+                                             net.views_linears.weight.detach().contiguous(), ren.hidden_dim, ren.N_layers_renderer)
+        # (bit patterns: the packed stream holds fp16 pairs; its tail beyond the per-layer scales is never written)
+        n_used = ren.N_layers_renderer * ren.hidden_dim ** 2 + 2 * ren.N_layers_renderer
+        bits = lambda t: t.reshape(-1)[:n_used].view(torch.int32)      # noqa: E731
+        assert torch.equal(bias, fresh_bias) and torch.equal(bits(packed), bits(fresh_packed)), step
+    assert ren._weights_key() != key0 and not torch.equal(bits(packed), bits(packed0)) and not torch.equal(bias, bias0)
+    # (b) through the projector
     t_rgb = torch.randn(2, 3, 32, 32, device=DEV, generator=g).clamp(-1, 1)
     t_thumb = torch.randn(2, 3, 8, 8, device=DEV, generator=g).clamp(-1, 1)
-    cam_cfg = {"img_size": 8, "fov_ang": 6, "dist_radius": 0.12}
-    nerf_cfg = {"N_samples": 6, "perturb": False, "static_viewdirs": True}
-
-    def run(hip_adam):
-        monkeypatch.setenv("CIPS3D_HIP_ADAM", "1" if hip_adam else "0")
-        G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=2)
-        losses = []
-        loss_fn = surrogate_loss(t_rgb, t_thumb)
-
-        def logged(*a, **k):
-            v = loss_fn(*a, **k)
-            losses.append(float(v.detach() if torch.is_tensor(v) else v[0].detach()))
-            return v
-        FlipProjector(G, DEV).project_wplus(cam_cfg, nerf_cfg, logged, N_steps_pose=8, N_steps_app=0, w_avg_samples=64,
-                                            optim_render_params=True)
-        return G, losses
-
-    G_hip, l_hip = run(True)
-    G_ref, l_ref = run(False)
-    assert len(l_hip) == len(l_ref) == 8
-    for a, b in zip(l_hip, l_ref):
-        assert abs(a - b) <= 2e-4 * max(1.0, abs(b)), (l_hip, l_ref)
-    # the module after the optimisation against a fresh one built from its state_dict: same render, bit for bit
-    fresh = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, state_dict={k: v.detach().clone() for k, v in G_hip.state_dict().items()})
+    G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=2)
+    out = FlipProjector(G, DEV).project_wplus({"img_size": 8, "fov_ang": 6, "dist_radius": 0.12},
+                                             {"N_samples": 6, "perturb": False, "static_viewdirs": True},
+                                             surrogate_loss(t_rgb, t_thumb), N_steps_pose=8, N_steps_app=0, w_avg_samples=64,
+                                             optim_render_params=True)
+    Gopt = out["G"]
+    hist = out["loss_history"]
+    assert bool(torch.isfinite(hist).all()) and float(hist[-1]) < float(hist[0])
+    fresh = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, state_dict={k: v.detach().clone() for k, v in Gopt.state_dict().items()})
     e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.tensor([[0.2, -0.1]], device=DEV), fov_ang=6, dist_radius=0.12)
-    styles = torch.randn(1, 3, G_hip.renderer.style_dim, device=DEV, generator=g)
+    styles = torch.randn(1, 3, Gopt.renderer.style_dim, device=DEV, generator=g)
     with torch.no_grad():
-        a = G_hip.renderer.render(e, f, n, fa, styles, 8, 6)
+        a = Gopt.renderer.render(e, f, n, fa, styles, 8, 6)
         b = fresh.renderer.render(e, f, n, fa, styles, 8, 6)
     for x, y in zip(a, b):
         if x is not None:
