@@ -35,7 +35,8 @@ sys.path.insert(0, ROOT)
 
 DTYPE_NAMES = {"fp32": "f32 (NeRF point MLP and decoder GEMMs: fp32-equivalent split-fp16 MFMA products -- three exact fp16 products per "
                        "fp32 product, fp32 accumulate, fp32 storage; operands range-tracked: per-tensor power-of-two scales)",
-               "fp32_exact": "f32 (decoder GEMMs on the fp32 matrix instruction v_mfma_f32_16x16x4_f32; NeRF point MLP split-fp16)",
+               "fp32_exact": "f32 (IEEE fp32 products everywhere: the NeRF point MLP AND the decoder GEMMs on the fp32 matrix instruction "
+                             "v_mfma_f32_16x16x4_f32, fp32 accumulate, fp32 storage)",
                "bf16": "bf16 decoder GEMM operands (f32 accumulate, f32 storage), f32 NeRF",
                "bf16_storage": "bf16 decoder GEMM operands + bf16 storage of the up-sampling stages' activations "
                                "(f32 accumulate), f32 NeRF"}
@@ -128,7 +129,7 @@ class ForwardWorkload:
         self.cfg = configs.ffhq_G_cfg(res, depth)
         self.nerf_cfg = {"N_samples": n_samples, "perturb": not deterministic, "static_viewdirs": False}
         self.G = pkg.build_generator(self.cfg, dev, seed=0)
-        self.G.set_decoder_precision(precision)
+        self.G.set_precision(precision)              # "fp32_exact" switches the renderer's point MLP as well as the decoder
         self.zs, locs = make_inputs(rank, batch, dev)
         self.cam = Camera.generate_camera_params(64, dev, locations=locs, **{k: v for k, v in configs.FFHQ_CAM_CFG.items()
                                                                              if k in ("fov_ang", "dist_radius")})
@@ -151,9 +152,9 @@ class ForwardWorkload:
                           noise_bufs=self.noise_bufs, nerf_cfg=self.nerf_cfg)["rgb"]
 
     def fp32_equivalence(self):
-        """One view rendered with the decoder on split-fp16 products (the default) and on the fp32 matrix instruction
-        ("fp32_exact"), same latents / camera / jitter / noise: how far apart the two images are.  (The render kernel has only
-        the split form; its distance to fp64 is pinned by tests/test_gpu_split_fp16.py: no larger than plain fp32's.)"""
+        """One view rendered in the default arithmetic (split-fp16 products in the point MLP and the decoder GEMMs) and with
+        IEEE-fp32 products everywhere ("fp32_exact": the fp32 matrix instruction in both), same latents / camera / jitter /
+        noise: how far apart the two images are.  (Against fp64 both err like plain fp32: tests/test_gpu_split_fp16.py.)"""
         e, f, n, fa, _ = self.cam
         nb = self.G.create_noise_bufs(64, self.dev)
         u = torch.rand(self.B, 64, 64, 1, device=self.dev)
@@ -161,10 +162,10 @@ class ForwardWorkload:
                   nerf_cfg=self.nerf_cfg)
         with torch.no_grad():
             a = self.G(**kw)["rgb"]
-            self.G.set_decoder_precision("fp32_exact")
+            self.G.set_precision("fp32_exact")
             b = self.G(**kw)["rgb"]
-            self.G.set_decoder_precision(self.precision)
-        return {"max_abs_rgb_difference_split_vs_fp32_mfma_decoder": float((a - b).abs().max()),
+            self.G.set_precision(self.precision)
+        return {"max_abs_rgb_difference_split_vs_fp32_mfma": float((a - b).abs().max()),
                 "rgb_max_abs": float(b.abs().max()),
                 "note": "split-fp16 = three exact fp16 products per fp32 product, fp32 accumulate; against fp64 it errs no more "
                         "than the fp32 instruction (tests/test_gpu_split_fp16.py); parity bar of the path: 1e-3 max-abs"}
@@ -350,12 +351,15 @@ class ForwardWorkload:
         # algorithmic fp32 multiply-add costs three fp16 ones, so the matrix-core ceiling for ALGORITHMIC flops is the fp16
         # dense peak / 3.  `achieved` counts algorithmic flops, as before; the fp32 matrix instruction's own peak
         # (what the round-1 kernel was bounded by) is kept beside it.
-        peak = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
-        return {"kernel": "nerf_render_kernel (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
+        exact = self.precision == "fp32_exact"
+        peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
+        return {"kernel": ("nerf_render_pair_kernel<16, 0, true> (exact fp32: v_mfma_f32_16x16x4_f32)" if exact else
+                           "nerf_render_kernel") + " (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                "peak_definition": f"fp16 dense MFMA peak {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s / {SPLIT_PRODUCTS} fp16 products per "
-                                   f"fp32 product (split-fp16 arithmetic, fp32 accumulate)",
-                "executed_f16_mfma_tflops": achieved * SPLIT_PRODUCTS,
+                "peak_definition": (f"fp32 matrix instruction peak {MFMA_F32_PEAK_TFLOPS:.1f} TFLOP/s" if exact else
+                                    f"fp16 dense MFMA peak {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s / {SPLIT_PRODUCTS} fp16 products per "
+                                    f"fp32 product (split-fp16 arithmetic, fp32 accumulate)"),
+                "executed_f16_mfma_tflops": None if exact else achieved * SPLIT_PRODUCTS,
                 "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src,
                 "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
@@ -551,8 +555,8 @@ def main():
             del wl
             torch.cuda.empty_cache()
             for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
-                            ("headline workload with the decoder GEMMs on the fp32 matrix instruction (fp32_exact) instead of the "
-                             "default split-fp16 products", dict(n_samples=24, batch=1, precision="fp32_exact")),
+                            ("headline workload with IEEE-fp32 products everywhere (fp32_exact: the point MLP and the decoder GEMMs on the "
+                             "fp32 matrix instruction) instead of the default split-fp16 products", dict(n_samples=24, batch=1, precision="fp32_exact")),
                             ("BASELINE config 2: FFHQ 256^2, D = 2, single view", dict(n_samples=24, batch=1, precision="fp32", res=256)),
                             ("BASELINE config 2 with the deep renderer: FFHQ 256^2, D = 8", dict(n_samples=24, batch=1, precision="fp32",
                                                                                                res=256, depth=8)),

@@ -72,7 +72,7 @@ class NerfParams(C.Structure):
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
                 ("features_planes", C.c_int32), ("raw_density", C.c_int32),
-                ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p)]
+                ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p), ("packed32", C.c_void_p)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -105,6 +105,7 @@ _SIGS = {
     "cips3d_camera_params": (c_int, [c_f32p, c_f32p, c_f32, c_f32p, c_f32, c_int, c_int, c_f32p, c_f32p, c_f32p,
                                      c_f32p, C.c_void_p]),
     "cips3d_nerf_pack_weights": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
+    "cips3d_nerf_pack_weights32": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, C.c_void_p]),
     "cips3d_nerf_packed_floats": (c_i64, [c_int, c_int]),
     "cips3d_nerf_suggest_chunks": (c_int, [c_int, c_int, c_int]),
     "cips3d_nerf_part_floats": (c_i64, [c_int, c_int, c_int, c_int]),
@@ -216,7 +217,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 21           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 22           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -1133,6 +1133,12 @@ struct FusedArgs {
 #ifndef CIPS3D_C32_MINW
 #define CIPS3D_C32_MINW 8      // A/B knob: waves per SIMD the C = 32 stage is compiled for
 #endif
+#ifndef CIPS3D_FUSED_AB
+// timing-only ablations of the fused stages (results garbage; tools/README.md): 1 no scale loads, 2 no y_next record, 4 no ToRGB
+// sums (at C = 32, where nothing else reads conv2's output, the compiler then drops conv2 altogether: read that one as "no
+// conv2"), 8 no FIR arithmetic, 16 no conv2 epilogue arithmetic, 32 no activation / split of conv1
+#define CIPS3D_FUSED_AB 0
+#endif
 #ifdef CIPS3D_FUSED_STAMPS
 // Diagnostic build only: per-phase cycle sums of wave 0 of every workgroup of the fused up-sampling stages, slot = log2(C) - 5
 // (C = 32, 64, 128, 256), accumulated in registers, flushed at the end of the workgroup.
@@ -1279,15 +1285,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
       float o[2][4];
-      up2_fir(pset[u], kf, o);
+      if constexpr (CIPS3D_FUSED_AB & 8) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o[0][c] = pset[u][0][c] + pset[u][1][c]; o[1][c] = pset[u][1][c] + pset[u][2][c]; }
+      } else {
+        up2_fir(pset[u], kf, o);
+      }
       const float bs = a.bias1[st * BK + ch];
 #pragma unroll
       for (int py = 0; py < 2; ++py) {
         const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * TW + qx * 4);
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((o[py][c] + nz[c]) + bs);
-        if constexpr (SPLIT) {          // split once here (with the activation's gain and range scale: cips3d_split_word);
+        for (int c = 0; c < 4; ++c) v[c] = (CIPS3D_FUSED_AB & 32) ? o[py][c] + nz[c] : lrelu02((o[py][c] + nz[c]) + bs);
+        if constexpr (SPLIT && !(CIPS3D_FUSED_AB & 32)) {          // split once here (with the activation's gain and range scale: cips3d_split_word);
 #pragma unroll                          // every wave row reads the packed halves
           for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c], kact1);
         } else {
@@ -1309,9 +1320,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // for the amax slots (lane = slot), issued here with the tile's first loads and waited for with them at the barrier below;
   // as scalar loads in front of the first patch_store their latency was exposed: +2.9 us at C = 32 -- and leaves them behind
   // the noise tile for everyone.
-#ifndef CIPS3D_FUSED_AB
-#define CIPS3D_FUSED_AB 0      // timing-only ablations: 1 no scale loads, 2 no y_next record, 3 neither
-#endif
+
   if constexpr (SPLIT) {
     if (a.x_amax && wave == 0 && !(CIPS3D_FUSED_AB & 1)) {
       const float t = lane < CIPS3D_AMAX_SLOTS ? a.x_amax[b * CIPS3D_AMAX_FLOATS + lane * CIPS3D_AMAX_STRIDE] : 0.f;
@@ -1465,7 +1474,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
       // (chained split form: v = out2 2^-e2 from here on -- the B operand of the next GEMM; the ToRGB sums are scaled back once)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz2[c]) + bias4[i][r]) * kact2;
+      for (int c = 0; c < 4; ++c) v[c] = (CIPS3D_FUSED_AB & 16) ? v[c] : lrelu02((v[c] + nz2[c]) + bias4[i][r]) * kact2;
       if (NEXT) {   // keep the activated value where the accumulator was: it is the next GEMM's B operand
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][c][r] = v[c];
@@ -1478,7 +1487,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           *reinterpret_cast<f32x4*>(a.out2 + (int64_t)b * C * HWo + ((obase + r) * HWo + oy * OW + ox)) = v;
         }
       }
-      if (a.wm_rgb) {
+      if (a.wm_rgb && !(CIPS3D_FUSED_AB & 4)) {
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
           const float w = s_wrgb[ch * C + obase + r];

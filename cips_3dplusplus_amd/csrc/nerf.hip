@@ -936,7 +936,8 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if ((P.o_features || P.o_thumb || P.o_xyz || P.o_mask) && !(P.o_features && P.o_thumb && P.o_xyz && P.o_mask))
     return CIPS3D_E_BADARG;
   const int fuse = cips3d_nerf_fuses_finish(p);
-  if (!P.near_ || !P.far_ || !P.w_first || !P.packed || !P.w_view || !P.film ||
+  if (P.packed32 && !cips3d_nerf_pair_applies(p)) return CIPS3D_E_UNSUPP;     // exact fp32 only exists in nerf_pair.hip's shape
+  if (!P.near_ || !P.far_ || !P.w_first || (!P.packed && !P.packed32) || !P.w_view || !P.film ||
       !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || (!P.sigmoid_beta && !P.raw_density) || (!P.part && !fuse))
     return CIPS3D_E_BADARG;
   if (P.x_pts ? (!P.x_rays_d || !P.x_viewdirs || !P.x_z_vals || P.n_rays <= 0) : (!P.cam_poses || !P.focals || P.n_rays != 0))

@@ -45,7 +45,10 @@ constexpr int PW = 4;           // waves per workgroup (one per SIMD)
 // wait + barrier.  X is dead afterwards (the epilogue overwrites it).
 // ABL: timing-only ablations (tools/nerf_pair_ab.py --abl; bit 0 no LDS-DMA, 1 no FiLM / sine epilogues, 2 no layer 0,
 // 3 no MFMAs); only compiled into a -DCIPS3D_PAIR_ABLATIONS build, results are garbage
-template <int NT, int ABL = 0>
+// F32: the exact-fp32 instantiation (cips3d_nerf_params.packed32): v_mfma_f32_16x16x4_f32 on fp32 weights and fp32 activations --
+// bit for bit an fmaf chain in k order -- instead of three fp16 products per fp32 product.  Same slabs, same ring: a 1 KiB piece
+// is the 16 x 16 fp32 block (o-tile, 16 input units) where the split stream has an (o-tile, 32 units, hi | lo) plane.
+template <int NT, int ABL = 0, bool F32 = false>
 struct PairMatrix {
   static constexpr int H = NT * 16;
   static constexpr int TILE = 16 * H;          // floats of one o-tile's A fragments in the packed stream
@@ -72,6 +75,55 @@ struct PairMatrix {
   __device__ static __forceinline__ void stage_slab_k(const float* __restrict__ packed, float* slot, int lp, int s, int wave, int lane) {
 #pragma unroll
     for (int j = 0; j < PPW; ++j) stage_piece_k(packed, slot, lp, s, j * PW + wave, lane);
+  }
+
+  // exact fp32: X[c][T] = this lane's 4 units (4 q + r) of o-tile T of the layer input (= the D layout of the layer before);
+  // k-step (T, r) multiplies the weights' column 16 T + 4 q + r -- the order cips3d_nerf_pack_weights32 stores them in
+  __device__ static __forceinline__ void run32(f32x4 (&acc)[2][NT], const f32x4 (&X)[2][NT], Ring& ring, int wave, int lane) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+      const int nxt = (ring.seq + 1) % ring.per_sample;
+      const int nlp = nxt / STEPS, ns = nxt - nlp * STEPS;
+      float* lnext = ring.lds + ((ring.seq + 1) & 1) * SLAB;
+      const float* slab = ring.lds + (ring.seq & 1) * SLAB;
+      f32x4 fa[2][2][2];                           // [buffer][o-tile of the pair][half of the k-block]
+      auto load_group = [&](int buf, int gi) {
+        const int kb = gi / GPK, j = gi % GPK;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf)
+            fa[buf][t][hf] = *reinterpret_cast<const f32x4*>(slab + ((kb * NT + 2 * j + t) * 2 + hf) * 256 + lane * 4);
+      };
+      load_group(0, 0);
+#pragma unroll
+      for (int gi = 0; gi < GPS; ++gi) {
+        const int kb = gi / GPK, j = gi % GPK, m = s * KPS + kb, cur = gi & 1;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(fa[cur][t][0]), "+v"(fa[cur][t][1]));
+        if (gi + 1 < GPS) load_group(cur ^ 1, gi + 1);
+#pragma unroll
+        for (int jj = 0; jj < PPW; ++jj)
+          if (jj * GPS / PPW == gi) stage_piece_k(ring.packed, lnext, nlp, ns, jj * PW + wave, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+              for (int c = 0; c < 2; ++c) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                acc[c][2 * j + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][t][hf][r], X[c][2 * m + hf][r],
+                                                                         (m == 0 && hf == 0 && r == 0) ? z : acc[c][2 * j + t], 0, 0, 0);
+              }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+      ++ring.seq;
+    }
   }
 
   __device__ static __forceinline__ void run(f32x4 (&acc)[2][NT], const h8 (&Xh)[2][MB], const h8 (&Xl)[2][MB], Ring& ring,
@@ -135,15 +187,16 @@ struct PairMatrix {
   }
 };
 
-template <int NT, int ABL>
+template <int NT, int ABL, bool F32>
 __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a) {
-  typedef PairMatrix<NT, ABL> MX;
+  typedef PairMatrix<NT, ABL, F32> MX;
   constexpr int H = NT * 16;
   constexpr int SLAB = MX::SLAB;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const cips3d_nerf_params& P = a.p;
   const int D = P.depth;
   const int L = D + 1;
+  const float* packed = F32 ? P.packed32 : P.packed;       // the stream this instantiation multiplies (scales behind it: 1 for fp32)
   float* ringmem = lds;                      // 2 * SLAB (>= the PW x 16 x (H + 4) partial exchange of the finish)
   float* s_film = ringmem + 2 * SLAB;        // L * 2 * H
   float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed
@@ -179,7 +232,7 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
   // ---- stage the small per-view tables (as nerf_render_kernel)
   {
     const float* film_b = P.film + (int64_t)b * L * 2 * H;
-    const float* scales = P.packed + (int64_t)D * H * H;
+    const float* scales = packed + (int64_t)D * H * H;
     for (int i = tid; i < L * H; i += PW * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
@@ -243,12 +296,12 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
   float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, ax = 0.f, ay = 0.f, az = 0.f, wlast = 0.f;
 
   Ring ring;
-  ring.packed = P.packed;
+  ring.packed = packed;
   ring.lds = ringmem;
   ring.seq = 0;
   ring.per_sample = D * MX::STEPS;            // slabs per sample pair
   ring.seq_end = (a.chunk / 2) * ring.per_sample;
-  MX::stage_slab_k(P.packed, ringmem, 0, 0, wave, lane);
+  MX::stage_slab_k(packed, ringmem, 0, 0, wave, lane);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
@@ -265,7 +318,16 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
     asm volatile("" : "+v"(opq));
     const int q4o = 4 * qd + opq;
 
-    h8 Xh[2][NT / 2], Xl[2][NT / 2];
+    h8 Xh[2][NT / 2], Xl[2][NT / 2];           // split: hi / lo B fragments per k-block
+    f32x4 Xf[2][NT];                           // F32: the activations themselves, per o-tile
+    auto put_act = [&](int cc, int m, const float (&v8)[8]) {       // units of o-tiles 2 m, 2 m + 1 -> the next layer's input
+      if constexpr (F32) {
+        Xf[cc][2 * m] = f32x4{v8[0], v8[1], v8[2], v8[3]};
+        Xf[cc][2 * m + 1] = f32x4{v8[4], v8[5], v8[6], v8[7]};
+      } else {
+        split8(v8, Xh[cc][m], Xl[cc][m]);
+      }
+    };
     float sdf[2] = {0.f, 0.f};
     // ---- layer 0: 3 -> H on the VALU, in D layout, split into the hi / lo B fragments of the first MFMA layer
     {
@@ -300,8 +362,8 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
               for (int i = 0; i < 4; ++i) sdf[cc] = fmaf(ws4[i], v8[cc][hf * 4 + i], sdf[cc]);
           }
         }
-        split8(v8[0], Xh[0][m], Xl[0][m]);
-        split8(v8[1], Xh[1][m], Xl[1][m]);
+        put_act(0, m, v8[0]);
+        put_act(1, m, v8[1]);
       }
     }
     f32x4 acc[2][NT];
@@ -331,7 +393,8 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
         w1 = live1 ? alpha1 * T : 0.f;
         if (live1) T *= (1.f - alpha1) + 1e-10f;
       }
-      MX::run(acc, Xh, Xl, ring, wave, lane);
+      if constexpr (F32) MX::run32(acc, Xf, ring, wave, lane);
+      else MX::run(acc, Xh, Xl, ring, wave, lane);
       const float* film_l = s_film + l * 2 * H;
       if (l < D) {
         // hidden: Y = sin(gamma' (W' X) + c), written over X as the next layer's B fragments
@@ -357,8 +420,8 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
                 for (int i = 0; i < 4; ++i) sdf[cc] = fmaf(ws4[i], v8[cc][hf * 4 + i], sdf[cc]);
             }
           }
-          split8(v8[0], Xh[0][m], Xl[0][m]);
-          split8(v8[1], Xh[1][m], Xl[1][m]);
+          put_act(0, m, v8[0]);
+          put_act(1, m, v8[1]);
         }
       } else {
         // view: f = sin(gamma' (W' h_D + Wd' v) + c), features folded into FA, rgb head partial sums.  The view-direction
@@ -498,7 +561,26 @@ __global__ void __launch_bounds__(PW * 64, 1) nerf_render_pair_kernel(NerfArgs a
   }
 }
 
-template <int NT, int ABL = 0>
+// exact-fp32 weight stream: packed32[l][t][m][half][lane][r] = W_l[16 t + (lane & 15)][32 m + 16 half + 4 (lane >> 4) + r] -- the
+// piece positions of the split stream ((o-tile t, k-block m, plane) <-> (t, m, half)), each piece the 16 x 16 fp32 block whose
+// lane-linear 16 bytes are the lane's A operands of four consecutive v_mfma_f32_16x16x4_f32 k-steps; scales (1, 1) per layer
+// behind the matrices, where the split stream keeps its powers of two
+__global__ void __launch_bounds__(256) nerf_pack32_kernel(const float* __restrict__ w_hidden, const float* __restrict__ w_view,
+                                                          float* __restrict__ packed, int H, int D) {
+  const int64_t per_layer = (int64_t)H * H, total = per_layer * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + 2 * D; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i >= total) { packed[i] = 1.f; continue; }
+    const int l = (int)(i / per_layer);
+    int64_t rem = i - l * per_layer;                 // (t, m, half, lane, r)
+    const int t = (int)(rem / (16 * H));
+    rem -= (int64_t)t * 16 * H;
+    const int m = (int)(rem / 512), half = (int)((rem % 512) / 256), lane = (int)((rem % 256) / 4), r = (int)(rem % 4);
+    const int o = t * 16 + (lane & 15), k = 32 * m + 16 * half + 4 * (lane >> 4) + r;
+    packed[i] = l < D - 1 ? w_hidden[(int64_t)l * per_layer + (int64_t)o * H + k] : w_view[(int64_t)o * (H + 3) + k];
+  }
+}
+
+template <int NT, int ABL = 0, bool F32 = false>
 int launch_pair(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
@@ -509,23 +591,36 @@ int launch_pair(const NerfArgs& a, hipStream_t st) {
   if (hipError_t e = hipGetDevice(&dev_id); e != hipSuccess) return (int)e;
   const unsigned long long bit = 1ull << (dev_id & 63);
   if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_pair_kernel<NT, ABL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_pair_kernel<NT, ABL, F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / PW;
-  hipLaunchKernelGGL((nerf_render_pair_kernel<NT, ABL>), dim3((unsigned)wgs), dim3(PW * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_pair_kernel<NT, ABL, F32>), dim3((unsigned)wgs), dim3(PW * 64), lds_bytes, st, a);
   return cips3d_launch_status();
 }
 
 }  // namespace
 
+extern "C" int cips3d_nerf_pack_weights32(const float* w_hidden, const float* w_view, float* packed32, int hidden, int depth,
+                                          void* stream) {
+  if (!w_view || !packed32 || hidden <= 0 || depth < 1 || (depth > 1 && !w_hidden)) return CIPS3D_E_BADARG;
+  if (hidden != 256 || depth > 64) return CIPS3D_E_UNSUPP;
+  const int64_t total = (int64_t)hidden * hidden * depth + 2 * depth;
+  hipLaunchKernelGGL(nerf_pack32_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, as_stream(stream), w_hidden,
+                     w_view, packed32, hidden, depth);
+  return cips3d_launch_status();
+}
+
 // 1 when cips3d_nerf_render runs the pair kernel for this call (library-internal; the decision is the kernel's own: the
 // caller's n_chunks only matters through the `part` layout, which this form never touches)
 int cips3d_nerf_pair_applies(const cips3d_nerf_params* p) {
-  const char* knob = getenv("CIPS3D_NERF_PAIR");      // A/B knob, read per call (tests switch it inside one process)
-  if (!knob || atoi(knob) == 0 || !p) return 0;       // opt-in while it is the slower of the two (tools/nerf_pair_ab.py)
+  if (!p) return 0;
+  if (!p->packed32) {       // the split-fp16 instantiation: opt-in while it is the slower of the two (tools/nerf_pair_ab.py)
+    const char* knob = getenv("CIPS3D_NERF_PAIR");    // A/B knob, read per call (tests switch it inside one process)
+    if (!knob || atoi(knob) == 0) return 0;
+  }
   const cips3d_nerf_params& P = *p;
   if (P.hidden != 256 || P.x_pts || P.n_rays != 0 || P.stash || P.bwd_sdf || P.bwd_crgb) return 0;
   if (!(P.o_features && P.o_thumb && P.o_xyz && P.o_mask)) return 0;
@@ -563,5 +658,6 @@ int cips3d_nerf_render_pair(const cips3d_nerf_params* p, void* stream) {
     default: break;
   }
 #endif
+  if (P.packed32) return launch_pair<16, 0, true>(a, as_stream(stream));
   return launch_pair<16>(a, as_stream(stream));
 }

@@ -218,6 +218,15 @@ def nerf_pack_weights(w_hidden, w_view, hidden, depth):
     return packed
 
 
+def nerf_pack_weights32(w_hidden, w_view, hidden, depth):
+    """The exact-fp32 weight stream (cips3d_nerf_params.packed32): fp32 A fragments of v_mfma_f32_16x16x4_f32."""
+    lib = _lib.load()
+    packed = torch.empty(int(lib.cips3d_nerf_packed_floats(hidden, depth)), device=w_view.device, dtype=torch.float32)
+    check(lib.cips3d_nerf_pack_weights32(dev_ptr(w_hidden, "w_hidden", True), dev_ptr(w_view, "w_view"), dev_ptr(packed),
+                                         hidden, depth, stream_ptr()), "cips3d_nerf_pack_weights32")
+    return packed
+
+
 def nerf_suggest_chunks(B, img_size, n_samples):
     return int(_lib.load().cips3d_nerf_suggest_chunks(B, img_size, n_samples))
 
@@ -228,6 +237,7 @@ def _nerf_params(kw):
                   "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta")
     for f in ptr_fields:
         setattr(p, f, dev_ptr(kw[f], f))
+    p.packed32 = dev_ptr(kw.get("packed32"), "packed32", True)          # exact-fp32 arithmetic (csrc/nerf_pair.hip)
     p.part = dev_ptr(kw.get("part"), "part", True)
     for f in ("cam_poses", "focals"):
         setattr(p, f, dev_ptr(kw.get(f), f, kw.get("x_pts") is not None))

@@ -298,6 +298,8 @@ class ForwardPlan:
         features = torch.empty(B, H, img_size, img_size, device=dev)
         n = p.nerf
         n.w_first, n.packed, n.w_view = dev_ptr(net.pts_linears[0].weight), dev_ptr(packed), dev_ptr(net.views_linears.weight)
+        packed32 = ren.packed32()            # "fp32_exact": the render kernel's exact-fp32 instantiation reads this stream instead
+        n.packed32 = dev_ptr(packed32, "packed32", True)
         n.film, n.layer_bias = dev_ptr(film), dev_ptr(layer_bias)
         n.w_sigma, n.w_rgb = dev_ptr(net.sigma_linear.weight), dev_ptr(net.rgb_linear.weight)
         n.b_sigma, n.b_rgb = dev_ptr(net.sigma_linear.bias), dev_ptr(net.rgb_linear.bias)
@@ -327,7 +329,7 @@ class ForwardPlan:
 
         self.plan = p
         self.key = self.weights_key(G)
-        self._keep += [lat, film, film_tab, mod_tab, s_buf, wm_buf, wm_tab_dev, packed, layer_bias, part, features, act,
+        self._keep += [packed32, lat, film, film_tab, mod_tab, s_buf, wm_buf, wm_tab_dev, packed, layer_bias, part, features, act,
                        y_lo, skip]
         self.noise_total = sum(s * s for s in self.noise_sizes)
         self.film, self.s_buf, self.range_ws = film, s_buf, range_ws
@@ -365,7 +367,7 @@ class ForwardPlan:
         ren = G.renderer
         return (G.style[0].weight.data_ptr(), G.decoder.conv1.conv.weight.data_ptr(), ren._weights_key(),
                 bool(getattr(G.decoder, "bf16", False)), bool(getattr(G.decoder, "bf16_storage", False)),
-                bool(getattr(G.decoder, "split", False)), bool(ren.with_sdf))
+                bool(getattr(G.decoder, "split", False)), bool(ren.with_sdf), bool(getattr(ren, "exact_fp32", False)))
 
     def _noise_bound(self, noise_bufs, fresh_noise):
         """Upper bound of |noise| over the call (cips3d_forward_io.noise_bound; the bound constants of a ranged plan): known

@@ -111,6 +111,8 @@ class VolumeFeatureRenderer(nn.Module):
                                       input_ch_views=view_dim, output_features=output_features)
         self._derived = None      # (key, packed, layer_bias)
         self._packed_t = None
+        self._packed32 = None     # (key, exact-fp32 weight stream): built on first use in "fp32_exact" precision
+        self.exact_fp32 = False
         self._tables = {}         # B -> (styles_buf, film_buf, LinearTable)
 
     # ---- derived, weight-dependent device buffers (re-made when a parameter changes) ------------
@@ -119,6 +121,31 @@ class VolumeFeatureRenderer(nn.Module):
         ps = [l.weight for l in net.pts_linears] + [l.bias for l in net.pts_linears] + \
              [net.views_linears.weight, net.views_linears.bias]
         return tuple((p.data_ptr(), p._version) for p in ps)
+
+    def set_precision(self, precision):
+        """"fp32" (default): the point MLP's GEMMs as fp32-equivalent split-fp16 products (three exact fp16 products per fp32
+        product, fp32 accumulate: csrc/nerf.hip); "fp32_exact": the fp32 matrix instruction on fp32 operands -- IEEE fp32
+        products, the arithmetic of the reference's F.linear (cips3d/volume_renderer.py:15-35, 74-85) -- through
+        csrc/nerf_pair.hip's exact instantiation (hidden_dim 256, camera-driven inference; ~2.5x the render time)."""
+        if precision not in ("fp32", "fp32_exact"):
+            raise ValueError(precision)
+        if precision == "fp32_exact" and self.hidden_dim != 256:
+            raise NotImplementedError("the exact-fp32 render kernel is built for hidden_dim = 256")
+        self.exact_fp32 = precision == "fp32_exact"
+        return self
+
+    def packed32(self):
+        """The exact-fp32 weight stream (None in the default precision), re-made when a weight changes."""
+        if not self.exact_fp32:
+            return None
+        key = self._weights_key()
+        if self._packed32 is None or self._packed32[0] != key:
+            net = self.network
+            D, H = self.N_layers_renderer, self.hidden_dim
+            with torch.no_grad():
+                w_hidden = torch.stack([l.weight for l in net.pts_linears[1:]]).contiguous() if D > 1 else None
+                self._packed32 = (key, hip.nerf_pack_weights32(w_hidden, net.views_linears.weight.detach().contiguous(), H, D))
+        return self._packed32[1]
 
     def _derived_buffers(self):
         key = self._weights_key()
@@ -193,7 +220,7 @@ class VolumeFeatureRenderer(nn.Module):
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=img_size, n_samples=N_samples, hidden=H, depth=D,
                         static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf,
-                        raw_density=not self.with_sdf,
+                        raw_density=not self.with_sdf, packed32=None if stash is not None else self.packed32(),
                         stash=None if stash is None else stash["stash"], bwd_sdf=None if stash is None else stash["sdf"],
                         bwd_crgb=None if stash is None else stash["crgb"])
         if sdf is not None:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 21  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 22  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -205,7 +205,16 @@ typedef struct cips3d_nerf_params {
   float* stash;
   float* bwd_sdf;
   float* bwd_crgb;
+  /* != NULL: exact-fp32 arithmetic (the reference's F.linear in IEEE fp32, cips3d/volume_renderer.py:15-35, 74-85): the point
+   * MLP's GEMMs run on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32: bit for bit an fmaf chain in k order) over the
+   * stream cips3d_nerf_pack_weights32 wrote, instead of three fp16 products per fp32 product over `packed` (which is then not
+   * read).  hidden == 256, camera-driven mode, final maps written by the kernel (o_* set), no stash; CIPS3D_E_UNSUPP otherwise. */
+  const float* packed32;
 } cips3d_nerf_params;
+
+/* The exact-fp32 weight stream of cips3d_nerf_params.packed32 (cips3d_nerf_packed_floats(hidden, depth) floats, as `packed`):
+ * fp32 A fragments of v_mfma_f32_16x16x4_f32 per (layer, 16 output units, 16 input units), unscaled. */
+int cips3d_nerf_pack_weights32(const float* w_hidden, const float* w_view, float* packed32, int hidden, int depth, void* stream);
 
 /* 1 when cips3d_nerf_render(p) will write p->o_* itself (o_* set, n_chunks == 8, LDS large enough), else 0 */
 int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p);

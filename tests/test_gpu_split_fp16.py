@@ -77,6 +77,54 @@ def test_split_nerf_is_as_accurate_as_fp32():
         assert e_hip <= 2.0 * e_32 + 2e-7, name
 
 
+@pytest.mark.parametrize("D,N,B", [(2, 24, 1), (8, 13, 2)])
+def test_exact_fp32_render_kernel_and_split_kernel_bracket_fp64_equally(D, N, B):
+    """VolumeFeatureRenderer.set_precision("fp32_exact") (csrc/nerf_pair.hip on v_mfma_f32_16x16x4_f32: IEEE fp32 products, the
+    reference's F.linear arithmetic, cips3d/volume_renderer.py:15-35, 74-85) and the default split-fp16 kernel against the fp64
+    oracle: both err like the fp32 oracle does; they differ from each other at the fp32 noise level; odd sample counts and
+    batches take the pair kernel's padded / multi-group paths; switching back restores the default bit for bit."""
+    cfg = configs.ffhq_G_cfg(256, D)
+    G = pkg.build_generator(cfg, DEV, seed=5)
+    sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+    S = 64
+    cam = O.camera_params(torch.tensor([[0.3, 0.1], [-0.4, 0.05]][:B]), S, 6, 0.12)
+    styles = weights.det_normal("sn.styles", (B, D + 1, 256), 0.5, 2)
+    u = weights.det_unit_uniform("sn.u", (B, S * S), 3)
+    args = (cu(cam[0]), cu(cam[1]), cu(cam[2]), cu(cam[3]), cu(styles), S, N)
+    out = {}
+    for prec in ("fp32", "fp32_exact", "fp32"):
+        G.renderer.set_precision(prec)
+        r = G.renderer.render(*args, perturb_u=cu(u), return_sdf=True)
+        if prec in out:
+            for a, b in zip(out[prec], r):
+                assert torch.equal(a, b)              # back in the default precision: the same bits as before
+        out[prec] = [t.clone() for t in r]
+
+    def oracle(dt):
+        sdd = {k: v.to(dt) if v.is_floating_point() else v for k, v in sd.items()}
+        c = [t.to(dt) for t in cam[:4]]
+        ro, rd, vd = O.rays_in_world(c[1], S, c[0], False)
+        z = O.z_vals(c[2], c[3], B, S, S, N, perturb_u=u.reshape(B, S, S, 1).to(dt))
+        pts = O.ray_points(ro, rd, z)
+        R = S * S
+        return O.renderer_forward(sdd, "renderer", pts.reshape(B, R, N, 3), rd.reshape(B, R, 3), vd.reshape(B, R, 3),
+                                  z.reshape(B, R, N), c[2], c[3], styles.to(dt), D)
+    r32, r64 = oracle(torch.float32), oracle(torch.float64)
+    to_img = lambda t: t.reshape(B, S, S, -1).permute(0, 3, 1, 2)       # noqa: E731
+    for name, idx, i in (("features", 1, 1), ("thumb", 0, 0), ("sdf", 2, 2)):
+        ref64 = r64[i] if name == "sdf" else to_img(r64[i])
+        ref32 = r32[i] if name == "sdf" else to_img(r32[i])
+        e_32 = float((ref32.double() - ref64).abs().max())
+        e_split = float((out["fp32"][idx].cpu().double().reshape(ref64.shape) - ref64).abs().max())
+        e_exact = float((out["fp32_exact"][idx].cpu().double().reshape(ref64.shape) - ref64).abs().max())
+        d = float((out["fp32"][idx] - out["fp32_exact"][idx]).abs().max())
+        print(f"D={D} {name}: |split - fp64| {e_split:.2e}  |exact - fp64| {e_exact:.2e}  |fp32 oracle - fp64| {e_32:.2e}  |split - exact| {d:.2e}")
+        assert e_exact <= 2.0 * e_32 + 2e-7 and e_split <= 2.0 * e_32 + 2e-7, name
+        assert 0 < d <= 4.0 * e_32 + 1e-6, name
+    with pytest.raises(NotImplementedError):
+        pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=0).renderer.set_precision("fp32_exact")
+
+
 def test_fp32_exact_mode_agrees_with_the_default():
     cfg = configs.ffhq_G_cfg(256, 2)
     G = pkg.build_generator(cfg, DEV, seed=1)
