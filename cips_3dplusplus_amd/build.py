@@ -39,7 +39,9 @@ def source_hash():
     import hashlib
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files += [os.path.join(os.path.dirname(PKG), "include", "cips3d_hip.h"), os.path.abspath(__file__)]
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    # (per-file flags included: a knob that only changes those -- CIPS3D_CHAIN_SLP -- must invalidate the library too; a probe of
+    # round 4 compared two "builds" that were the same file because it did not)
+    h = hashlib.sha256((" ".join(FLAGS) + " | " + repr(sorted(FILE_FLAGS.items()))).encode())
     for f in files:
         if os.path.exists(f):
             h.update(os.path.basename(f).encode())
@@ -56,7 +58,7 @@ def up_to_date():
 
 
 # per-file flags (chain.hip: see the build note in its header; its ToRGB fold no longer depends on the flag)
-FILE_FLAGS = {"chain.hip": ["-fno-slp-vectorize"],
+FILE_FLAGS = {"chain.hip": [] if os.environ.get("CIPS3D_CHAIN_SLP") == "1" else ["-fno-slp-vectorize"],
               # nerf_pair.hip: one wave per SIMD -- a packed-fp32 instruction beside MFMAs costs more than the two it replaces
               "nerf_pair.hip": ["-fno-slp-vectorize"]}
 

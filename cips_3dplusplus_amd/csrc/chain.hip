@@ -58,6 +58,13 @@
 #include <stdlib.h>
 #include "common.h"
 
+#ifndef CIPS3D_FOLD_PK
+#define CIPS3D_FOLD_PK 0
+#endif
+#ifndef CIPS3D_FOLD_NOP
+#define CIPS3D_FOLD_NOP 0
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -338,6 +345,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
     kback = cips3d_uniform(cips3d_pow2(e));
     if (blockIdx.y == 0 && tid == 0) a.out_exp[b * ((HW + BN - 1) / BN) + blockIdx.x] = e;
   }
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 4)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // probe: every load of this wave -- the epilogue's operands -- has returned
+#endif
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
   float prgb[3][4];
 #pragma unroll
@@ -362,15 +372,46 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       }
       // (columns past HW repeat the last pixel without its noise: a value the patch maximum may include -- it only has to bound)
       mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
+#if CIPS3D_FOLD_PK == 2
+      // probe (tools/pk_fold_probe.sh): the SLP build's instruction pattern written by hand -- channel 0 as v_fmac_f32, channels
+      // 1 / 2 as ONE register pair per product assembled by two v_mov_b32 into fixed registers and consumed by v_pk_fma_f32 with
+      // an op_sel_hi broadcast of v[r] -- with CIPS3D_FOLD_NOP wait states between the v_movs and the packed instruction
       if (a.rgb_part) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+          const f32x2_t vb = {v[r], 0.f};
+          asm volatile("v_mov_b32 v126, %1\n\tv_mov_b32 v127, %2\n\t"
+                       ".if %4 > 0\n\ts_nop %4 - 1\n\t.endif\n\t"
+                       "v_pk_fma_f32 %0, v[126:127], %3, %0 op_sel_hi:[1,0,1]"
+                       : "+v"(p12) : "v"(wrgb[i][1][r]), "v"(wrgb[i][2][r]), "v"(vb), "n"(CIPS3D_FOLD_NOP) : "v126", "v127");
+        }
+        prgb[1][c] = p12[0];
+        prgb[2][c] = p12[1];
+      }
+#else
+      if (a.rgb_part) {
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 2)
+        asm volatile("s_nop 7\n\ts_nop 7");          // probe: distance between the producers of v[] and the packed chain
+#endif
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             // one v_fmac_f32 per product, written out: nothing can pair the channel-1 / channel-2 accumulations into
             // v_pk_fma_f32 (see the build note in the header of this file; VALU results feed VALU here: no hazard state to keep)
+#if CIPS3D_FOLD_PK        /* reproducer builds only (tools/pk_fold_probe.sh): the C form SLP packs */
+            prgb[ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[ch][c]);
+#else
             asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[ch][c]) : "v"(wrgb[i][ch][r]), "v"(v[r]));
+#endif
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 1)
+        asm volatile("s_nop 7\n\ts_nop 7");          // probe: distance between the packed chain and whatever follows it
+#endif
       }
+#endif
       if (npx[c] < HW) {
         if (a.out_fmt == 1) {
           // planes: channels obase + 4 q + r live in channel block (obase >> 3) + (q >> 1), elements 4 (q & 1) + r
@@ -437,6 +478,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
     if (tid == 0) cips3d_amax_raise_if(a.out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
   }
   if (!a.rgb_part) return;
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 8)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // probe: nothing of this wave in flight, then everybody here
+  __syncthreads();
+#endif
   // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
   // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
 #pragma unroll

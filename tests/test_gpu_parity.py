@@ -474,6 +474,36 @@ def test_fused_stage_also_computes_next_low_res_gemm(C, bf16):
     assert torch.equal(rgb3, rgb) and torch.equal(y3, y_next)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_storage"])
+def test_full_size_forward_repeats_bit_for_bit_at_batch_4(precision):
+    """Sixty one-call forwards at 1024^2, batch 4 (fixed noise, no jitter) must produce the same bits: every kernel of the
+    decoder runs with several workgroups per CU there, and the four fused up-sampling stages are compiled WITH hipcc's SLP
+    vectoriser (v_pk_*_f32 in their FIR / epilogue arithmetic).  The planes kernels (csrc/chain.hip) once differed from run to
+    run in exactly that situation when SLP had packed their ToRGB fold (tools/pk_fold_probe.sh, profiles/r04_pk_fold_probe.txt:
+    a property of that build's code, not of v_pk_fma_f32 -- the same pattern written by hand repeats); this is the tripwire for
+    the rest of the decoder."""
+    from cips_3dplusplus_amd.camera import Camera
+    cfg = configs.ffhq_G_cfg(1024, 2)
+    G = pkg.build_generator(cfg, DEV, seed=2)
+    G.set_decoder_precision(precision)
+    B = 4
+    g = torch.Generator(device=DEV).manual_seed(5)
+    zs = [torch.randn(B, 256, device=DEV, generator=g), torch.randn(B, 256, device=DEV, generator=g)]
+    locs = torch.randn(B, 2, device=DEV, generator=g) * 0.2
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=locs)
+    nb = [torch.randn(b.shape, device=DEV, generator=g) for b in G.create_noise_bufs(64, DEV)]
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=nb,
+              nerf_cfg=dict(N_samples=24, perturb=False, static_viewdirs=False))
+    with torch.no_grad():
+        first = G(**kw)
+        first = {k: first[k].clone() for k in ("rgb", "thumb_rgb")}
+        assert bool(torch.isfinite(first["rgb"]).all())
+        for rep in range(59):
+            out = G(**kw)
+            for k, v in first.items():
+                assert torch.equal(out[k], v), (precision, rep, k, int((out[k] != v).sum()))
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_chained_stages_equal_unchained_full_size(bf16):
     """The one-call forward with every up-sampling stage computing the next stage's low-res GEMM (plan.CHAIN_STAGES) against

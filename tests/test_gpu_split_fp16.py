@@ -125,6 +125,28 @@ def test_exact_fp32_render_kernel_and_split_kernel_bracket_fp64_equally(D, N, B)
         pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=0).renderer.set_precision("fp32_exact")
 
 
+@pytest.mark.parametrize("N,B", [(24, 1), (23, 2), (24, 4)])
+def test_pair_kernel_split_instantiation_matches_the_default_kernel(monkeypatch, N, B):
+    """csrc/nerf_pair.hip in its split-fp16 instantiation (32 points per wave, k-outer; opt-in with CIPS3D_NERF_PAIR=1 because it
+    is the slower of the two on MI355X: DESIGN.md) computes the default kernel's arithmetic in another work shape: same products
+    in the same order per accumulator, a different chunking of the samples -- maps equal to fp32 summation noise, sdf bit for bit."""
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=3)
+    S = 64
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.3, -0.1]] * B, device=DEV) *
+                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
+    styles = cu(weights.det_normal("pk.styles", (B, 3, 256), 0.5, 2))
+    u = cu(weights.det_unit_uniform("pk.u", (B, S * S), 3))
+    monkeypatch.setenv("CIPS3D_NERF_PAIR", "0")
+    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    monkeypatch.setenv("CIPS3D_NERF_PAIR", "1")
+    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    names = ("thumb", "features", "sdf", "mask", "xyz")
+    for k, a, b in zip(names, ref, new):
+        d, r = maxdiff(a, b), float(a.abs().max())
+        assert bool(torch.isfinite(b).all()) and d <= 2e-6 * max(r, 1.0), (k, d, r)
+    assert torch.equal(ref[2], new[2])
+
+
 def test_fp32_exact_mode_agrees_with_the_default():
     cfg = configs.ffhq_G_cfg(256, 2)
     G = pkg.build_generator(cfg, DEV, seed=1)

@@ -1,0 +1,21 @@
+# Reproducer of the packed-fp32 ToRGB-fold nondeterminism of csrc/chain.hip (bf16 planes kernel, two workgroups per CU): builds
+# the library with the fold's FMAs in several forms and counts repeats whose partial sums differ (tools/fold_repeat.py, 60 runs
+# each).  CIPS3D_FOLD_PK=1: the C form (hipcc's SLP vectoriser packs channels 1 / 2 into v_pk_fma_f32 chains when CIPS3D_CHAIN_SLP=1);
+# CIPS3D_FOLD_PK=2: that instruction pattern written by hand (v_mov_b32 x 2 into a register pair -> v_pk_fma_f32 op_sel_hi) with
+# CIPS3D_FOLD_NOP wait states between the moves and the packed instruction.  Output -> profiles/r04_pk_fold_probe.txt
+O=gpurun_out/pk_probe.txt; : > $O
+run() {  # name, CIPS3D_CHAIN_SLP, flags
+  export CIPS3D_CHAIN_SLP=$2 CIPS3D_HIPCC_FLAGS="$3"
+  python -m cips_3dplusplus_amd.build > /dev/null 2>&1
+  echo "== $1  (CIPS3D_CHAIN_SLP=$2 $3)" >> $O
+  python tools/fold_repeat.py 60 2>&1 | grep "repeats differ" >> $O
+}
+run "shipped: asm v_fmac_f32, no SLP"                                  0 ""
+run "C fmaf, SLP on (compiler-made v_pk_fma_f32 chains)"                1 "-DCIPS3D_FOLD_PK=1"
+run "C fmaf, SLP off"                                                   0 "-DCIPS3D_FOLD_PK=1"
+run "compiler-made chains + 16 wait states behind each"                 1 "-DCIPS3D_FOLD_PK=1 -DCIPS3D_FOLD_NOP=1"
+run "compiler-made chains + 16 wait states in front of each"            1 "-DCIPS3D_FOLD_PK=1 -DCIPS3D_FOLD_NOP=2"
+run "hand-made v_mov pair -> v_pk_fma_f32, 0 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=0"
+run "hand-made v_mov pair -> v_pk_fma_f32, 1 wait state between"        0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=1"
+run "hand-made v_mov pair -> v_pk_fma_f32, 3 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=3"
+cat $O
