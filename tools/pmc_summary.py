@@ -5,7 +5,10 @@
               SQ_VALU_MFMA_BUSY_CYCLES -d OUT/sq -o p --output-format csv -- python3 bench.py --steps 12 --warmup 3 --no-cpu-baseline
     rocprofv3 --kernel-trace --pmc FETCH_SIZE -d OUT/fetch -o p --output-format csv -- python3 bench.py ...   (own pass)
     rocprofv3 --kernel-trace --pmc WRITE_SIZE -d OUT/write -o p --output-format csv -- python3 bench.py ...   (own pass)
-    python tools/pmc_summary.py OUT/sq/p_counter_collection.csv [OUT/fetch/... OUT/write/...] > summary.json
+    python tools/pmc_summary.py [--workload "text"] OUT/sq/p_counter_collection.csv [OUT/fetch/... OUT/write/...] > summary.json
+
+The summary carries `lib_srchash` = the source hash of the library that is built in this tree (cips_3dplusplus_amd/build.py's
+stamp): bench.py replays HBM traffic from a summary only when that hash is the loaded library's.
 
 Derived columns: clock = GRBM_GUI_ACTIVE / 8 XCDs / duration (meaningful for launches of >~20 us only); MFMA-pipe busy =
 SQ_VALU_MFMA_BUSY_CYCLES / (clock cycles x 256 CUs x 4 SIMDs); wave fractions relative to SQ_WAVE_CYCLES; FETCH_SIZE (KB)
@@ -31,7 +34,18 @@ def mean(v):
     return sum(v) / len(v)
 
 
+def lib_srchash():
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from cips_3dplusplus_amd import build
+    with open(build.STAMP) as fh:
+        return fh.read().strip()
+
+
 def main(paths):
+    workload = "bench.py defaults (1024^2, D=2, N=24, batch 1)"
+    if paths and paths[0] == "--workload":
+        workload, paths = paths[1], paths[2:]
     out = {}
     for p in paths:
         for k, v in load(p).items():
@@ -54,7 +68,8 @@ def main(paths):
                 e["hbm_write_MB"] = round(mean(v["WRITE_SIZE"]) * 1024 / 1e6, 1)
     ks = sorted((e for e in out.values() if e.get("avg_us_under_pmc", 0) >= 3.0), key=lambda e: -e["avg_us_under_pmc"])
     json.dump({"source": "tools/pmc_summary.py over rocprofv3 --kernel-trace --pmc passes of bench.py --steps 12 --warmup 3 "
-                         "--no-cpu-baseline (SQ/GRBM set, FETCH_SIZE, WRITE_SIZE: three separate passes)", "kernels": ks},
+                         "--no-cpu-baseline (SQ/GRBM set, FETCH_SIZE, WRITE_SIZE: three separate passes)",
+               "workload": workload, "lib_srchash": lib_srchash(), "kernels": ks},
               sys.stdout, indent=1)
 
 
