@@ -1136,7 +1136,8 @@ struct FusedArgs {
 #ifndef CIPS3D_FUSED_AB
 // timing-only ablations of the fused stages (results garbage; tools/README.md): 1 no scale loads, 2 no y_next record, 4 no ToRGB
 // sums (at C = 32, where nothing else reads conv2's output, the compiler then drops conv2 altogether: read that one as "no
-// conv2"), 8 no FIR arithmetic, 16 no conv2 epilogue arithmetic, 32 no activation / split of conv1
+// conv2"), 8 no FIR arithmetic, 16 no conv2 epilogue arithmetic, 32 no activation / split of conv1, 64 no patch loads (register
+// values instead), 128 no noise / skip loads of the epilogues
 #define CIPS3D_FUSED_AB 0
 #endif
 #ifdef CIPS3D_FUSED_STAMPS
@@ -1220,7 +1221,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
   f32x4 bias4[WM];
   auto load_epilogue_ops = [&]() {
-    if (a.noise2 && a.nw2) {
+    if (a.noise2 && a.nw2 && !(CIPS3D_FUSED_AB & 128)) {
       nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (oy * OW + ox));
       const float nw = a.nw2[0];
 #pragma unroll
@@ -1242,7 +1243,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   auto load_skip_ops = [&]() {
     if (rgb_lane) {
       rgb_bias = a.bias_rgb[q];
-      if (a.skip) {
+      if (a.skip && !(CIPS3D_FUSED_AB & 128)) {
         if (a.skip_up) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
         else skv = *reinterpret_cast<const f32x4*>(a.skip + (int64_t)b * 3 * HWo + (q * HWo + oy * OW + ox));
       }
@@ -1273,6 +1274,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
       const ylo_t* src = reinterpret_cast<const ylo_t*>(a.y_lo) + (int64_t)b * C * HWlo + (st * BK + ch) * HWlo;
+      if constexpr (CIPS3D_FUSED_AB & 64) {        // no patch loads: what the latency chain behind them costs
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pset[u][r][c] = __int_as_float(0x3c000000 + ((tid + st + r * 4 + c) << 8));
+      } else
       if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
       else up2_load(src, H, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
     }
@@ -1351,7 +1358,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   if (tid < BN / 4) {
     const int r = tid / (TW / 4), x4 = tid % (TW / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (a.noise1 && a.nw1) {
+    if (a.noise1 && a.nw1 && !(CIPS3D_FUSED_AB & 128)) {
       v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + ((oy0 + r) * OW + ox0 + x4 * 4));
       const float nw = a.nw1[0];
 #pragma unroll

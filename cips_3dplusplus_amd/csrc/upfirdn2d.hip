@@ -8,12 +8,16 @@
 //   out[oy][ox] = sum_{ky,kx} u[oy*down_y + ky][ox*down_x + kx] * k[kh-1-ky][kw-1-kx]
 // Only every up-th tap hits a non-zero sample (polyphase), so the inner loops step by `up`.
 //
-// HBM-bound: 4 B/elem in (x 1/up^2 .. down^2) + 4 B/elem out.  The tiled kernel stages the
-// input footprint of a 32x64 output tile in LDS (one coalesced pass), the FIR taps in LDS too;
-// each thread produces 8 outputs of one column strip so consecutive lanes write consecutive x.
+// HBM-bound: 4 B/elem in (x 1/up^2 .. down^2) + 4 B/elem out.  Three kernels: upfirdn2d_fast (4 x 4 FIR, up / down factors the
+// generator and its discriminator use: compile-time polyphase structure, 16-byte LDS reads and stores), upfirdn2d_tiled (any
+// factors and FIR up to 64 taps: stages the input footprint of a 32x64 output tile in LDS, the taps too; run-time tap stepping),
+// upfirdn2d_generic (anything else, e.g. minor > 1).
+#include <cstdlib>
 #include "common.h"
 
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct UfdParams {
   int64_t major;
@@ -89,6 +93,118 @@ __global__ void __launch_bounds__(256) upfirdn2d_tiled(const float* __restrict__
   }
 }
 
+// Fast path for the shapes the generator's Blur / Upsample (and the discriminator-side down-sampling) issue: minor == 1, a
+// 4 x 4 FIR, (up, down) in {(1, 1), (2, 1), (1, 2)}.  Everything that depended on a run-time division in the tile kernel above
+// is a compile-time constant here.  With the tile origin at ox0 (a multiple of the tile width) write ox0 * D - pad_x0 =
+// U * q0 + RX, 0 <= RX < U: RX is the same for every tile (TW * D is a multiple of U), so it is a template parameter, and output
+// column ox0 + 4 tx + j reads input columns q0 + 4 tx D / U + ceil((RX + j D) / U) + t with taps kx = (U - (RX + j D) % U) % U
+// + U t, t = 0 .. ceil(K / U) - 1 -- offsets and tap numbers known per (j, t).  A thread owns a 4 x BY block of outputs: it
+// walks the rows of its input window once (vector LDS reads, a row feeds every output row whose taps touch it), the 16 taps
+// sit in scalar registers, the accumulation order per output is the tile kernel's (ky ascending, kx ascending: bit-identical
+// results), stores are 16 bytes per lane.  Rows of the footprint are staged by whole waves (no division per element).
+template <int U, int D, int K, int RX, int RY>
+struct UfdFast {
+  static constexpr int BX = 4, BY = (D == 2 ? 2 : 4);       // outputs per thread
+  static constexpr int LX = 32, LY = 8;                       // threads per tile row / column
+  static constexpr int TW = BX * LX, TH = BY * LY;            // 128 x 32 outputs (x 16 when D == 2)
+  static constexpr int NT = (K + U - 1) / U;                  // taps per output and dimension that can hit a sample
+  static constexpr int off(int r, int j) { return (r + j * D + U - 1) / U; }
+  static constexpr int k0(int r, int j) { return (U - (r + j * D) % U) % U; }
+  static constexpr int WX = off(RX, BX - 1) + NT, WY = off(RY, BY - 1) + NT;      // a thread's input window
+  static constexpr int AL = ((BX * D / U) % 4 == 0) ? 4 : 2;  // floats the window start is aligned to
+  static constexpr int WXP = (WX + AL - 1) / AL * AL;
+  static constexpr int FW = TW * D / U + NT, FH = TH * D / U + NT;                // footprint of a tile
+  static constexpr int PITCH = (FW + AL + 3) / 4 * 4;
+  static_assert((BX * D) % U == 0 && (BY * D) % U == 0 && PITCH * FH * 4 <= 48 * 1024, "tile shape");
+};
+
+template <int U, int D, int K, int RX, int RY>
+__global__ void __launch_bounds__(256) upfirdn2d_fast(const float* __restrict__ in, const float* __restrict__ kernel,
+                                                      float* __restrict__ out, UfdParams p, int tiles_x, int tiles_y) {
+  typedef UfdFast<U, D, K, RX, RY> T;
+  __shared__ __attribute__((aligned(16))) float s_in[T::PITCH * T::FH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int64_t blk = blockIdx.x;
+  const int tx_i = (int)(blk % tiles_x); blk /= tiles_x;
+  const int ty_i = (int)(blk % tiles_y); blk /= tiles_y;
+  const int64_t m = blk;
+  const int ox0 = tx_i * T::TW, oy0 = ty_i * T::TH;
+  const int q0x = floor_div_i(ox0 * D - p.pad_x0, U), q0y = floor_div_i(oy0 * D - p.pad_y0, U);
+  const float* src = in + m * (int64_t)p.in_h * p.in_w;
+  // flipped taps, uniform addresses: scalar registers
+  float kf[K * K];
+#pragma unroll
+  for (int i = 0; i < K * K; ++i) kf[i] = kernel[K * K - 1 - i];
+  for (int r = wave; r < T::FH; r += 4) {
+    const int iy = q0y + r;
+    const bool yok = iy >= 0 && iy < p.in_h;
+    const float* row = src + (int64_t)(yok ? iy : 0) * p.in_w;
+    for (int c = lane; c < T::PITCH; c += 64) {
+      const int ix = q0x + c;
+      s_in[r * T::PITCH + c] = (yok && ix >= 0 && ix < p.in_w) ? row[ix] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int tx = tid % T::LX, ty = tid / T::LX;
+  const float* win0 = s_in + (T::BY * ty * D / U) * T::PITCH + T::BX * tx * D / U;
+  float acc[T::BY][T::BX];
+#pragma unroll
+  for (int i = 0; i < T::BY; ++i)
+#pragma unroll
+    for (int j = 0; j < T::BX; ++j) acc[i][j] = 0.f;
+#pragma unroll
+  for (int wy = 0; wy < T::WY; ++wy) {
+    float win[T::WXP];
+#pragma unroll
+    for (int c = 0; c < T::WXP; c += T::AL) {
+      if (T::AL == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(win0 + wy * T::PITCH + c);
+        win[c] = v[0]; win[c + 1] = v[1]; win[c + 2] = v[2]; win[c + 3] = v[3];
+      } else {
+        const float2 v = *reinterpret_cast<const float2*>(win0 + wy * T::PITCH + c);
+        win[c] = v.x; win[c + 1] = v.y;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < T::BY; ++i) {
+      const int t = wy - T::off(RY, i);
+      const int ky = T::k0(RY, i) + U * t;
+      if (t < 0 || t >= T::NT || ky >= K) continue;
+#pragma unroll
+      for (int j = 0; j < T::BX; ++j)
+#pragma unroll
+        for (int tt = 0; tt < T::NT; ++tt) {
+          const int kx = T::k0(RX, j) + U * tt;
+          if (kx < K) acc[i][j] = fmaf(win[T::off(RX, j) + tt], kf[ky * K + kx], acc[i][j]);
+        }
+    }
+  }
+  float* dst = out + m * (int64_t)p.out_h * p.out_w;
+  const int ox = ox0 + T::BX * tx;
+  const bool vec = (p.out_w & 3) == 0 && ox + 3 < p.out_w;
+#pragma unroll
+  for (int i = 0; i < T::BY; ++i) {
+    const int oy = oy0 + T::BY * ty + i;
+    if (oy >= p.out_h) break;
+    float* o = dst + (int64_t)oy * p.out_w + ox;
+    if (vec) {
+      *reinterpret_cast<f32x4*>(o) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < T::BX; ++j)
+        if (ox + j < p.out_w) o[j] = acc[i][j];
+    }
+  }
+}
+
+template <int U, int D, int RX, int RY>
+void launch_fast(const float* in, const float* kernel, float* out, const UfdParams& p, hipStream_t st) {
+  typedef UfdFast<U, D, 4, RX, RY> T;
+  const int tiles_x = ceil_div(p.out_w, T::TW), tiles_y = ceil_div(p.out_h, T::TH);
+  hipLaunchKernelGGL((upfirdn2d_fast<U, D, 4, RX, RY>), dim3((unsigned)((int64_t)tiles_x * tiles_y * p.major)), dim3(256), 0, st,
+                     in, kernel, out, p, tiles_x, tiles_y);
+}
+
 // Any size / any minor: one thread per output element, taps read straight from global/L2.
 __global__ void __launch_bounds__(256) upfirdn2d_generic(const float* __restrict__ in,
                                                          const float* __restrict__ kernel,
@@ -143,7 +259,23 @@ extern "C" int cips3d_upfirdn2d(const float* input, const float* kernel, float* 
   const int tin_h = ((TILE_OH - 1) * down_y + kernel_h - 1) / up_y + 2;
   const int tin_w = ((TILE_OW - 1) * down_x + kernel_w - 1) / up_x + 2;
   const bool tiled = minor == 1 && kernel_h * kernel_w <= MAX_TAPS && tin_h * tin_w <= LDS_IN_FLOATS;
-  if (tiled) {
+  static const bool fast_on = [] { const char* e = getenv("CIPS3D_UPFIRDN_FAST"); return !(e && e[0] == '0'); }();   // A/B and test knob
+  const bool fast = fast_on && minor == 1 && kernel_h == 4 && kernel_w == 4 && up_x == up_y && down_x == down_y &&
+                    ((up_x == 1 && down_x <= 2) || (up_x == 2 && down_x == 1)) &&
+                    (int64_t)ceil_div(p.out_w, 128) * ceil_div(p.out_h, 16) * major <= 0x7fffffffLL &&
+                    (int64_t)p.out_w * down_x + 4 + (pad_x0 < 0 ? -(int64_t)pad_x0 : pad_x0) < (1 << 30) &&
+                    (int64_t)p.out_h * down_y + 4 + (pad_y0 < 0 ? -(int64_t)pad_y0 : pad_y0) < (1 << 30);
+  if (fast) {
+    if (up_x == 1 && down_x == 1) launch_fast<1, 1, 0, 0>(input, kernel, out, p, st);
+    else if (up_x == 1) launch_fast<1, 2, 0, 0>(input, kernel, out, p, st);
+    else {
+      const int rx = ((-pad_x0) % 2 + 2) % 2, ry = ((-pad_y0) % 2 + 2) % 2;
+      if (rx == 0 && ry == 0) launch_fast<2, 1, 0, 0>(input, kernel, out, p, st);
+      else if (rx == 1 && ry == 0) launch_fast<2, 1, 1, 0>(input, kernel, out, p, st);
+      else if (rx == 0) launch_fast<2, 1, 0, 1>(input, kernel, out, p, st);
+      else launch_fast<2, 1, 1, 1>(input, kernel, out, p, st);
+    }
+  } else if (tiled) {
     const int tiles_x = ceil_div(p.out_w, TILE_OW), tiles_y = ceil_div(p.out_h, TILE_OH);
     const int64_t blocks = (int64_t)tiles_x * tiles_y * major;
     if (blocks > 0x7fffffffLL) return CIPS3D_E_UNSUPP;
