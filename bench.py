@@ -353,7 +353,7 @@ class ForwardWorkload:
         # (what the round-1 kernel was bounded by) is kept beside it.
         exact = self.precision == "fp32_exact"
         peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
-        return {"kernel": ("nerf_render_pair_kernel<16, 0, true> (exact fp32: v_mfma_f32_16x16x4_f32)" if exact else
+        head = {"kernel": ("nerf_render_pair_kernel<16, 0, true> (exact fp32: v_mfma_f32_16x16x4_f32)" if exact else
                            "nerf_render_kernel") + " (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_definition": (f"fp32 matrix instruction peak {MFMA_F32_PEAK_TFLOPS:.1f} TFLOP/s" if exact else
@@ -363,8 +363,12 @@ class ForwardWorkload:
                 "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "fp32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
                 "traffic": traffic, "traffic_source": src,
                 "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
-                "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE),
-                **({"kernels": self.decoder_kernels()[0]} if kernels else {})}
+                "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE)}
+        if kernels:       # every big kernel of the step, the dominant one first (its row repeats the fields above)
+            head["kernels"] = [{"kind": "render", "launches_per_step": 1, **{k: head[k] for k in (
+                "kernel", "avg_launch_ms", "bound", "flop_per_launch", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")}}] \
+                + self.decoder_kernels()[0]
+        return head
 
 
 def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24):

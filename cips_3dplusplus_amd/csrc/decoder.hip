@@ -1653,20 +1653,40 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   if (!a.wm_rgb && !NEXT) { FSTAMP_FLUSH(); return; }
   // ---- ToRGB: reduce over the 4 lane quarters, then over the WGM wave rows through LDS
   if (a.wm_rgb) {
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = prgb[ch][c];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        prgb[ch][c] = (NEXT && SPLIT) ? v * kback2 : v;
-      }
-    if (q == 0) {
+    // Quarter q ends up with colour channel q of the wave's four pixels, in the order the shuffles added them ((q0 + q1) + (q2 +
+    // q3): same bits).  v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second,
+    // v_permlane32_swap the upper half of the first with the lower half of the second: two colours share a register after
+    // the first step, all three after the second -- 3 swaps + 3 adds per pixel where the ds_bpermute form spent 6 + 6.
+    // (not at C = 32: the swaps work in place on both operands, the copies do not fit that instantiation's 64 registers)
+    if constexpr (MINW >= 8) {
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch)
-        *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) =
-            f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float v = prgb[ch][c];
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          prgb[ch][c] = (NEXT && SPLIT) ? v * kback2 : v;
+        }
+      if (q == 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + ch) * BN + nloc) =
+              f32x4{prgb[ch][0], prgb[ch][1], prgb[ch][2], prgb[ch][3]};
+      }
+    } else {
+    f32x4 tot;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const auto rg = __builtin_amdgcn_permlane16_swap(__float_as_uint(prgb[0][c]), __float_as_uint(prgb[1][c]), false, false);
+      const auto bb = __builtin_amdgcn_permlane16_swap(__float_as_uint(prgb[2][c]), __float_as_uint(prgb[2][c]), false, false);
+      const float p = __uint_as_float(rg[0]) + __uint_as_float(rg[1]);        // [R01, G01, R23, G23] by quarter
+      const float u = __uint_as_float(bb[0]) + __uint_as_float(bb[1]);        // [B01, B01, B23, B23]
+      const auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(p), __float_as_uint(u), false, false);
+      const float v = __uint_as_float(h[0]) + __uint_as_float(h[1]);          // [R, G, B, B]
+      tot[c] = (NEXT && SPLIT) ? v * kback2 : v;
+    }
+    if (q < 3) *reinterpret_cast<f32x4*>(s_red + (wm_i * 3 + q) * BN + nloc) = tot;
     }
   }
   __syncthreads();

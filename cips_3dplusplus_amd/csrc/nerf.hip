@@ -203,7 +203,23 @@ __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict_
 //   last (hidden layers): Y is h_D, the sigma head's partial sum  sdf_acc += Ws . Y  is taken from the epilogue's fp32 values
 // The caller guarantees slab `seq` is resident in slot (seq & 1); every slab step prefetches seq+1
 // while multiplying and ends with wait + barrier.
-template <int NT, int TPS, bool VIEW, bool STASH>
+// F32: the exact-fp32 instantiation (Generator.set_precision("fp32_exact"); cips3d_nerf_params.packed32): the same slabs, ring
+// and register images hold fp32 -- a 1 KiB piece is a 16 x 16 block of W where the split stream has one plane of a 16 x 32
+// block, (Xh[m], Xl[m]) are the bits of the fp32 activations of o-tiles 2m, 2m + 1 (the MFMA D layout IS the B operand of
+// v_mfma_f32_16x16x4_f32: k-step r of k-quarter q <-> unit 16 T + 4 q + r), eight 32-cycle MFMAs per (tile, k-block) where the
+// split kernel issues three 16-cycle ones.  Two waves per SIMD as in the split kernel: one wave's sine epilogue runs under
+// the other's matrix block, which nerf_pair.hip's one-wave form of the same arithmetic cannot do (252 us; this one: see DESIGN).
+template <bool F32>
+__device__ __forceinline__ void put8(const float (&v)[8], h8& hi, h8& lo) {
+  if constexpr (F32) {
+    hi = __builtin_bit_cast(h8, f32x4{v[0], v[1], v[2], v[3]});
+    lo = __builtin_bit_cast(h8, f32x4{v[4], v[5], v[6], v[7]});
+  } else {
+    split8(v, hi, lo);
+  }
+}
+
+template <int NT, int TPS, bool VIEW, bool STASH, bool F32 = false>
 __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], h8 (&Yh)[NT / 2], h8 (&Yl)[NT / 2],
                                            float (&FA)[NT * 4], float wgt, float (&chead)[3], float& sdf_acc, bool last,
                                            Ring& ring, const float* film_l, const float* s_wd, const float* s_wc,
@@ -270,6 +286,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #define CIPS3D_ASM_FRAGS 0      // 1: nerf_mlp.h:matrix_block (inline-asm reads three groups ahead, hand-counted waits): 87.6 against
 #endif                          // 88.5 us on one box -- not worth leaving the compiler's hazard handling (see matrix_block)
 #if CIPS3D_ASM_FRAGS
+    static_assert(!F32, "the inline-asm matrix block is the split kernel's");
     matrix_block<NT, TPS>(slab, Xh, Xl, acc, lane);
 #else
     {     // A/B form: reads one half k-block ahead through the compiler, its wait provoked in front of the next reads
@@ -291,6 +308,21 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));
         if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (F32) {      // fh / fl: the fp32 fragments of the k-block's two 16-unit halves; k ascending, the bit-exact chain
+          const f32x4 x0 = __builtin_bit_cast(f32x4, Xh[m]), x1 = __builtin_bit_cast(f32x4, Xl[m]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+              acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, fh[cur][t])[r], x0[r],
+                                                                        acc[half * HT + t], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < HT; ++t)
+              acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, fl[cur][t])[r], x1[r],
+                                                                        acc[half * HT + t], 0, 0, 0);
+        } else {
 #pragma unroll
         for (int t = 0; t < HT; ++t)
           acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
@@ -300,6 +332,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
         for (int t = 0; t < HT; ++t)
           acc[half * HT + t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[cur][t], Xh[m], acc[half * HT + t], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -353,7 +386,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         float v8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = res[(2 * bb) * 4 + j];
-        split8(v8, Yh[sl * BPS + bb], Yl[sl * BPS + bb]);
+        put8<F32>(v8, Yh[sl * BPS + bb], Yl[sl * BPS + bb]);
       }
     }
     STAMP(11);   // epilogue
@@ -374,8 +407,9 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 }
 
 // XG: explicit-geometry instantiation (compile-time so that the camera-driven hot path keeps its register allocation)
-template <int NT, int TPS, bool XG, bool STASH>
+template <int NT, int TPS, bool XG, bool STASH, bool F32 = false>
 __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) {
+  static_assert(!(F32 && STASH), "the differentiable forward stashes the split kernel's accumulators");
   constexpr int H = NT * 16;
   constexpr int SLAB = 16 * H * TPS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -430,7 +464,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // MFMA layers (l >= 1) run on weights pre-scaled by 2^s (packed layer l - 1): their gamma carries 2^-s, the
     // view-direction columns that are pre-loaded into the view layer's accumulator carry 2^s (both exact).
     const float* film_b = P.film + (int64_t)b * L * 2 * H;
-    const float* scales = P.packed + (int64_t)D * H * H;
+    const float* scales = (F32 ? P.packed32 : P.packed) + (int64_t)D * H * H;      // (packed32: all ones)
     for (int i = tid; i < L * H; i += WAVES * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
@@ -508,12 +542,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, ax = 0.f, ay = 0.f, az = 0.f, wlast = 0.f;
 
   Ring ring;
-  ring.packed = P.packed;
+  ring.packed = F32 ? P.packed32 : P.packed;
   ring.lds = ringmem;
   ring.seq = 0;
   ring.per_sample = D * (NT / TPS);
   ring.seq_end = a.chunk * ring.per_sample;
-  stage_slab<SLAB>(P.packed, ringmem, wave, lane);
+  stage_slab<SLAB>(ring.packed, ringmem, wave, lane);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 
@@ -568,13 +602,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
           for (int i = 0; i < 4; ++i) sdf = fmaf(ws4[i], v8[hf * 4 + i], sdf);
         }
       }
-      split8(v8, Xh[m], Xl[m]);
+      put8<F32>(v8, Xh[m], Xl[m]);
     }
     float chead[3] = {0.f, 0.f, 0.f};
     STAMP(1);   // sample setup + layer 0
     // ---- hidden layers 1 .. D-1
     for (int l = 1; l < D; ++l) {
-      mfma_layer<NT, TPS, false, STASH>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
+      mfma_layer<NT, TPS, false, STASH, F32>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
                                         s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
                                         q4o STAMP_ARG);
 #pragma unroll
@@ -602,7 +636,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     STAMP(3);   // sigma head + weight
     // ---- view layer -> features, folded into FA; rgb head partial sums
     float sdf_unused = 0.f;
-    mfma_layer<NT, TPS, true, STASH>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
+    mfma_layer<NT, TPS, true, STASH, F32>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
                                      vx, vy, vz, STASH ? stash_s + (int64_t)(D - 1) * 16 * H : nullptr, wave, lane,
                                      q4o STAMP_ARG);
     float c0 = chead[0], c1 = chead[1], c2 = chead[2];
@@ -850,7 +884,7 @@ __global__ void __launch_bounds__(256) nerf_finish4_kernel(const float* __restri
   }
 }
 
-template <int NT, int TPS, bool XG, bool STASH>
+template <int NT, int TPS, bool XG, bool STASH, bool F32 = false>
 int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
@@ -862,18 +896,22 @@ int launch_render_x(const NerfArgs& a, hipStream_t st) {
   if (hipError_t e = hipGetDevice(&dev_id); e != hipSuccess) return (int)e;
   const unsigned long long bit = 1ull << (dev_id & 63);
   if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG, STASH>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG, STASH, F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
-  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG, STASH>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG, STASH, F32>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
   return cips3d_launch_status();
 }
 
 template <int NT, int TPS>
 int launch_render(const NerfArgs& a, hipStream_t st) {
+  if (a.p.packed32) {       // exact fp32 (hidden 256 only: cips3d_nerf_pack_weights32)
+    if constexpr (NT == 16) return a.p.x_pts ? launch_render_x<NT, TPS, true, false, true>(a, st) : launch_render_x<NT, TPS, false, false, true>(a, st);
+    else return CIPS3D_E_UNSUPP;
+  }
   if (a.p.x_pts) return launch_render_x<NT, TPS, true, false>(a, st);
   return a.p.stash ? launch_render_x<NT, TPS, false, true>(a, st) : launch_render_x<NT, TPS, false, false>(a, st);
 }
@@ -936,7 +974,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if ((P.o_features || P.o_thumb || P.o_xyz || P.o_mask) && !(P.o_features && P.o_thumb && P.o_xyz && P.o_mask))
     return CIPS3D_E_BADARG;
   const int fuse = cips3d_nerf_fuses_finish(p);
-  if (P.packed32 && !cips3d_nerf_pair_applies(p)) return CIPS3D_E_UNSUPP;     // exact fp32 only exists in nerf_pair.hip's shape
+  if (P.packed32 && (P.hidden != 256 || P.stash)) return CIPS3D_E_UNSUPP;     // exact fp32: hidden 256, no differentiable forward
   if (!P.near_ || !P.far_ || !P.w_first || (!P.packed && !P.packed32) || !P.w_view || !P.film ||
       !P.layer_bias || !P.w_sigma || !P.w_rgb || !P.b_sigma || !P.b_rgb || (!P.sigmoid_beta && !P.raw_density) || (!P.part && !fuse))
     return CIPS3D_E_BADARG;

@@ -617,7 +617,7 @@ extern "C" int cips3d_nerf_pack_weights32(const float* w_hidden, const float* w_
 // caller's n_chunks only matters through the `part` layout, which this form never touches)
 int cips3d_nerf_pair_applies(const cips3d_nerf_params* p) {
   if (!p) return 0;
-  if (!p->packed32) {       // the split-fp16 instantiation: opt-in while it is the slower of the two (tools/nerf_pair_ab.py)
+  {       // opt-in in both arithmetics while it is the slower form (tools/nerf_pair_ab.py; exact fp32: 252 us against nerf.hip's F32 instantiation)
     const char* knob = getenv("CIPS3D_NERF_PAIR");    // A/B knob, read per call (tests switch it inside one process)
     if (!knob || atoi(knob) == 0) return 0;
   }

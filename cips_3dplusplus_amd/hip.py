@@ -237,7 +237,7 @@ def _nerf_params(kw):
                   "w_sigma", "w_rgb", "b_sigma", "b_rgb", "sigmoid_beta")
     for f in ptr_fields:
         setattr(p, f, dev_ptr(kw[f], f))
-    p.packed32 = dev_ptr(kw.get("packed32"), "packed32", True)          # exact-fp32 arithmetic (csrc/nerf_pair.hip)
+    p.packed32 = dev_ptr(kw.get("packed32"), "packed32", True)          # exact-fp32 arithmetic (csrc/nerf.hip, F32 instantiation)
     p.part = dev_ptr(kw.get("part"), "part", True)
     for f in ("cam_poses", "focals"):
         setattr(p, f, dev_ptr(kw.get(f), f, kw.get("x_pts") is not None))

@@ -126,7 +126,7 @@ class VolumeFeatureRenderer(nn.Module):
         """"fp32" (default): the point MLP's GEMMs as fp32-equivalent split-fp16 products (three exact fp16 products per fp32
         product, fp32 accumulate: csrc/nerf.hip); "fp32_exact": the fp32 matrix instruction on fp32 operands -- IEEE fp32
         products, the arithmetic of the reference's F.linear (cips3d/volume_renderer.py:15-35, 74-85) -- through
-        csrc/nerf_pair.hip's exact instantiation (hidden_dim 256, camera-driven inference; ~2.5x the render time)."""
+        the F32 instantiation of the same kernel (hidden_dim 256, inference; ~2.3x the render time)."""
         if precision not in ("fp32", "fp32_exact"):
             raise ValueError(precision)
         if precision == "fp32_exact" and self.hidden_dim != 256:
@@ -264,6 +264,7 @@ class VolumeFeatureRenderer(nn.Module):
                         layer_bias=layer_bias, w_sigma=net.sigma_linear.weight, w_rgb=net.rgb_linear.weight,
                         b_sigma=net.sigma_linear.bias, b_rgb=net.rgb_linear.bias, sigmoid_beta=self.sigmoid_beta,
                         B=B, img_size=1, n_samples=N, hidden=H, depth=D, static_viewdirs=0, n_chunks=n_chunks,
-                        sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R, raw_density=not self.with_sdf)
+                        sdf=sdf, x_pts=p, x_rays_d=d, x_viewdirs=v, x_z_vals=z, n_rays=R, raw_density=not self.with_sdf,
+                        packed32=self.packed32())
         to_rays = lambda t: t.view(B, t.shape[1], R).transpose(1, 2).reshape(*lead, t.shape[1]).contiguous()
         return to_rays(thumb), to_rays(features), sdf.view(*lead, N, 1), to_rays(mask), to_rays(xyz), None

@@ -208,7 +208,7 @@ typedef struct cips3d_nerf_params {
   /* != NULL: exact-fp32 arithmetic (the reference's F.linear in IEEE fp32, cips3d/volume_renderer.py:15-35, 74-85): the point
    * MLP's GEMMs run on the fp32 matrix instruction (v_mfma_f32_16x16x4_f32: bit for bit an fmaf chain in k order) over the
    * stream cips3d_nerf_pack_weights32 wrote, instead of three fp16 products per fp32 product over `packed` (which is then not
-   * read).  hidden == 256, camera-driven mode, final maps written by the kernel (o_* set), no stash; CIPS3D_E_UNSUPP otherwise. */
+   * read).  hidden == 256, no stash (CIPS3D_E_UNSUPP otherwise); camera-driven or explicit geometry, fused or separate finish. */
   const float* packed32;
 } cips3d_nerf_params;
 

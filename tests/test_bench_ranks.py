@@ -96,3 +96,27 @@ def test_the_drivers_eight_rank_command_runs_end_to_end():
     assert line["config"]["parallelism"] == "views x8" and line["value"] > 0 and line["ms_per_step"] > 0
     assert line["roofline"] is None or line["roofline"]["frac"] > 0
     assert "also" not in line and "cpu_baseline" not in line            # rank-0-at-N=1-only legs
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_prices_every_big_kernel():
+    """`roofline.kernels` of the N = 1 line: the render kernel, the 64^2 chain GEMM and the four fused up-sampling stages, each
+    with an in-run launch time, algorithmic work, a fraction of its bound in (0, 1) -- and launch times that add up to no more
+    than the step they are part of."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "10", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline", "--no-also"],
+                       env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rows = line["roofline"]["kernels"]
+    assert rows[0]["kind"] == "render" and rows[0]["frac"] == line["roofline"]["frac"]
+    kinds = [(k["kind"], k.get("c_in")) for k in rows]
+    assert ("planes_gemm", 512) in kinds and {("fused_stage", c) for c in (32, 64, 128, 256)} <= set(kinds)
+    total = 0.0
+    for k in rows:
+        assert k["avg_launch_ms"] > 0 and k["launches_per_step"] >= 1
+        total += k["avg_launch_ms"] * k["launches_per_step"]
+        if k["kind"] in ("render", "planes_gemm", "lowres_gemm", "fused_stage"):
+            assert 0.0 < k["frac"] < 1.0 and k["achieved"] > 0 and k["bound"] in ("mfma", "hbm")
+            assert k.get("flop_per_launch", 0) > 0 or k.get("algorithmic_bytes", 0) > 0
+            assert "traffic" in k               # measured bytes from a summary of THIS library build, or null
+    assert 0.6 * line["ms_per_step"] < total < 1.05 * line["ms_per_step"]

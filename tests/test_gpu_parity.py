@@ -661,6 +661,13 @@ def test_renderer_explicit_points_entry_vs_oracle(hidden, D, R, N):
     for a, b, name in zip(out[:5], ref, ("rgb_map", "feature_map", "sdf", "mask", "xyz")):
         assert a.shape == b.shape, (name, a.shape, b.shape)
         assert maxdiff(a.cpu(), b) < tol * max(1.0, float(b.abs().max())), name
+    if hidden == 256:       # the exact-fp32 instantiation of the explicit-geometry kernel (csrc/nerf.hip: <.., XG, .., F32>)
+        G.renderer.set_precision("fp32_exact")
+        out_x = G.renderer(cu(pts), cu(rays_d), cu(viewdirs), cu(z), cu(near), cu(far), styles=cu(styles))
+        G.renderer.set_precision("fp32")
+        for a, b, name in zip(out_x[:5], ref, ("rgb_map", "feature_map", "sdf", "mask", "xyz")):
+            assert maxdiff(a.cpu(), b) < tol * max(1.0, float(b.abs().max())), name
+        assert not torch.equal(out_x[1], out[1])            # another arithmetic really ran
     # (b, h, w, ...) input layout
     if R == 64:
         o4 = G.renderer(cu(pts).view(B, 8, 8, N, 3), cu(rays_d).view(B, 8, 8, 3), cu(viewdirs).view(B, 8, 8, 3),

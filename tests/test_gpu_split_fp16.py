@@ -125,12 +125,14 @@ def test_exact_fp32_render_kernel_and_split_kernel_bracket_fp64_equally(D, N, B)
         pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=0).renderer.set_precision("fp32_exact")
 
 
-@pytest.mark.parametrize("N,B", [(24, 1), (23, 2), (24, 4)])
-def test_pair_kernel_split_instantiation_matches_the_default_kernel(monkeypatch, N, B):
-    """csrc/nerf_pair.hip in its split-fp16 instantiation (32 points per wave, k-outer; opt-in with CIPS3D_NERF_PAIR=1 because it
-    is the slower of the two on MI355X: DESIGN.md) computes the default kernel's arithmetic in another work shape: same products
-    in the same order per accumulator, a different chunking of the samples -- maps equal to fp32 summation noise, sdf bit for bit."""
+@pytest.mark.parametrize("N,B,precision", [(24, 1, "fp32"), (23, 2, "fp32"), (24, 4, "fp32"), (24, 1, "fp32_exact"), (23, 2, "fp32_exact")])
+def test_pair_kernel_instantiations_match_the_default_kernel(monkeypatch, N, B, precision):
+    """csrc/nerf_pair.hip (32 points per wave, k-outer; opt-in with CIPS3D_NERF_PAIR=1 because it is the slower form on MI355X in
+    both arithmetics: DESIGN.md) computes the default kernel's arithmetic -- split-fp16, or exact fp32 against csrc/nerf.hip's F32
+    instantiation -- in another work shape: same products in the same order per accumulator, a different chunking of the
+    samples -- maps equal to fp32 summation noise, sdf bit for bit."""
     G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=3)
+    G.renderer.set_precision(precision)
     S = 64
     e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.3, -0.1]] * B, device=DEV) *
                                                     torch.linspace(1, 2, B, device=DEV)[:, None])
