@@ -39,7 +39,13 @@ class Range(C.Structure):
     _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("x_exp_const", C.c_int32), ("x_max_const", C.c_float),
                 ("x_pmax", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
                 ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p), ("out_pmax", C.c_void_p),
-                ("next_gain", C.c_float), ("pad2_", C.c_int32)]
+                ("next_gain", C.c_float), ("pad2_", C.c_int32), ("ride", C.c_void_p)]
+
+
+class ReduceJob(C.Structure):
+    """cips3d_reduce_job: a ToRGB fold that rides on a split-planes GEMM launch (include/cips3d_hip.h)."""
+    _fields_ = [("part", C.c_void_p), ("bias", C.c_void_p * 8), ("skip", C.c_void_p), ("out", C.c_void_p),
+                ("n4", C.c_int64), ("HW4", C.c_int64), ("slot_stride", C.c_int64), ("n_slots", C.c_int32), ("n_bias", C.c_int32)]
 
 
 class AdamEntry(C.Structure):
@@ -217,7 +223,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 22           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 23           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 
@@ -225,7 +231,7 @@ def _struct_table():
     """index of cips3d_sizeof_struct -> the ctypes mirror of that struct (plan.py holds the two big ones)."""
     from . import plan
     return {0: plan.GeneratorPlan, 1: plan.ForwardIO, 2: NerfParams, 3: LinearDesc, 4: ModulateDesc, 5: plan.DecLayer,
-            6: NerfBwdGeom, 7: NerfBwdFusedParams, 8: Range}
+            6: NerfBwdGeom, 7: NerfBwdFusedParams, 8: Range, 9: ReduceJob}
 
 
 def load(build_if_missing=True):

@@ -104,6 +104,7 @@ struct ChainArgs {
   // x_pmax / out_pmax: [B][ceil(HW / 64)][C / 16] patch maxima; x_pmax NULL: max|in| = x_max_const
   const int* x_exp; int x_exp_const; const float* x_pmax; float x_max_const; const float* lconst; float* out_amax; int* out_exp;
   float* out_pmax;
+  cips3d_reduce_job ride;   // part == NULL: none.  A ToRGB fold this launch carries (cips3d_range::ride)
 };
 
 
@@ -132,6 +133,54 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   const int q = lane >> 4, col = lane & 15;
   const int b = blockIdx.z;
 
+  // The riding ToRGB fold (cips3d_reduce_job): one extra row of workgroups (blockIdx.y == Cout / BM) that the host adds to the
+  // grid of a launch that leaves CUs free (the 512 -> 256 exit of the 64^2 run: 128 tiles).  As in torgb_reduce_kernel a float4
+  // position is shared by four slot groups (group g adds slots g, g + 4, ... in that order, absent ones of a batch of four as
+  // zeros; then the groups 0 .. 3, the biases, the skip): here the groups are the lane quarters of a wave, 16 positions per wave.
+  if constexpr (NP == 2) {
+    if (a.ride.part && (int)blockIdx.y == a.Cout / BM) {
+      constexpr int RIDE_K = 12;                 // loads per lane: n_slots <= 4 * RIDE_K
+      const int64_t wv = ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+      const int64_t ride_i = wv * 16 + col;
+      const bool ride_on = ride_i < a.ride.n4;
+      f32x4 rsl[RIDE_K], rsk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RIDE_K; ++k)
+        rsl[k] = (ride_on && q + 4 * k < a.ride.n_slots)
+                     ? *reinterpret_cast<const f32x4*>(a.ride.part + (q + 4 * k) * a.ride.slot_stride + ride_i * 4)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ride_on && a.ride.skip && q == 0) rsk = *reinterpret_cast<const f32x4*>(a.ride.skip + ride_i * 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < RIDE_K / 4; ++it)
+        if (q + 16 * it < a.ride.n_slots) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += rsl[4 * it + u][c];
+        }
+#pragma unroll
+      for (int g = 1; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float o = __shfl(v[c], col + 16 * g, 64);
+          if (q == 0) v[c] += o;
+        }
+      if (ride_on && q == 0) {
+        const int ch = (int)((ride_i / a.ride.HW4) % 3);
+        float bs = 0.f;
+        for (int k = 0; k < a.ride.n_bias; ++k) bs += a.ride.bias[k][ch];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bs;
+        if (a.ride.skip) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += rsk[c];
+        }
+        *reinterpret_cast<f32x4*>(a.ride.out + ride_i * 4) = v;
+      }
+      return;
+    }
+  }
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int HW = a.HW, K = a.Cin;
   const int nstage = K / BK;
@@ -675,7 +724,8 @@ extern "C" int cips3d_modconv1x1_planes16(const void* x_planes16, const float* w
   if (B == 0) return 0;
   ChainArgs a{reinterpret_cast<const _Float16*>(x_planes16), wm, out, out_format, B, Cin, Cout, (int)HW, epilogue, noise,
               noise_bstride, noise_w, bias, rgb_w, rgb_part, nullptr, 0, nullptr, 0.f, nullptr, rg ? rg->out_amax : nullptr, nullptr,
-              nullptr};
+              nullptr, cips3d_reduce_job{}};
+  if (rg && rg->ride) return CIPS3D_E_UNSUPP;       // the riding fold exists in the split-planes kernel only
   // 64 x 128 tiles, 64-deep stages of 24 KB in a 3-slot ring (72 KB: two workgroups per CU).  Same-box sweep (rocprofv3, 512 -> 512
   // at 64^2): batch 1 7.45 us / batch 4 17.4 us; a 2-slot ring 8.0 / 17.5; 128-deep stages 7.4 / 24.2 (one workgroup per CU);
   // 128 x 128 tiles (2/3 of the operand bytes per flop) 9.6 / 19.8; 64 x 64 tiles 7.5 / 19.9.
@@ -702,10 +752,19 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
               noise_bstride, noise_w, bias, rgb_w, rgb_part, rg ? rg->x_exp : nullptr, rg ? rg->x_exp_const : 0,
               rg ? rg->x_pmax : nullptr, rg ? rg->x_max_const : 0.f, (rg && out_format == 1) ? rg->lconst : nullptr,
               (rg && out_format != 1) ? rg->out_amax : nullptr, rg ? rg->out_exp : nullptr,
-              (rg && out_format == 1) ? rg->out_pmax : nullptr};
+              (rg && out_format == 1) ? rg->out_pmax : nullptr, cips3d_reduce_job{}};
   if (rg && out_format == 1 && rg->x_pmax && Cin > 512) return CIPS3D_E_UNSUPP;
+  if (rg && rg->ride) {            // a ToRGB fold riding on this launch: one float4 position per thread of the grid
+    const cips3d_reduce_job& j = *rg->ride;
+    if (!j.part || !j.out || j.n_slots < 1 || j.n_bias < 0 || j.n_bias > CIPS3D_TORGB_FOLD_MAX || j.n4 <= 0 || j.HW4 <= 0 ||
+        j.slot_stride <= 0)
+      return CIPS3D_E_BADARG;
+    // one extra row of workgroups, 16 positions per wave, at most 48 slots (12 loads per lane)
+    if (j.n_slots > 48 || j.n4 > (int64_t)ceil_div<int64_t>(HW, 128) * B * 8 * 16) return CIPS3D_E_UNSUPP;
+    a.ride = j;
+  }
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
-  dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64), (unsigned)B);
+  dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64) + (a.ride.part ? 1u : 0u), (unsigned)B);
   static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)
   // (Round 3, measured and not kept: 128 x 128 tiles -- 2/3 of the operand bytes per flop through the L2 -> LDS path, 256
   // workgroups -- 16.3 us per 512 -> 512 layer against 12.2: twice the MFMAs and fragment reads per wave at the same one

@@ -26,6 +26,7 @@ extern "C" int64_t cips3d_sizeof_struct(int which) {
     case 6: return (int64_t)sizeof(cips3d_nerf_bwd_geom);
     case 7: return (int64_t)sizeof(cips3d_nerf_bwd_fused_params);
     case 8: return (int64_t)sizeof(cips3d_range);
+    case 9: return (int64_t)sizeof(cips3d_reduce_job);
     default: return -1;
   }
 }
@@ -244,8 +245,33 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       const float* nz = L.noise_index >= 0 ? IO.noise[L.noise_index] : nullptr;
       const int64_t nbs = L.noise_index >= 0 ? IO.noise_bstride[L.noise_index] : 0;
       float* out = P.act[act_i];
-      if (L.kind == 1 && fold_slots) {          // resolution changes: the folded sum becomes the skip of this stage
-        TRY(fold_flush(P.skip[skip_i]));
+      // resolution changes: the folded sum becomes the skip of this stage.  When the stage's low-resolution GEMM is the next
+      // launch and runs on split planes, the fold rides on it (cips3d_reduce_job) instead of taking a launch of its own
+      cips3d_reduce_job ride_job{};
+      bool ride = false;
+      if (L.kind == 1 && fold_slots) {
+        static const int ride_on = getenv("CIPS3D_TORGB_RIDE") ? atoi(getenv("CIPS3D_TORGB_RIDE")) : 1;      // A/B knob
+        const bool fused_next = li + 2 < P.n_dec_layers && P.layers[li + 1].kind == 0 && P.layers[li + 2].kind == 3 &&
+                                P.layers[li + 1].Cin == L.Cout && P.layers[li + 1].Cout == L.Cout && P.layers[li + 2].Cin == L.Cout &&
+                                cips3d_fused_up_conv_supported(L.Cout, L.H, L.W);
+        const int64_t fhw = (int64_t)fold_H * fold_W;
+        if (ride_on && ranged && fused_next && !ylo_ready && (L.flags & 4) && !(L.flags & 32) && fold_slots <= 48 && fhw % 4 == 0 &&
+            (int64_t)B * 3 * fhw / 4 <= ((int64_t)L.H * L.W + 127) / 128 * B * 128) {
+          ride_job.part = P.rgb_part;
+          for (int k = 0; k < fold_nb; ++k) ride_job.bias[k] = fold_bias[k];
+          ride_job.skip = skip;
+          ride_job.out = P.skip[skip_i];
+          ride_job.n4 = (int64_t)B * 3 * fhw / 4;
+          ride_job.HW4 = fhw / 4;
+          ride_job.slot_stride = (int64_t)B * 3 * fhw;
+          ride_job.n_slots = fold_slots;
+          ride_job.n_bias = fold_nb;
+          ride = true;
+          skip = P.skip[skip_i];
+          fold_slots = fold_nb = 0;
+        } else {
+          TRY(fold_flush(P.skip[skip_i]));
+        }
         skip_i ^= 1;
       }
       // up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] with equal widths: low-res GEMM, then ONE fused
@@ -271,8 +297,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           else if (L.flags & 4) {  // ... as split-fp16 planes
             rg.x_exp = x_exp;
             rg.x_exp_const = CIPS3D_FEATURES_EXP;
+            rg.ride = ride ? &ride_job : nullptr;
             TRY(cips3d_modconv1x1_planes(x, L.wm, ylo_cur, ybf_flag ? 2 : 0, B, L.Cin, L.Cout, (int64_t)L.H * L.W, 0, nullptr, 0,
                                          nullptr, nullptr, nullptr, nullptr, nullptr, ranged ? &rg : nullptr, stream));
+            ride = false;
           } else {
             if (L.flags & 2) TRY(amax_of(x, L.Cin, (int64_t)L.H * L.W));
             rg.x_amax = x_amax;

@@ -609,12 +609,15 @@ def from_planes(p, H, W):
 
 
 def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, noise=None, noise_w=None, bias=None,
-                      rgb_w=None, rgb_part=None, demodulated=True, lconst=None):
+                      rgb_w=None, rgb_part=None, demodulated=True, lconst=None, ride=None):
     """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call (its exponents are read
     from its attribute; a planes output carries its own); wm_split from
     modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW]).
     demodulated: the weights were demodulated (unit row norm -> the sqrt(Cin) gain of the output bound); for others pass lconst
-    from a modulate table that measured the row L1 norms."""
+    from a modulate table that measured the row L1 norms.
+    ride: a ToRGB fold carried by this launch (cips3d_reduce_job; range-tracked inputs only) -- dict(part [n_slots, Br, 3, HWr],
+    biases [list of [3]], skip [Br, 3, HWr] or None, out [Br, 3, HWr]): out = skip + sum of the slots + sum of the biases, the
+    arithmetic and order of torgb_reduce."""
     lib = _lib.load()
     B, Cin = xp.shape[0], xp.shape[1] * 8
     dev = xp.device
@@ -643,6 +646,20 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
         # (x_pmax None: the kernel bounds max|in| by what the input's exponent encodes -- looser, still rigorous)
         rg, _keep = _range(x_exp=x_exp, x_pmax=x_pmax if fmt == 1 else None, lconst=lconst if fmt == 1 else None,
                            out_amax=out_amax, out_exp=out_exp, out_pmax=out_pmax)
+    job = None
+    if ride is not None:
+        if rg is None:
+            raise RuntimeError("a riding ToRGB fold needs range-tracked input planes (to_planes with x_amax)")
+        part, r_out = ride["part"], ride["out"]
+        n_slots, Br, _, HWr = part.shape
+        job = _lib.ReduceJob()
+        job.part, job.out = dev_ptr(part, "ride.part"), dev_ptr(r_out, "ride.out")
+        job.skip = dev_ptr(ride.get("skip"), "ride.skip", True)
+        for k, bk in enumerate(ride.get("biases", [])):
+            job.bias[k] = dev_ptr(bk, "ride.bias")
+        job.n4, job.HW4, job.slot_stride = Br * 3 * HWr // 4, HWr // 4, Br * 3 * HWr
+        job.n_slots, job.n_bias = n_slots, len(ride.get("biases", []))
+        rg.ride = C.addressof(job)
     check(lib.cips3d_modconv1x1_planes(dev_ptr(xp, "x_planes", dtype=torch.float16), dev_ptr(wm_split, "wm"), out.data_ptr(), fmt,
                                        B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
                                        dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),

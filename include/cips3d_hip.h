@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 22  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 23  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -277,7 +277,22 @@ typedef struct cips3d_range {
                               |out2|; next_gain = sqrt(C) for a demodulated next up-conv) in slot 0 instead of the measured
                               maximum -- no workgroup reduction, no atomics; for a consumer that is the decoder's last stage */
   int32_t pad2_;
+  const struct cips3d_reduce_job* ride;   /* cips3d_modconv1x1_planes only (HOST pointer, may be NULL): a ToRGB fold that rides on
+                              this launch -- see cips3d_reduce_job */
 } cips3d_range;
+/* The job of one cips3d_torgb_reduce (same arithmetic, same fixed order, same bits) carried by a split-planes GEMM launch that
+ * does not depend on it and leaves CUs free: one extra row of workgroups of that launch does the fold, so it costs no launch
+ * of its own (4.7 us at 64^2 on MI355X).  out[b][r][n] = skip + sum_s part[s] + sum_k bias[k][r] with
+ * n4 = B * 3 * HW / 4 float4 positions, HW4 = HW / 4, slot_stride = B * 3 * HW; n_slots <= 48, n_bias <= CIPS3D_TORGB_FOLD_MAX;
+ * part / skip / out must not alias the GEMM's operands.  (CIPS3D_TORGB_FOLD_MAX is defined below: 8.) */
+typedef struct cips3d_reduce_job {
+  const float* part;
+  const float* bias[8];
+  const float* skip;       /* may be NULL */
+  float* out;
+  int64_t n4, HW4, slot_stride;
+  int32_t n_slots, n_bias;
+} cips3d_reduce_job;
 /* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
 int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
 /* Test hook for the split itself (n even): words[i] = {hi | lo << 16} of x[i] * k -- even i through the fused form (the exact

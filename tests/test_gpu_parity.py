@@ -1051,6 +1051,35 @@ def test_modconv1x1_torgb_fold_vs_oracle():
     assert maxdiff(rgb.cpu(), rgb_ref) < 5e-5 * max(1.0, float(rgb_ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,hw,n_slots,with_skip,n_bias", [(1, 64, 40, True, 5), (1, 64, 8, True, 1), (2, 32, 5, False, 2),
+                                                            (1, 16, 1, True, 0), (4, 64, 48, True, 6), (2, 16, 17, False, 1)])
+def test_torgb_fold_riding_on_a_planes_gemm_equals_the_stand_alone_reduce(B, hw, n_slots, with_skip, n_bias):
+    """cips3d_reduce_job: the ToRGB fold carried by a split-planes GEMM launch (the low-resolution GEMM of the first up-sampling
+    stage in the one-call forward) writes the bits cips3d_torgb_reduce writes, and leaves the GEMM's own result untouched."""
+    import ctypes as C
+    from cips_3dplusplus_amd import _lib
+    dec = _dec_mod()
+    g = torch.Generator().manual_seed(B * 100 + hw + n_slots)
+    cin, cout = 128, 64
+    sc = dec.StyledConv(cin, cout, 1, 32).to(DEV)
+    wm = sc.conv.modulated_weight(cu(torch.randn(B, 32, generator=g)), packed=True, split=True)
+    xp = hip.to_planes(cu(torch.randn(B, cin, hw, hw, generator=g)))
+    part = cu(torch.randn(n_slots, B, 3, hw * hw, generator=g))
+    skip = cu(torch.randn(B, 3, hw * hw, generator=g)) if with_skip else None
+    biases = [cu(torch.randn(3, generator=g)) for _ in range(n_bias)]
+    ref = torch.empty(B, 3, hw * hw, device=DEV)
+    lib = _lib.load()
+    barr = (C.c_void_p * max(n_bias, 1))(*[b.data_ptr() for b in biases])
+    _lib.check(lib.cips3d_torgb_reduce(part.data_ptr(), n_slots, barr, n_bias, skip.data_ptr() if with_skip else None, ref.data_ptr(),
+                                       B, hw * hw, hip.stream_ptr()), "cips3d_torgb_reduce")
+    y_plain = hip.modconv1x1_planes(xp, wm, cout, hw * hw, out_format="fp32")
+    out = torch.full((B, 3, hw * hw), float("nan"), device=DEV)
+    y_ride = hip.modconv1x1_planes(xp, wm, cout, hw * hw, out_format="fp32",
+                                   ride=dict(part=part, biases=biases, skip=skip, out=out))
+    assert torch.equal(out, ref)
+    assert torch.equal(y_ride, y_plain)
+
+
 def test_empty_and_degenerate_inputs():
     """Edge cases at the op boundary: empty batches are legal and launch nothing; single-sample rays; 1x1 images."""
     k = torch.tensor([[1., 3., 3., 1.]]).t() @ torch.tensor([[1., 3., 3., 1.]]) / 64
