@@ -118,7 +118,7 @@ struct UfdFast {
   static_assert((BX * D) % U == 0 && (BY * D) % U == 0 && PITCH * FH * 4 <= 48 * 1024, "tile shape");
 };
 
-template <int U, int D, int K, int RX, int RY>
+template <int U, int D, int K, int RX, int RY, bool NT>
 __global__ void __launch_bounds__(256) upfirdn2d_fast(const float* __restrict__ in, const float* __restrict__ kernel,
                                                       float* __restrict__ out, UfdParams p, int tiles_x, int tiles_y) {
   typedef UfdFast<U, D, K, RX, RY> T;
@@ -135,13 +135,26 @@ __global__ void __launch_bounds__(256) upfirdn2d_fast(const float* __restrict__ 
   float kf[K * K];
 #pragma unroll
   for (int i = 0; i < K * K; ++i) kf[i] = kernel[K * K - 1 - i];
-  for (int r = wave; r < T::FH; r += 4) {
-    const int iy = q0y + r;
-    const bool yok = iy >= 0 && iy < p.in_h;
-    const float* row = src + (int64_t)(yok ? iy : 0) * p.in_w;
-    for (int c = lane; c < T::PITCH; c += 64) {
-      const int ix = q0x + c;
-      s_in[r * T::PITCH + c] = (yok && ix >= 0 && ix < p.in_w) ? row[ix] : 0.f;
+  // footprint -> LDS: element e = tid + 256 j is (row e / PITCH, column e % PITCH); 8 or 16 loads are in flight per lane before
+  // the first LDS store (as a load -> store loop per element the read-dominated shapes -- blur, down-sampling -- ran at 1.7-2.8 TB/s)
+  {
+    constexpr int TOTAL = T::PITCH * T::FH, PER = (TOTAL + 255) / 256, UNR = D == 2 ? 8 : 16;   // (same-box sweep of 4 / 8 / 16: blur 4.5 / 4.5 / 5.4 TB/s, down-sampling 2.8 / 3.0 / 2.9)
+#pragma unroll 1
+    for (int j0 = 0; j0 < PER; j0 += UNR) {
+      float v[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int e = tid + 256 * (j0 + u);
+        const int r = e / T::PITCH, c = e - r * T::PITCH;
+        const int iy = q0y + r, ix = q0x + c;
+        const bool ok = e < TOTAL && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        v[u] = ok ? src[(int64_t)iy * p.in_w + ix] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int e = tid + 256 * (j0 + u);
+        if (e < TOTAL) s_in[e] = v[u];
+      }
     }
   }
   __syncthreads();
@@ -188,7 +201,11 @@ __global__ void __launch_bounds__(256) upfirdn2d_fast(const float* __restrict__ 
     if (oy >= p.out_h) break;
     float* o = dst + (int64_t)oy * p.out_w + ox;
     if (vec) {
-      *reinterpret_cast<f32x4*>(o) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+      // NT: an output that cannot stay in the 256 MB Infinity Cache anyway leaves with non-temporal stores (same-box A/B on a
+      // 134 MB -> 537 MB up-sampling: 3.6 -> 5.6 TB/s; no difference below ~270 MB of traffic, where the default policy keeps
+      // the result on-die for its consumer; non-temporal LOADS of the input lost 20-25 % everywhere)
+      if (NT) __builtin_nontemporal_store(f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]}, reinterpret_cast<f32x4*>(o));
+      else *reinterpret_cast<f32x4*>(o) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
     } else {
 #pragma unroll
       for (int j = 0; j < T::BX; ++j)
@@ -201,8 +218,11 @@ template <int U, int D, int RX, int RY>
 void launch_fast(const float* in, const float* kernel, float* out, const UfdParams& p, hipStream_t st) {
   typedef UfdFast<U, D, 4, RX, RY> T;
   const int tiles_x = ceil_div(p.out_w, T::TW), tiles_y = ceil_div(p.out_h, T::TH);
-  hipLaunchKernelGGL((upfirdn2d_fast<U, D, 4, RX, RY>), dim3((unsigned)((int64_t)tiles_x * tiles_y * p.major)), dim3(256), 0, st,
-                     in, kernel, out, p, tiles_x, tiles_y);
+  const dim3 grid((unsigned)((int64_t)tiles_x * tiles_y * p.major));
+  if ((int64_t)p.major * p.out_h * p.out_w * 4 > (int64_t)192 << 20)
+    hipLaunchKernelGGL((upfirdn2d_fast<U, D, 4, RX, RY, true>), grid, dim3(256), 0, st, in, kernel, out, p, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((upfirdn2d_fast<U, D, 4, RX, RY, false>), grid, dim3(256), 0, st, in, kernel, out, p, tiles_x, tiles_y);
 }
 
 // Any size / any minor: one thread per output element, taps read straight from global/L2.

@@ -1,7 +1,9 @@
 """Timing of the stand-alone `upfirdn2d` op (csrc/upfirdn2d.hip) on the shapes the path uses it with when a caller goes
 through the op-level API instead of the fused stages: the 2x FIR up-sampling of the RGB skip (Upsample, models/model_v3.py
 blur kernel [1, 3, 3, 1]), the blur after a transposed 3x3 conv (pad (1, 1)), a 2x down-sampling (the discriminator-side
-use of the op), priced against HBM: the op reads every input element and writes every output element once.
+use of the op), priced against HBM: the op reads every input element and writes every output element once.  Calls are timed back to back through the
+Python wrapper (about 20 us of host time per call): only the cases of >= 250 MB are GPU-bound here, the rocprofv3 summary of
+this script (profiles/) has the kernel times of the small ones.
 
     python tools/bench_upfirdn2d.py
 """
@@ -22,7 +24,10 @@ for name, shape, kern, up, down, pad in (
         ("blur 32ch 1025->1024", (1, 32, 1025, 1025), k * 4, 1, 1, (1, 1)),
         ("blur 256ch 129->128", (1, 256, 129, 129), k * 4, 1, 1, (1, 1)),
         ("down 64ch 512->256", (1, 64, 512, 512), k, 1, 2, (1, 1)),
-        ("batch 4 up 32ch 512->1024", (4, 32, 512, 512), k * 4, 2, 1, (2, 1))):
+        ("batch 4 up 32ch 512->1024", (4, 32, 512, 512), k * 4, 2, 1, (2, 1)),
+        ("batch 8 up 64ch 256->512", (8, 64, 256, 256), k * 4, 2, 1, (2, 1)),
+        ("batch 4 blur 32ch 1025->1024", (4, 32, 1025, 1025), k * 4, 1, 1, (1, 1)),
+        ("batch 8 down 64ch 512->256", (8, 64, 512, 512), k, 1, 2, (1, 1))):
     x = torch.randn(*shape, device=dev)
     y = op.upfirdn2d(x, kern, up=up, down=down, pad=pad)
     torch.cuda.synchronize()

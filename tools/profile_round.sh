@@ -16,8 +16,8 @@ stats config3_bf16 $B --batch 4 --decoder-precision bf16 --steps 30 --repeats 2
 stats fp32_exact $B --decoder-precision fp32_exact --steps 30 --repeats 2
 stats conv3x3_tool python3 tools/bench_conv3x3.py
 stats upfirdn2d_tool python3 tools/bench_upfirdn2d.py
-python3 tools/bench_conv3x3.py > $O/conv3x3_tool.jsonl 2>&1
-python3 tools/bench_upfirdn2d.py > $O/upfirdn2d_tool.jsonl 2>&1
+python3 tools/bench_conv3x3.py > $O/conv3x3_tool.jsonl 2> /dev/null
+python3 tools/bench_upfirdn2d.py > $O/upfirdn2d_tool.jsonl 2> /dev/null
 P="--steps 12 --warmup 3 --repeats 1"
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq -o p -- $B $P > $O/sq.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA --output-format csv -d $O/insts -o p -- $B $P > $O/insts.log 2>&1
