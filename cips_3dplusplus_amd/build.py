@@ -17,7 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libcips3d_hip.so")
 ARCH = "gfx950"
-SOURCES = ["bias_act.hip", "upfirdn2d.hip", "linear.hip", "camera.hip", "nerf.hip", "nerf_pair.hip", "decoder.hip", "chain.hip", "conv3x3.hip", "forward.hip", "backward.hip", "decoder_grad.hip", "nerf_bwd.hip", "nerf_bwd_fused.hip", "render_ops.hip", "rng.hip", "optim.hip"]
+SOURCES = ["bias_act.hip", "upfirdn2d.hip", "linear.hip", "camera.hip", "nerf.hip", "nerf_pair.hip", "nerf_ws.hip", "decoder.hip", "chain.hip", "conv3x3.hip", "forward.hip", "backward.hip", "decoder_grad.hip", "nerf_bwd.hip", "nerf_bwd_fused.hip", "render_ops.hip", "rng.hip", "optim.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-fno-gpu-rdc", "-fgpu-flush-denormals-to-zero" if False else ""]
 FLAGS = [f for f in FLAGS if f] + os.environ.get("CIPS3D_HIPCC_FLAGS", "").split()

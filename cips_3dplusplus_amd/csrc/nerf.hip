@@ -960,7 +960,7 @@ extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
   if (!p || !p->o_features || !p->o_thumb || !p->o_xyz || !p->o_mask) return 0;
   static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
   if (off) return 0;
-  if (cips3d_nerf_pair_applies(p)) return 1;     // nerf_pair.hip only exists in the fused form, with its own chunking
+  if (cips3d_nerf_ws_applies(p) || cips3d_nerf_pair_applies(p)) return 1;     // those forms only exist fused, with their own work split
   const int H = p->hidden, L = p->depth + 1;
   if (p->n_chunks < 1 || WAVES % p->n_chunks != 0 || (H != 32 && H != 64 && H != 128 && H != 256)) return 0;
   const int tables = L * 2 * H + 10 * H;
@@ -985,6 +985,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
   if (P.B == 0) return 0;
+  if (fuse && cips3d_nerf_ws_applies(p)) return cips3d_nerf_render_ws(p, stream);
   if (fuse && cips3d_nerf_pair_applies(p)) return cips3d_nerf_render_pair(p, stream);
   NerfArgs a;
   a.p = P;

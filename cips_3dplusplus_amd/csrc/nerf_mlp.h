@@ -21,6 +21,9 @@
 // nerf_pair.hip: the 32-points-per-wave render kernel (library-internal)
 int cips3d_nerf_pair_applies(const cips3d_nerf_params* p);
 int cips3d_nerf_render_pair(const cips3d_nerf_params* p, void* stream);
+// nerf_ws.hip: the weight-stationary render kernel (library-internal)
+int cips3d_nerf_ws_applies(const cips3d_nerf_params* p);
+int cips3d_nerf_render_ws(const cips3d_nerf_params* p, void* stream);
 
 namespace {
 

@@ -149,6 +149,29 @@ def test_pair_kernel_instantiations_match_the_default_kernel(monkeypatch, N, B, 
     assert torch.equal(ref[2], new[2])
 
 
+@pytest.mark.parametrize("N,B,D", [(24, 1, 2), (23, 2, 2), (9, 1, 3), (24, 1, 1), (6, 2, 6)])
+def test_weight_stationary_kernel_matches_the_default_kernel(monkeypatch, N, B, D):
+    """csrc/nerf_ws.hip (a workgroup owns a ray group, a wave 32 output units of every layer with their weights in registers, the
+    activations in LDS; opt-in with CIPS3D_NERF_WS=1: the slower dataflow on MI355X) computes the default kernel's
+    arithmetic -- the same products in the same order per accumulator -- with sums over units and samples in another order: maps
+    equal to fp32 summation noise.  Depths whose tables do not fit beside the activation images fall back to the default kernel."""
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, D), DEV, seed=5)
+    S = 64
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.25, -0.15]] * B, device=DEV) *
+                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
+    styles = cu(weights.det_normal("ws.styles", (B, D + 1, 256), 0.5, 2))
+    u = cu(weights.det_unit_uniform("ws.u", (B, S * S), 3))
+    monkeypatch.setenv("CIPS3D_NERF_WS", "0")
+    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    monkeypatch.setenv("CIPS3D_NERF_WS", "1")
+    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
+        d, r = maxdiff(a, b), float(a.abs().max())
+        assert bool(torch.isfinite(b).all()) and d <= 4e-6 * max(r, 1.0), (k, d, r)
+    if D <= 5:
+        assert not torch.equal(ref[1], new[1])              # the other kernel really ran
+
+
 def test_fp32_exact_mode_agrees_with_the_default():
     cfg = configs.ffhq_G_cfg(256, 2)
     G = pkg.build_generator(cfg, DEV, seed=1)

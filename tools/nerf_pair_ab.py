@@ -14,6 +14,7 @@ ap.add_argument("--depth", type=int, default=2)
 ap.add_argument("--n-samples", type=int, default=24)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--no-perturb", action="store_true")
+ap.add_argument("--ws", action="store_true", help="compare the weight-stationary kernel (csrc/nerf_ws.hip, CIPS3D_NERF_WS=1) instead")
 ap.add_argument("--abl", default="", help="comma list of CIPS3D_PAIR_ABL values to time as well (a -DCIPS3D_PAIR_ABLATIONS build)")
 a = ap.parse_args()
 dev = "cuda"
@@ -27,7 +28,7 @@ pu = None if a.no_perturb else torch.rand(B, 64 * 64, device=dev)
 
 
 def run(pair):
-    os.environ["CIPS3D_NERF_PAIR"] = "1" if pair else "0"
+    os.environ["CIPS3D_NERF_WS" if a.ws else "CIPS3D_NERF_PAIR"] = "1" if pair else "0"
     out = G.renderer.render(e, f, n, fa, styles, 64, a.n_samples, perturb_u=pu, return_sdf=True)
     out = dict(zip(("thumb", "features", "sdf", "mask", "xyz"), out))
     for _ in range(3):
@@ -44,7 +45,7 @@ def run(pair):
 
 ref, t_ref, m_ref = run(False)
 new, t_new, m_new = run(True)
-print(f"D={a.depth} N={a.n_samples} B={B}: 16-point kernel {t_ref:.1f} us (min {m_ref:.1f})   pair kernel {t_new:.1f} us (min {m_new:.1f})")
+print(f"D={a.depth} N={a.n_samples} B={B}: 16-point kernel {t_ref:.1f} us (min {m_ref:.1f})   {'weight-stationary' if a.ws else 'pair'} kernel {t_new:.1f} us (min {m_new:.1f})")
 for ab in [x for x in a.abl.split(",") if x]:
     os.environ["CIPS3D_PAIR_ABL"] = ab
     _, t_ab, m_ab = run(True)
