@@ -250,9 +250,34 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #else
   const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
 #endif
+  // CIPS3D_HALF_PERIOD (A/B): the upper half of the waves runs HALF A STEP behind the lower half instead of taking the one step
+  // barrier early -- two workgroup barriers per step, one in front of every wave's matrix block and one behind it, and the upper
+  // waves execute one more at the start of the kernel (the lower ones one more at its end).  Barrier "beta_g" is then the lower
+  // waves' barrier in front of matrix block g and the upper waves' behind block g - 1: behind it nobody reads slab g - 1 any
+  // more, every wave requests its pieces of slab g + 1 there and waits for them in front of its own beta_{g+1}.  Between two
+  // barriers one wave of every SIMD is in its matrix block and the other in its epilogue.  Measured (round 4, same box,
+  // rocprofv3): 86.4 us against the stagger's 80.6 -- as with round 2's fp16-less attempt (127 against 97): a matrix block that has
+  // the SIMD to itself does not run twice as fast as two that share it.  Not the default.
+#ifndef CIPS3D_HALF_PERIOD
+#define CIPS3D_HALF_PERIOD 0
+#endif
+  auto issue_slab = [&](int seq_next) {
+    if (seq_next < ring.seq_end) {
+      const int nxt = seq_next % ring.per_sample;
+      stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + (seq_next & 1) * SLAB, wave, lane);
+    }
+  };
 #pragma unroll
   for (int sl = 0; sl < STEPS; ++sl) {
-    if (ring.seq + 1 < ring.seq_end) {
+    if (CIPS3D_HALF_PERIOD) {
+      if (!late_epilogue) {                  // beta_g in front of the lower waves' block
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of slab g
+        __syncthreads();
+        issue_slab(ring.seq + 1);
+      } else {
+        __syncthreads();                     // gamma_g
+      }
+    } else if (ring.seq + 1 < ring.seq_end) {
       const int nxt = (ring.seq + 1) % ring.per_sample;
       stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
     }
@@ -338,7 +363,15 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
     }
 #endif
     STAMP(9);    // matrix block
-    if (late_epilogue) {
+    if (CIPS3D_HALF_PERIOD) {
+      if (late_epilogue) {                   // beta_{g+1} behind the upper waves' block g
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        issue_slab(ring.seq + 2);
+      } else {
+        __syncthreads();                     // gamma_g
+      }
+    } else if (late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's piece of slab seq+1 has landed
       __syncthreads();
     }
@@ -391,7 +424,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
     }
     STAMP(11);   // epilogue
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
-    if (!late_epilogue) {
+    if (!CIPS3D_HALF_PERIOD && !late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
       __syncthreads();
     }
@@ -550,6 +583,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   stage_slab<SLAB>(ring.packed, ringmem, wave, lane);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
+#if CIPS3D_HALF_PERIOD
+  if (__builtin_amdgcn_readfirstlane(wave) >= WAVES / 2) {      // beta_0 of the upper waves: half a step behind from here on
+    __syncthreads();
+    if (1 < ring.seq_end) stage_slab<SLAB>(ring.packed + (int64_t)(1 % ring.per_sample) * SLAB, ringmem + SLAB, wave, lane);
+  }
+#endif
 
   const int s_begin = c * a.chunk;
   STAMP(0);   // prologue
@@ -662,6 +701,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     }
   }
 
+#if CIPS3D_HALF_PERIOD
+  if (__builtin_amdgcn_readfirstlane(wave) < WAVES / 2) __syncthreads();      // the barrier the upper waves took at the start
+#endif
   STAMP(5);   // last compositing tail
 #ifdef CIPS3D_CLOCK
   if (tid == 0) {
