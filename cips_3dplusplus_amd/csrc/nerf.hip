@@ -311,9 +311,9 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #define CIPS3D_ASM_FRAGS 0      // 1: nerf_mlp.h:matrix_block (inline-asm reads three groups ahead, hand-counted waits): 87.6 against
 #endif                          // 88.5 us on one box -- not worth leaving the compiler's hazard handling (see matrix_block)
 #if CIPS3D_ASM_FRAGS
-    static_assert(!F32, "the inline-asm matrix block is the split kernel's");
-    matrix_block<NT, TPS>(slab, Xh, Xl, acc, lane);
-#else
+    if constexpr (!F32) matrix_block<NT, TPS>(slab, Xh, Xl, acc, lane);      // (the inline-asm matrix block is the split kernel's)
+    else
+#endif
     {     // A/B form: reads one half k-block ahead through the compiler, its wait provoked in front of the next reads
       constexpr int HT = TPS / 2;
       h8 fh[2][HT], fl[2][HT];
@@ -361,7 +361,6 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#endif
     STAMP(9);    // matrix block
     if (CIPS3D_HALF_PERIOD) {
       if (late_epilogue) {                   // beta_{g+1} behind the upper waves' block g
