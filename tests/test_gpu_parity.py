@@ -64,6 +64,10 @@ def test_upfirdn2d_vs_oracle(shape, k, up, down, pad):
     ((1, 2, 100, 37), 1, 2, (1, 1, 1, 1)),
     ((1, 3, 64, 530), 1, 2, (2, 1, 0, 2)),
     ((1, 1, 4, 4), 2, 1, (2, 1, 2, 1)),
+    ((2, 1, 1, 1), 2, 1, (2, 1, 2, 1)),          # one pixel in, 2 x 2 out
+    ((1, 2, 3, 5), 1, 1, (2, 1, 1, 2)),          # output narrower than one 4-pixel block row
+    ((1, 1, 7, 1), 1, 2, (2, 2, 2, 2)),          # a single input column
+    ((3, 1, 130, 6), 2, 1, (2, 1, 2, 1)),        # more than one tile high, narrower than one tile
 ])
 def test_upfirdn2d_fast_kernel_vs_oracle_and_bit_identical_to_the_tiled_kernel(shape, up, down, pads):
     """The compile-time polyphase kernel (csrc/upfirdn2d.hip: upfirdn2d_fast, the 4 x 4 FIR of the generator's Blur / Upsample)

@@ -172,6 +172,24 @@ def test_weight_stationary_kernel_matches_the_default_kernel(monkeypatch, N, B, 
         assert not torch.equal(ref[1], new[1])              # the other kernel really ran
 
 
+@pytest.mark.parametrize("S", [10, 12, 33])
+def test_weight_stationary_kernel_on_ragged_ray_counts(monkeypatch, S):
+    """Ray counts that are not a multiple of the 16-ray group (and not of the default kernel's task grid): the last workgroup's
+    missing rays carry zero weights and are never stored."""
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=6)
+    B, N = 2, 7
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.1, 0.2], [-0.3, 0.0]], device=DEV))
+    styles = cu(weights.det_normal("wsr.styles", (B, 3, 256), 0.5, 2))
+    u = cu(weights.det_unit_uniform("wsr.u", (B, S * S), 3))
+    monkeypatch.setenv("CIPS3D_NERF_WS", "0")
+    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    monkeypatch.setenv("CIPS3D_NERF_WS", "1")
+    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
+        assert a.shape == b.shape and bool(torch.isfinite(b).all()), k
+        assert maxdiff(a, b) <= 4e-6 * max(float(a.abs().max()), 1.0), k
+
+
 def test_fp32_exact_mode_agrees_with_the_default():
     cfg = configs.ffhq_G_cfg(256, 2)
     G = pkg.build_generator(cfg, DEV, seed=1)
