@@ -411,6 +411,35 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
     line["route"] = ("decoder = one autograd node (cips3d_decoder_grad_forward / _backward), fused NeRF backward, HIP Adam (optim.HipAdam)"
                      if AG.ONE_CALL_DECODER else "decoder = one autograd node per op (CIPS3D_ONE_CALL_DECODER=0)")
     line["roofline"] = hip.inversion_roofline(G.renderer, B=2, n_samples=n_samples)
+    # the decoder node's two C calls (forward with kept activations; the whole backward), between HIP events on a few extra steps
+    # outside the timed regions: algorithmic flop of the node's GEMMs against the split-fp16 ceiling
+    if AG.ONE_CALL_DECODER:
+        from cips_3dplusplus_amd import decoder_grad as DG
+        hip.KERNEL_EVENTS["decoder_grad_forward"], hip.KERNEL_EVENTS["decoder_grad_backward"] = [], []
+        stride, hip.KERNEL_EVENTS_STRIDE = hip.KERNEL_EVENTS_STRIDE, 1
+        res = proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=14, N_steps_app=0, w_avg_samples=2000,
+                                 azim_init=(-1.0, 3.0))          # (kept: the node's plans are keyed weakly by the loop's copy of the decoder)
+        torch.cuda.synchronize()
+        hip.KERNEL_EVENTS_STRIDE = stride
+        evf, evb = hip.KERNEL_EVENTS.pop("decoder_grad_forward"), hip.KERNEL_EVENTS.pop("decoder_grad_backward")
+        # (the loop works on a deep copy of G: take the layer list from whichever decoder the node planned for)
+        infos = [pl.info for plans in DG._PLANS.values() for pl in plans.values()]
+        if evf and evb and infos:
+            info = infos[-1]
+            gemm = sum(2.0 * 2 * i["Cin"] * i["Cout"] * i["H"] * i["W"] for i in info if i["kind"] < 2)
+            rgbf = sum(2.0 * 2 * i["Cin"] * 3 * i["Ho"] * i["Wo"] for i in info if i["kind"] >= 2)
+            med = lambda ev: statistics.median(sorted(a.elapsed_time(b) for a, b in ev)[2:])      # noqa: E731 (ms; the first steps build plans)
+            peak = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
+            rows = []
+            for name, ev, mult, what in (("decoder_node_forward", evf, 1.0, "cips3d_decoder_grad_forward: modulation heads + table, 26 GEMMs, FIR / activation / ToRGB launches, outputs kept"),
+                                         ("decoder_node_backward", evb, 2.0, "cips3d_decoder_grad_backward: per layer the weight-gradient and the data-gradient GEMM (+ fused activation / ToRGB backward), modulation and style backward")):
+                ms = med(ev)
+                fl = mult * (gemm + rgbf)
+                rows.append({"kind": name, "what": what, "launch_group_ms": ms, "flop": fl, "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+                             "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
+                             "share_of_step": ms / line["ms_per_step"]})
+            line["roofline"]["kernels"] = rows
+        del res
     return line
 
 

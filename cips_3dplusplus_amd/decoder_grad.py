@@ -325,7 +325,14 @@ class GradPlan:
         rgb = torch.empty(self.B, 3, H, W, device=self.dev)
         io = self._io(features, noise)
         io.rgb = rgb.data_ptr()
+        ev = hip.want_events("decoder_grad_forward")          # (bench.py: the node's launches between two events)
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if ev is not None else None
+        if pair:
+            pair[0].record()
         _lib.check(lib.cips3d_decoder_grad_forward(C.byref(self.plan), C.byref(io), _lib.stream_ptr()), "cips3d_decoder_grad_forward")
+        if pair:
+            pair[1].record()
+            ev.append(pair)
         return rgb
 
     def backward(self, features, noise, d_rgb, need_features=True):
@@ -336,7 +343,14 @@ class GradPlan:
         io.d_rgb = dev_ptr(d_rgb, "d_rgb")
         d_features = torch.empty_like(features) if need_features else None
         io.d_features = dev_ptr(d_features, "d_features", True)
+        ev = hip.want_events("decoder_grad_backward")
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if ev is not None else None
+        if pair:
+            pair[0].record()
         _lib.check(lib.cips3d_decoder_grad_backward(C.byref(self.plan), C.byref(io), _lib.stream_ptr()), "cips3d_decoder_grad_backward")
+        if pair:
+            pair[1].record()
+            ev.append(pair)
         o0, o1 = self.out_range
         out = self.ws[o0:o1].clone()
         v = lambda o, *shape: out[o - o0:o - o0 + int(torch.Size(shape).numel())].view(*shape)     # noqa: E731
