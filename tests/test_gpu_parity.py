@@ -417,6 +417,35 @@ def test_full_size_generator_golden(golden, tag, res, D, N, static, trunc):
     assert maxdiff(r["sdf"].flatten()[::stride].cpu(), fx[f"{tag}.sdf_s"]) < 1e-4
 
 
+@pytest.mark.parametrize("mode", ["fp32_exact", "pair", "ws"])
+@pytest.mark.parametrize("tag,res,D,N,static,trunc", [FULL[2], FULL[0]])
+def test_full_size_generator_golden_in_the_other_render_arithmetics(golden, monkeypatch, mode, tag, res, D, N, static, trunc):
+    """The release-size reference goldens through the whole forward in IEEE-fp32 arithmetic (Generator.set_precision("fp32_exact"):
+    render kernel AND decoder on the fp32 matrix instruction) and through the two opt-in render kernels (32 points per wave,
+    CIPS3D_NERF_PAIR=1; weight-stationary, CIPS3D_NERF_WS=1): the same bars as the default path."""
+    fx = golden("full_size")
+    cfg = configs.ffhq_G_cfg(res, D)
+    G = pkg.build_generator(cfg, DEV, seed=1)
+    if mode == "fp32_exact":
+        G.set_precision("fp32_exact")
+    else:
+        monkeypatch.setenv("CIPS3D_NERF_PAIR" if mode == "pair" else "CIPS3D_NERF_WS", "1")
+    zs, nb, means = weights.synth_inputs(cfg, batch=1, seed=12345)
+    G.style_render_mean, G.style_decoder_mean = cu(means[0]), cu(means[1])
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[0.31, -0.08]], device=DEV))
+    r = G(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+          truncation=trunc, nerf_cfg=dict(N_samples=N, perturb=False, static_viewdirs=static), return_sdf=True,
+          return_xyz=True)
+    stride = int(fx["stride"])
+    d_rgb = maxdiff(r["rgb"].flatten()[::stride].cpu(), fx[f"{tag}.rgb_s"])
+    d_thumb = maxdiff(r["thumb_rgb"].cpu(), fx[f"{tag}.thumb_rgb"])
+    print(f"{tag} [{mode}]: rgb diff {d_rgb:.2e}, thumb diff {d_thumb:.2e}")
+    assert d_rgb < 1e-3 and d_thumb < 1e-3
+    for k in ("mask", "depth", "xyz"):
+        assert maxdiff(r[k].cpu(), fx[f"{tag}.{k}"]) < 1e-4, k
+    assert maxdiff(r["sdf"].flatten()[::stride].cpu(), fx[f"{tag}.sdf_s"]) < 1e-4
+
+
 def test_planned_forward_equals_per_op_path(golden):
     """cips3d_generator_forward (one call) and the per-op launches run the same kernels: identical outputs."""
     fx = golden("tiny_generator")
