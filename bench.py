@@ -22,6 +22,7 @@ Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
+import math
 import os
 import statistics
 import subprocess
@@ -365,9 +366,12 @@ class ForwardWorkload:
                 "avg_launch_ms": kern_ms, "flop_per_launch": flops, "launches_timed": n_events,
                 "timed_every_nth_step": getattr(self, "event_stride", EVENT_STRIDE)}
         if kernels:       # every big kernel of the step, the dominant one first (its row repeats the fields above)
-            head["kernels"] = [{"kind": "render", "launches_per_step": 1, **{k: head[k] for k in (
-                "kernel", "avg_launch_ms", "bound", "flop_per_launch", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")}}] \
-                + self.decoder_kernels()[0]
+            try:
+                head["kernels"] = [{"kind": "render", "launches_per_step": 1, **{k: head[k] for k in (
+                    "kernel", "avg_launch_ms", "bound", "flop_per_launch", "achieved", "peak", "unit", "frac", "traffic", "traffic_source")}}] \
+                    + self.decoder_kernels()[0]
+            except Exception as exc:           # noqa: BLE001 (the per-kernel table is secondary to the line)
+                head["kernels_error"] = f"{type(exc).__name__}: {exc}"[:400]
         return head
 
 
@@ -575,7 +579,10 @@ def main():
         }
         if world == 1 and a.decoder_precision == "fp32":
             # the default arithmetic (split-fp16 products) against the fp32 matrix instruction on this run's own inputs
-            line["fp32_equivalence"] = wl.fp32_equivalence()
+            try:
+                line["fp32_equivalence"] = wl.fp32_equivalence()
+            except Exception as exc:           # noqa: BLE001
+                line["fp32_equivalence"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
         if world > 1:
             # ranks that actually exchanged over RCCL: 0 when the gather ran over gloo (ranks sharing a device on a small box)
             line["rccl_ranks"] = torch.distributed.get_world_size() if backend == "nccl" else 0
@@ -602,27 +609,54 @@ def main():
                             ("BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
                              "(HBM bytes of those stages halved; slower: the stages are VALU-bound)",
                              dict(n_samples=24, batch=4, precision="bf16_storage"))):
-                w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False)
-                steps2 = max(10, a.steps // 2)
-                m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
-                also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
-                             "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
-                             "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
-                             "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
-                             "dtype": DTYPE_NAMES[kw["precision"]],
-                             "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
-                del w2
+                # (a secondary entry must never cost the headline line: a failure is reported in its place)
+                try:
+                    w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False)
+                    steps2 = max(10, a.steps // 2)
+                    m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
+                    also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
+                                 "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
+                                 "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
+                                 "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
+                                 "dtype": DTYPE_NAMES[kw["precision"]],
+                                 "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
+                    del w2
+                except Exception as exc:       # noqa: BLE001
+                    also.append({"what": tag, "error": f"{type(exc).__name__}: {exc}"[:400]})
                 torch.cuda.empty_cache()
-            also.append(multiview_workload(dev, min(a.repeats, 3)))
-            inv = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3))
-            inv["what"] = "BASELINE config 5: one flip-inversion step"
-            also.append(inv)
+            try:
+                also.append(multiview_workload(dev, min(a.repeats, 3)))
+            except Exception as exc:           # noqa: BLE001
+                also.append({"what": "BASELINE config 4 (sample_multi_view)", "error": f"{type(exc).__name__}: {exc}"[:400]})
+            try:
+                inv = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3))
+                inv["what"] = "BASELINE config 5: one flip-inversion step"
+                also.append(inv)
+            except Exception as exc:           # noqa: BLE001
+                also.append({"what": "BASELINE config 5: one flip-inversion step", "error": f"{type(exc).__name__}: {exc}"[:400]})
             line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             from cips_3dplusplus_amd import configs
-            line["cpu_baseline"] = cpu_baseline(configs.ffhq_G_cfg(a.res, a.depth),
-                                                {"N_samples": a.n_samples, "perturb": True, "static_viewdirs": False}, B)
-        print(json.dumps(line, allow_nan=False), flush=True)
+            try:
+                line["cpu_baseline"] = cpu_baseline(configs.ffhq_G_cfg(a.res, a.depth),
+                                                    {"N_samples": a.n_samples, "perturb": True, "static_viewdirs": False}, B)
+            except Exception as exc:           # noqa: BLE001 (the reported baseline must not cost the measured line)
+                line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
+        try:
+            text = json.dumps(line, allow_nan=False)
+        except ValueError:                     # a non-finite number in a secondary entry: name it, keep the line
+            def finite(o):
+                if isinstance(o, float) and not math.isfinite(o):
+                    return None
+                if isinstance(o, dict):
+                    return {k: finite(v) for k, v in o.items()}
+                if isinstance(o, (list, tuple)):
+                    return [finite(v) for v in o]
+                return o
+            line = finite(line)
+            line["note"] = "non-finite numbers were replaced by null"
+            text = json.dumps(line, allow_nan=False)
+        print(text, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
