@@ -49,9 +49,7 @@ EVENT_STRIDE = 8                           # HIP events around the dominant kern
 # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot share a pass with timing or
 # with each other): tools/profile_round.sh writes one summary per workload, stamped with the source hash of the library that ran.
 # An entry is replayed only while that hash equals the loaded library's (a kernel edit silently invalidated round 3's file).
-TRAFFIC_FILES = {"headline": os.path.join("profiles", "r04_pmc_all_kernels.json"),
-                 "n64": os.path.join("profiles", "r04_pmc_n64_traffic.json"),
-                 "b4_bf16": os.path.join("profiles", "r04_pmc_b4_traffic.json")}
+TRAFFIC_FILES = {"headline": "pmc_all_kernels.json", "n64": "pmc_n64_traffic.json", "b4_bf16": "pmc_b4_traffic.json"}   # profiles/rNN_<name>, newest round first
 HBM_PEAK_TBS = 8.0                         # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured with a float4 copy)
 PREROLL_MAX = 10                           # untimed regions until two consecutive ones agree within 1 % (clocks / caches settled)
 
@@ -142,9 +140,11 @@ class ForwardWorkload:
         self.last_gathered = None
 
     def name(self):
-        return (f"ffhq_r{self.res}_nerf64x64x{self.n_samples}_D{self.depth}_B{self.B}_{self.precision} "
-                f"(test__rendering_time loop body: perturb={not self.deterministic}, "
-                f"{'fixed' if self.deterministic else 'fresh'} decoder noise, random-init weights)")
+        return f"ffhq_r{self.res}_nerf64x64x{self.n_samples}_D{self.depth}_B{self.B}_{self.precision}"
+
+    def note(self):
+        return (f"test__rendering_time loop body: perturb={not self.deterministic}, "
+                f"{'fixed' if self.deterministic else 'fresh'} decoder noise, random-init weights")
 
     def render(self):
         e, f, n, fa, _ = self.cam
@@ -256,23 +256,33 @@ class ForwardWorkload:
             key = "b4_bf16"
         if key is None:
             return {}, "no PMC pass committed for this workload"
-        tp = os.path.join(ROOT, TRAFFIC_FILES[key])
-        if not os.path.exists(tp):
-            return {}, f"{TRAFFIC_FILES[key]} not present"
-        d = json.load(open(tp))
+        import glob
         try:
             with open(build.STAMP) as fh:
                 lib_hash = fh.read().strip()
         except OSError:
             lib_hash = None
-        if not d.get("lib_srchash") or d.get("lib_srchash") != lib_hash:
-            return {}, (f"{TRAFFIC_FILES[key]} was collected on library {str(d.get('lib_srchash'))[:12]}, this run loads "
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + TRAFFIC_FILES[key])), reverse=True)
+        if not cands:
+            return {}, f"no profiles/rNN_{TRAFFIC_FILES[key]}"
+        d, rel = None, None
+        for tp in cands:
+            try:
+                dd = json.load(open(tp))
+            except (OSError, ValueError):
+                continue
+            if dd.get("lib_srchash") and dd.get("lib_srchash") == lib_hash:
+                d, rel = dd, os.path.relpath(tp, ROOT)
+                break
+        if d is None:
+            return {}, (f"{os.path.relpath(cands[0], ROOT)} was collected on another library build than the loaded "
                         f"{str(lib_hash)[:12]}: not replayed")
         out = {}
-        for e in d.get("kernels", []):
+        # summaries since round 5 carry one row per (kernel, grid); the row with the most launches is the kernel's dominant shape
+        for e in sorted(d.get("kernels", []), key=lambda e: e.get("launches", 0)):
             if "hbm_fetch_MB_x2" in e and "hbm_write_MB" in e:
                 out[e["kernel"]] = (e["hbm_fetch_MB_x2"] * 1e6 + e["hbm_write_MB"] * 1e6,
-                                    f"replayed from {TRAFFIC_FILES[key]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                    f"replayed from {rel} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                     f"this workload on this library build; FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md)")
         return out, None
 
@@ -335,6 +345,12 @@ class ForwardWorkload:
             else:
                 row["traffic"] = None
             rows.append(row)
+        # a replayed counter belongs to the kernel's dominant shape only (same name, same grid, different K: the 256 -> 512 layer
+        # reads half the planes of the 512 -> 512 ones): the other rows of that kernel carry no traffic
+        for r in rows:
+            same = [q for q in rows if q.get("kernel") == r.get("kernel") and q["kind"] != "fused_stage"]
+            if r.get("traffic") is not None and r is not max(same, key=lambda q: q["launches_per_step"]):
+                r["traffic"], r["traffic_source"] = None, "no counter pass keyed on this shape"
         return rows, why
 
     def roofline(self, kern_ms, n_events, kernels=False):
@@ -354,8 +370,8 @@ class ForwardWorkload:
         # (what the round-1 kernel was bounded by) is kept beside it.
         exact = self.precision == "fp32_exact"
         peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
-        head = {"kernel": ("nerf_render_pair_kernel<16, 0, true> (exact fp32: v_mfma_f32_16x16x4_f32)" if exact else
-                           "nerf_render_kernel") + " (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
+        head = {"kernel": ("nerf_render_kernel<16,4,F32> (v_mfma_f32_16x16x4_f32)" if exact else
+                           "nerf_render_kernel<16,4>") + " (FiLM-SIREN point MLP + compositing)", "bound": "mfma",
                 "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                 "peak_definition": (f"fp32 matrix instruction peak {MFMA_F32_PEAK_TFLOPS:.1f} TFLOP/s" if exact else
                                     f"fp16 dense MFMA peak {MFMA_F16_PEAK_TFLOPS:.0f} TFLOP/s / {SPLIT_PRODUCTS} fp16 products per "
@@ -421,7 +437,7 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
         from cips_3dplusplus_amd import decoder_grad as DG
         hip.KERNEL_EVENTS["decoder_grad_forward"], hip.KERNEL_EVENTS["decoder_grad_backward"] = [], []
         stride, hip.KERNEL_EVENTS_STRIDE = hip.KERNEL_EVENTS_STRIDE, 1
-        res = proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=14, N_steps_app=0, w_avg_samples=2000,
+        kept = proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=14, N_steps_app=0, w_avg_samples=2000,
                                  azim_init=(-1.0, 3.0))          # (kept: the node's plans are keyed weakly by the loop's copy of the decoder)
         torch.cuda.synchronize()
         hip.KERNEL_EVENTS_STRIDE = stride
@@ -432,7 +448,7 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
             info = infos[-1]
             gemm = sum(2.0 * 2 * i["Cin"] * i["Cout"] * i["H"] * i["W"] for i in info if i["kind"] < 2)
             rgbf = sum(2.0 * 2 * i["Cin"] * 3 * i["Ho"] * i["Wo"] for i in info if i["kind"] >= 2)
-            med = lambda ev: statistics.median(sorted(a.elapsed_time(b) for a, b in ev)[2:])      # noqa: E731 (ms; the first steps build plans)
+            med = lambda ev: statistics.median([a.elapsed_time(b) for a, b in ev][2:])      # noqa: E731 (ms; the first two steps build plans)
             peak = MFMA_F16_PEAK_TFLOPS / SPLIT_PRODUCTS
             rows = []
             for name, ev, mult, what in (("decoder_node_forward", evf, 1.0, "cips3d_decoder_grad_forward: modulation heads + table, 26 GEMMs, FIR / activation / ToRGB launches, outputs kept"),
@@ -443,7 +459,7 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
                              "peak": peak, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / peak,
                              "share_of_step": ms / line["ms_per_step"]})
             line["roofline"]["kernels"] = rows
-        del res
+        del kept
     return line
 
 
@@ -475,11 +491,110 @@ def multiview_workload(dev, repeats, n_frames=8, n_samples=128, res=1024):
         elapsed.append((time.perf_counter() - t0) / 3)
     med = statistics.median(elapsed)
     assert out["rgb"].dtype == torch.uint8 and out["rgb"].shape[0] == n_frames
-    return {"what": "BASELINE config 4, the demo loop's semantics on one GPU: sample_multi_view(yaw, 8 frames, N = 128, truncation 0.5, "
+    return {"tag": "config4_multiview_8f_n128", "what": "BASELINE config 4, the demo loop's semantics on one GPU: sample_multi_view(yaw, 8 frames, N = 128, truncation 0.5, "
                     "fixed noise buffers, perturb off, xyz returned, uint8 frames)",
             "metric": "rendered views/s", "value": n_frames / med, "unit": "views/s", "ms_per_step": med / n_frames * 1e3,
             "steps": 3 * n_frames, "repeats": repeats, "ms_per_step_repeats": [e / n_frames * 1e3 for e in elapsed], "dtype": DTYPE_NAMES["fp32"],
             "config": {"workload": f"ffhq_r{res}_nerf64x64x{n_samples}_D2_B1 x {n_frames} frames (multiview.sample_multi_view)"}}
+
+
+LINE_LIMIT = 6144                          # the driver's record keeps a bounded tail of stdout: round 4's 36 KB line was not parsed
+DTYPE_SHORT = {"fp32": "f32 (split-fp16 MFMA products x3, f32 accumulate and storage)",
+               "fp32_exact": "f32 (IEEE fp32 MFMA products everywhere)",
+               "bf16": "bf16 decoder GEMM operands (f32 accumulate/storage), f32 NeRF",
+               "bf16_storage": "bf16 decoder GEMM operands + bf16 stage activations, f32 NeRF"}
+
+
+def _r(x, sig=4):
+    """Numbers of the compact line carry `sig` significant digits (the detail file keeps them whole)."""
+    if isinstance(x, float):
+        return float(f"{x:.{sig}g}") if math.isfinite(x) else None
+    return x
+
+
+def _roof_head(rf):
+    if not rf:
+        return None
+    keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")
+    out = {k: _r(rf.get(k)) for k in keys}
+    out["kernel"] = str(out["kernel"] or "")[:60]
+    return out
+
+
+def compact(line, detail_name):
+    """The driver's line: the contract's fields, the roofline head with one short row per big kernel, cpu_baseline, one short
+    row per `also` entry.  Everything else (repeats, pre-roll, marks, bounds, provenance prose) stays in the detail file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "data", "repeats", "rccl_ranks", "ranks", "dist_backend", "physical_gpus")
+    out = {k: _r(line[k], 6) for k in keep if k in line}
+    out["dtype"] = line.get("dtype_short", line.get("dtype", ""))[:80]
+    out["ms_per_step_repeats"] = [_r(v) for v in line.get("ms_per_step_repeats", [])][:8]
+    out["config"] = {k: (v[:100] if isinstance(v, str) else v) for k, v in line.get("config", {}).items()}
+    rf = line.get("roofline")
+    out["roofline"] = _roof_head(rf)
+    if rf and rf.get("kernels"):
+        rows = []
+        for k in rf["kernels"][:10]:
+            rows.append({"kind": k.get("kind"), "c_in": k.get("c_in"), "res": k.get("out_res"), "n": k.get("launches_per_step"),
+                         "us": _r(k["avg_launch_ms"] * 1e3) if k.get("avg_launch_ms") else None, "bound": k.get("bound"),
+                         "frac": _r(k.get("frac")), "traffic": _r(k.get("traffic"))})
+        out["roofline"]["kernels"] = rows
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: (_r(v) if not isinstance(v, str) else v[:120]) for k, v in cb.items()
+                               if k in ("value", "unit", "cores", "kind", "sample", "error")}
+    if "also" in line:
+        rows = []
+        for e in line["also"][:14]:
+            row = {"workload": str(e.get("tag") or e.get("config", {}).get("workload") or e.get("what", ""))[:48]}
+            if "error" in e:
+                row["error"] = e["error"][:80]
+            else:
+                row.update(value=_r(e.get("value")), unit=e.get("unit"), ms_per_step=_r(e.get("ms_per_step")),
+                           frac=_r((e.get("roofline") or {}).get("frac")))
+            rows.append(row)
+        out["also"] = rows
+    if "fp32_equivalence" in line and "max_abs_rgb_difference_split_vs_fp32_mfma" in line["fp32_equivalence"]:
+        out["split_vs_fp32_exact_max_abs"] = _r(line["fp32_equivalence"]["max_abs_rgb_difference_split_vs_fp32_mfma"])
+    out["detail"] = detail_name
+    text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    # never exceed the limit: drop the secondary tables from the end, one at a time (the detail file has them)
+    for victim in ("also", "ms_per_step_repeats", "cpu_baseline.sample", "roofline.kernels"):
+        if len(text) <= LINE_LIMIT:
+            break
+        a, _, b = victim.partition(".")
+        if b and isinstance(out.get(a), dict):
+            out[a].pop(b, None)
+        else:
+            out.pop(a, None)
+        out["truncated"] = out.get("truncated", []) + [victim]
+        text = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    return text
+
+
+def finite(o):
+    if isinstance(o, float) and not math.isfinite(o):
+        return None
+    if isinstance(o, dict):
+        return {k: finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [finite(v) for v in o]
+    return o
+
+
+def emit(line, detail_path):
+    """Full record -> `detail_path` (JSON, one object); compact line -> the LAST line of stdout."""
+    line = finite(line)
+    name = os.path.relpath(detail_path, ROOT) if detail_path else None
+    if detail_path:
+        try:
+            with open(detail_path, "w") as fh:
+                json.dump(line, fh, allow_nan=False, indent=1)
+        except OSError as exc:                 # a read-only tree must not cost the line
+            name = f"not written: {exc}"[:80]
+    text = compact(line, name)
+    print(text, flush=True)
+    return text
 
 
 def spawn_ranks(a):
@@ -515,6 +630,8 @@ def main():
     ap.add_argument("--decoder-precision", default="fp32", choices=["fp32", "fp32_exact", "bf16", "bf16_storage"],
                     help="bf16 = BASELINE config 3 (decoder GEMMs on bf16 MFMA, fp32 accumulate; NeRF stays fp32); "
                          "bf16_storage = additionally the up-sampling stages' pre-FIR activations live in HBM as bf16")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where rank 0 writes the full record (repeats, pre-roll, per-kernel bounds, provenance); '' = nowhere")
     ap.add_argument("--dump-gathered", default=None, help="rank 0 saves the last step's gathered uint8 frames (torch.save)")
     a = ap.parse_args()
 
@@ -569,11 +686,11 @@ def main():
             "value": value, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": med / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (value / PUBLISHED_VIEWS_PER_S) if published_cfg else None,
-            "dtype": DTYPE_NAMES[a.decoder_precision],
+            "dtype": DTYPE_NAMES[a.decoder_precision], "dtype_short": DTYPE_SHORT[a.decoder_precision],
             "data": "synthetic",
             "repeats": a.repeats, "ms_per_step_repeats": [e / a.steps * 1e3 for e in elapsed],
             "preroll_ms_per_step": [e / a.steps * 1e3 for e in wl.preroll],
-            "config": {"workload": wl.name(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
+            "config": {"workload": wl.name(), "loop": wl.note(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
                        "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
             "roofline": wl.roofline(kern_ms, n_ev, kernels=(world == 1)),
         }
@@ -594,19 +711,20 @@ def main():
             also = []
             del wl
             torch.cuda.empty_cache()
-            for tag, kw in (("metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
-                            ("headline workload with IEEE-fp32 products everywhere (fp32_exact: the point MLP and the decoder GEMMs on the "
+            for short, tag, kw in (
+                            ("n64", "metric's '64^3' reading: 64x64 rays x 64 samples", dict(n_samples=64, batch=1, precision="fp32")),
+                            ("fp32_exact", "headline workload with IEEE-fp32 products everywhere (fp32_exact: the point MLP and the decoder GEMMs on the "
                              "fp32 matrix instruction) instead of the default split-fp16 products", dict(n_samples=24, batch=1, precision="fp32_exact")),
-                            ("BASELINE config 2: FFHQ 256^2, D = 2, single view", dict(n_samples=24, batch=1, precision="fp32", res=256)),
-                            ("BASELINE config 2 with the deep renderer: FFHQ 256^2, D = 8", dict(n_samples=24, batch=1, precision="fp32",
+                            ("config2_r256_D2", "BASELINE config 2: FFHQ 256^2, D = 2, single view", dict(n_samples=24, batch=1, precision="fp32", res=256)),
+                            ("config2_r256_D8", "BASELINE config 2 with the deep renderer: FFHQ 256^2, D = 8", dict(n_samples=24, batch=1, precision="fp32",
                                                                                                res=256, depth=8)),
-                            ("BASELINE config 1 on the HIP path: FFHQ 64x64 output (no up-sampling), D = 8, N = 24, single view (its CPU "
+                            ("config1_r64_D8_hip", "BASELINE config 1 on the HIP path: FFHQ 64x64 output (no up-sampling), D = 8, N = 24, single view (its CPU "
                              "figure: profiles/r01_config1_cpu_vs_gpu.json)", dict(n_samples=24, batch=1, precision="fp32", res=64, depth=8)),
-                            ("BASELINE config 4's per-view shape on one GPU: 1024^2 with N = 128 samples per ray (the reference demo's "
+                            ("config4_shape_n128", "BASELINE config 4's per-view shape on one GPU: 1024^2 with N = 128 samples per ray (the reference demo's "
                              "value; the 8-GPU leg of the metric shards whole views, `--gpus N`)", dict(n_samples=128, batch=1, precision="fp32")),
-                            ("BASELINE config 3: 1024^2, batch 4, bf16 decoder GEMM operands (fp32 storage: the faster of the two bf16 "
+                            ("config3_B4_bf16", "BASELINE config 3: 1024^2, batch 4, bf16 decoder GEMM operands (fp32 storage: the faster of the two bf16 "
                              "modes on this build)", dict(n_samples=24, batch=4, precision="bf16")),
-                            ("BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
+                            ("config3_B4_bf16_storage", "BASELINE config 3, storage mode: bf16 operands + bf16 storage of the up-sampling stages' activations "
                              "(HBM bytes of those stages halved; slower: the stages are VALU-bound)",
                              dict(n_samples=24, batch=4, precision="bf16_storage"))):
                 # (a secondary entry must never cost the headline line: a failure is reported in its place)
@@ -614,7 +732,7 @@ def main():
                     w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False)
                     steps2 = max(10, a.steps // 2)
                     m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
-                    also.append({"what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
+                    also.append({"tag": short, "what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
                                  "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
                                  "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
                                  "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
@@ -622,18 +740,18 @@ def main():
                                  "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
                     del w2
                 except Exception as exc:       # noqa: BLE001
-                    also.append({"what": tag, "error": f"{type(exc).__name__}: {exc}"[:400]})
+                    also.append({"tag": short, "what": tag, "error": f"{type(exc).__name__}: {exc}"[:400]})
                 torch.cuda.empty_cache()
             try:
                 also.append(multiview_workload(dev, min(a.repeats, 3)))
             except Exception as exc:           # noqa: BLE001
-                also.append({"what": "BASELINE config 4 (sample_multi_view)", "error": f"{type(exc).__name__}: {exc}"[:400]})
+                also.append({"tag": "config4_multiview_8f_n128", "what": "BASELINE config 4 (sample_multi_view)", "error": f"{type(exc).__name__}: {exc}"[:400]})
             try:
                 inv = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3))
-                inv["what"] = "BASELINE config 5: one flip-inversion step"
+                inv["what"], inv["tag"] = "BASELINE config 5: one flip-inversion step", "config5_inversion_pose"
                 also.append(inv)
             except Exception as exc:           # noqa: BLE001
-                also.append({"what": "BASELINE config 5: one flip-inversion step", "error": f"{type(exc).__name__}: {exc}"[:400]})
+                also.append({"tag": "config5_inversion_pose", "what": "BASELINE config 5: one flip-inversion step", "error": f"{type(exc).__name__}: {exc}"[:400]})
             line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             from cips_3dplusplus_amd import configs
@@ -642,21 +760,7 @@ def main():
                                                     {"N_samples": a.n_samples, "perturb": True, "static_viewdirs": False}, B)
             except Exception as exc:           # noqa: BLE001 (the reported baseline must not cost the measured line)
                 line["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:400]}
-        try:
-            text = json.dumps(line, allow_nan=False)
-        except ValueError:                     # a non-finite number in a secondary entry: name it, keep the line
-            def finite(o):
-                if isinstance(o, float) and not math.isfinite(o):
-                    return None
-                if isinstance(o, dict):
-                    return {k: finite(v) for k, v in o.items()}
-                if isinstance(o, (list, tuple)):
-                    return [finite(v) for v in o]
-                return o
-            line = finite(line)
-            line["note"] = "non-finite numbers were replaced by null"
-            text = json.dumps(line, allow_nan=False)
-        print(text, flush=True)
+        emit(line, a.detail)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -152,7 +152,8 @@ class Generator(nn.Module):
         """Arithmetic of the whole forward.  "fp32_exact": IEEE-fp32 products everywhere a GEMM computes -- the decoder on the
         fp32 matrix instruction AND the renderer's point MLP (VolumeFeatureRenderer.set_precision) -- i.e. the reference's own
         arithmetic (cips3d/volume_renderer.py:74-85, models/model_v3.py:296-312); any other value: the decoder precision of
-        that name with the renderer in its default (fp32-equivalent split-fp16 products)."""
+        that name with the renderer in its default (fp32-equivalent split-fp16 products).  "fp32_exact" is an inference mode:
+        the differentiable forward raises NotImplementedError in it (renderer.py: no exact-fp32 stash / fused backward)."""
         self.decoder.set_precision(precision)
         self.renderer.set_precision("fp32_exact" if precision == "fp32_exact" else "fp32")
         return self

@@ -207,6 +207,11 @@ class VolumeFeatureRenderer(nn.Module):
         else:                       # FiLM table computed by the caller (differentiable path: autograd.film_table)
             film = film.detach().float().contiguous()
         if stash is not None:       # differentiable forward: hip.nerf_forward_stash buffers, filled for the fused backward
+            if self.exact_fp32:
+                # the stash instantiation and the fused backward exist in split-fp16 arithmetic only: gradients would be taken
+                # against another forward than the one inference runs in this mode
+                raise NotImplementedError('set_precision("fp32_exact") is inference-only: the differentiable forward (stash + fused '
+                                          'backward) has no exact-fp32 instantiation; use set_precision("fp32") for gradients')
             n_chunks = stash["n_chunks"]
         if n_chunks is None:
             n_chunks = hip.nerf_suggest_chunks(B, img_size, N_samples)

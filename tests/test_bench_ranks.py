@@ -48,7 +48,7 @@ def test_two_rank_bench_step_gathers_the_single_rank_frames(tmp_path):
                        text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    assert len(lines) == 1 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0], r.stdout
     line = json.loads(lines[0])
     rccl = 2 if torch.cuda.device_count() >= 2 else 0      # `rccl_ranks` counts ranks that exchanged over RCCL: none over gloo
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["rccl_ranks"] == rccl and line["scaling"] == "weak"
@@ -99,24 +99,42 @@ def test_the_drivers_eight_rank_command_runs_end_to_end():
 
 
 @pytest.mark.gpu
-def test_single_gpu_line_prices_every_big_kernel():
-    """`roofline.kernels` of the N = 1 line: the render kernel, the 64^2 chain GEMM and the four fused up-sampling stages, each
-    with an in-run launch time, algorithmic work, a fraction of its bound in (0, 1) -- and launch times that add up to no more
-    than the step they are part of."""
-    r = subprocess.run([sys.executable, BENCH, "--steps", "10", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline", "--no-also"],
-                       env=_env(), capture_output=True, text=True, timeout=900)
+def test_single_gpu_line_prices_every_big_kernel(tmp_path):
+    """The N = 1 line as the driver reads it: the LAST stdout line, one compact JSON object under bench.LINE_LIMIT bytes, whose
+    `roofline.kernels` prices the render kernel, the 64^2 chain GEMM and the four fused up-sampling stages -- each with an in-run
+    launch time and a fraction of its bound in (0, 1), launch times adding up to no more than the step they are part of -- and
+    the full record (bounds, flop / bytes per launch, provenance) in the detail file beside it."""
+    sys.path.insert(0, ROOT)
+    import bench
+    detail = str(tmp_path / "detail.json")
+    r = subprocess.run([sys.executable, BENCH, "--steps", "10", "--warmup", "3", "--repeats", "2", "--no-cpu-baseline", "--no-also",
+                        "--detail", detail], env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < bench.LINE_LIMIT, len(last)
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert len(line["dtype"]) <= 80 and line["steps"] == 10 and line["value"] > 0
     rows = line["roofline"]["kernels"]
     assert rows[0]["kind"] == "render" and rows[0]["frac"] == line["roofline"]["frac"]
     kinds = [(k["kind"], k.get("c_in")) for k in rows]
     assert ("planes_gemm", 512) in kinds and {("fused_stage", c) for c in (32, 64, 128, 256)} <= set(kinds)
     total = 0.0
     for k in rows:
-        assert k["avg_launch_ms"] > 0 and k["launches_per_step"] >= 1
-        total += k["avg_launch_ms"] * k["launches_per_step"]
+        assert k["us"] > 0 and k["n"] >= 1
+        total += k["us"] * 1e-3 * k["n"]
         if k["kind"] in ("render", "planes_gemm", "lowres_gemm", "fused_stage"):
-            assert 0.0 < k["frac"] < 1.0 and k["achieved"] > 0 and k["bound"] in ("mfma", "hbm")
-            assert k.get("flop_per_launch", 0) > 0 or k.get("algorithmic_bytes", 0) > 0
+            assert 0.0 < k["frac"] < 1.0 and k["bound"] in ("mfma", "hbm")
             assert "traffic" in k               # measured bytes from a summary of THIS library build, or null
     assert 0.6 * line["ms_per_step"] < total < 1.05 * line["ms_per_step"]
+    # a replayed counter is keyed on the kernel's dominant shape: two GEMM rows of one kernel never carry the same bytes
+    gemm = [k["traffic"] for k in rows if k["kind"] in ("planes_gemm", "lowres_gemm") and k["traffic"] is not None]
+    assert len(gemm) == len(set(gemm))
+    full = json.load(open(detail))
+    assert full["value"] == pytest.approx(line["value"], rel=1e-4)
+    for k in full["roofline"]["kernels"]:
+        if k["kind"] in ("render", "planes_gemm", "lowres_gemm", "fused_stage"):
+            assert k.get("flop_per_launch", 0) > 0 or k.get("algorithmic_bytes", 0) > 0
+            assert k["achieved"] > 0 and k["avg_launch_ms"] > 0

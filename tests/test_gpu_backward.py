@@ -535,6 +535,12 @@ def test_path_selection_by_grad_requirements():
     close(r1["rgb"], r["rgb"].cpu(), 1e-5, "rgb on the two paths")
     r1["rgb"].square().mean().backward()
     assert G.decoder.conv1.conv.weight.grad is not None and float(G.decoder.conv1.conv.weight.grad.abs().max()) > 0
+    G.set_precision("fp32_exact")                       # an inference mode: a differentiable forward must not silently
+    with pytest.raises(NotImplementedError, match="inference-only"):    # run in another arithmetic
+        G(**kw)
+    with torch.no_grad():
+        close(G(**kw)["rgb"], r["rgb"].cpu(), 1e-4, "exact-fp32 inference next to the split forward")
+    G.set_precision("fp32")
     G.renderer.requires_grad_(True)                     # optim_render_params: the renderer's weights get gradients too
     r2 = G(**kw)
     (r2["rgb"].square().mean() + r2["thumb_rgb"].square().mean()).backward()

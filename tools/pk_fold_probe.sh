@@ -6,7 +6,7 @@
 O=gpurun_out/pk_probe.txt; : > $O
 run() {  # name, CIPS3D_CHAIN_SLP, flags
   export CIPS3D_CHAIN_SLP=$2 CIPS3D_HIPCC_FLAGS="$3"
-  python -m cips_3dplusplus_amd.build > /dev/null 2>&1
+  python -m cips_3dplusplus_amd.build > /tmp/pk_probe_build.log 2>&1 || { echo "== $1: BUILD FAILED (no result)" >> $O; tail -3 /tmp/pk_probe_build.log >> $O; return; }
   echo "== $1  (CIPS3D_CHAIN_SLP=$2 $3)" >> $O
   python tools/fold_repeat.py 60 2>&1 | grep "repeats differ" >> $O
 }
@@ -18,4 +18,7 @@ run "compiler-made chains + 16 wait states in front of each"            1 "-DCIP
 run "hand-made v_mov pair -> v_pk_fma_f32, 0 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=0"
 run "hand-made v_mov pair -> v_pk_fma_f32, 1 wait state between"        0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=1"
 run "hand-made v_mov pair -> v_pk_fma_f32, 3 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=3"
+# leave the tree as it was found: default flags, default library (as tools/ab_build.sh does)
+unset CIPS3D_CHAIN_SLP CIPS3D_HIPCC_FLAGS
+python -m cips_3dplusplus_amd.build > /tmp/pk_probe_build.log 2>&1 && echo "default rebuilt" || { echo "default rebuild FAILED"; tail -3 /tmp/pk_probe_build.log; }
 cat $O

@@ -25,6 +25,9 @@ def load(path):
     for r in csv.DictReader(open(path)):
         k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])
         k = re.sub(r"^void ", "", k).split("(")[0]
+        # one row per (kernel, grid): launches of one kernel on different shapes (the 512->512 chain GEMM and the half-grid
+        # 512->256 exit) must not share a mean
+        k = (k, int(r["Grid_Size"]))
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         agg[k]["_dur"].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return agg
@@ -49,7 +52,7 @@ def main(paths):
     out = {}
     for p in paths:
         for k, v in load(p).items():
-            e = out.setdefault(k, {"kernel": k})
+            e = out.setdefault(k, {"kernel": k[0], "grid": k[1]})
             e.setdefault("avg_us_under_pmc", round(mean(v["_dur"]) / 1e3, 1))
             e.setdefault("launches", len(v["_dur"]))
             if "GRBM_GUI_ACTIVE" in v:
