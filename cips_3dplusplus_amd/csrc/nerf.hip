@@ -113,11 +113,17 @@ extern "C" int cips3d_debug_sin(const float* x, float* ya, float* yh, int n, voi
 // one stamp pair around the whole kernel per workgroup (MI355X_MICROARCH.md, DVFS give-back item 6).  The sums go to a
 // buffer nothing else reads.
 __device__ unsigned long long g_nerf_clock[2];
+__device__ unsigned long long g_nerf_clock_wg[2 * 4096];      // the last launch's pair per workgroup (median over workgroups)
 extern "C" int cips3d_debug_read_clock(unsigned long long* out2) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out2, HIP_SYMBOL(g_nerf_clock), 16);
   unsigned long long z[2] = {0, 0};
   hipMemcpyToSymbol(HIP_SYMBOL(g_nerf_clock), z, 16);
+  return 0;
+}
+extern "C" int cips3d_debug_read_clock_wg(unsigned long long* out, int n_wg) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(g_nerf_clock_wg), (size_t)16 * (n_wg < 4096 ? n_wg : 4096));
   return 0;
 }
 #endif
@@ -706,8 +712,10 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   STAMP(5);   // last compositing tail
 #ifdef CIPS3D_CLOCK
   if (tid == 0) {
-    atomicAdd(&g_nerf_clock[0], __builtin_amdgcn_s_memtime() - clk_t0);
-    atomicAdd(&g_nerf_clock[1], __builtin_amdgcn_s_memrealtime() - clk_r0);
+    const unsigned long long dt_ = __builtin_amdgcn_s_memtime() - clk_t0, dr_ = __builtin_amdgcn_s_memrealtime() - clk_r0;
+    atomicAdd(&g_nerf_clock[0], dt_);
+    atomicAdd(&g_nerf_clock[1], dr_);
+    if (blockIdx.x < 4096) { g_nerf_clock_wg[2 * blockIdx.x] = dt_; g_nerf_clock_wg[2 * blockIdx.x + 1] = dr_; }
   }
 #endif
   if (a.fuse_finish) {

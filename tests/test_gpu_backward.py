@@ -535,12 +535,6 @@ def test_path_selection_by_grad_requirements():
     close(r1["rgb"], r["rgb"].cpu(), 1e-5, "rgb on the two paths")
     r1["rgb"].square().mean().backward()
     assert G.decoder.conv1.conv.weight.grad is not None and float(G.decoder.conv1.conv.weight.grad.abs().max()) > 0
-    G.set_precision("fp32_exact")                       # an inference mode: a differentiable forward must not silently
-    with pytest.raises(NotImplementedError, match="inference-only"):    # run in another arithmetic
-        G(**kw)
-    with torch.no_grad():
-        close(G(**kw)["rgb"], r["rgb"].cpu(), 1e-4, "exact-fp32 inference next to the split forward")
-    G.set_precision("fp32")
     G.renderer.requires_grad_(True)                     # optim_render_params: the renderer's weights get gradients too
     r2 = G(**kw)
     (r2["rgb"].square().mean() + r2["thumb_rgb"].square().mean()).backward()
@@ -551,6 +545,27 @@ def test_path_selection_by_grad_requirements():
         G(**kw)
     with torch.no_grad():
         G(**kw)                                          # inference is unaffected
+
+
+def test_exact_fp32_mode_is_inference_only():
+    """set_precision("fp32_exact") covers the whole inference forward; a differentiable forward in that mode must raise instead of
+    silently running the split-fp16 stash kernel (gradients against another forward than inference runs)."""
+    from cips_3dplusplus_amd.camera import Camera
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=1)
+    e, f, n, fa, _ = Camera.generate_camera_params(16, DEV, locations=torch.zeros(1, 2, device=DEV))
+    zs = [torch.randn(1, 256, device=DEV), torch.randn(1, 256, device=DEV)]
+    kw = dict(zs=zs, cam_poses=e, focals=f, img_size=16, near=n, far=fa, nerf_cfg=dict(N_samples=8, perturb=False),
+              noise_bufs=G.create_noise_bufs(16, DEV))
+    with torch.no_grad():
+        r = G(**kw)["rgb"].cpu()
+    G.set_precision("fp32_exact")
+    with torch.no_grad():
+        close(G(**kw)["rgb"], r, 1e-4, "exact-fp32 inference next to the split forward")
+    G.decoder.requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        G(**kw)
+    G.set_precision("fp32")
+    assert G(**kw)["rgb"].requires_grad
 
 
 def test_flip_inversion_loop_reduces_loss():

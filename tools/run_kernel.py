@@ -14,10 +14,13 @@ ap.add_argument("--depth", type=int, default=2)
 ap.add_argument("--n-samples", type=int, default=24)
 ap.add_argument("--res", type=int, default=1024)
 ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--precision", default="fp32", choices=["fp32", "fp32_exact"])
+ap.add_argument("--clock-json", default=None, help="-DCIPS3D_CLOCK build: append the in-kernel clock record to this file")
 a = ap.parse_args()
 dev = "cuda"
 cfg = configs.ffhq_G_cfg(a.res, a.depth)
 G = pkg.build_generator(cfg, dev, seed=0)
+G.set_precision(a.precision)
 B = a.batch
 e, f, n, fa, _ = Camera.generate_camera_params(64, dev, locations=torch.zeros(B, 2, device=dev))
 torch.manual_seed(0)
@@ -88,5 +91,24 @@ if a.what in ("nerf", "forward"):
         for _ in range(300):
             fn()
         raw.cips3d_debug_read_clock(buf)
-        print(f"  in-kernel shader clock of nerf_render_kernel ({a.what} loop): {buf[0] / buf[1] * 100:.0f} MHz "
+        print(f"  in-kernel shader clock of nerf_render_kernel ({a.what} loop, {a.precision}): {buf[0] / buf[1] * 100:.0f} MHz "
               f"(sum over workgroups: {buf[0]} shader cycles / {buf[1]} ticks of the 100 MHz reference)")
+        rec = {"loop": a.what, "precision": a.precision, "n_samples": a.n_samples, "depth": a.depth, "batch": a.batch,
+               "launches_summed": 300, "MHz_sum_over_workgroups": buf[0] / buf[1] * 100,
+               "cycles_per_workgroup_mean": buf[0] / 300 / (256 * a.batch)}
+        if hasattr(raw, "cips3d_debug_read_clock_wg"):
+            import statistics
+            nwg = 256 * a.batch
+            wg = (ctypes.c_ulonglong * (2 * nwg))()
+            raw.cips3d_debug_read_clock_wg(wg, nwg)
+            mhz = sorted(wg[2 * i] / wg[2 * i + 1] * 100 for i in range(nwg) if wg[2 * i + 1])
+            rec.update(MHz_median_over_workgroups=statistics.median(mhz), MHz_p05=mhz[len(mhz) // 20], MHz_p95=mhz[-1 - len(mhz) // 20],
+                       workgroups=len(mhz), stamped_ticks_median=statistics.median(wg[2 * i + 1] for i in range(nwg)),
+                       stamped_cycles_median=statistics.median(wg[2 * i] for i in range(nwg)))
+            print(f"  median over {len(mhz)} workgroups of the last launch: {rec['MHz_median_over_workgroups']:.0f} MHz "
+                  f"(p05 {rec['MHz_p05']:.0f}, p95 {rec['MHz_p95']:.0f}); stamped span {rec['stamped_ticks_median'] * 10:.0f} ns, "
+                  f"{rec['stamped_cycles_median']:.0f} shader cycles")
+        if a.clock_json:
+            import json
+            with open(a.clock_json, "a") as fh:
+                fh.write(json.dumps(rec) + "\n")
