@@ -223,7 +223,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 23           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 24           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

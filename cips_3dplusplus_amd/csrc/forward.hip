@@ -13,6 +13,14 @@
     if (rc_ != 0) return rc_; \
   } while (0)
 
+namespace {
+// a frame of a sequence (io.styles_resident): the measured range rows start from zero, as after the style phase's zeroing launch
+__global__ void __launch_bounds__(256) range_reset_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+}  // namespace
+
 extern "C" int64_t cips3d_sizeof_plan(void) { return (int64_t)sizeof(cips3d_generator_plan); }
 extern "C" int64_t cips3d_sizeof_io(void) { return (int64_t)sizeof(cips3d_forward_io); }
 extern "C" int64_t cips3d_sizeof_struct(int which) {
@@ -160,8 +168,24 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   // draws stay below 5.89).
   const bool ranged = P.range_ws != nullptr;
   if (ranged && (P.range_ws_words <= 0 || P.range_ws_words > (1 << 30) || !P.feat_amax || !P.feat_exp || !P.tmp_amax)) return CIPS3D_E_BADARG;
-  TRY(cips3d_style_phase(plan, io, -1, stream));
-  TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, IO.noise_bound > 0.f ? IO.noise_bound : 6.f, stream));
+  if (IO.styles_resident) {
+    // a frame of a sequence: styles, FiLM / modulation tables and the modulated weights (with their range constants) are the
+    // plan's, as the last full forward left them.  What every forward measures anew is zeroed; the call's draws (if any) take
+    // a launch of their own.
+    if (ranged) {
+      if (P.range_volatile_words <= 0 || P.range_volatile_words > P.range_ws_words) return CIPS3D_E_BADARG;
+      hipLaunchKernelGGL(range_reset_kernel, dim3((P.range_volatile_words + 255) / 256), dim3(256), 0, as_stream(stream), P.range_ws,
+                         P.range_volatile_words);
+      TRY(cips3d_launch_status());
+    }
+    if (IO.rng_n_normal < 0 || IO.rng_n_uniform < 0 || (IO.rng_n_normal > 0 && !IO.rng_normal) || (IO.rng_n_uniform > 0 && !IO.rng_uniform))
+      return CIPS3D_E_BADARG;
+    if (IO.rng_n_normal > 0 || IO.rng_n_uniform > 0)
+      TRY(cips3d_rng_fill(IO.rng_seed, IO.rng_base, IO.rng_normal, IO.rng_n_normal, IO.rng_uniform, IO.rng_n_uniform, stream));
+  } else {
+    TRY(cips3d_style_phase(plan, io, -1, stream));
+    TRY(cips3d_modulate_table(P.wm_table, P.wm_n, P.wm_rows, B, IO.noise_bound > 0.f ? IO.noise_bound : 6.f, stream));
+  }
 
   // ---- NeRF: rays -> samples -> FiLM-SIREN -> compositing
   cips3d_nerf_params np = P.nerf;

@@ -189,18 +189,31 @@ class Generator(nn.Module):
         return ent
 
     def _planned_forward(self, plan, zs, cam_poses, focals, near, far, perturb_u, noise_bufs, truncation, style_render,
-                         style_decoder, return_sdf, return_xyz, fresh_perturb=False):
+                         style_decoder, return_sdf, return_xyz, fresh_perturb=False, styles_resident=False):
         from . import hip
         B = plan.B
         z_r = z_d = mean_r = mean_d = None
+        ident = lambda t: (t.data_ptr(), t._version, tuple(t.shape))     # noqa: E731 (what a style table was computed from)
         if style_render is not None and style_decoder is not None:
-            plan.styles_r.copy_(style_render)       # explicit W+ styles bypass the mapping networks
-            plan.styles_d.copy_(style_decoder)
+            stamp = ("w+", ident(style_render), ident(style_decoder))
+            if not styles_resident:
+                plan.styles_r.copy_(style_render)       # explicit W+ styles bypass the mapping networks
+                plan.styles_d.copy_(style_decoder)
         else:
-            z_r, z_d = zs[0].float().contiguous(), zs[1].float().contiguous()
+            stamp = ("z", ident(zs[0]), ident(zs[1]), float(truncation))
             if truncation < 1:
-                mean_r = self.style_render_mean.reshape(-1).contiguous()
-                mean_d = self.style_decoder_mean.reshape(-1).contiguous()
+                stamp += (ident(self.style_render_mean), ident(self.style_decoder_mean))
+            if not styles_resident:
+                z_r, z_d = zs[0].float(), zs[1].float()
+                if z_r.shape[0] != B or z_d.shape[0] != B:
+                    # one latent for a batch of views (the multi-view loop with chunk > 1): the kernels read B rows
+                    if z_r.shape[0] != 1 or z_d.shape[0] != 1:
+                        raise ValueError(f"zs hold {z_r.shape[0]} / {z_d.shape[0]} latents for a batch of {B} views")
+                    z_r, z_d = z_r.expand(B, -1), z_d.expand(B, -1)
+                z_r, z_d = z_r.contiguous(), z_d.contiguous()
+                if truncation < 1:
+                    mean_r = self.style_render_mean.reshape(-1).contiguous()
+                    mean_d = self.style_decoder_mean.reshape(-1).contiguous()
         marks, hip.DECODER_MARKS = hip.DECODER_MARKS, None
         events = None
         lst = hip.want_events("nerf_render")
@@ -213,7 +226,7 @@ class Generator(nn.Module):
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
-            marks=None if marks is None else marks.io_fields())
+            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp)
         # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
         m2 = mask.transpose(0, 1).contiguous()
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
@@ -315,7 +328,13 @@ class Generator(nn.Module):
                        path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
                        eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
                        N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
-                       renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, **kwargs):
+                       renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, styles_resident=False,
+                       **kwargs):
+        """styles_resident (extension of the reference's call surface; multiview.sample_multi_view uses it): this call is a frame
+        of a sequence that renders ONE latent from many cameras (render_video_web_v10.py:1792-1824) -- the previous call of the
+        same shape already ran the mapping networks, the style heads and the modulate table for exactly these zs / styles /
+        truncation / noise buffers, and this call reuses its tables (bit-identical to recomputing them; plan.run checks the
+        promise).  Ignored on the per-op path."""
         assert len(zs) == 2
         if eikonal_reg or path_reg:
             raise NotImplementedError("eikonal_reg / path_reg are training-only (double backward); inference path here")
@@ -349,7 +368,7 @@ class Generator(nn.Module):
                 self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, dev)
             return self._planned_forward(plan, zs, cam_poses, per_view(focals), per_view(near), per_view(far), perturb_u,
                                          noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz,
-                                         fresh_perturb=fresh_perturb)
+                                         fresh_perturb=fresh_perturb, styles_resident=bool(styles_resident))
         if fresh_perturb:
             perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)
 

@@ -118,6 +118,11 @@ def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False,
     return out
 
 
+# Bumped by everything that rewrites a module's style tables (FiLM table, modulation table: LinearTable.run, a full
+# ForwardPlan.run).  A forward with styles_resident=True (plan.py) is only valid while nothing did since its plan's last full run.
+STYLE_EPOCH = 0
+
+
 class LinearTable:
     """A device-resident table of independent dense heads evaluated by one launch."""
 
@@ -161,6 +166,8 @@ class LinearTable:
             return
         if self._dev is None:
             self._upload()
+        global STYLE_EPOCH
+        STYLE_EPOCH += 1
         check(_lib.load().cips3d_linear_table(self._dev.data_ptr(), len(self._descs), self._rows, B, stream_ptr()),
               "cips3d_linear_table")
 
@@ -828,11 +835,15 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
     return out2, rgb
 
 
-def rgb_to_uint8(rgb):
-    """[-1,1] float image -> uint8 (clamp, scale, round to nearest) on the device."""
+def rgb_to_uint8(rgb, out=None):
+    """[-1,1] float image -> uint8 (clamp, scale, round to nearest) on the device; `out`: a contiguous uint8 tensor of the
+    same shape to write into (a slice of a sequence's frame buffer: multiview.sample_multi_view)."""
     lib = _lib.load()
     x = rgb.contiguous()
-    out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    elif out.dtype != torch.uint8 or out.shape != x.shape or not out.is_contiguous() or out.device != x.device:
+        raise RuntimeError("rgb_to_uint8: `out` must be a contiguous uint8 tensor of the input's shape on its device")
     check(lib.cips3d_rgb_to_uint8(dev_ptr(x, "rgb"), out.data_ptr(), x.numel(), stream_ptr()), "cips3d_rgb_to_uint8")
     return out
 

@@ -74,6 +74,24 @@ def gather_views_async(local, n_views, dst=0, group=None):
     return PendingGather(work, outs, counts if rank == dst else None, buf)
 
 
+def _join(parts):
+    """torch.cat(parts, 0) -- without the copy when the parts already are consecutive dim-0 slices of one buffer (a render
+    function that writes its frames into a preallocated block)."""
+    p0 = parts[0]
+    if len(parts) == 1:
+        return p0
+    if all(p.is_contiguous() and p.dtype == p0.dtype and p.shape[1:] == p0.shape[1:] and
+           p.untyped_storage().data_ptr() == p0.untyped_storage().data_ptr() for p in parts):
+        off, ok = p0.storage_offset(), True
+        for p in parts:
+            ok = ok and p.storage_offset() == off
+            off += p.numel()
+        if ok:
+            n = sum(p.shape[0] for p in parts)
+            return p0.as_strided((n,) + tuple(p0.shape[1:]), p0.stride(), p0.storage_offset())
+    return torch.cat(parts, 0)
+
+
 def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, chunk=1):
     """render_fn(lo, hi) -> dict of tensors whose dim 0 is the view index for views [lo, hi).
     Every rank renders its block in `chunk`-view calls; the entries named in `keys` are gathered to dst."""
@@ -91,7 +109,7 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
     result = {}
     for k in keys:
         if parts[k]:
-            local = torch.cat(parts[k], 0)
+            local = _join(parts[k])
         else:
             local = None
         if ws > 1:
@@ -104,13 +122,19 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
 def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, truncation_ratio=0.5, N_samples=128,
                       zero_noise_bufs=False, noise_bufs=None, azim_range=(-0.77, 0.77), elev=0.0, circle=None,
                       trans_max=0.04, only_rotate=False, chunk=1, gather=("rgb", "thumb_rgb", "xyz"), to_uint8=True,
-                      group=None):
+                      group=None, hoist=True):
     """The frame loop of `_sample_multi_view_web` (render_video_web_v10.py:1651-1899) without the web page: one z pair,
     one set of noise buffers, `perturb=False`, a camera trajectory (`yaw` / `circle` / `translate_rotate`), one
     `G(...)` call per `chunk` frames with `truncation=truncation_ratio, return_xyz=True`.  With torch.distributed
     initialised the frames are dealt to the ranks (contiguous blocks) and gathered to rank 0; `rgb` travels as uint8
     (the `img_tensor_to_pil` step, :1825-1826) unless `to_uint8=False`.  Video encoding / mesh shading stay with the
-    caller (`gen_images.xyz_to_mesh` gives the surface of a frame's `xyz`)."""
+    caller (`gen_images.xyz_to_mesh` gives the surface of a frame's `xyz`).
+
+    `hoist` (default): the loop renders every frame with the same sample_z, noise_bufs and truncation, so both mapping networks, the
+    FiLM table and all modulated / demodulated decoder matrices are the same for the whole sequence: the first call of each call shape
+    computes them, every later frame reuses them (`styles_resident=True`: no mapping / style-head / modulate-table launches between
+    frames; the reference offers the same hoist through `style_render=` / `style_decoder=`, models/model_v3.py:875-914).
+    Bit-identical to `hoist=False`, which recomputes them per frame."""
     from . import hip
     from .camera import yaw_trajectory, circle_trajectory, cameras_from_trajectory, translate_rotate_cameras
     dev = next(G.parameters()).device
@@ -141,14 +165,25 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
     if zero_noise_bufs:
         noise_bufs = [torch.zeros_like(b) for b in noise_bufs]
 
+    full_done = set()                  # call shapes (views per call) whose tables this sequence has computed
+    ws = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = view_slice(n_views, dist.get_rank(group) if ws > 1 else 0, ws)
+    frames_u8 = None                   # this rank's uint8 frames land in ONE block (no concatenation copy at the end)
+
     def render(a, b):
         with torch.no_grad():
             r = G(zs=zs, cam_poses=ext[a:b].contiguous(), focals=foc[a:b].contiguous(), img_size=img_size,
                   near=near[a:b].contiguous(), far=far[a:b].contiguous(), noise_bufs=noise_bufs,
-                  truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True)
+                  truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True,
+                  styles_resident=hoist and full_done == {b - a})
+        full_done.clear()              # (a call of another shape rewrites the shared style tables: only the last shape is resident)
+        full_done.add(b - a)
         if to_uint8:
+            nonlocal frames_u8
             r = dict(r)
-            r["rgb"] = hip.rgb_to_uint8(r["rgb"])
+            if frames_u8 is None:
+                frames_u8 = torch.empty((hi - lo,) + tuple(r["rgb"].shape[1:]), dtype=torch.uint8, device=dev)
+            r["rgb"] = hip.rgb_to_uint8(r["rgb"], out=frames_u8[a - lo:b - lo])
         return r
 
     out = render_views_sharded(render, n_views, keys=gather, group=group, chunk=chunk)

@@ -39,7 +39,7 @@ class GeneratorPlan(C.Structure):
                 ("rgb_part_slots", C.c_int64),
                 ("range_ws", C.c_void_p), ("range_ws_words", C.c_int64), ("feat_amax", C.c_void_p), ("feat_exp", C.c_void_p),
                 ("feat_pmax", C.c_void_p), ("tmp_amax", C.c_void_p),
-                ("style_xch", C.c_void_p), ("style_sync", C.c_void_p), ("style_xch_dim", C.c_int32), ("pad3_", C.c_int32)]
+                ("style_xch", C.c_void_p), ("style_sync", C.c_void_p), ("style_xch_dim", C.c_int32), ("range_volatile_words", C.c_int32)]
 
 
 class ForwardIO(C.Structure):
@@ -54,7 +54,7 @@ class ForwardIO(C.Structure):
                 ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
                 ("noise_bound", C.c_float), ("pad2_", C.c_int32),
                 ("ev_marks", C.c_void_p), ("ev_info", C.c_void_p), ("ev_count", C.c_void_p), ("n_ev_marks", C.c_int32),
-                ("pad3_", C.c_int32)]
+                ("styles_resident", C.c_int32)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -231,13 +231,16 @@ class ForwardPlan:
         # output and its bound constants; the feature map's rows; one scratch amax array.  One buffer, zeroed by every forward.
         AF = hip.amax_floats()
         nblk = (img_size * img_size + _lib.PLANES_EXP_BLOCK - 1) // _lib.PLANES_EXP_BLOCK      # planes exponents per sample
-        per_layer = B * (AF + nblk + 4)
+        # Layout: [per StyledConv: amax | aexp] [feature-map rows] -- what every forward measures anew, the "volatile" words -- then
+        # [per StyledConv: lconst], which the modulate table writes: a frame of a sequence (io.styles_resident) zeroes only the former
+        per_layer = B * (AF + nblk)
         n_sc = sum(1 for li in layer_info if li["kind"] in (0, 1))
-        range_ws = torch.zeros(n_sc * per_layer + B * (2 * AF + nblk), device=dev) if use_split else None
+        volatile = n_sc * per_layer + B * (2 * AF + nblk)
+        range_ws = torch.zeros(volatile + n_sc * B * 4, device=dev) if use_split else None
         self.ranged = range_ws is not None
         rw = range_ws.data_ptr() if self.ranged else 0
         if self.ranged:
-            p.range_ws, p.range_ws_words = rw, range_ws.numel()
+            p.range_ws, p.range_ws_words, p.range_volatile_words = rw, range_ws.numel(), volatile
             tail = rw + 4 * n_sc * per_layer
             p.feat_amax, p.tmp_amax, p.feat_exp = tail, tail + 4 * B * AF, tail + 4 * 2 * B * AF
             # patch maxima of the planes tensors (one array per layer of the run + the feature map's for the conversion pass):
@@ -276,7 +279,7 @@ class ForwardPlan:
             L.fir = dev_ptr(info["fir"], allow_none=True)
             if self.ranged and info["kind"] in (0, 1):
                 base = rw + 4 * sc_i * per_layer
-                L.amax, L.aexp, L.lconst = base, base + 4 * B * AF, base + 4 * B * (AF + nblk)
+                L.amax, L.aexp, L.lconst = base, base + 4 * B * AF, rw + 4 * (volatile + sc_i * B * 4)
                 d.lconst, d.bias, d.n_bias = L.lconst, L.bias, conv.out_channel
                 d.noise_w, d.fir = L.noise_w, L.fir
                 sc_i += 1
@@ -399,9 +402,13 @@ class ForwardPlan:
         return bound
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
-            events=None, fresh_perturb=False, marks=None):
+            events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
-        one cips3d_rng_fill launch when both are fresh."""
+        one cips3d_rng_fill launch when both are fresh.
+        styles_resident: a frame of a sequence (cips3d_forward_io.styles_resident): the style phase and the modulate table are
+        skipped and the plan's tables are used as the last FULL run left them.  `style_stamp` identifies what those tables were
+        computed from (latents / styles, truncation, means): a full run records it (with the call's bound of |noise|, which the
+        range constants carry), a resident run must present the same one or it raises."""
         lib = _lib.load()
         B, S, dev = self.B, self.img_size, self.device
         fresh_noise = noise_bufs is None or all(nb is None for nb in noise_bufs)
@@ -413,6 +420,17 @@ class ForwardPlan:
                 perturb_u = torch.rand(B, S * S, device=dev)
         io = ForwardIO()
         io.noise_bound = self._noise_bound(noise_bufs, fresh_noise)
+        stamp = None if style_stamp is None else (style_stamp, float(io.noise_bound))
+        if styles_resident:
+            # (the FiLM / modulation tables belong to the modules and are shared by every plan of this batch size: nothing may
+            # have rewritten them since -- hip.STYLE_EPOCH)
+            if stamp is None or (stamp, hip.STYLE_EPOCH) != getattr(self, "_resident_stamp", None):
+                raise RuntimeError("styles_resident=True, but this plan's style tables were not computed from these latents / "
+                                   "truncation / noise bound by the last full forward (run one frame without styles_resident first)")
+            io.styles_resident = 1
+        else:
+            hip.STYLE_EPOCH += 1
+            self._resident_stamp = (stamp, hip.STYLE_EPOCH)
         if hip.FAST_RNG and (fresh_noise or fresh_perturb):
             # the draw is made by the forward call itself (cips3d_forward_io.rng_*: spread over the mapping launches)
             n_n, n_u = (B * self.noise_total if fresh_noise else 0), (B * S * S if fresh_perturb else 0)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 23  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 24  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -584,7 +584,9 @@ typedef struct cips3d_generator_plan {
   void* style_sync;              /* 256 bytes, zeroed once: [0] generation of the last launch, [1] waits that gave up (stays 0),
                                     [3..] diagnostics: 10 ns ticks from the start of workgroup 0 to its end / to each stage */
   int32_t style_xch_dim;         /* >= every width of the two mapping networks, % 4 == 0 */
-  int32_t pad3_;
+  int32_t range_volatile_words;  /* the first range_volatile_words words of range_ws hold what every forward measures anew (amax /
+                                    aexp rows, the feature map's rows); the lconst rows the modulate table writes lie behind them.
+                                    A forward with io.styles_resident zeroes only these (0: such forwards are refused on a ranged plan) */
 } cips3d_generator_plan;
 
 typedef struct cips3d_forward_io {
@@ -620,7 +622,15 @@ typedef struct cips3d_forward_io {
    * n_ev_marks of them; further launches are not marked); ev_info[4 k .. 4 k + 3] receives what launch k was:
    * {CIPS3D_MARK_* kind, input channels, output channels, output height}.  *ev_count = marks recorded.  A record between two dependent
    * launches costs ~1-2 us of queue drain: intervals are upper bounds of the kernel times. */
-  void** ev_marks; int32_t* ev_info; int32_t* ev_count; int32_t n_ev_marks; int32_t pad3_;
+  void** ev_marks; int32_t* ev_info; int32_t* ev_count; int32_t n_ev_marks;
+  /* != 0: a frame of a SEQUENCE (multi-view rendering of one latent: models/render_video_web_v10.py:1792-1824 calls G with the same
+   * sample_z / truncation / noise_bufs for every frame).  The plan's style tables -- styles_r / styles_d, the FiLM table, the
+   * modulation table and all modulated / demodulated decoder matrices with their range constants -- are taken as left by the last
+   * full forward of this plan: the mapping networks, the style heads and the modulate table are NOT run (z_r / z_d / mean_* /
+   * trunc_psi are ignored); only the measured range rows are zeroed.  The reference offers the same hoist through its
+   * style_render= / style_decoder= arguments (models/model_v3.py:875-914).  Results are bit-identical to a full forward with the
+   * same inputs.  The caller owns the promise that styles, truncation, weights and the bound of |noise| have not changed. */
+  int32_t styles_resident;
 } cips3d_forward_io;
 
 #define CIPS3D_MARK_START 0

@@ -275,3 +275,62 @@ def test_sample_multi_view_single_gpu(mode, n):
     u8 = sample_multi_view(G, cam_cfg, {"N_samples": 24, "static_viewdirs": True}, [z.cuda() for z in zs], view_mode=mode,
                            N_frames=n, truncation_ratio=0.5, N_samples=6, noise_bufs=[b.cuda() for b in nb])
     assert u8["rgb"].dtype == torch.uint8 and torch.equal(u8["rgb"], hip.rgb_to_uint8(out["rgb"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res,n_samples,chunk", [(256, 12, 1), (256, 12, 3), (1024, 24, 1)])
+def test_sample_multi_view_hoisted_tables_are_bit_identical(res, n_samples, chunk):
+    """The sequence plan of config 4: frames after the first reuse the plan's style tables
+    (`styles_resident`: no mapping network, style head or modulate-table launch) -- every output must carry the bits of the
+    per-frame recomputation (`hoist=False`), at chunk 1 and with several frames per call, in the release recipe's split-fp16
+    arithmetic whose range rows are zeroed per frame."""
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs
+    from cips_3dplusplus_amd.multiview import sample_multi_view
+    G = pkg.build_generator(configs.ffhq_G_cfg(res, 2), "cuda", seed=3)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    zs = [torch.randn(1, 256, device="cuda", generator=g), torch.randn(1, 256, device="cuda", generator=g)]
+    nb = [torch.randn(b.shape, device="cuda", generator=g) for b in G.create_noise_bufs(64, "cuda")]
+    G.style_render_mean = 0.1 * torch.randn(1, 256, device="cuda", generator=g)
+    G.style_decoder_mean = 0.1 * torch.randn(1, 512, device="cuda", generator=g)
+    cam_cfg = {"img_size": 64, "fov_ang": 12, "dist_radius": 0.12}
+    kw = dict(view_mode="yaw", N_frames=5, truncation_ratio=0.7, N_samples=n_samples, noise_bufs=nb, to_uint8=False, chunk=chunk)
+    a = sample_multi_view(G, cam_cfg, {"static_viewdirs": False}, zs, hoist=False, **kw)
+    b = sample_multi_view(G, cam_cfg, {"static_viewdirs": False}, zs, hoist=True, **kw)
+    for k in ("rgb", "thumb_rgb", "xyz"):
+        assert a[k].shape[0] == 5 and torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["rgb"][0], a["rgb"][1])
+
+
+@pytest.mark.gpu
+def test_styles_resident_refuses_a_stale_plan():
+    """`styles_resident=True` is a promise the plan checks: other latents, another truncation, a modified latent tensor, or any
+    rewrite of the modules' style tables since the plan's last full forward (another plan of the same batch size, the per-op
+    renderer) must raise instead of rendering with the wrong styles."""
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs
+    from cips_3dplusplus_amd.camera import Camera
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), "cuda", seed=3)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, "cuda", locations=torch.zeros(1, 2, device="cuda"))
+    zs = [torch.randn(1, 256, device="cuda"), torch.randn(1, 256, device="cuda")]
+    nb = G.create_noise_bufs(64, "cuda")
+    kw = dict(cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=nb, nerf_cfg=dict(N_samples=8, perturb=False))
+    with torch.no_grad():
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=zs, styles_resident=True, **kw)                  # no full forward yet
+        full = G(zs=zs, **kw)["rgb"]
+        assert torch.equal(G(zs=zs, styles_resident=True, **kw)["rgb"], full)
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=[zs[0].clone(), zs[1]], styles_resident=True, **kw)     # other latents
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=zs, truncation=0.9, styles_resident=True, **kw)         # another truncation
+        zs[0].mul_(1.0)                                           # an in-place write bumps the version
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=zs, styles_resident=True, **kw)
+        full = G(zs=zs, **kw)["rgb"]
+        kw2 = dict(kw, nerf_cfg=dict(N_samples=12, perturb=False))
+        G(zs=[z.clone() for z in zs], **kw2)                      # another plan of the same batch size rewrote the shared tables
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=zs, styles_resident=True, **kw)
+        assert torch.equal(G(zs=zs, **kw)["rgb"], full)
+        assert torch.equal(G(zs=zs, styles_resident=True, **kw)["rgb"], full)

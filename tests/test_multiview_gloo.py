@@ -114,3 +114,21 @@ def test_view_slice_partition():
             assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
             sizes = [hi - lo for lo, hi in sl]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_join_reuses_a_block_of_consecutive_slices():
+    """multiview._join: consecutive dim-0 slices of one buffer come back as a view of it (the frame block sample_multi_view
+    fills), anything else is concatenated."""
+    import torch
+    from cips_3dplusplus_amd.multiview import _join
+    buf = torch.arange(24.).reshape(6, 4)
+    j = _join([buf[0:2], buf[2:3], buf[3:6]])
+    assert j.data_ptr() == buf.data_ptr() and torch.equal(j, buf)
+    j = _join([buf[1:3], buf[3:4]])
+    assert j.data_ptr() == buf[1:].data_ptr() and torch.equal(j, buf[1:4])
+    j = _join([buf[0:2], buf[3:6]])                      # a gap: copied
+    assert j.shape == (5, 4) and j.data_ptr() != buf.data_ptr() and torch.equal(j, torch.cat([buf[0:2], buf[3:6]]))
+    j = _join([torch.ones(2, 3), torch.zeros(1, 3)])
+    assert j.shape == (3, 3)
+    one = torch.ones(2, 3)
+    assert _join([one]) is one
