@@ -391,7 +391,7 @@ class ForwardWorkload:
         return head
 
 
-def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24):
+def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=24, phase="pose"):
     """BASELINE config 5: CompCars 256^2, D = 6, batch 2 (image + mirrored view): steps/s of the pose phase of the
     flip-inversion loop (forward + backward + Adam; /root/reference/exp/cips3d/models/projector_v10.py:915-1216)."""
     import cips_3dplusplus_amd as pkg
@@ -415,8 +415,15 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
                 torch.cuda.synchronize()
                 marks["t0"] = time.perf_counter()
 
-        proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=warmup + steps, N_steps_app=0,
-                           w_avg_samples=2000, on_step=on_step, azim_init=(-1.0, 3.0))
+        if phase == "pose":
+            proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=warmup + steps, N_steps_app=0,
+                               w_avg_samples=2000, on_step=on_step, azim_init=(-1.0, 3.0))
+        else:
+            # the appearance phase of the released recipe (train_cips3d_compcars_v10.yaml:585-596: decoder W+ and decoder parameters
+            # trainable at their learning rates, truncated NeRF style, decoder-style flips every 10th step, zero noise buffers that
+            # are not optimised): every step of the call is an appearance step
+            proj.project_wplus(cam_cfg, ncfg, surrogate_loss(t_rgb, t_thumb), N_steps_pose=0, N_steps_app=warmup + steps,
+                               w_avg_samples=2000, on_step=on_step, azim_init=(-1.0, 3.0), truncation_psi=0.7)
         torch.cuda.synchronize()
         elapsed.append(time.perf_counter() - marks["t0"])
     med = statistics.median(elapsed)
@@ -424,9 +431,11 @@ def inversion_workload(dev, steps, warmup, repeats, depth=6, res=256, n_samples=
     line = {"metric": "flip-inversion steps/s (forward + backward + Adam, batch 2 = image + mirrored view)",
             "value": steps / med, "unit": "steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "repeats": repeats,
             "ms_per_step_repeats": [e / steps * 1e3 for e in elapsed], "dtype": "f32",
-            "config": {"workload": f"BASELINE config 5: compcars_r{res}_nerf64x64x{n_samples}_D{depth}_B2 pose phase "
+            "config": {"workload": f"BASELINE config 5: compcars_r{res}_nerf64x64x{n_samples}_D{depth}_B2 {phase} phase "
                                    f"(surrogate loss, random-init weights)"},
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30}
+    if phase != "pose":
+        return line
     from cips_3dplusplus_amd import autograd as AG
     line["route"] = ("decoder = one autograd node (cips3d_decoder_grad_forward / _backward), fused NeRF backward, HIP Adam (optim.HipAdam)"
                      if AG.ONE_CALL_DECODER else "decoder = one autograd node per op (CIPS3D_ONE_CALL_DECODER=0)")
@@ -758,6 +767,12 @@ def main():
                 also.append(inv)
             except Exception as exc:           # noqa: BLE001
                 also.append({"tag": "config5_inversion_pose", "what": "BASELINE config 5: one flip-inversion step", "error": f"{type(exc).__name__}: {exc}"[:400]})
+            try:
+                app = inversion_workload(dev, max(10, min(a.steps, 60)), max(4, a.warmup // 2), min(a.repeats, 3), phase="appearance")
+                app["what"], app["tag"] = "BASELINE config 5: one step of the appearance phase (decoder trainable)", "config5_inversion_appearance"
+                also.append(app)
+            except Exception as exc:           # noqa: BLE001
+                also.append({"tag": "config5_inversion_appearance", "what": "BASELINE config 5, appearance phase", "error": f"{type(exc).__name__}: {exc}"[:400]})
             line["also"] = also
         if world == 1 and not a.no_cpu_baseline:
             from cips_3dplusplus_amd import configs

@@ -17,10 +17,16 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libcips3d_hip.so")
 ARCH = "gfx950"
-SOURCES = ["bias_act.hip", "upfirdn2d.hip", "linear.hip", "camera.hip", "nerf.hip", "nerf_pair.hip", "nerf_ws.hip", "decoder.hip", "chain.hip", "conv3x3.hip", "forward.hip", "backward.hip", "decoder_grad.hip", "nerf_bwd.hip", "nerf_bwd_fused.hip", "render_ops.hip", "rng.hip", "optim.hip"]
+# CIPS3D_EXPERIMENTAL=1: also compile the two measured-slower render-kernel dataflows of csrc/experimental/  and their
+# dispatch (-DCIPS3D_EXPERIMENTAL); the default library carries neither
+EXPERIMENTAL = os.environ.get("CIPS3D_EXPERIMENTAL") == "1"
+SOURCES = ["bias_act.hip", "upfirdn2d.hip", "linear.hip", "camera.hip", "nerf.hip", "decoder.hip", "chain.hip", "conv3x3.hip", "forward.hip", "backward.hip", "decoder_grad.hip", "nerf_bwd.hip", "nerf_bwd_fused.hip", "render_ops.hip", "rng.hip", "optim.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-fno-gpu-rdc", "-fgpu-flush-denormals-to-zero" if False else ""]
 FLAGS = [f for f in FLAGS if f] + os.environ.get("CIPS3D_HIPCC_FLAGS", "").split()
+if EXPERIMENTAL:
+    SOURCES += ["experimental/nerf_pair.hip", "experimental/nerf_ws.hip"]
+    FLAGS += ["-DCIPS3D_EXPERIMENTAL", f"-I{CSRC}"]
 
 
 def hipcc():
@@ -38,6 +44,8 @@ def source_hash():
     snapshot copy to the GPU box, contents do."""
     import hashlib
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    if EXPERIMENTAL:
+        files += sorted(os.path.join(CSRC, "experimental", f) for f in os.listdir(os.path.join(CSRC, "experimental")) if f.endswith(".hip"))
     files += [os.path.join(os.path.dirname(PKG), "include", "cips3d_hip.h"), os.path.abspath(__file__)]
     # (per-file flags included: a knob that only changes those -- CIPS3D_CHAIN_SLP -- must invalidate the library too; a probe of
     # round 4 compared two "builds" that were the same file because it did not)
@@ -60,13 +68,13 @@ def up_to_date():
 # per-file flags (chain.hip: see the build note in its header; its ToRGB fold no longer depends on the flag)
 FILE_FLAGS = {"chain.hip": [] if os.environ.get("CIPS3D_CHAIN_SLP") == "1" else ["-fno-slp-vectorize"],
               # nerf_pair.hip: one wave per SIMD -- a packed-fp32 instruction beside MFMAs costs more than the two it replaces
-              "nerf_pair.hip": ["-fno-slp-vectorize"]}
+              "experimental/nerf_pair.hip": ["-fno-slp-vectorize"]}
 
 
 def _compile(src, keep_temps):
     # per-process object names: two builders that slipped past the lock (different checkouts of one tree on a shared
     # file system) never write the same file
-    obj = os.path.join(OBJ, src.replace(".hip", f".{os.getpid()}.o"))
+    obj = os.path.join(OBJ, os.path.basename(src).replace(".hip", f".{os.getpid()}.o"))
     cmd = [hipcc(), *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
     if keep_temps:
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]

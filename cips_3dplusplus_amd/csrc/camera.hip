@@ -4,6 +4,13 @@
 #include "common.h"
 
 extern "C" int cips3d_abi_version(void) { return CIPS3D_ABI_VERSION; }
+extern "C" int cips3d_build_features(void) {
+#ifdef CIPS3D_EXPERIMENTAL
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 extern "C" const char* cips3d_strerror(int code) {
   if (code == 0) return "success";

@@ -203,6 +203,25 @@ __global__ void __launch_bounds__(256) nerf_pack_kernel(const float* __restrict_
   }
 }
 
+// exact-fp32 weight stream: packed32[l][t][m][half][lane][r] = W_l[16 t + (lane & 15)][32 m + 16 half + 4 (lane >> 4) + r] -- the
+// piece positions of the split stream ((o-tile t, k-block m, plane) <-> (t, m, half)), each piece the 16 x 16 fp32 block whose
+// lane-linear 16 bytes are the lane's A operands of four consecutive v_mfma_f32_16x16x4_f32 k-steps; scales (1, 1) per layer
+// behind the matrices, where the split stream keeps its powers of two
+__global__ void __launch_bounds__(256) nerf_pack32_kernel(const float* __restrict__ w_hidden, const float* __restrict__ w_view,
+                                                          float* __restrict__ packed, int H, int D) {
+  const int64_t per_layer = (int64_t)H * H, total = per_layer * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + 2 * D; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i >= total) { packed[i] = 1.f; continue; }
+    const int l = (int)(i / per_layer);
+    int64_t rem = i - l * per_layer;                 // (t, m, half, lane, r)
+    const int t = (int)(rem / (16 * H));
+    rem -= (int64_t)t * 16 * H;
+    const int m = (int)(rem / 512), half = (int)((rem % 512) / 256), lane = (int)((rem % 256) / 4), r = (int)(rem % 4);
+    const int o = t * 16 + (lane & 15), k = 32 * m + 16 * half + 4 * (lane >> 4) + r;
+    packed[i] = l < D - 1 ? w_hidden[(int64_t)l * per_layer + (int64_t)o * H + k] : w_view[(int64_t)o * (H + 3) + k];
+  }
+}
+
 // One MFMA layer for the wave's 16 points (split-fp16 products, fp32 accumulation; see the file header).
 //   VIEW = false: Y = sin(gamma' * (W' X) + c)            gamma' = gamma 2^-s, W' = 2^s W (s_film holds gamma')
 //   VIEW = true : f = sin(gamma' * (W' X + Wd' v) + c);  FA += w * f;  rgb head partial sums += Wc f
@@ -966,6 +985,16 @@ int launch_render(const NerfArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" int cips3d_nerf_pack_weights32(const float* w_hidden, const float* w_view, float* packed32, int hidden, int depth,
+                                          void* stream) {
+  if (!w_view || !packed32 || hidden <= 0 || depth < 1 || (depth > 1 && !w_hidden)) return CIPS3D_E_BADARG;
+  if (hidden != 256 || depth > 64) return CIPS3D_E_UNSUPP;
+  const int64_t total = (int64_t)hidden * hidden * depth + 2 * depth;
+  hipLaunchKernelGGL(nerf_pack32_kernel, dim3((unsigned)ceil_div<int64_t>(total, 256)), dim3(256), 0, as_stream(stream), w_hidden,
+                     w_view, packed32, hidden, depth);
+  return cips3d_launch_status();
+}
 
 extern "C" int cips3d_nerf_pack_weights(const float* w_hidden, const float* w_view, float* packed, int hidden,
                                         int depth, void* stream) {

@@ -18,12 +18,22 @@
 #define FILM_SIN cips3d_sin
 #endif
 
-// nerf_pair.hip: the 32-points-per-wave render kernel (library-internal)
+// Two measured-slower dataflows of the render kernel live under csrc/experimental/ and are compiled only into a
+// library built with CIPS3D_EXPERIMENTAL=1 (cips_3dplusplus_amd/build.py: -DCIPS3D_EXPERIMENTAL + the two sources); the default
+// library has neither their code nor their dispatch.  cips3d_build_features() bit 0 says which library is loaded.
+#ifdef CIPS3D_EXPERIMENTAL
+// experimental/nerf_pair.hip: the 32-points-per-wave render kernel (library-internal; run-time opt-in CIPS3D_NERF_PAIR=1)
 int cips3d_nerf_pair_applies(const cips3d_nerf_params* p);
 int cips3d_nerf_render_pair(const cips3d_nerf_params* p, void* stream);
-// nerf_ws.hip: the weight-stationary render kernel (library-internal)
+// experimental/nerf_ws.hip: the weight-stationary render kernel (library-internal; run-time opt-in CIPS3D_NERF_WS=1)
 int cips3d_nerf_ws_applies(const cips3d_nerf_params* p);
 int cips3d_nerf_render_ws(const cips3d_nerf_params* p, void* stream);
+#else
+static inline int cips3d_nerf_pair_applies(const cips3d_nerf_params*) { return 0; }
+static inline int cips3d_nerf_render_pair(const cips3d_nerf_params*, void*) { return CIPS3D_E_UNSUPP; }
+static inline int cips3d_nerf_ws_applies(const cips3d_nerf_params*) { return 0; }
+static inline int cips3d_nerf_render_ws(const cips3d_nerf_params*, void*) { return CIPS3D_E_UNSUPP; }
+#endif
 
 namespace {
 

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import cips_3dplusplus_amd as pkg
-from cips_3dplusplus_amd import configs, hip, op, weights
+from cips_3dplusplus_amd import _lib, configs, hip, op, weights
 from cips_3dplusplus_amd.camera import Camera
 from conftest import maxdiff
 from oracle import path as O
@@ -429,6 +429,8 @@ def test_full_size_generator_golden_in_the_other_render_arithmetics(golden, monk
     if mode == "fp32_exact":
         G.set_precision("fp32_exact")
     else:
+        if not (_lib.load().cips3d_build_features() & 1):
+            pytest.skip("library built without CIPS3D_EXPERIMENTAL=1 (csrc/experimental/ is not in it)")
         monkeypatch.setenv("CIPS3D_NERF_PAIR" if mode == "pair" else "CIPS3D_NERF_WS", "1")
     zs, nb, means = weights.synth_inputs(cfg, batch=1, seed=12345)
     G.style_render_mean, G.style_decoder_mean = cu(means[0]), cu(means[1])

@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+
+def _needs_experimental():
+    """The 32-points-per-wave and weight-stationary render kernels (csrc/experimental/) are compiled only into a library built with
+    CIPS3D_EXPERIMENTAL=1 (cips_3dplusplus_amd/build.py); the default library answers cips3d_build_features() == 0."""
+    from cips_3dplusplus_amd import _lib
+    if not (_lib.load().cips3d_build_features() & 1):
+        pytest.skip("library built without CIPS3D_EXPERIMENTAL=1: the experimental render kernels are not in it")
+
+
 def cu(t):
     return t.to(DEV).contiguous()
 
@@ -131,6 +140,7 @@ def test_pair_kernel_instantiations_match_the_default_kernel(monkeypatch, N, B, 
     both arithmetics: DESIGN.md) computes the default kernel's arithmetic -- split-fp16, or exact fp32 against csrc/nerf.hip's F32
     instantiation -- in another work shape: same products in the same order per accumulator, a different chunking of the
     samples -- maps equal to fp32 summation noise, sdf bit for bit."""
+    _needs_experimental()
     G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=3)
     G.renderer.set_precision(precision)
     S = 64
@@ -155,6 +165,7 @@ def test_weight_stationary_kernel_matches_the_default_kernel(monkeypatch, N, B, 
     activations in LDS; opt-in with CIPS3D_NERF_WS=1: the slower dataflow on MI355X) computes the default kernel's
     arithmetic -- the same products in the same order per accumulator -- with sums over units and samples in another order: maps
     equal to fp32 summation noise.  Depths whose tables do not fit beside the activation images fall back to the default kernel."""
+    _needs_experimental()
     G = pkg.build_generator(configs.ffhq_G_cfg(256, D), DEV, seed=5)
     S = 64
     e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.25, -0.15]] * B, device=DEV) *
@@ -176,6 +187,7 @@ def test_weight_stationary_kernel_matches_the_default_kernel(monkeypatch, N, B, 
 def test_weight_stationary_kernel_on_ragged_ray_counts(monkeypatch, S):
     """Ray counts that are not a multiple of the 16-ray group (and not of the default kernel's task grid): the last workgroup's
     missing rays carry zero weights and are never stored."""
+    _needs_experimental()
     G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=6)
     B, N = 2, 7
     e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.1, 0.2], [-0.3, 0.0]], device=DEV))
