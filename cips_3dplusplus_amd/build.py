@@ -65,7 +65,10 @@ def up_to_date():
         return fh.read().strip() == source_hash()
 
 
-# per-file flags (chain.hip: see the build note in its header; its ToRGB fold no longer depends on the flag)
+# per-file flags.  chain.hip: hipcc's SLP vectoriser packs the ToRGB fold's channel-1 / channel-2 accumulations into v_pk_fma_f32 chains
+# one of whose forms -- op_sel:[0,1,0], the low lane reading the HIGH register of the src1 pair -- returns run-to-run different sums in
+# the bf16 chain kernel (named and reproduced by hand in profiles/r05_slp_fold_cause.md); the shipped fold spells its FMAs in inline
+# asm as well, and tests/test_host.py checks the kernel's assembly for the form
 FILE_FLAGS = {"chain.hip": [] if os.environ.get("CIPS3D_CHAIN_SLP") == "1" else ["-fno-slp-vectorize"],
               # nerf_pair.hip: one wave per SIMD -- a packed-fp32 instruction beside MFMAs costs more than the two it replaces
               "experimental/nerf_pair.hip": ["-fno-slp-vectorize"]}

@@ -421,7 +421,37 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       }
       // (columns past HW repeat the last pixel without its noise: a value the patch maximum may include -- it only has to bound)
       mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
-#if CIPS3D_FOLD_PK == 2
+#if CIPS3D_FOLD_PK == 3
+      // probe (tools/pk_fold_probe.sh, round 5): EXACTLY the four instruction forms hipcc's SLP build emits for one column (read
+      // off its assembly: profiles/r05_slp_fold_isa.md) -- r = 0: v_pk_fma_f32 D, W, V01, 0 op_sel_hi:[1,0,0] (fresh accumulator,
+      // inline constant 0, broadcast of the pair's low register); r = 1: ... V01 ... op_sel:[0,1,0] (broadcast of the pair's HIGH
+      // register); r = 2, 3: op_sel_hi:[1,0,1] -- round 4's hand-written probe covered only the last form.  CIPS3D_FOLD_FORMS
+      // masks which of the first two are used (bit 0: r = 0, bit 1: r = 1); a cleared bit falls back to the last form.
+#ifndef CIPS3D_FOLD_FORMS
+#define CIPS3D_FOLD_FORMS 3
+#endif
+      if (a.rgb_part) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+        const f32x2_t v01 = {v[0], v[1]}, v23 = {v[2], v[3]}, v1x = {v[1], 0.f}, v3x = {v[3], 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+        const f32x2_t w0 = {wrgb[i][1][0], wrgb[i][2][0]}, w1 = {wrgb[i][1][1], wrgb[i][2][1]}, w2 = {wrgb[i][1][2], wrgb[i][2][2]},
+                      w3 = {wrgb[i][1][3], wrgb[i][2][3]};
+        if ((CIPS3D_FOLD_FORMS & 1) && i == 0) {
+          // (the compiler's first instruction starts the accumulator: prgb is zero before the first row tile)
+          asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(p12) : "v"(w0), "v"(v01));
+        } else {
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w0), "v"(v01));
+        }
+        if (CIPS3D_FOLD_FORMS & 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p12) : "v"(w1), "v"(v01));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w1), "v"(v1x));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w2), "v"(v23));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w3), "v"(v3x));
+        prgb[1][c] = p12[0];
+        prgb[2][c] = p12[1];
+      }
+#elif CIPS3D_FOLD_PK == 2
       // probe (tools/pk_fold_probe.sh): the SLP build's instruction pattern written by hand -- channel 0 as v_fmac_f32, channels
       // 1 / 2 as ONE register pair per product assembled by two v_mov_b32 into fixed registers and consumed by v_pk_fma_f32 with
       // an op_sel_hi broadcast of v[r] -- with CIPS3D_FOLD_NOP wait states between the v_movs and the packed instruction

@@ -50,6 +50,7 @@ struct NerfArgs {
   int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
   int chunk;           // samples per chunk (uniform trip count)
   int fuse_finish;     // the workgroup's eight chunk waves combine their partials in LDS and write the final maps
+  int l0m;             // nerf.hip: the L0M instantiation runs (layer 0 + view-direction columns on the matrix cores)
   float t_end, t_step; // torch.linspace(0, 1 - 1/N, N): last value and step, computed on the host (kernel arguments are
                        // re-readable scalars; computed in the kernel they ended up as spilled VGPR copies)
 };

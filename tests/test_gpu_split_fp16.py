@@ -449,3 +449,29 @@ def test_the_two_instruction_split_is_the_split():
             hi = r16(xe.double())
             lo = r16(xe.double() - hi.double())
             assert torch.equal(pr[:, 0].float(), hi.float()) and torch.equal(pr[:, 1].float(), lo.float())
+
+
+@pytest.mark.parametrize("N,B,D", [(24, 1, 2), (23, 2, 2), (9, 1, 3), (12, 1, 1), (8, 1, 6)])
+def test_layer0_on_the_matrix_cores_matches_the_valu_form(monkeypatch, N, B, D):
+    """The L0M instantiations of the render kernel (csrc/nerf.hip: layer 0's three columns and the view layer's three direction
+    columns as one more k-block of the split MFMA; only in a library built with -DCIPS3D_NERF_L0M, because they measured slower --
+    DESIGN.md) compute the default kernel's values with split-fp16 products where it uses fp32 FMAs: every map within fp32
+    summation noise of the VALU form, nothing non-finite; depths whose fragment table does not fit fall back to the VALU form."""
+    from cips_3dplusplus_amd import _lib
+    if not (_lib.load().cips3d_build_features() & 2):
+        pytest.skip("library built without -DCIPS3D_NERF_L0M")
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, D), DEV, seed=7)
+    S = 64
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.25, -0.15]] * B, device=DEV) *
+                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
+    styles = cu(weights.det_normal("l0m.styles", (B, D + 1, 256), 0.5, 2))
+    u = cu(weights.det_unit_uniform("l0m.u", (B, S * S), 3))
+    monkeypatch.setenv("CIPS3D_NERF_L0M", "0")
+    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    monkeypatch.setenv("CIPS3D_NERF_L0M", "1")
+    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
+    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
+        d, r = maxdiff(a, b), float(a.abs().max())
+        assert bool(torch.isfinite(b).all()) and d <= 4e-6 * max(r, 1.0), (k, d, r)
+    if D <= 4:
+        assert not torch.equal(ref[1], new[1])              # the other instantiation really ran

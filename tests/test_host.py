@@ -192,3 +192,32 @@ def test_decoder_grad_plan_layout(res, D, B, S0, monkeypatch):
     del dec, plan, p, ws
     gc.collect()
     assert len(dg._PLANS) == n0 and ws_ref() is None
+
+
+def test_chain_kernels_carry_no_high_register_broadcast_of_packed_fp32(tmp_path):
+    """profiles/r05_slp_fold_cause.md: `v_pk_fma_f32 ... op_sel:[0,1,0]` (a packed-fp32 instruction whose low lane reads the HIGH
+    register of its src1 pair) is what made the bf16 chain kernel return run-to-run different ToRGB partial sums when hipcc's SLP
+    vectoriser packed its epilogue.  csrc/chain.hip is built with -fno-slp-vectorize and spells the fold's FMAs in inline asm; this
+    test compiles it to assembly with the shipped flags (no GPU needed) and fails if the form shows up in a chain kernel again."""
+    import re
+    import subprocess
+    from cips_3dplusplus_amd import build
+    src = os.path.join(build.CSRC, "chain.hip")
+    out = tmp_path / "chain.s"
+    r = subprocess.run([build.hipcc(), *build.FLAGS, *build.FILE_FLAGS.get("chain.hip", []), "--cuda-device-only", "-S", src, "-o", str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    assert "-fno-slp-vectorize" in build.FILE_FLAGS.get("chain.hip", []) or os.environ.get("CIPS3D_CHAIN_SLP") == "1"
+    cur, bad, n_kernels = None, [], 0
+    for line in text.splitlines():
+        m = re.match(r"^(_Z\S*chain_gemm_kernel\S*):", line)
+        if m:
+            cur = m.group(1)
+            n_kernels += 1
+        elif re.match(r"^_Z\S+:", line):
+            cur = None
+        if cur and re.search(r"v_pk_[a-z]+_f32 .*op_sel:\[[01],1", line):
+            bad.append((cur, line.strip()))
+    assert n_kernels >= 3, "chain_gemm_kernel instantiations not found in the assembly"
+    assert not bad, bad[:3]

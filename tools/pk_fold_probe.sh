@@ -18,6 +18,13 @@ run "compiler-made chains + 16 wait states in front of each"            1 "-DCIP
 run "hand-made v_mov pair -> v_pk_fma_f32, 0 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=0"
 run "hand-made v_mov pair -> v_pk_fma_f32, 1 wait state between"        0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=1"
 run "hand-made v_mov pair -> v_pk_fma_f32, 3 wait states between"       0 "-DCIPS3D_FOLD_PK=2 -DCIPS3D_FOLD_NOP=3"
+# round 5: the two compiler-made forms round 4's hand-written probe did not cover (csrc/chain.hip, CIPS3D_FOLD_PK=3)
+run "hand-made, all four compiler forms (constant-0 start, op_sel high-register broadcast)"   0 "-DCIPS3D_FOLD_PK=3 -DCIPS3D_FOLD_FORMS=3"
+run "hand-made, constant-0 start form only"                              0 "-DCIPS3D_FOLD_PK=3 -DCIPS3D_FOLD_FORMS=1"
+run "hand-made, op_sel:[0,1,0] high-register broadcast only"             0 "-DCIPS3D_FOLD_PK=3 -DCIPS3D_FOLD_FORMS=2"
+run "hand-made, neither (four op_sel_hi:[1,0,1] forms)"                  0 "-DCIPS3D_FOLD_PK=3 -DCIPS3D_FOLD_FORMS=0"
+run "compiler-made chains, every load of the wave drained before the epilogue"  1 "-DCIPS3D_FOLD_PK=1 -DCIPS3D_FOLD_NOP=4"
+run "compiler-made chains, drained + workgroup barrier before the fold"  1 "-DCIPS3D_FOLD_PK=1 -DCIPS3D_FOLD_NOP=8"
 # leave the tree as it was found: default flags, default library (as tools/ab_build.sh does)
 unset CIPS3D_CHAIN_SLP CIPS3D_HIPCC_FLAGS
 python -m cips_3dplusplus_amd.build > /tmp/pk_probe_build.log 2>&1 && echo "default rebuilt" || { echo "default rebuild FAILED"; tail -3 /tmp/pk_probe_build.log; }
