@@ -501,8 +501,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
           const h4 hi = __builtin_bit_cast(h4, u32x2_t{h0, h1}), lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
           _Float16* dst = reinterpret_cast<_Float16*>(a.out) +
                           ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
-          *reinterpret_cast<h4*>(dst) = hi;
-          *reinterpret_cast<h4*>(dst + (int64_t)HW * 8) = lo;
+          cips3d_store_wt8(dst, hi);                      // (write-through: common.h)
+          cips3d_store_wt8(dst + (int64_t)HW * 8, lo);
         } else if (a.out_fmt == 3) {
           // planes16: the same channel block / element positions, one bf16 plane (round to nearest even: the operand rounding
           // of the bf16 mode)
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
           typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
           const bf16x2_t p0 = __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t);
           const bf16x2_t p1 = __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t);
-          *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)};
+          cips3d_store_wt8(dst, u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)});
         } else if (a.out_fmt == 2) {
           unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
           typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -528,7 +528,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
         } else {
           float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) dst[(int64_t)r * HW] = v[r];
+          for (int r = 0; r < 4; ++r) cips3d_store_wt(dst + (int64_t)r * HW, v[r]);
         }
       }
     }

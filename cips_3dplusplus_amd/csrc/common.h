@@ -236,6 +236,46 @@ __device__ static inline float cips3d_amax_load(const float* __restrict__ slots)
   for (int s_ = 1; s_ < CIPS3D_AMAX_SLOTS; ++s_) m = fmaxf(m, slots[s_ * CIPS3D_AMAX_STRIDE]);
   return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));
 }
+// ---- Write-through stores (round 5).  A kernel's dirty lines leave its XCD's L2 in the end-of-kernel write-back, in front of the
+// next launch; a tensor that the NEXT launch reads (on all eight XCDs) can go to memory while the kernel still runs instead: an
+// agent-scope relaxed atomic store is a plain store with the sc1 bit (LLVM's gfx942+ memory model), the line stays valid in this
+// L2.  Measured on the 64^2 chain (9 planes outputs of 8.4 MB per view): -5.6 us per view, same-box, three interleaved rounds
+// (DESIGN.md 5.2); non-temporal stores: no change.  CIPS3D_WT_STORES=0 compiles every helper to the plain store (A/B).
+#ifndef CIPS3D_WT_STORES
+#define CIPS3D_WT_STORES 1
+#endif
+__device__ static inline void cips3d_store_wt(float* p, float v) {
+#if CIPS3D_WT_STORES
+  typedef __attribute__((address_space(1))) float gf32_t;
+  __hip_atomic_store(reinterpret_cast<gf32_t*>(reinterpret_cast<uintptr_t>(p)), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *p = v;
+#endif
+}
+template <class T8>
+__device__ static inline void cips3d_store_wt8(void* p, T8 v) {        // any 8-byte value (four halfs, two words)
+  static_assert(sizeof(T8) == 8, "8-byte payload");
+#if CIPS3D_WT_STORES
+  typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+  __hip_atomic_store(reinterpret_cast<gu64_t*>(reinterpret_cast<uintptr_t>(p)), __builtin_bit_cast(unsigned long long, v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+  *reinterpret_cast<T8*>(p) = v;
+#endif
+}
+template <class T16>
+__device__ static inline void cips3d_store_wt16(void* p, T16 v) {      // any 16-byte value; p 16-byte aligned
+  static_assert(sizeof(T16) == 16, "16-byte payload");
+#if CIPS3D_WT_STORES
+  typedef float f32x4_t_ __attribute__((ext_vector_type(4)));
+  // (no 16-byte atomic store exists: the instruction written out.  The trailing s_nop 1 covers the store-data hazard the compiler
+  // pads for its own stores -- a VALU write of the data registers right behind a > 64-bit store)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(__builtin_bit_cast(f32x4_t_, v)) : "memory");
+#else
+  *reinterpret_cast<T16*>(p) = v;
+#endif
+}
+
 __device__ static inline float cips3d_uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
 // raise slot `slot` of a sample to v (v >= 0; non-negative floats order like their bit patterns).  No return value.
 __device__ static inline void cips3d_amax_raise(float* __restrict__ slots, float v, int slot) {

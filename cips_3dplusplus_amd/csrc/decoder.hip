@@ -626,10 +626,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (ACTBWD && NS == 2 && BK == 32
       if (col_ok) {
         mx = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), mx);
         if (a.out_bf16)
-          *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.Cout * HW + ncol + (obase + r) * HW) =
-              pack_bf16(v[0], v[1], v[2], v[3]);
+          cips3d_store_wt8(reinterpret_cast<unsigned short*>(a.out) + (int64_t)b * a.Cout * HW + ncol + (obase + r) * HW,
+                           pack_bf16(v[0], v[1], v[2], v[3]));
         else
-          *reinterpret_cast<f32x4*>(ob + (obase + r) * HW) = v;
+          cips3d_store_wt16(ob + (obase + r) * HW, v);                // (write-through: common.h)
       }
       if (a.rgb_part) {
 #pragma unroll
@@ -1587,8 +1587,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         const float ys = SPLIT ? kyn : 1.f;                  // the chained weights carried 2^8 as well, out2 2^-e2
         const f32x4 yv = {accx[tp][0][r] * ys, accx[tp][1][r] * ys, accx[tp][2][r] * ys, accx[tp][3][r] * ys};
         mxn = fmaxf(fmaxf(fmaxf(fabsf(yv[0]), fabsf(yv[1])), fmaxf(fabsf(yv[2]), fabsf(yv[3]))), mxn);
-        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + r * HWo) = pack_bf16(yv[0], yv[1], yv[2], yv[3]);
-        else *reinterpret_cast<f32x4*>(yn + r * HWo) = yv;
+        if constexpr (YB) cips3d_store_wt8(yn + r * HWo, pack_bf16(yv[0], yv[1], yv[2], yv[3]));
+        else cips3d_store_wt16(yn + r * HWo, yv);
       }
     }
     if (a.next_amax && !(a.next_gain > 0.f) && !(CIPS3D_FUSED_AB & 2)) {     // the workgroup's largest |y_next| raises one slot of the sample's amax array; s_nz1 is dead (K loop over)
@@ -1711,8 +1711,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         const float ys = SPLIT ? kyn : 1.f;
         const f32x4 yv = {accn[t][0][r] * ys, accn[t][1][r] * ys, accn[t][2][r] * ys, accn[t][3][r] * ys};
         mxn = fmaxf(fmaxf(fmaxf(fabsf(yv[0]), fabsf(yv[1])), fmaxf(fabsf(yv[2]), fabsf(yv[3]))), mxn);
-        if constexpr (YB) *reinterpret_cast<s16x4*>(yn + (t * 16 + 4 * q + r) * HWo) = pack_bf16(yv[0], yv[1], yv[2], yv[3]);
-        else *reinterpret_cast<f32x4*>(yn + (t * 16 + 4 * q + r) * HWo) = yv;
+        if constexpr (YB) cips3d_store_wt8(yn + (t * 16 + 4 * q + r) * HWo, pack_bf16(yv[0], yv[1], yv[2], yv[3]));
+        else cips3d_store_wt16(yn + (t * 16 + 4 * q + r) * HWo, yv);
       }
   }
   if (NEXT && !XCHG && a.next_amax && !(a.next_gain > 0.f) && !(CIPS3D_FUSED_AB & 2)) {     // (only wave row 0 stored: the other rows bring 0)
@@ -1744,7 +1744,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int c = 0; c < 4; ++c) v[c] += skv[c];
       }
     }
-    *reinterpret_cast<f32x4*>(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox)) = v;
+    cips3d_store_wt16(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox), v);
   }
   FSTAMP(6);        // rgb: bias, FIR of the skip, store
   FSTAMP_FLUSH();

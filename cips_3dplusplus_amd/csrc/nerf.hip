@@ -920,8 +920,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
           const h4 hi = __builtin_bit_cast(h4, u32x2_t{h0, h1}), lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
           _Float16* o = reinterpret_cast<_Float16*>(P.o_features) +
                         ((((int64_t)b * (H / 8) + (cq >> 1)) * 2) * R + gray) * 8 + 4 * (cq & 1);
-          *reinterpret_cast<h4*>(o) = hi;
-          *reinterpret_cast<h4*>(o + (int64_t)R * 8) = lo;
+          cips3d_store_wt8(o, hi);                     // (write-through: the next launch reads the planes on every XCD)
+          cips3d_store_wt8(o + (int64_t)R * 8, lo);
         } else {
           float* o = P.o_features + ((int64_t)b * H + 4 * cq) * R + gray;
 #pragma unroll
