@@ -588,7 +588,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       float v = 0.f;
 #pragma unroll
       for (int m = 0; m < WGM; ++m) v += s_red[(m * 3 + q) * BN + nl + 16 * c];
-      a.rgb_part[((int64_t)blockIdx.y * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c])] = v;
+      cips3d_store_wt(a.rgb_part + ((int64_t)blockIdx.y * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c]), v);
     }
   }
 }

@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
       r.y = lrelu02((o[py][1] + noise_w * nz.y) + bs) * 1.41421356237309515f;
       r.z = lrelu02((o[py][2] + noise_w * nz.z) + bs) * 1.41421356237309515f;
       r.w = lrelu02((o[py][3] + noise_w * nz.w) + bs) * 1.41421356237309515f;
-      *reinterpret_cast<float4*>(dst + (int64_t)py * OW) = r;
+      cips3d_store_wt16(dst + (int64_t)py * OW, r);
       mx = fmaxf(fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))), mx);
     }
   }

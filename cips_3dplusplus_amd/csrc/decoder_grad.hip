@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) act_tail_kernel(const float* __restrict__
       mx = fmaxf(mx, fabsf(g[e]));
       s0 = fmaf(r0[e], v[e], s0); s1 = fmaf(r1[e], v[e], s1); s2 = fmaf(r2[e], v[e], s2);
     }
-    *reinterpret_cast<f32x4*>(dpre + base + p0) = g;
+    cips3d_store_wt16(dpre + base + p0, g);
     if (d_nw) {
       const f32x4 nz = *reinterpret_cast<const f32x4*>(noise + (int64_t)b * noise_bstride + p0);
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) up2_fir_bwd_kernel(const float* __restric
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[j] = fmaf(v[2 * j + u], k[t * 4 + u], acc[j]);
     }
-    *reinterpret_cast<f32x4*>(g_lo + (((int64_t)b * C + c) * H + iy) * W + 4 * xq) = acc;
+    cips3d_store_wt16(g_lo + (((int64_t)b * C + c) * H + iy) * W + 4 * xq, acc);
     mx = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
   }
   if (out_amax) {

@@ -50,7 +50,14 @@ __device__ __forceinline__ void rng_fill_thread(unsigned seed_lo, unsigned seed_
   if (first + 4 <= n && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0)) {
     // (plain stores: non-temporal ones were measured -- the noise then reaches the up-sampling stages from HBM instead of the
     // L2 / infinity cache, C = 32 stage 35.8 -> 38.4 us, 0.3477 -> 0.3520 ms per view on one box)
+#ifndef CIPS3D_RNG_WT
+#define CIPS3D_RNG_WT 1      // A/B (round 5): the draw leaves as write-through stores (common.h) -- it rides on launches whose end-of-
+#endif                       // kernel write-back the next mapping layer waits for
+#if CIPS3D_RNG_WT
+    cips3d_store_wt16(dst + first, make_float4(v[0], v[1], v[2], v[3]));
+#else
     *reinterpret_cast<float4*>(dst + first) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
   } else {
 #pragma unroll
     for (int p = 0; p < 4; ++p)
