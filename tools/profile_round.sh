@@ -1,8 +1,8 @@
-# final-build profiles of round 4 (r04), all from ONE box: smoke, bench lines, kernel-trace summaries (headline, N = 64, config 3,
+# final-build profiles of round 5 (r05), all from ONE box: smoke, bench lines, kernel-trace summaries (headline, N = 64, config 3,
 # fp32_exact, stand-alone 3x3 and upfirdn2d tools), the PMC passes of the headline + FETCH / WRITE passes of the N = 64 and batch-4
 # workloads, each summary stamped with the library's source hash (bench.py replays traffic only from a matching one)
 export TMPDIR=/tmp
-O=gpurun_out/r04; rm -rf $O; mkdir -p $O
+O=gpurun_out/r05; rm -rf $O; mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-also"
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 stats() {   # stats <name> <program...>: rocprofv3 --kernel-trace --stats of a command, the kernel_stats.csv kept as <name>_kernel_stats.csv
@@ -14,6 +14,7 @@ stats final $B --steps 50 --repeats 2
 stats n64 $B --steps 30 --repeats 2 --n-samples 64
 stats config3_bf16 $B --batch 4 --decoder-precision bf16 --steps 30 --repeats 2
 stats fp32_exact $B --decoder-precision fp32_exact --steps 30 --repeats 2
+stats multiview python3 tools/bench_multiview.py --chunks 1 --rounds 2
 stats conv3x3_tool python3 tools/bench_conv3x3.py
 stats upfirdn2d_tool python3 tools/bench_upfirdn2d.py
 python3 tools/bench_conv3x3.py > $O/conv3x3_tool.jsonl 2> /dev/null
@@ -46,7 +47,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["_dur"])):
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 # the bench lines last: with the summaries of THIS library copied where bench.py looks for them, the line carries measured traffic
-mkdir -p profiles; for f in pmc_all_kernels pmc_n64_traffic pmc_b4_traffic; do cp $O/$f.json profiles/r04_$f.json; done
-python3 bench.py > $O/bench_default.json 2> $O/bench_default.err
-python3 bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err
+mkdir -p profiles; for f in pmc_all_kernels pmc_n64_traffic pmc_b4_traffic; do cp $O/$f.json profiles/r05_$f.json; done
+python3 bench.py --detail $O/bench_default_detail.json > $O/bench_default.json 2> $O/bench_default.err
+python3 bench.py --steps 20 --warmup 5 --detail $O/bench_driver_form_detail.json > $O/bench_driver_form.json 2> $O/bench_driver_form.err
+python3 tools/bench_multiview.py > $O/multiview_ab.txt 2> /dev/null
+bash tools/render_clock.sh > $O/render_clock.log 2>&1 || true; cp gpurun_out/render_clock.jsonl $O/render_clock.jsonl 2> /dev/null
 du -sh $O
