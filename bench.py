@@ -54,6 +54,19 @@ HBM_PEAK_TBS = 8.0                         # MI355X_MICROARCH.md: HBM3E spec pea
 PREROLL_MAX = 10                           # untimed regions until two consecutive ones agree within 1 % (clocks / caches settled)
 
 
+def dedupe_traffic(rows):
+    """A replayed counter belongs to the kernel's dominant shape only (same name, same grid, different K: the 256 -> 512 chain layer
+    reads half the planes of the 512 -> 512 ones): of the GEMM rows that share a kernel name only the one with the most launches
+    per step keeps `traffic`.  Fused-stage rows are keyed by their width already."""
+    for r in rows:
+        if r.get("traffic") is None or r.get("kind") == "fused_stage":
+            continue
+        same = [q for q in rows if q.get("kernel") == r.get("kernel") and q.get("kind") != "fused_stage"]
+        if r is not max(same, key=lambda q: q.get("launches_per_step", 0)):
+            r["traffic"], r["traffic_source"] = None, "no counter pass keyed on this shape"
+    return rows
+
+
 def nerf_flops_per_point(H, D):
     # SURVEY.md 8(d): first layer + (D-1) hidden + view layer (H+3 inputs) + sigma head + rgb head
     return 2 * 3 * H + (D - 1) * 2 * H * H + 2 * (H + 3) * H + 2 * H * 1 + 2 * H * 3
@@ -345,12 +358,7 @@ class ForwardWorkload:
             else:
                 row["traffic"] = None
             rows.append(row)
-        # a replayed counter belongs to the kernel's dominant shape only (same name, same grid, different K: the 256 -> 512 layer
-        # reads half the planes of the 512 -> 512 ones): the other rows of that kernel carry no traffic
-        for r in rows:
-            same = [q for q in rows if q.get("kernel") == r.get("kernel") and q["kind"] != "fused_stage"]
-            if r.get("traffic") is not None and r is not max(same, key=lambda q: q["launches_per_step"]):
-                r["traffic"], r["traffic_source"] = None, "no counter pass keyed on this shape"
+        dedupe_traffic(rows)
         return rows, why
 
     def roofline(self, kern_ms, n_events, kernels=False):

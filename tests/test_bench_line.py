@@ -80,3 +80,16 @@ def test_emit_writes_the_detail_file_and_prints_one_line(tmp_path, capsys):
     full = json.load(open(p))
     assert full["roofline"]["kernels"][1]["launch_ms_bounds"] == rec["roofline"]["kernels"][1]["launch_ms_bounds"]
     assert len(full["also"]) == len(rec["also"])
+
+
+def test_replayed_traffic_stays_with_a_kernels_dominant_shape():
+    rows = [{"kind": "render", "kernel": "nerf_render_kernel<16,4>", "launches_per_step": 1, "traffic": 9.6e6},
+            {"kind": "planes_gemm", "kernel": "chain_gemm_kernel", "launches_per_step": 8, "traffic": 24.2e6, "c_in": 512},
+            {"kind": "planes_gemm", "kernel": "chain_gemm_kernel", "launches_per_step": 1, "traffic": 24.2e6, "c_in": 256},
+            {"kind": "lowres_gemm", "kernel": "modconv1x1_kernel", "launches_per_step": 1, "traffic": 24.6e6},
+            {"kind": "fused_stage", "kernel": "fused_up_conv_kernel<32, ...>", "launches_per_step": 1, "traffic": 58.9e6},
+            {"kind": "fused_stage", "kernel": "fused_up_conv_kernel<64, ...>", "launches_per_step": 1, "traffic": None},
+            {"kind": "torgb", "kernel": "torgb", "launches_per_step": 1, "traffic": None}]
+    out = bench.dedupe_traffic([dict(r) for r in rows])
+    assert [r["traffic"] for r in out] == [9.6e6, 24.2e6, None, 24.6e6, 58.9e6, None, None]
+    assert out[2]["traffic_source"].startswith("no counter pass")
