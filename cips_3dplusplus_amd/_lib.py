@@ -224,7 +224,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 25           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 26           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

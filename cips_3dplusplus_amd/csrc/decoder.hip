@@ -1244,7 +1244,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     if (rgb_lane) {
       rgb_bias = a.bias_rgb[q];
       if (a.skip && !(CIPS3D_FUSED_AB & 128)) {
-        if (a.skip_up) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
+        if (a.skip_up & 1) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
         else skv = *reinterpret_cast<const f32x4*>(a.skip + (int64_t)b * 3 * HWo + (q * HWo + oy * OW + ox));
       }
     }
@@ -1733,7 +1733,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] += rgb_bias;
     if (a.skip) {
-      if (a.skip_up) {
+      if (a.skip_up & 1) {
         float so[2][4];
         up2_fir(skp, kf, so);
         const int py = oy & 1;
@@ -1744,7 +1744,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         for (int c = 0; c < 4; ++c) v[c] += skv[c];
       }
     }
-    cips3d_store_wt16(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox), v);
+    if (a.skip_up & 2) {
+      // CIPS3D_RGB_U8: the image leaves as uint8 -- cips3d_rgb_to_uint8's arithmetic (clamp to [-1, 1], (c + 1) 127.5, round to
+      // nearest even) on the value that would have been stored: the multi-view loop's img_tensor_to_pil step
+      // (render_video_web_v10.py:1825-1826) without the fp32 image's round trip through memory
+      unsigned pk = 0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float cl = fminf(fmaxf(v[c], -1.f), 1.f);
+        pk |= (unsigned)__float2int_rn((cl + 1.f) * 127.5f) << (8 * c);
+      }
+      *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.rgb) + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox)) = pk;
+    } else {
+      cips3d_store_wt16(a.rgb + (int64_t)b * 3 * HWo + (ch * HWo + oy * OW + ox), v);
+    }
   }
   FSTAMP(6);        // rgb: bias, FIR of the skip, store
   FSTAMP_FLUSH();
@@ -2018,7 +2031,7 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
   if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
-              wm_rgb, bias_rgb, skip, skip_up & 1, rgb, B, H, W,
+              wm_rgb, bias_rgb, skip, (skip_up & 1) | ((skip_up & CIPS3D_RGB_U8) ? 2 : 0), rgb, B, H, W,
               (skip_up & CIPS3D_GEMM_SPLIT) ? 3 : (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next,
               y_next, rg ? rg->x_amax : nullptr, rg ? rg->lconst : nullptr, rg ? rg->lconst2 : nullptr,
               rg ? rg->next_amax : nullptr, rg ? rg->next_gain : 0.f};

@@ -159,6 +159,14 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   if (!IO.cam_poses || !IO.focals || !IO.near_ || !IO.far_ || !IO.rgb || !IO.thumb || !IO.xyz || !IO.mask)
     return CIPS3D_E_BADARG;
   const int B = P.B;
+  if (IO.rgb_is_u8) {      // a uint8 image leaves through a fused up-sampling stage only: decided before anything is enqueued
+    const int n = P.n_dec_layers;
+    const bool ok = n >= 3 && P.layers[n - 3].kind == 1 && P.layers[n - 2].kind == 0 && P.layers[n - 1].kind == 3 &&
+                    P.layers[n - 2].Cin == P.layers[n - 3].Cout && P.layers[n - 2].Cout == P.layers[n - 3].Cout &&
+                    P.layers[n - 1].Cin == P.layers[n - 3].Cout &&
+                    cips3d_fused_up_conv_supported(P.layers[n - 3].Cout, P.layers[n - 3].H, P.layers[n - 3].W);
+    if (!ok) return CIPS3D_E_UNSUPP;
+  }
   const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
   // decoder_bf16 == 2: the low-resolution GEMM results of the fused up-sampling stages (y_lo / y_next) live in HBM as bf16
   const int ybf_flag = P.decoder_bf16 == 2 ? CIPS3D_Y_BF16 : 0;
@@ -249,6 +257,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   float* ylo_cur = P.y_lo;                       // low-resolution GEMM result of the stage being run
   float* ylo_alt = P.y_lo2;                      // ... of the next stage, when the current stage's kernel computes it
   bool ylo_ready = false;                        // ylo_cur was already filled by the previous stage's kernel
+  bool u8_done = false;                          // the final image left through a fused stage (the only form that writes uint8)
   // ToRGB folding: a non-up-sampling ToRGB that follows a StyledConv is computed from that conv's registers (partial sums
   // per row block, cips3d_modconv1x1_torgb); the slots of consecutive such layers are folded by ONE cips3d_torgb_reduce
   // when their sum is first needed (the skip chain at an unchanged resolution is a plain sum).
@@ -342,6 +351,8 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         if (LN && LN->kind == 1 && (LN->flags & 1) && !chain) return CIPS3D_E_BADARG;
         float* out2 = (stage_last || chain) ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
+        const int u8_flag = (stage_last && IO.rgb_is_u8) ? CIPS3D_RGB_U8 : 0;
+        if (stage_last) u8_done = true;
         // flags bit 4: conv2's (and the chained up-conv's) weights are CIPS3D_MOD_SPLIT16-packed: the stage runs split-fp16
         const int stage_split = (L2.flags & 16) ? CIPS3D_GEMM_SPLIT : 0;
         if (chain && ((LN->flags & 16) != (L2.flags & 16))) return CIPS3D_E_BADARG;
@@ -358,7 +369,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           srg.next_gain = (ln_last && (LN->flags & 64)) ? sqrtf((float)L.Cout) : 0.f;
         }
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split, rgb, chain ? LN->wm : nullptr,
+                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split | u8_flag, rgb, chain ? LN->wm : nullptr,
                                       chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stage_ranged ? &srg : nullptr, stream));
         mark(CIPS3D_MARK_FUSED_STAGE, L.Cout, chain ? LN->Cout : 0, 2 * L.H);
         ylo_ready = chain;
@@ -469,6 +480,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         TRY(fold_flush(P.skip[skip_i]));
         skip_i ^= 1;
       }
+      if (last && IO.rgb_is_u8) return CIPS3D_E_UNSUPP;     // a stand-alone ToRGB writes fp32 only
       float* out = last ? IO.rgb : P.skip[skip_i];
       TRY(cips3d_torgb(x, L.wm, L.bias, skip, L.kind == 3 ? 1 : 0, L.fir, out, B, L.Cin, L.H, L.W, stream));
       mark(CIPS3D_MARK_TORGB, L.Cin, 3, L.kind == 3 ? 2 * L.H : L.H);
@@ -478,5 +490,6 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       return CIPS3D_E_BADARG;
     }
   }
+  if (IO.rgb_is_u8 && !u8_done) return CIPS3D_E_UNSUPP;
   return 0;
 }

@@ -189,18 +189,26 @@ class Generator(nn.Module):
         return ent
 
     def _planned_forward(self, plan, zs, cam_poses, focals, near, far, perturb_u, noise_bufs, truncation, style_render,
-                         style_decoder, return_sdf, return_xyz, fresh_perturb=False, styles_resident=False):
+                         style_decoder, return_sdf, return_xyz, fresh_perturb=False, styles_resident=False, rgb_out=None):
         from . import hip
         B = plan.B
         z_r = z_d = mean_r = mean_d = None
         ident = lambda t: (t.data_ptr(), t._version, tuple(t.shape))     # noqa: E731 (what a style table was computed from)
+        # (a resident frame also promises unchanged WEIGHTS behind the tables: an optimiser step on the decoder or the mapping
+        # networks between two frames bumps these versions; the renderer's are part of the plan's key)
+        plist = self.__dict__.get("_stamp_params")
+        if plist is None or plist[0] != id(self.decoder.conv1.conv.weight):
+            plist = (id(self.decoder.conv1.conv.weight),
+                     [p for m in (self.decoder, self.style, self.style_decoder) for p in m.parameters()])
+            self.__dict__["_stamp_params"] = plist
+        wver = sum(p._version for p in plist[1])          # (versions only grow: the sum changes whenever one of them does)
         if style_render is not None and style_decoder is not None:
-            stamp = ("w+", ident(style_render), ident(style_decoder))
+            stamp = ("w+", ident(style_render), ident(style_decoder), wver)
             if not styles_resident:
                 plan.styles_r.copy_(style_render)       # explicit W+ styles bypass the mapping networks
                 plan.styles_d.copy_(style_decoder)
         else:
-            stamp = ("z", ident(zs[0]), ident(zs[1]), float(truncation))
+            stamp = ("z", ident(zs[0]), ident(zs[1]), float(truncation), wver)
             if truncation < 1:
                 stamp += (ident(self.style_render_mean), ident(self.style_decoder_mean))
             if not styles_resident:
@@ -226,12 +234,17 @@ class Generator(nn.Module):
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
-            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp)
+            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp, rgb_out=rgb_out)
         # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
         m2 = mask.transpose(0, 1).contiguous()
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
                 "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
                 "mask": m2[0].unsqueeze(1), "depth": m2[1].unsqueeze(1)}
+
+    def can_emit_uint8(self, B, img_size, N_samples, static_viewdirs=False):
+        """True when a forward of this shape can write its image as uint8 (`rgb_out` of dtype uint8)."""
+        plan = self._forward_plan(B, img_size, int(N_samples), bool(static_viewdirs))
+        return plan is not None and bool(getattr(plan, "u8_capable", False))
 
     # ---------------------------------------------------------------- forward
     def forward(self, zs, cam_poses, focals, img_size, near=0.88, far=1.12, truncation=1, inject_index=None,
@@ -329,12 +342,15 @@ class Generator(nn.Module):
                        eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
                        N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
                        renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, styles_resident=False,
-                       **kwargs):
+                       rgb_out=None, **kwargs):
         """styles_resident (extension of the reference's call surface; multiview.sample_multi_view uses it): this call is a frame
         of a sequence that renders ONE latent from many cameras (render_video_web_v10.py:1792-1824) -- the previous call of the
         same shape already ran the mapping networks, the style heads and the modulate table for exactly these zs / styles /
         truncation / noise buffers, and this call reuses its tables (bit-identical to recomputing them; plan.run checks the
-        promise).  Ignored on the per-op path."""
+        promise).  Ignored on the per-op path.
+        rgb_out (extension): a preallocated contiguous [B, 3, R, R] tensor that receives `rgb` -- float32, or uint8 (the image
+        leaves the last up-sampling stage as uint8: hip.rgb_to_uint8's bits without the fp32 image's round trip; planned
+        forwards whose decoder ends in a fused stage, `can_emit_uint8`).  `ret["rgb"]` is that tensor."""
         assert len(zs) == 2
         if eikonal_reg or path_reg:
             raise NotImplementedError("eikonal_reg / path_reg are training-only (double backward); inference path here")
@@ -368,7 +384,9 @@ class Generator(nn.Module):
                 self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, dev)
             return self._planned_forward(plan, zs, cam_poses, per_view(focals), per_view(near), per_view(far), perturb_u,
                                          noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz,
-                                         fresh_perturb=fresh_perturb, styles_resident=bool(styles_resident))
+                                         fresh_perturb=fresh_perturb, styles_resident=bool(styles_resident), rgb_out=rgb_out)
+        if rgb_out is not None:
+            raise NotImplementedError("rgb_out needs the planned forward (k = 1 decoder with tiled widths, no style mixing)")
         if fresh_perturb:
             perturb_u = torch.rand(B, img_size, img_size, 1, device=dev)
 

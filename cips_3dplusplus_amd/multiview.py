@@ -122,7 +122,7 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
 def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, truncation_ratio=0.5, N_samples=128,
                       zero_noise_bufs=False, noise_bufs=None, azim_range=(-0.77, 0.77), elev=0.0, circle=None,
                       trans_max=0.04, only_rotate=False, chunk=1, gather=("rgb", "thumb_rgb", "xyz"), to_uint8=True,
-                      group=None, hoist=True):
+                      group=None, hoist=True, uint8_in_kernel=True):
     """The frame loop of `_sample_multi_view_web` (render_video_web_v10.py:1651-1899) without the web page: one z pair,
     one set of noise buffers, `perturb=False`, a camera trajectory (`yaw` / `circle` / `translate_rotate`), one
     `G(...)` call per `chunk` frames with `truncation=truncation_ratio, return_xyz=True`.  With torch.distributed
@@ -134,7 +134,9 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
     FiLM table and all modulated / demodulated decoder matrices are the same for the whole sequence: the first call of each call shape
     computes them, every later frame reuses them (`styles_resident=True`: no mapping / style-head / modulate-table launches between
     frames; the reference offers the same hoist through `style_render=` / `style_decoder=`, models/model_v3.py:875-914).
-    Bit-identical to `hoist=False`, which recomputes them per frame."""
+    Bit-identical to `hoist=False`, which recomputes them per frame.
+    `uint8_in_kernel` (default): where the decoder ends in a fused up-sampling stage (the 1024^2 recipes) the uint8 frame is written
+    by that kernel, straight into the rank's frame block (`rgb_out`); False: fp32 image + `hip.rgb_to_uint8` (same bits)."""
     from . import hip
     from .camera import yaw_trajectory, circle_trajectory, cameras_from_trajectory, translate_rotate_cameras
     dev = next(G.parameters()).device
@@ -171,15 +173,24 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
     frames_u8 = None                   # this rank's uint8 frames land in ONE block (no concatenation copy at the end)
 
     def render(a, b):
+        nonlocal frames_u8
+        direct = None
+        static = bool(ncfg.get("static_viewdirs", False))
+        if to_uint8 and uint8_in_kernel and G.can_emit_uint8(b - a, img_size, N_samples, static):
+            # this rank's frames land in ONE uint8 block; where the decoder ends in a fused up-sampling stage the image leaves
+            # that kernel as uint8 straight into its slice of the block (no fp32 image, no conversion launch)
+            if frames_u8 is None:
+                R = G._forward_plan(b - a, img_size, int(N_samples), static).out_res
+                frames_u8 = torch.empty(hi - lo, 3, R, R, dtype=torch.uint8, device=dev)
+            direct = frames_u8[a - lo:b - lo]
         with torch.no_grad():
             r = G(zs=zs, cam_poses=ext[a:b].contiguous(), focals=foc[a:b].contiguous(), img_size=img_size,
                   near=near[a:b].contiguous(), far=far[a:b].contiguous(), noise_bufs=noise_bufs,
                   truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True,
-                  styles_resident=hoist and full_done == {b - a})
+                  styles_resident=hoist and full_done == {b - a}, rgb_out=direct)
         full_done.clear()              # (a call of another shape rewrites the shared style tables: only the last shape is resident)
         full_done.add(b - a)
-        if to_uint8:
-            nonlocal frames_u8
+        if to_uint8 and direct is None:
             r = dict(r)
             if frames_u8 is None:
                 frames_u8 = torch.empty((hi - lo,) + tuple(r["rgb"].shape[1:]), dtype=torch.uint8, device=dev)

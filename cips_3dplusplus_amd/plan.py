@@ -54,7 +54,7 @@ class ForwardIO(C.Structure):
                 ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
                 ("noise_bound", C.c_float), ("pad2_", C.c_int32),
                 ("ev_marks", C.c_void_p), ("ev_info", C.c_void_p), ("ev_count", C.c_void_p), ("n_ev_marks", C.c_int32),
-                ("styles_resident", C.c_int32)]
+                ("styles_resident", C.c_int32), ("rgb_is_u8", C.c_int32), ("pad4_", C.c_int32)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -167,6 +167,7 @@ class ForwardPlan:
             wm_sizes.append(B * conv.out_channel * conv.in_channel)
             layer_info.append(info)
         self.out_res = res
+        self._layer_info = layer_info
         self.noise_sizes = [li["Hout"] for li in layer_info if li["kind"] in (0, 1)]
         # An up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] of equal widths runs as low-res GEMM + one fused kernel
         # (forward.hip).  When the NEXT stage is one too and the fused kernel has the chained form for this width, that kernel
@@ -178,6 +179,8 @@ class ForwardPlan:
             a, b_, c = layer_info[i], layer_info[i + 1], layer_info[i + 2]
             return (a["kind"] == 1 and b_["kind"] == 0 and c["kind"] == 3 and b_["Cin"] == a["Cout"] and b_["Cout"] == a["Cout"]
                     and c["Cin"] == a["Cout"] and bool(lib.cips3d_fused_up_conv_supported(a["Cout"], a["H"], a["W"])))
+        # the image can leave as uint8 (cips3d_forward_io.rgb_is_u8) when the decoder ends in a fused up-sampling stage
+        self.u8_capable = len(layer_info) >= 3 and fused_stage(len(layer_info) - 3)
         for i in range(len(layer_info) - 3):
             a, nx = layer_info[i], layer_info[i + 3]
             if (CHAIN_STAGES and fused_stage(i) and fused_stage(i + 3) and lib.cips3d_fused_up_conv_chains(a["Cout"])
@@ -402,13 +405,15 @@ class ForwardPlan:
         return bound
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
-            events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None):
+            events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None, rgb_out=None):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
         one cips3d_rng_fill launch when both are fresh.
         styles_resident: a frame of a sequence (cips3d_forward_io.styles_resident): the style phase and the modulate table are
         skipped and the plan's tables are used as the last FULL run left them.  `style_stamp` identifies what those tables were
         computed from (latents / styles, truncation, means): a full run records it (with the call's bound of |noise|, which the
-        range constants carry), a resident run must present the same one or it raises."""
+        range constants carry), a resident run must present the same one or it raises.
+        rgb_out: a contiguous tensor [B, 3, R, R] the image is written into instead of a fresh one -- float32, or uint8 on a plan
+        that is `u8_capable` (the last up-sampling stage then stores cips3d_rgb_to_uint8 of the image directly)."""
         lib = _lib.load()
         B, S, dev = self.B, self.img_size, self.device
         fresh_noise = noise_bufs is None or all(nb is None for nb in noise_bufs)
@@ -473,7 +478,17 @@ class ForwardPlan:
                     raise RuntimeError(f"noise buffer {i} has shape {tuple(nb.shape)}, expected (1|{B},1,{s},{s})")
                 io.noise[i] = dev_ptr(nb, f"noise_bufs[{i}]")
                 io.noise_bstride[i] = s * s if (nb.shape[0] == B and B > 1) else 0
-        rgb = torch.empty(B, 3, self.out_res, self.out_res, device=dev)
+        if rgb_out is None:
+            rgb = torch.empty(B, 3, self.out_res, self.out_res, device=dev)
+        else:
+            rgb = rgb_out
+            if (tuple(rgb.shape) != (B, 3, self.out_res, self.out_res) or not rgb.is_contiguous() or rgb.device != dev or
+                    rgb.dtype not in (torch.float32, torch.uint8)):
+                raise RuntimeError(f"rgb_out must be a contiguous float32 / uint8 tensor of shape {(B, 3, self.out_res, self.out_res)} on {dev}")
+            if rgb.dtype == torch.uint8:
+                if not self.u8_capable:
+                    raise RuntimeError("this decoder does not end in a fused up-sampling stage: no uint8 output (render float32, then hip.rgb_to_uint8)")
+                io.rgb_is_u8 = 1
         thumb = torch.empty(B, 3, S, S, device=dev)
         xyz = torch.empty(B, 3, S, S, device=dev)
         mask = torch.empty(B, 2, S, S, device=dev)

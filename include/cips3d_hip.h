@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 25  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 26  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -357,6 +357,10 @@ int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, flo
  * (together with CIPS3D_GEMM_BF16) `y_lo` is read and `y_next` is written as bf16.  FIR, epilogues and accumulation stay
  * fp32.  Halves the activation bytes the >= 128^2 stages move through HBM (BASELINE config 3). */
 #define CIPS3D_Y_BF16         0x200
+/* OR-ed into `skip_up` of cips3d_fused_up_conv[_next]: `rgb` points to a uint8 [B,3,2H,2W] image and receives
+ * cips3d_rgb_to_uint8(rgb) -- clamp to [-1, 1], (c + 1) * 127.5, round to nearest even -- instead of the fp32 values (bit-identical
+ * to converting the stored fp32 image; the reference's img_tensor_to_pil step, models/render_video_web_v10.py:1825-1826). */
+#define CIPS3D_RGB_U8         0x800
 int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
                             int B, int Cout, int Cin, int ksq, float scale, int flags,
                             void* stream);
@@ -606,7 +610,7 @@ typedef struct cips3d_forward_io {
   float* sdf;              /* [B, R, N] or NULL */
   const float* noise[CIPS3D_MAX_DEC_LAYERS];      /* per StyledConv: [1 or B][Hout*Wout] or NULL */
   int64_t noise_bstride[CIPS3D_MAX_DEC_LAYERS];   /* 0 (shared) or Hout*Wout */
-  float* rgb;              /* [B, 3, Hout, Wout] final image (written by the last ToRGB) */
+  float* rgb;              /* [B, 3, Hout, Wout] final image (written by the last ToRGB); with rgb_is_u8 a uint8 image of that shape */
   float* thumb;            /* [B, 3, S, S] */
   float* xyz;              /* [B, 3, S, S] */
   float* mask;             /* [B, 2, S, S]: background weight, -|xyz| */
@@ -636,6 +640,11 @@ typedef struct cips3d_forward_io {
    * style_render= / style_decoder= arguments (models/model_v3.py:875-914).  Results are bit-identical to a full forward with the
    * same inputs.  The caller owns the promise that styles, truncation, weights and the bound of |noise| have not changed. */
   int32_t styles_resident;
+  /* != 0: `rgb` points to uint8 [B, 3, Hout, Wout] and receives cips3d_rgb_to_uint8 of the image (CIPS3D_RGB_U8 of the last
+   * up-sampling stage).  Only plans whose last layers form a fused up-sampling stage can do it: CIPS3D_E_UNSUPP otherwise (the
+   * caller then renders fp32 and converts). */
+  int32_t rgb_is_u8;
+  int32_t pad4_;
 } cips3d_forward_io;
 
 #define CIPS3D_MARK_START 0
