@@ -336,7 +336,11 @@ class ForwardWorkload:
             hw = hh * hh
             if kind in ("planes_gemm", "gemm", "lowres_gemm"):
                 flops = 2.0 * B * ci * co * hw
-                row.update(kernel="chain_gemm_kernel" if kind == "planes_gemm" else "modconv1x1_kernel", bound="mfma",
+                # (the low-resolution exit of a planes run is the chain kernel on half a grid + the riding ToRGB fold: no counter pass is
+                # keyed on that shape, and modconv1x1_kernel's bytes -- the fp32_exact check's launches -- are not its)
+                kname = "chain_gemm_kernel" if kind == "planes_gemm" else (
+                    "chain_gemm_kernel (low-res exit)" if (kind == "lowres_gemm" and split) else "modconv1x1_kernel")
+                row.update(kernel=kname, bound="mfma",
                            flop_per_launch=flops, achieved=flops / (us * 1e-6) / 1e12, peak=mm_peak, unit="TFLOP/s")
             elif kind == "fused_stage":
                 C = ci
