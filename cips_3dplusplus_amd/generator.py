@@ -276,6 +276,8 @@ class Generator(nn.Module):
         if differentiable:
             if not torch.is_grad_enabled():
                 raise RuntimeError("differentiable=True under torch.no_grad()")
+            if kwargs.get("styles_resident") or kwargs.get("rgb_out") is not None:
+                raise NotImplementedError("styles_resident / rgb_out belong to the inference forward (call under torch.no_grad())")
             # the renderer's weights may be optimised (`optim_render_params`, projector_v10.py:848-872, 968); the two mapping
             # networks may not: the inversion loop never runs them (it optimises W+ directly)
             frozen = [n for mod in ("style", "style_decoder")
