@@ -236,8 +236,11 @@ __global__ void __launch_bounds__(256) nerf_pack32_kernel(const float* __restric
 // the other's matrix block, which nerf_pair.hip's one-wave form of the same arithmetic cannot do (252 us; this one: see DESIGN).
 // L0M (layer 0 and the view-direction columns on the matrix cores): fragment table geometry and the power of two of the points
 constexpr int L0M_TILE_FLOATS = 48 * 4;      // one o-tile of the table: 48 lane slots x 16 bytes
+#ifndef CIPS3D_L0M_VIEW
+#define CIPS3D_L0M_VIEW 1                    // 0: L0M covers layer 0 only, the view-direction columns stay three FMAs per unit (A/B)
+#endif
 constexpr int L0M_POINT_EXP = 8;             // the point fragment holds n 2^8 (|n| <~ 1.5: normalised coordinates)
-__host__ __device__ constexpr int nerf_table_floats(int H, int L, bool l0m) { return L * 2 * H + (l0m ? 16 : 10) * H; }
+__host__ __device__ constexpr int nerf_table_floats(int H, int L, bool l0m) { return L * 2 * H + (l0m ? (CIPS3D_L0M_VIEW ? 16 : 19) : 10) * H; }
 
 template <bool F32>
 __device__ __forceinline__ void put8(const float (&v)[8], h8& hi, h8& lo) {
@@ -318,16 +321,16 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
     f32x4 acc[TPS];
     // (opaque per step: as loop invariants the operand copies of vx, vy, vz were hoisted out of the sample loop and spilled)
     float vxo = vx, vyo = vy, vzo = vz;
-    if (VIEW && !L0M) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
-    if constexpr (VIEW && L0M) {
+    if (VIEW && !(L0M && CIPS3D_L0M_VIEW)) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
+    if constexpr (VIEW && L0M && CIPS3D_L0M_VIEW) {
       // the three view-direction columns as ONE more k-block of the split MFMA (L0M: see the layer-0 block of the kernel): the
       // lane's A fragment of o-tile (sl * TPS + tt) from the fragment table, the ray's direction fragment bd (built once per ray)
-      h8 fa[TPS];
 #pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) fa[tt] = *reinterpret_cast<const h8*>(afrag_lane + (sl * TPS + tt) * L0M_TILE_FLOATS);
-#pragma unroll
-      for (int tt = 0; tt < TPS; ++tt)
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[tt], bd, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int tt = 0; tt < TPS; ++tt) {
+        h8 fa = *reinterpret_cast<const h8*>(afrag_lane + (sl * TPS + tt) * L0M_TILE_FLOATS);
+        asm volatile("" : "+v"(fa));          // (one fragment at a time: four in flight were part of the nine spilled registers)
+        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, bd, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      }
     } else
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
@@ -499,8 +502,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   // lane (r, q) of an A fragment holds k = 8 q .. 8 q + 7 of row r: lane slots 0..47 (q = 0, 1, 2); q = 3 re-reads q = 2's slot,
   // whose k 24..31 face zeros in both B fragments (every table entry is a finite fp16 value).
   float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed      (L0M: the fragment table, 12 H floats)
-  float* s_wd = s_w0 + (L0M ? 6 : 3) * H;    // [3][H]  view-direction columns of the view layer   (L0M: second half of the table)
-  float* s_ws = s_wd + (L0M ? 6 : 3) * H;    // [H]     sigma head
+  float* s_wd = s_w0 + (L0M ? (CIPS3D_L0M_VIEW ? 6 : 12) : 3) * H;    // [3][H]  view-direction columns of the view layer   (L0M: second half of the table; layer-0-only L0M: behind it)
+  float* s_ws = s_wd + (L0M && CIPS3D_L0M_VIEW ? 6 : 3) * H;    // [H]     sigma head
   float* s_wc = s_ws + H;                    // [3][H]  rgb head
 
   const int tid = threadIdx.x;
@@ -604,10 +607,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     }
     for (int i = tid; i < 3 * H; i += WAVES * 64) {
       const int k = i / H, o = i - k * H;
-      if constexpr (!L0M) {
-        s_w0[i] = P.w_first[o * 3 + k];
-        s_wd[i] = P.w_view[o * (H + 3) + H + k] * view_scale;
-      }
+      if constexpr (!L0M) s_w0[i] = P.w_first[o * 3 + k];
+      if constexpr (!(L0M && CIPS3D_L0M_VIEW)) s_wd[i] = P.w_view[o * (H + 3) + H + k] * view_scale;
       s_wc[i] = P.w_rgb[i];
     }
     for (int i = tid; i < H; i += WAVES * 64) s_ws[i] = P.w_sigma[i];
@@ -754,10 +755,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       float v8[8];
       f32x4 pre2[2];
       if constexpr (L0M) {
-        const h8 fa0 = *reinterpret_cast<const h8*>(afrag_lane + opq + (2 * m) * L0M_TILE_FLOATS);
-        const h8 fa1 = *reinterpret_cast<const h8*>(afrag_lane + opq + (2 * m + 1) * L0M_TILE_FLOATS);
-        pre2[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa0, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        pre2[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa1, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        // (one o-tile at a time where registers are short: both fragments in flight together spilled nine registers)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const h8 fa = *reinterpret_cast<const h8*>(afrag_lane + opq + (2 * m + hf) * L0M_TILE_FLOATS);
+          pre2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
@@ -818,7 +821,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // ---- view layer -> features, folded into FA; rgb head partial sums
     float sdf_unused = 0.f;
     h8 bd = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (L0M) bd = dir_fragment();
+    if constexpr (L0M && CIPS3D_L0M_VIEW) bd = dir_fragment();
     mfma_layer<NT, TPS, true, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
                                      vx, vy, vz, STASH ? stash_s + (int64_t)(D - 1) * 16 * H : nullptr, wave, lane,
                                      q4o, afrag_lane + opq, bd STAMP_ARG);
