@@ -540,6 +540,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const bool ray_ok = task_ok && ray < R;
   const int rayc = ray < R ? ray : R - 1;
 
+#ifndef CIPS3D_EARLY_SLAB
+#define CIPS3D_EARLY_SLAB 0      // A/B (round 5): 1 = the first weight slab's LDS-DMA is requested in FRONT of the table staging
+#endif
+#if CIPS3D_EARLY_SLAB
+  stage_slab<SLAB>(F32 ? P.packed32 : P.packed, ringmem, wave, lane);
+#endif
   // ---- stage the small per-view tables
   int dir_exp = 0;                             // L0M: power of two the direction fragment carries
   {
@@ -696,7 +702,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   ring.seq = 0;
   ring.per_sample = D * (NT / TPS);
   ring.seq_end = a.chunk * ring.per_sample;
+#if !CIPS3D_EARLY_SLAB
   stage_slab<SLAB>(ring.packed, ringmem, wave, lane);
+#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
 #if CIPS3D_HALF_PERIOD
