@@ -605,6 +605,57 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         *reinterpret_cast<h8*>(tab + (int64_t)i * 8) = v;
       }
     }
+#ifndef CIPS3D_BATCHED_STAGING
+#define CIPS3D_BATCHED_STAGING 1     // 0: the round-1 form -- one loop per table, every iteration its own dependent round trips (A/B)
+#endif
+#if CIPS3D_BATCHED_STAGING
+    // Every global load of the staging is requested before the first one is waited for: the loops below used to be a chain of
+    // ~12 dependent memory round trips (each table's loop: load -> wait -> LDS store, per iteration; L2 is cold at a kernel's
+    // start) -- ~10 k cycles of a workgroup's 146 k at the published shape (in-kernel stamps).  Two elements per
+    // thread and table are in flight at a time (the whole staging at hidden 256, depth 2).
+    constexpr int NTH = WAVES * 64;
+    for (int base = 0; base < L * H || base < 3 * H; base += 2 * NTH) {
+      float gm[2], bt[2], lb[2], sc[2], w0v[2], wdv[2], wcv[2], wsv = 0.f;
+      int fi[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = base + e * NTH + tid;
+        fi[e] = i;
+        gm[e] = bt[e] = lb[e] = 0.f; sc[e] = 1.f; w0v[e] = wdv[e] = wcv[e] = 0.f;
+        if (i < L * H) {
+          const int l = i / H, o = i - l * H;
+          gm[e] = film_b[(l * 2) * H + o];
+          bt[e] = film_b[(l * 2 + 1) * H + o];
+          lb[e] = P.layer_bias[i];
+          if (l >= 1) sc[e] = scales[2 * (l - 1) + 1];
+        }
+        if (i < 3 * H) {
+          const int k = i / H, o = i - k * H;
+          if constexpr (!L0M) w0v[e] = P.w_first[o * 3 + k];
+          if constexpr (!(L0M && CIPS3D_L0M_VIEW)) wdv[e] = P.w_view[o * (H + 3) + H + k];
+          wcv[e] = P.w_rgb[i];
+        }
+      }
+      if (base == 0 && tid < H) wsv = P.w_sigma[tid];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int i = fi[e];
+        if (i < L * H) {
+          const int l = i / H, o = i - l * H;
+          s_film[(l * 2) * H + o] = (l >= 1 ? gm[e] * sc[e] : gm[e] * l0_unscale) * FILM_UNIT;
+          s_film[(l * 2 + 1) * H + o] = fmaf(gm[e], lb[e], bt[e]) * FILM_UNIT;
+        }
+        if (i < 3 * H) {
+          if constexpr (!L0M) s_w0[i] = w0v[e];
+          if constexpr (!(L0M && CIPS3D_L0M_VIEW)) s_wd[i] = wdv[e] * view_scale;
+          s_wc[i] = wcv[e];
+        }
+      }
+      if (base == 0 && tid < H) s_ws[tid] = wsv;
+    }
+    for (int i = tid + NTH; i < H; i += NTH) s_ws[i] = P.w_sigma[i];      // (hidden widths above the workgroup size: none today)
+  }
+#else
     for (int i = tid; i < L * H; i += WAVES * 64) {
       const int l = i / H, o = i - l * H;
       const float gm = film_b[(l * 2) * H + o];
@@ -619,6 +670,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     }
     for (int i = tid; i < H; i += WAVES * 64) s_ws[i] = P.w_sigma[i];
   }
+#endif
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
   const bool raw_density = __builtin_amdgcn_readfirstlane(P.raw_density) != 0;
