@@ -242,35 +242,43 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #define CIPS3D_CHAIN_AB 0        // timing-only ablations: 1 no range work at all, 2 no patch-maxima store, 3 no patch-maxima load
 #endif
   const bool track = CIPS3D_CHAIN_AB != 1 && NP == 2 && a.out_fmt == 1 && a.lconst;
-  auto load_ops = [&]() {
+  // The epilogue's operands are REQUESTED here (pure loads into registers, right behind the first stage's LDS-DMA) and only
+  // turned into what the epilogue needs after the main loop (finish_ops).  Round 5: in the old form -- loads and their arithmetic
+  // interleaved -- `a.x_exp ? a.x_exp[..] : a.x_exp_const` became ONE flat load of a selected address (array or kernarg word), a
+  // flat load's result needs vmcnt(0), and that wait sat in front of every other operand load: the whole first stage had to land
+  // before the remaining ~5 dependent round trips (bound constants, patch maxima, noise, bias, ToRGB rows) even started --
+  // 1-2 us per launch in front of the main loop.
+#ifndef CIPS3D_CHAIN_LATE_OPS
+#define CIPS3D_CHAIN_LATE_OPS 1     // 0: finish_ops right behind issue_ops, as before round 5 (A/B)
+#endif
+  int e_raw = 0;
+  f32x4 lc_raw = {0.f, 0.f, 0.f, 0.f};
+  auto issue_ops = [&]() {
     if constexpr (NP == 2) {
       const int nblk = (HW + BN - 1) / BN;
-      const int e_in = a.x_exp ? a.x_exp[b * nblk + blockIdx.x] : a.x_exp_const;      // (uniform address: a scalar load)
-      kin = cips3d_uniform(kin * cips3d_pow2(e_in));
+      if (a.x_exp) {        // (an agent-scope relaxed load: a plain global load the compiler cannot fold into a select of addresses)
+        typedef const __attribute__((address_space(1))) int gi32_t;
+        e_raw = __hip_atomic_load(reinterpret_cast<gi32_t*>(reinterpret_cast<uintptr_t>(a.x_exp + b * nblk + blockIdx.x)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (track) {
         const float* lc = a.lconst + b * 4;
-        lc0 = lc[0];
-        lc1 = fmaxf(lc[1], 1.41421356237309515f * lc[2]);
+        lc_raw = f32x4{lc[0], lc[1], lc[2], 0.f};
         if (a.x_pmax && CIPS3D_CHAIN_AB != 3) {      // the 2 x Cin/16 patch maxima of this pixel block are contiguous: one load per wave (Cin <= 512)
           const int n_half = (HW + 63) / 64, per = K >> 4;
           const int n_ent = (2 * (int)blockIdx.x + 1 < n_half ? 2 : 1) * per;
           const float* pp = a.x_pmax + ((int64_t)b * n_half + 2 * blockIdx.x) * per;
-          for (int i = lane; i < n_ent; i += 64) pin = fmaxf(pin, pp[i]);
-        } else {
-          // no patch maxima: the caller's constant, or what the input's own exponent says -- its producer put a bound of ITS
-          // output below 2^15 2^e_in.  That is a bound of a bound (another ~2^5 of slack: the stored values then top out near
-          // 2^5 instead of 2^10, still > 27 bits above the pair's floor), so a run alternates: every other layer leaves patch
-          // maxima for its consumer (forward.hip), which halves what the tracking costs (0.45 us per writing layer)
-          pin = a.x_max_const > 0.f ? a.x_max_const : cips3d_pow2(e_in + 15);
+          if (lane < n_ent) pin = pp[lane];        // (entries past the first 64 -- Cin > 512 only -- follow in finish_ops)
         }
       }
     }
     if (a.epilogue == 1) {
       if (a.noise && a.noise_w) {
         nw = a.noise_w[0];
+        const float* nzp = a.noise + (int64_t)b * a.noise_bstride;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          if (npx[c] < HW) nz[c] = a.noise[(int64_t)b * a.noise_bstride + npx[c]];
+          if (npx[c] < HW) nz[c] = nzp[npx[c]];
       }
 #pragma unroll
       for (int i = 0; i < WM; ++i)
@@ -283,6 +291,32 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
         for (int ch = 0; ch < 3; ++ch)
           wrgb[i][ch] = *reinterpret_cast<const f32x4*>(a.rgb_w + (int64_t)b * 3 * a.Cout + ch * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q);
     }
+  };
+  auto finish_ops = [&]() {
+    if constexpr (NP == 2) {
+      const int e_in = a.x_exp ? __builtin_amdgcn_readfirstlane(e_raw) : a.x_exp_const;
+      kin = cips3d_uniform(kin * cips3d_pow2(e_in));
+      if (track) {
+        lc0 = lc_raw[0];
+        lc1 = fmaxf(lc_raw[1], 1.41421356237309515f * lc_raw[2]);
+        if (a.x_pmax && CIPS3D_CHAIN_AB != 3) {
+          const int n_half = (HW + 63) / 64, per = K >> 4;
+          const int n_ent = (2 * (int)blockIdx.x + 1 < n_half ? 2 : 1) * per;
+          const float* pp = a.x_pmax + ((int64_t)b * n_half + 2 * blockIdx.x) * per;
+          for (int i = lane + 64; i < n_ent; i += 64) pin = fmaxf(pin, pp[i]);
+        } else {
+          // no patch maxima: the caller's constant, or what the input's own exponent says -- its producer put a bound of ITS
+          // output below 2^15 2^e_in.  That is a bound of a bound (another ~2^5 of slack: the stored values then top out near
+          // 2^5 instead of 2^10, still > 27 bits above the pair's floor), so a run alternates: every other layer leaves patch
+          // maxima for its consumer (forward.hip), which halves what the tracking costs (0.45 us per writing layer)
+          pin = a.x_max_const > 0.f ? a.x_max_const : cips3d_pow2(e_in + 15);
+        }
+      }
+    }
+  };
+  auto load_ops = [&]() {
+    issue_ops();
+    if (!CIPS3D_CHAIN_LATE_OPS) finish_ops();
   };
   f32x4 acc[WM][4];
 #pragma unroll
@@ -386,6 +420,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   }
 
   CSTAMP(2);                         // main loop
+  if (CIPS3D_CHAIN_LATE_OPS) finish_ops();
   if (track) {
     // max|in| of the pixel block from the lanes' entries (wave-uniform, no LDS), the bound, the exponent, its powers of two
     const float m_in = cips3d_wave_max_uniform(pin);
