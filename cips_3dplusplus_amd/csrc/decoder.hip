@@ -1175,7 +1175,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // 3 KB of LDS less per workgroup, which with <= 64 VGPRs admits an eighth workgroup per CU)
   __shared__ __attribute__((aligned(16))) float s_red_own[NEXT ? WGM * 3 * BN : 4];
   float* s_red = NEXT ? s_red_own : sB;
-  __shared__ float s_wrgb[3 * C];
+  __shared__ __attribute__((aligned(16))) float s_wrgb[3 * C];
 
   const int tid = threadIdx.x;
 #ifdef CIPS3D_FUSED_STAMPS
@@ -1207,6 +1207,23 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // scale factors of the split operands (cips3d_range); set right before the first patch_store below
   float kact1 = 1.41421356237309515f, k2in = kSplitInv, kact2 = 1.41421356237309515f, kback2 = 1.f, kyn = kSplitInv;
 
+#ifndef CIPS3D_FUSED_TILE_DMA
+#define CIPS3D_FUSED_TILE_DMA 1      // 0: the noise tile and the ToRGB rows go through registers behind the range block, as before round 5 (A/B)
+#endif
+  constexpr bool TILE_DMA = CIPS3D_FUSED_TILE_DMA != 0;
+  float nw1_u = 0.f;                        // NoiseInjection.weight of conv1 (TILE_DMA: applied where the tile is read)
+  // the layer's range constants (uniform addresses: scalar loads -- as long as they are read in FRONT of the LDS-DMA below)
+  float c10_u = 0.f, c11_u = 0.f, c20_u = 0.f, c21a_u = 0.f, c21b_u = 0.f;
+  if constexpr (SPLIT && TILE_DMA) {
+    if (a.x_amax && !(CIPS3D_FUSED_AB & 1)) {
+      const float* l1 = a.lconst1 + b * 4;
+      c10_u = l1[0]; c11_u = l1[1];
+      if (NEXT) {
+        const float* l2 = a.lconst2 + b * 4;
+        c20_u = l2[0]; c21a_u = l2[1]; c21b_u = l2[2];
+      }
+    }
+  }
   // Everything that does not depend on a barrier is requested first: conv2's first A fragments, its noise / bias.
   const float* ab = a.wm2 + (int64_t)b * C * C;   // packed [ot][kq][256]
   f32x4 afr_next[KQ][WM];
@@ -1304,7 +1321,11 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         const f32x4 nz = *reinterpret_cast<const f32x4*>(s_nz1 + (2 * by + py) * TW + qx * 4);
         f32x4 v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = (CIPS3D_FUSED_AB & 32) ? o[py][c] + nz[c] : lrelu02((o[py][c] + nz[c]) + bs);
+        for (int c = 0; c < 4; ++c) {
+          // (TILE_DMA: the tile holds the raw noise, its weight rides in the FMA -- one rounding where `o + (nw * noise)` had two)
+          const float on = TILE_DMA ? fmaf(nw1_u, nz[c], o[py][c]) : o[py][c] + nz[c];
+          v[c] = (CIPS3D_FUSED_AB & 32) ? on : lrelu02(on + bs);
+        }
         if constexpr (SPLIT && !(CIPS3D_FUSED_AB & 32)) {          // split once here (with the activation's gain and range scale: cips3d_split_word);
 #pragma unroll                          // every wave row reads the packed halves
           for (int c = 0; c < 4; ++c) v[c] = pack_split(v[c], kact1);
@@ -1317,6 +1338,39 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     }
   };
   auto patch_store = [&](int st, float* dst) { patch_store_from(st, dst, pv); };
+  // Round 5: the first conv's noise tile and the ToRGB rows have to be in LDS at the first barrier.  Loaded where they were stored
+  // -- behind the range block, `load -> wait -> LDS store` each -- they were two more dependent round trips of every workgroup's
+  // prologue (three in all, with the patches + amax slots).  Now they travel by LDS-DMA, requested with the first patches: no
+  // registers (the C = 32 / 64 stages have none to spare: five more live values spilled 34 / 20), no wait of their own -- the one
+  // vmcnt(0) in front of the first barrier covers them, the patches and the range slots.  The tile holds the RAW noise; its weight
+  // rides in the FMA that adds it (patch_store).  The request sits BEHIND the uniform loads of the prologue (FIR taps, biases): an
+  // LDS-DMA counts as a memory write for the compiler, and uniform loads behind one are no longer scalar loads -- issued at the very
+  // top, the 16 taps alone came back in vector registers and the C = 32 / 64 stages spilled 43 / 34.
+  if constexpr (TILE_DMA) {
+    const bool have_nz = a.noise1 && a.nw1 && !(CIPS3D_FUSED_AB & 128);
+    if (have_nz) nw1_u = a.nw1[0];
+    if (wave == 0) {                        // BN / 4 <= 64 lanes (BN = 128 in every instantiation): one wave's worth of 16-byte pieces
+      static_assert(BN / 4 <= 64 && (3 * C) % 4 == 0, "one LDS-DMA instruction per tile");
+      if (lane < BN / 4) {
+        if (have_nz) {
+          const int r = lane / (TW / 4), x4 = lane % (TW / 4);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.noise1 + (int64_t)b * a.nbs1 + ((oy0 + r) * OW + ox0 + x4 * 4)),
+                                           (__attribute__((address_space(3))) void*)s_nz1, 16, 0, 0);
+        } else {
+          *reinterpret_cast<f32x4*>(s_nz1 + lane * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if (a.wm_rgb) {                         // 3 C floats = 3 C / 4 pieces of 16 bytes, 64 per wave-instruction
+#pragma unroll
+      for (int p0 = 0; p0 < 3 * C / 4; p0 += 64 * WGM * WGN) {
+        const int pbase = p0 + wave * 64;   // (wave-uniform LDS base: the hardware adds lane * 16)
+        if (pbase < 3 * C / 4 && pbase + lane < 3 * C / 4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.wm_rgb + (int64_t)b * 3 * C + (pbase + lane) * 4),
+                                           (__attribute__((address_space(3))) void*)(s_wrgb + pbase * 4), 16, 0, 0);
+      }
+    }
+  }
   patch_load(0);
   if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
 
@@ -1331,13 +1385,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   if constexpr (SPLIT) {
     if (a.x_amax && wave == 0 && !(CIPS3D_FUSED_AB & 1)) {
       const float t = lane < CIPS3D_AMAX_SLOTS ? a.x_amax[b * CIPS3D_AMAX_FLOATS + lane * CIPS3D_AMAX_STRIDE] : 0.f;
-      const float* l1 = a.lconst1 + b * 4;            // (uniform addresses: scalar loads)
-      const float c10 = l1[0], c11 = l1[1];
-      float c20 = 0.f, c21 = 0.f;
-      if (NEXT) {
-        const float* l2 = a.lconst2 + b * 4;
-        c20 = l2[0];
-        c21 = fmaxf(l2[1], 1.41421356237309515f * l2[2]);
+      float c10, c11, c20 = 0.f, c21 = 0.f;
+      if constexpr (TILE_DMA) {
+        c10 = c10_u; c11 = c11_u;
+        if (NEXT) { c20 = c20_u; c21 = fmaxf(c21a_u, 1.41421356237309515f * c21b_u); }
+      } else {
+        const float* l1 = a.lconst1 + b * 4;            // (uniform addresses: scalar loads)
+        c10 = l1[0]; c11 = l1[1];
+        if (NEXT) {
+          const float* l2 = a.lconst2 + b * 4;
+          c20 = l2[0];
+          c21 = fmaxf(l2[1], 1.41421356237309515f * l2[2]);
+        }
       }
       const float m_in = cips3d_wave_max_uniform(t);
       const float u1 = fmaf(c11, m_in, c10);
@@ -1354,7 +1413,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       if (lane == 0) *reinterpret_cast<f32x4*>(s_nz1 + BN) = sc;
     }
   }
-  // noise of the first conv for this tile (scaled), ToRGB weights
+  // noise of the first conv for this tile, ToRGB weights (TILE_DMA: on their way since the top of the kernel)
+  if constexpr (TILE_DMA) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's LDS-DMA pieces (and, needed right behind the barrier anyway, its patches)
+  } else {
   if (tid < BN / 4) {
     const int r = tid / (TW / 4), x4 = tid % (TW / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -1368,6 +1430,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   }
   if (a.wm_rgb)
     for (int i = tid; i < 3 * C; i += NT) s_wrgb[i] = a.wm_rgb[(int64_t)b * 3 * C + i];
+  }
   __syncthreads();
 
   f32x4 acc[WM][4];
