@@ -137,6 +137,7 @@ _SIGS = {
                                    c_f32p, C.c_void_p]),
     "cips3d_noise_bias_act": (c_int, [c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_fused_up_conv_supported": (c_int, [c_int, c_int, c_int]),
+    "cips3d_fused_flat_conv_supported": (c_int, [c_int, c_int, c_int]),
     "cips3d_fused_up_conv": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p,
                                      c_f32p, c_f32p, c_f32p, c_f32p, c_int, c_f32p, c_int, c_int, c_int, c_int,
                                      C.c_void_p, C.c_void_p]),
@@ -224,7 +225,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 26           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 27           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

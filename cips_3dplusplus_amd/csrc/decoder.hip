@@ -807,6 +807,24 @@ __device__ __forceinline__ void up2_load(const float* __restrict__ src, int H, i
   }
 }
 
+// FLAT stages (no up-sampling): the 2 x 4 block itself, rows y, y + 1, columns x .. x + 3 (x % 4 == 0), into rows 0 / 1 of the set
+__device__ __forceinline__ void flat_load(const float* __restrict__ src, int W, int y, int x, float (&v)[3][4]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(src + ((y + r) * W + x));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[r][c] = t[c];
+  }
+}
+__device__ __forceinline__ void flat_load(const bf16_t* __restrict__ src, int W, int y, int x, float (&v)[3][4]) {
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const uint2 t = *reinterpret_cast<const uint2*>(src + ((y + r) * W + x));
+    v[r][0] = bf16_f32(t.x & 0xffffu); v[r][1] = __uint_as_float(t.x & 0xffff0000u);
+    v[r][2] = bf16_f32(t.y & 0xffffu); v[r][3] = __uint_as_float(t.y & 0xffff0000u);
+  }
+}
+
 // polyphase FIR of the patch; all tap indices are compile-time constants
 __device__ __forceinline__ void up2_fir(const float (&v)[3][4], const float (&kf)[16], float (&o)[2][4]) {
 #pragma unroll
@@ -1108,7 +1126,7 @@ struct FusedArgs {
   const float* y_lo; const float* fir; const float* noise1; int64_t nbs1; const float* nw1; const float* bias1;
   const float* wm2; const float* noise2; int64_t nbs2; const float* nw2; const float* bias2; float* out2;
   const float* wm_rgb; const float* bias_rgb; const float* skip; int skip_up; float* rgb;
-  int B, H, W;   // low-resolution size; the stage outputs 2H x 2W
+  int B, H, W;   // low-resolution size; the stage outputs 2H x 2W (FLAT: the size of y_lo AND of the outputs)
   int bf16;      // 0: exact fp32; 1: bf16 GEMM operands (CIPS3D_GEMM_BF16); 2: additionally y_lo / y_next are bf16 arrays (CIPS3D_Y_BF16);
                  // 3: fp32-equivalent split-fp16 products (CIPS3D_GEMM_SPLIT; wm2 / wm_next CIPS3D_MOD_SPLIT16-packed)
   // optional (NEXT instantiation): the next stage's low-resolution GEMM y_next = wm_next (C/2 x C, chained pack) out2
@@ -1120,6 +1138,10 @@ struct FusedArgs {
   // 4 us at the 4096 workgroups of the C = 64 stage) but its BOUND next_gain * U2 (next_gain: sqrt(C) for a demodulated next
   // up-conv), written once -- good enough for a consumer that is the last stage of the decoder (cips3d_range)
   float next_gain;
+  // FLAT stage (CIPS3D_STAGE_FLAT): a decoder block that does not up-sample -- [StyledConv, StyledConv, ToRGB] at ONE resolution.
+  // y_lo is conv1's GEMM result at that resolution, `fir` is unused, the skip image (if any) has the output's size and is added
+  // as it is.  Everything behind the first activation is the up-sampling stage's code.
+  int flat;
 };
 
 // MINW = waves per SIMD the register allocation must leave room for (the per-workgroup chain load -> FIR -> LDS -> MFMA ->
@@ -1153,7 +1175,7 @@ __device__ unsigned long long g_fused_stamps[4][8];
 #endif
 
 template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, int PREC, bool NEXT = false, bool XPREF = false,
-          bool LATE_OPS = false>
+          bool LATE_OPS = false, bool FLAT = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(FusedArgs a) {
   constexpr bool BF16 = PREC == 1 || PREC == 2;  // bf16 MFMA operands, fp32 accumulate
   constexpr bool YB = PREC == 2;                 // y_lo (in) and y_next (out) stored as bf16
@@ -1188,7 +1210,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   const int lrow = jn / LPR, lx4 = jn % LPR;
   const int nloc = (wn_i * RW + lrow) * TW + lx4 * 4;     // this lane's first pixel inside the tile
   const int b = blockIdx.z;
-  const int H = a.H, W = a.W, OH = 2 * H, OW = 2 * W;
+  const int H = a.H, W = a.W, OH = FLAT ? H : 2 * H, OW = FLAT ? W : 2 * W;
   const int tiles_x = OW / TW;
   // XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear id, and each XCD has its own L2: in row-major
   // tile order the horizontal neighbours of a tile -- whose FIR halo columns sit in the SAME 128-byte lines as its own
@@ -1251,7 +1273,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 
   float kf[16];   // flipped taps
 #pragma unroll
-  for (int i = 0; i < 16; ++i) kf[i] = a.fir[15 - i];
+  for (int i = 0; i < 16; ++i) kf[i] = FLAT ? 0.f : a.fir[15 - i];
   // the lanes that will finish a colour channel (wave row 0, quarter = channel) fetch their skip operands now
   const bool rgb_lane = a.wm_rgb && wm_i == 0 && q < 3;
   float skp[3][4];
@@ -1261,7 +1283,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
     if (rgb_lane) {
       rgb_bias = a.bias_rgb[q];
       if (a.skip && !(CIPS3D_FUSED_AB & 128)) {
-        if (a.skip_up & 1) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
+        if (!FLAT && (a.skip_up & 1)) up2_load(a.skip + (int64_t)b * 3 * HWlo + q * HWlo, H, W, oy >> 1, ox >> 2, skp);
         else skv = *reinterpret_cast<const f32x4*>(a.skip + (int64_t)b * 3 * HWo + (q * HWo + oy * OW + ox));
       }
     }
@@ -1271,7 +1293,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // FIR patches of one K stage: loaded early (before the MFMAs that precede their use), filtered late.  Tiles whose
   // low-resolution window (rows oy0/2-1 .. oy0/2+TH/2, columns ox0/2-1 .. ox0/2+TW/2) lies inside the image take loads
   // without edge predication (workgroup-uniform branch; 87 % of the tiles at 1024^2).
-  const bool interior = oy0 / 2 >= 1 && oy0 / 2 + TH / 2 < H && ox0 / 2 >= 1 && ox0 / 2 + TW / 2 < W;
+  const bool interior = FLAT || (oy0 / 2 >= 1 && oy0 / 2 + TH / 2 < H && ox0 / 2 >= 1 && ox0 / 2 + TW / 2 < W);
   // Two patch register sets when the K loop has >= 3 stages and it pays (C = 256): the patches of stage
   // st + 2 are requested at the START of stage st and filtered at the END of stage st + 1 -- two stages of lead.  With one
   // stage of lead (the form C = 64 keeps) a stage lasted as long as a patch round trip: in-kernel stamps (tools/
@@ -1297,7 +1319,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
           for (int c = 0; c < 4; ++c) pset[u][r][c] = __int_as_float(0x3c000000 + ((tid + st + r * 4 + c) << 8));
       } else
-      if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
+      if constexpr (FLAT) flat_load(src, W, oy0 + 2 * by, ox0 + 4 * qx, pset[u]);
+      else if (interior) up2_load_interior(src, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
       else up2_load(src, H, W, oy0 / 2 + by, ox0 / 4 + qx, pset[u]);
     }
   };
@@ -1309,7 +1332,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       const int ch = g / NBLK, rem = g % NBLK;
       const int by = rem / (TW / 4), qx = rem % (TW / 4);
       float o[2][4];
-      if constexpr (CIPS3D_FUSED_AB & 8) {
+      if constexpr (FLAT) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o[0][c] = pset[u][0][c]; o[1][c] = pset[u][1][c]; }
+      } else if constexpr (CIPS3D_FUSED_AB & 8) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { o[0][c] = pset[u][0][c] + pset[u][1][c]; o[1][c] = pset[u][1][c] + pset[u][2][c]; }
       } else {
@@ -1398,6 +1424,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
           c21 = fmaxf(l2[1], 1.41421356237309515f * l2[2]);
         }
       }
+      // (FLAT: x_amax is the maximum of conv1's GEMM RESULT -- what the FIR's gain multiplies in the up-sampling form; the row
+      // gain of a plain StyledConv's constants is relative to that conv's INPUT)
+      if (FLAT) c11 = 1.41421356237309515f;
       const float m_in = cips3d_wave_max_uniform(t);
       const float u1 = fmaf(c11, m_in, c10);
       const int e1 = cips3d_split_exp(u1);
@@ -1796,7 +1825,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] += rgb_bias;
     if (a.skip) {
-      if (a.skip_up & 1) {
+      if (!FLAT && (a.skip_up & 1)) {
         float so[2][4];
         up2_fir(skp, kf, so);
         const int py = oy & 1;
@@ -1826,15 +1855,21 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   FSTAMP_FLUSH();
 }
 
+template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT, bool XPREF, bool LATE, bool FLAT>
+int launch_fused_as(const FusedArgs& a, hipStream_t st) {
+  constexpr int TH = RW * WGN, TW = 64 / RW;
+  const int up = FLAT ? 1 : 2;
+  dim3 grid((unsigned)((up * a.W / TW) * (up * a.H / TH)), 1, (unsigned)a.B);
+  if (a.bf16 == 3) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 3, NEXT, XPREF, LATE, FLAT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else if (a.bf16 == 2) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 2, NEXT, XPREF, LATE, FLAT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 1, NEXT, XPREF, LATE, FLAT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 0, NEXT, XPREF, LATE, FLAT>), grid, dim3(64 * WGM * WGN), 0, st, a);
+  return cips3d_launch_status();
+}
 template <int C, int WM, int WGM, int WGN, int RW, int BK, int MINW, bool NEXT = false, bool XPREF = false, bool LATE = false>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-  constexpr int TH = RW * WGN, TW = 64 / RW;
-  dim3 grid((unsigned)((2 * a.W / TW) * (2 * a.H / TH)), 1, (unsigned)a.B);
-  if (a.bf16 == 3) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 3, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else if (a.bf16 == 2) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 2, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else if (a.bf16) hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 1, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  else hipLaunchKernelGGL((fused_up_conv_kernel<C, WM, WGM, WGN, RW, BK, MINW, 0, NEXT, XPREF, LATE>), grid, dim3(64 * WGM * WGN), 0, st, a);
-  return cips3d_launch_status();
+  return a.flat ? launch_fused_as<C, WM, WGM, WGN, RW, BK, MINW, NEXT, XPREF, LATE, true>(a, st)
+                : launch_fused_as<C, WM, WGM, WGN, RW, BK, MINW, NEXT, XPREF, LATE, false>(a, st);
 }
 
 }  // namespace
@@ -2069,6 +2104,12 @@ extern "C" int cips3d_fused_up_conv_supported(int C, int H, int W) {
          (int64_t)C * 4 * H * W < ((int64_t)1 << 31);
 }
 
+extern "C" int cips3d_fused_flat_conv_supported(int C, int H, int W) {
+  // the same tiles over an H x W output: 64 pixels per wave row, up to 4 image rows per workgroup
+  return (C == 32 || C == 64 || C == 128 || C == 256) && W % 64 == 0 && H % 4 == 0 && H >= 4 &&
+         (int64_t)C * H * W < ((int64_t)1 << 31);
+}
+
 extern "C" int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise1, int64_t noise1_bstride,
                                     const float* noise_w1, const float* bias1, const float* wm2, const float* noise2,
                                     int64_t noise2_bstride, const float* noise_w2, const float* bias2, float* out2,
@@ -2086,18 +2127,20 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
                                          const float* wm_rgb, const float* bias_rgb, const float* skip, int skip_up,
                                          float* rgb, const float* wm_next, float* y_next, int B, int C, int H, int W,
                                          const cips3d_range* rg, void* stream) {
-  if (!y_lo || !fir || !bias1 || !wm2 || !bias2 || B < 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
+  const int flat = (skip_up & CIPS3D_STAGE_FLAT) ? 1 : 0;
+  if (!y_lo || (!fir && !flat) || !bias1 || !wm2 || !bias2 || B < 0 || H <= 0 || W <= 0) return CIPS3D_E_BADARG;
+  if (flat && (skip_up & 1)) return CIPS3D_E_BADARG;           // a flat stage's skip image has the output's size
   if ((wm_next == nullptr) != (y_next == nullptr)) return CIPS3D_E_BADARG;
   if (wm_next && !cips3d_fused_up_conv_chains(C)) return CIPS3D_E_UNSUPP;
   if (!out2 && !wm_rgb && !wm_next) return CIPS3D_E_BADARG;
   if (wm_rgb && (!bias_rgb || !rgb)) return CIPS3D_E_BADARG;
-  if (!cips3d_fused_up_conv_supported(C, H, W)) return CIPS3D_E_UNSUPP;
+  if (!(flat ? cips3d_fused_flat_conv_supported(C, H, W) : cips3d_fused_up_conv_supported(C, H, W))) return CIPS3D_E_UNSUPP;
   if (B == 0) return 0;
   FusedArgs a{y_lo, fir, noise1, noise1_bstride, noise_w1, bias1, wm2, noise2, noise2_bstride, noise_w2, bias2, out2,
               wm_rgb, bias_rgb, skip, (skip_up & 1) | ((skip_up & CIPS3D_RGB_U8) ? 2 : 0), rgb, B, H, W,
               (skip_up & CIPS3D_GEMM_SPLIT) ? 3 : (skip_up & CIPS3D_GEMM_BF16) ? ((skip_up & CIPS3D_Y_BF16) ? 2 : 1) : 0, wm_next,
               y_next, rg ? rg->x_amax : nullptr, rg ? rg->lconst : nullptr, rg ? rg->lconst2 : nullptr,
-              rg ? rg->next_amax : nullptr, rg ? rg->next_gain : 0.f};
+              rg ? rg->next_amax : nullptr, rg ? rg->next_gain : 0.f, flat};
   // split mode with range tracking: the bound of act1 needs conv1's constants, the chained form conv2's as well
   if ((skip_up & CIPS3D_GEMM_SPLIT) && rg && rg->x_amax && (!rg->lconst || (wm_next && !rg->lconst2))) return CIPS3D_E_BADARG;
   if ((skip_up & CIPS3D_Y_BF16) && !(skip_up & CIPS3D_GEMM_BF16)) return CIPS3D_E_BADARG;   // bf16 storage implies bf16 operands

@@ -159,12 +159,15 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   if (!IO.cam_poses || !IO.focals || !IO.near_ || !IO.far_ || !IO.rgb || !IO.thumb || !IO.xyz || !IO.mask)
     return CIPS3D_E_BADARG;
   const int B = P.B;
-  if (IO.rgb_is_u8) {      // a uint8 image leaves through a fused up-sampling stage only: decided before anything is enqueued
+  if (IO.rgb_is_u8) {      // a uint8 image leaves through a fused stage only: decided before anything is enqueued
     const int n = P.n_dec_layers;
-    const bool ok = n >= 3 && P.layers[n - 3].kind == 1 && P.layers[n - 2].kind == 0 && P.layers[n - 1].kind == 3 &&
-                    P.layers[n - 2].Cin == P.layers[n - 3].Cout && P.layers[n - 2].Cout == P.layers[n - 3].Cout &&
-                    P.layers[n - 1].Cin == P.layers[n - 3].Cout &&
-                    cips3d_fused_up_conv_supported(P.layers[n - 3].Cout, P.layers[n - 3].H, P.layers[n - 3].W);
+    bool ok = n >= 3 && P.layers[n - 2].kind == 0 && P.layers[n - 2].Cin == P.layers[n - 3].Cout &&
+              P.layers[n - 2].Cout == P.layers[n - 3].Cout && P.layers[n - 1].Cin == P.layers[n - 3].Cout;
+    if (ok) {
+      const cips3d_dec_layer& h = P.layers[n - 3];
+      ok = (h.kind == 1 && P.layers[n - 1].kind == 3 && cips3d_fused_up_conv_supported(h.Cout, h.H, h.W)) ||
+           (h.kind == 0 && (h.flags & 128) && P.layers[n - 1].kind == 2 && cips3d_fused_flat_conv_supported(h.Cout, h.H, h.W));
+    }
     if (!ok) return CIPS3D_E_UNSUPP;
   }
   const int gemm_flag = P.decoder_bf16 ? CIPS3D_GEMM_BF16 : 0;
@@ -309,10 +312,21 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
       }
       // up-sampling stage [StyledConv(up), StyledConv, ToRGB(up)] with equal widths: low-res GEMM, then ONE fused
       // kernel for FIR + act -> conv2 + act -> ToRGB (+ FIR-upsampled skip); the full-resolution intermediate
-      // never reaches HBM and the last stage stores only the image
-      if (L.kind == 1 && li + 2 < P.n_dec_layers && P.layers[li + 1].kind == 0 && P.layers[li + 2].kind == 3 &&
-          P.layers[li + 1].Cin == L.Cout && P.layers[li + 1].Cout == L.Cout && P.layers[li + 2].Cin == L.Cout &&
-          cips3d_fused_up_conv_supported(L.Cout, L.H, L.W)) {
+      // never reaches HBM and the last stage stores only the image.
+      // FLAT stage (flags bit 7, set by the plan): [StyledConv, StyledConv, ToRGB] of equal widths at one resolution -- a block
+      // above the last up-sampling one (model_v3.py:553-590 builds every block up to size_end) -- through the same kernel
+      // without the FIR (CIPS3D_STAGE_FLAT): conv1's GEMM, then one launch; chained with its neighbours like the others.
+      const bool same_w = li + 2 < P.n_dec_layers && P.layers[li + 1].kind == 0 && P.layers[li + 1].Cin == L.Cout &&
+                          P.layers[li + 1].Cout == L.Cout && P.layers[li + 2].Cin == L.Cout;
+      const bool flat = L.kind == 0 && (L.flags & 128);
+      if (flat && (!same_w || P.layers[li + 2].kind != 2 || (L.flags & 4) || !cips3d_fused_flat_conv_supported(L.Cout, L.H, L.W)))
+        return CIPS3D_E_BADARG;                      // the plan promised a block this kernel takes
+      if (flat && fold_slots) {                      // (a pending fold of ToRGB partial sums becomes this block's skip image)
+        TRY(fold_flush(P.skip[skip_i]));
+        skip_i ^= 1;
+      }
+      if (flat || (L.kind == 1 && same_w && P.layers[li + 2].kind == 3 && cips3d_fused_up_conv_supported(L.Cout, L.H, L.W))) {
+        const int OHs = flat ? L.H : 2 * L.H, OWs = flat ? L.W : 2 * L.W;       // the stage's output resolution
         const cips3d_dec_layer& L2 = P.layers[li + 1];
         const cips3d_dec_layer& L3 = P.layers[li + 2];
         const bool stage_last = li + 2 == P.n_dec_layers - 1;
@@ -346,9 +360,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
         // the next stage's 1x1 up-conv reads nothing but this stage's output: when the plan packed its weights for it
         // (flags bit 0) this kernel computes that GEMM from its registers and the activations are never stored
         const cips3d_dec_layer* LN = li + 3 < P.n_dec_layers ? &P.layers[li + 3] : nullptr;
-        const bool chain = LN && LN->kind == 1 && (LN->flags & 1) && LN->Cin == L.Cout && LN->Cout * 2 == L.Cout &&
-                           LN->H == 2 * L.H && LN->W == 2 * L.W && ylo_alt && cips3d_fused_up_conv_chains(L.Cout);
-        if (LN && LN->kind == 1 && (LN->flags & 1) && !chain) return CIPS3D_E_BADARG;
+        const bool ln_head = LN && (LN->kind == 1 || (LN->kind == 0 && (LN->flags & 128)));
+        const bool chain = ln_head && (LN->flags & 1) && LN->Cin == L.Cout && LN->Cout * 2 == L.Cout &&
+                           LN->H == OHs && LN->W == OWs && ylo_alt && cips3d_fused_up_conv_chains(L.Cout);
+        if (ln_head && (LN->flags & 1) && !chain) return CIPS3D_E_BADARG;
         float* out2 = (stage_last || chain) ? nullptr : P.act[act_i];
         float* rgb = stage_last ? IO.rgb : P.skip[skip_i];
         const int u8_flag = (stage_last && IO.rgb_is_u8) ? CIPS3D_RGB_U8 : 0;
@@ -369,9 +384,9 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           srg.next_gain = (ln_last && (LN->flags & 64)) ? sqrtf((float)L.Cout) : 0.f;
         }
         TRY(cips3d_fused_up_conv_next(ylo_cur, L.fir, nz, nbs, L.noise_w, L.bias, L2.wm, nz2, nbs2, L2.noise_w, L2.bias, out2,
-                                      L3.wm, L3.bias, skip, 1 | gemm_flag | ybf_flag | stage_split | u8_flag, rgb, chain ? LN->wm : nullptr,
+                                      L3.wm, L3.bias, skip, (flat ? CIPS3D_STAGE_FLAT : 1) | gemm_flag | ybf_flag | stage_split | u8_flag, rgb, chain ? LN->wm : nullptr,
                                       chain ? ylo_alt : nullptr, B, L.Cout, L.H, L.W, stage_ranged ? &srg : nullptr, stream));
-        mark(CIPS3D_MARK_FUSED_STAGE, L.Cout, chain ? LN->Cout : 0, 2 * L.H);
+        mark(CIPS3D_MARK_FUSED_STAGE, L.Cout, chain ? LN->Cout : 0, OHs);
         ylo_ready = chain;
         if (chain) { float* t = ylo_cur; ylo_cur = ylo_alt; ylo_alt = t; }
         x = out2;

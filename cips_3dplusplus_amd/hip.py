@@ -502,6 +502,7 @@ def _range(**kw):
 GEMM_BF16 = 0x100      # CIPS3D_GEMM_BF16: bf16 compute mode of the decoder GEMMs (BASELINE config 3)
 Y_BF16 = 0x200         # CIPS3D_Y_BF16: the pre-FIR low-resolution GEMM result of an up-sampling stage is stored as bf16
 GEMM_SPLIT = 0x400     # CIPS3D_GEMM_SPLIT: fp32-equivalent split-fp16 products (weights packed with MOD_SPLIT)
+STAGE_FLAT = 0x1000    # CIPS3D_STAGE_FLAT: the fused stage kernel on a block that does not up-sample
 
 
 def modconv1x1(x, wm_packed, Cout, epilogue=0, noise=None, noise_w=None, bias=None, out=None, bf16=False, out_bf16=False,
@@ -792,15 +793,20 @@ def fused_up_conv_chains(C_):
 
 
 def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_w2, bias2, wm_rgb=None, bias_rgb=None,
-                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None, split=False, ranged=True):
+                  skip=None, skip_up=True, want_out2=True, bf16=False, wm_next=None, split=False, ranged=True, flat=False):
     """FIR up-sampling + act -> 1x1 conv + act -> ToRGB for one up-sampling stage (see cips3d_fused_up_conv).
     wm_next (MOD_PACKED | MOD_CHAINED weights of the next stage's C -> C/2 up-conv): also returns its low-res GEMM y_next.
     A torch.bfloat16 `y_lo` selects the bf16-storage form (CIPS3D_Y_BF16, needs bf16=True): y_next is then bf16 as well.
     split: fp32-equivalent split-fp16 products; wm2_packed / wm_next must then be MOD_SPLIT16-packed.  The stage's operands are
     then split under power-of-two scales from rigorous bounds (cips3d_range): y_lo's amax array is taken from its tag or
-    measured, the two layers' constants are made here (noise bounds measured on the device); out2 / y_next leave tagged."""
+    measured, the two layers' constants are made here (noise bounds measured on the device); out2 / y_next leave tagged.
+    flat: a block that does not up-sample (CIPS3D_STAGE_FLAT): y_lo is conv1's GEMM result at the block's resolution, fir is
+    not read, outputs and skip have y_lo's size (skip_up must be False)."""
     lib = _lib.load()
     B, Cc, H, W = y_lo.shape
+    up = 1 if flat else 2
+    if flat:
+        skip_up = False          # (the skip image of a flat stage has the output's size and is added as it is)
     rg, _keep, next_amax = None, None, None
     if split and ranged:
         lc1 = range_consts(B, bias1, noise_w1, 0.0, fir=fir, noise=noise1)
@@ -811,20 +817,20 @@ def fused_up_conv(y_lo, fir, noise1, noise_w1, bias1, wm2_packed, noise2, noise_
     ydt = y_lo.dtype
     if ydt == torch.bfloat16 and not bf16:
         raise RuntimeError("a bf16 y_lo needs the bf16 GEMM mode (bf16=True)")
-    out2 = torch.empty(B, Cc, 2 * H, 2 * W, device=dev) if want_out2 else None
-    rgb = torch.empty(B, 3, 2 * H, 2 * W, device=dev) if wm_rgb is not None else None
-    y_next = torch.empty(B, Cc // 2, 2 * H, 2 * W, device=dev, dtype=ydt) if wm_next is not None else None
+    out2 = torch.empty(B, Cc, up * H, up * W, device=dev) if want_out2 else None
+    rgb = torch.empty(B, 3, up * H, up * W, device=dev) if wm_rgb is not None else None
+    y_next = torch.empty(B, Cc // 2, up * H, up * W, device=dev, dtype=ydt) if wm_next is not None else None
 
     def bs(nz):
-        return 4 * H * W if (nz is not None and nz.shape[0] == B and B > 1) else 0
+        return up * up * H * W if (nz is not None and nz.shape[0] == B and B > 1) else 0
 
-    check(lib.cips3d_fused_up_conv_next(dev_ptr(y_lo, "y_lo", dtype=ydt), dev_ptr(fir, "fir"), dev_ptr(noise1, "noise1", True), bs(noise1),
+    check(lib.cips3d_fused_up_conv_next(dev_ptr(y_lo, "y_lo", dtype=ydt), dev_ptr(fir, "fir", flat), dev_ptr(noise1, "noise1", True), bs(noise1),
                                         dev_ptr(noise_w1, "noise_w1", True), dev_ptr(bias1, "bias1"), dev_ptr(wm2_packed, "wm2"),
                                         dev_ptr(noise2, "noise2", True), bs(noise2), dev_ptr(noise_w2, "noise_w2", True),
                                         dev_ptr(bias2, "bias2"), dev_ptr(out2, "out2", True), dev_ptr(wm_rgb, "wm_rgb", True),
                                         dev_ptr(bias_rgb, "bias_rgb", True), dev_ptr(skip, "skip", True),
-                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) | (Y_BF16 if ydt == torch.bfloat16 else 0) |
-                                        (GEMM_SPLIT if split else 0),
+                                        int(bool(skip_up)) | (GEMM_BF16 if bf16 else 0) |
+                                        (Y_BF16 if ydt == torch.bfloat16 else 0) | (GEMM_SPLIT if split else 0) | (STAGE_FLAT if flat else 0),
                                         dev_ptr(rgb, "rgb", True), dev_ptr(wm_next, "wm_next", True),
                                         dev_ptr(y_next, "y_next", True, dtype=ydt), B, Cc, H, W,
                                         C.byref(rg) if rg is not None else None, stream_ptr()), "cips3d_fused_up_conv_next")

@@ -65,6 +65,10 @@ CHAIN_STAGES = os.environ.get("CIPS3D_CHAIN_STAGES", "1") != "0"
 PLANES_RUN = os.environ.get("CIPS3D_PLANES", "1") != "0"
 # ... and as one bf16 plane in the bf16 decoder modes (cips3d_modconv1x1_planes16); 0 = fp32 activations, rounded in registers
 PLANES16_RUN = os.environ.get("CIPS3D_PLANES16", "1") != "0"
+# Decoder blocks ABOVE the NeRF resolution that do not up-sample ([StyledConv, StyledConv, ToRGB] at one resolution: the 512 / 1024
+# blocks of a 256^2 generator) run as ONE launch of the fused stage kernel in its flat form (CIPS3D_STAGE_FLAT), chained like the
+# up-sampling stages; 0 = two GEMM launches + a ToRGB launch per block (A/B knob)
+FLAT_STAGES = os.environ.get("CIPS3D_FLAT_STAGES", "1") != "0"
 
 
 class PlanUnsupported(RuntimeError):
@@ -173,18 +177,33 @@ class ForwardPlan:
         # (forward.hip).  When the NEXT stage is one too and the fused kernel has the chained form for this width, that kernel
         # also computes the next stage's low-res GEMM from its registers: the next up-conv's weights are then packed in the
         # chained order and its own GEMM launch disappears.
-        def fused_stage(i):
+        # A block of the same shape that does NOT up-sample, above the NeRF resolution (the blocks at the NeRF resolution belong
+        # to the planes run below), takes the same kernel in its flat form: stage_kind 2.
+        def stage_kind(i):
             if i + 2 >= len(layer_info):
-                return False
+                return 0
             a, b_, c = layer_info[i], layer_info[i + 1], layer_info[i + 2]
-            return (a["kind"] == 1 and b_["kind"] == 0 and c["kind"] == 3 and b_["Cin"] == a["Cout"] and b_["Cout"] == a["Cout"]
-                    and c["Cin"] == a["Cout"] and bool(lib.cips3d_fused_up_conv_supported(a["Cout"], a["H"], a["W"])))
-        # the image can leave as uint8 (cips3d_forward_io.rgb_is_u8) when the decoder ends in a fused up-sampling stage
-        self.u8_capable = len(layer_info) >= 3 and fused_stage(len(layer_info) - 3)
+            if not (b_["kind"] == 0 and b_["Cin"] == a["Cout"] and b_["Cout"] == a["Cout"] and c["Cin"] == a["Cout"]):
+                return 0
+            if a["kind"] == 1 and c["kind"] == 3 and lib.cips3d_fused_up_conv_supported(a["Cout"], a["H"], a["W"]):
+                return 1
+            if (FLAT_STAGES and a["kind"] == 0 and c["kind"] == 2 and a["H"] > img_size
+                    and lib.cips3d_fused_flat_conv_supported(a["Cout"], a["H"], a["W"])):
+                return 2
+            return 0
+
+        def fused_stage(i):
+            return stage_kind(i) == 1
+        for i, li in enumerate(layer_info):
+            if stage_kind(i) == 2:
+                li["flat_head"] = True
+                max_lo = max(max_lo, B * li["Cout"] * li["H"] * li["W"])       # conv1's GEMM result, at the block's resolution
+        # the image can leave as uint8 (cips3d_forward_io.rgb_is_u8) when the decoder ends in a fused stage
+        self.u8_capable = len(layer_info) >= 3 and stage_kind(len(layer_info) - 3) != 0
         for i in range(len(layer_info) - 3):
             a, nx = layer_info[i], layer_info[i + 3]
-            if (CHAIN_STAGES and fused_stage(i) and fused_stage(i + 3) and lib.cips3d_fused_up_conv_chains(a["Cout"])
-                    and nx["Cin"] == a["Cout"] and nx["Cout"] * 2 == a["Cout"] and nx["H"] == 2 * a["H"]):
+            if (CHAIN_STAGES and stage_kind(i) and stage_kind(i + 3) and lib.cips3d_fused_up_conv_chains(a["Cout"])
+                    and nx["Cin"] == a["Cout"] and nx["Cout"] * 2 == a["Cout"] and nx["H"] == a["Hout"]):
                 nx["chained"] = True
         # Which packed layers the stand-alone GEMM consumes (everything but conv2 of a fused stage and chained up-convs): in the
         # default "fp32" precision those are packed as split-fp16 fragments and run in CIPS3D_GEMM_SPLIT mode.
@@ -192,7 +211,7 @@ class ForwardPlan:
         for i, li in enumerate(layer_info):
             if not (use_split and li["packed"]):
                 continue
-            conv2_of_fused = li["kind"] == 0 and i >= 1 and fused_stage(i - 1)
+            conv2_of_fused = li["kind"] == 0 and i >= 1 and stage_kind(i - 1) != 0
             chained = bool(li.get("chained"))
             li["split"] = not conv2_of_fused and not chained
             li["split16"] = conv2_of_fused or chained           # consumed inside cips3d_fused_up_conv_next
@@ -275,7 +294,7 @@ class ForwardPlan:
                                                               info["W"], info["noise_index"])
             L.flags = ((1 if info.get("chained") else 0) | (2 if info.get("split") else 0) | (4 if info.get("planes_in") else 0) |
                        (8 if info.get("planes_out") else 0) | (16 if info.get("split16") else 0) |
-                       (32 if info.get("p16") else 0) | (64 if conv.demodulate else 0))
+                       (32 if info.get("p16") else 0) | (64 if conv.demodulate else 0) | (128 if info.get("flat_head") else 0))
             L.wm = d.out
             L.bias = dev_ptr(info["bias"])
             L.noise_w = dev_ptr(info["noise_w"], allow_none=True)
@@ -487,7 +506,7 @@ class ForwardPlan:
                 raise RuntimeError(f"rgb_out must be a contiguous float32 / uint8 tensor of shape {(B, 3, self.out_res, self.out_res)} on {dev}")
             if rgb.dtype == torch.uint8:
                 if not self.u8_capable:
-                    raise RuntimeError("this decoder does not end in a fused up-sampling stage: no uint8 output (render float32, then hip.rgb_to_uint8)")
+                    raise RuntimeError("this decoder does not end in a fused stage: no uint8 output (render float32, then hip.rgb_to_uint8)")
                 io.rgb_is_u8 = 1
         thumb = torch.empty(B, 3, S, S, device=dev)
         xyz = torch.empty(B, 3, S, S, device=dev)

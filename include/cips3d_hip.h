@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 26  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 27  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -361,6 +361,13 @@ int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, flo
  * cips3d_rgb_to_uint8(rgb) -- clamp to [-1, 1], (c + 1) * 127.5, round to nearest even -- instead of the fp32 values (bit-identical
  * to converting the stored fp32 image; the reference's img_tensor_to_pil step, models/render_video_web_v10.py:1825-1826). */
 #define CIPS3D_RGB_U8         0x800
+/* OR-ed into `skip_up` of cips3d_fused_up_conv[_next]: a FLAT stage -- a decoder block that does not up-sample,
+ * [StyledConv, StyledConv, ToRGB] at one resolution (the blocks above the last entry of `upsample_list`: a 256^2 generator still
+ * walks the 512 and 1024 blocks, at 256^2; models/model_v3.py:553-590).  `y_lo` is then conv1's GEMM result at the OUTPUT size
+ * H x W, `fir` is not read (may be NULL), the outputs are H x W, `skip` (if any) is [B,3,H,W] and is added as it is (bit 0 of
+ * skip_up must be clear); rg->x_amax = the maximum of |y_lo| as always, rg->lconst[b][1] (a row gain relative to conv1's INPUT)
+ * is not used.  Supported shapes: cips3d_fused_flat_conv_supported. */
+#define CIPS3D_STAGE_FLAT     0x1000
 int cips3d_modulate_weights(const float* W, const float* s, int64_t s_stride, float* wm,
                             int B, int Cout, int Cin, int ksq, float scale, int flags,
                             void* stream);
@@ -446,6 +453,9 @@ int cips3d_torgb(const float* x, const float* wm, const float* bias, const float
  * y_lo [B,C,H,W]; wm2 in the PACKED order of cips3d_modulate_weights, wm_rgb plain [B,3,C]; skip [B,3,H,W] when
  * skip_up else [B,3,2H,2W] (or NULL).  C in {32,64,128,256}, W % 32 == 0, H % 2 == 0. */
 int cips3d_fused_up_conv_supported(int C, int H, int W);
+/* ... and for a FLAT stage (CIPS3D_STAGE_FLAT in `skip_up`; H x W = the one resolution of the block): C in {32,64,128,256},
+ * W % 64 == 0, H % 4 == 0.  The same kernel without the FIR: act1 = lrelu(y_lo + nw1*noise1 + bias1) * sqrt(2), skip added as is. */
+int cips3d_fused_flat_conv_supported(int C, int H, int W);
 /* The stage above plus the low-resolution GEMM of the NEXT up-sampling stage (its `StyledConv(up)` 1x1 conv, C -> C/2,
  * which reads out2): y_next[b] = wm_next[b] (C/2 x C) out2[b], taken from the registers that hold out2, so out2 need not be
  * stored (pass NULL) and the next stage starts at its own cips3d_fused_up_conv with y_lo = y_next.  wm_next in the
@@ -535,13 +545,15 @@ typedef struct cips3d_dec_layer {
   int32_t kind;            /* 0 StyledConv, 1 StyledConv with 2x up-sampling, 2 ToRGB, 3 ToRGB + up-sampled skip */
   int32_t Cin, Cout, H, W; /* H, W = INPUT resolution of the layer (ToRGB: its own resolution) */
   int32_t noise_index;     /* index into cips3d_forward_io.noise (StyledConv) or -1 */
-  int32_t flags;           /* bit 0 (kind 1 only): wm is in the CIPS3D_MOD_CHAINED order and this conv's low-resolution GEMM is
+  int32_t flags;           /* bit 0 (kind 1, or kind 0 with bit 7): wm is in the CIPS3D_MOD_CHAINED order and this conv's GEMM is
                               computed by the previous stage's kernel (cips3d_fused_up_conv_next);
                               bit 1: wm is CIPS3D_MOD_SPLIT-packed and this layer's stand-alone GEMM runs in CIPS3D_GEMM_SPLIT mode;
                               bit 2: the layer's input is stored as split-fp16 planes, bit 3: its output is (cips3d_modconv1x1_planes);
                               bit 5 (with bit 2 / 3): the planes are bf16 planes16 and wm is CIPS3D_MOD_BF16-packed (cips3d_modconv1x1_planes16);
                               bit 4: wm is CIPS3D_MOD_SPLIT16-packed (conv2 / chained up-conv of a fused stage run in CIPS3D_GEMM_SPLIT mode);
-                              bit 6: the conv is demodulated (its rows have unit norm: the sqrt(Cin) gain of the range bounds) */
+                              bit 6: the conv is demodulated (its rows have unit norm: the sqrt(Cin) gain of the range bounds);
+                              bit 7 (kind 0): head of a FLAT stage -- this conv, the next StyledConv and the ToRGB behind them (equal
+                              widths, one resolution) run as one launch of the fused stage kernel (CIPS3D_STAGE_FLAT) */
   int32_t pad_;
   const float* wm;         /* this layer's modulated weights (workspace, written by the modulate table) */
   const float* bias;       /* activate.bias [Cout] or ToRGB.bias [3] */

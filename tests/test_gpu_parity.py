@@ -512,6 +512,143 @@ def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
     assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
 
 
+@pytest.mark.parametrize("C,H,B,last", [(32, 64, 1, True), (64, 64, 2, False), (128, 64, 1, False), (256, 64, 1, False), (32, 128, 2, True)])
+def test_flat_stage_vs_oracle(C, H, B, last):
+    """CIPS3D_STAGE_FLAT: a block that does not up-sample -- StyledConv + StyledConv + ToRGB at one resolution (the 512 / 1024
+    blocks of a 256^2 generator, model_v3.py:553-590) -- through the fused stage kernel, against the oracle's three modules."""
+    import cips_3dplusplus_amd.decoder as dec
+    torch.manual_seed(3 * C + H)
+    S = 64
+    c1 = dec.StyledConv(2 * C, C, 1, S)
+    c2 = dec.StyledConv(C, C, 1, S)
+    tr = dec.ToRGB(C, S, upsample=False)
+    for m in (c1, c2):
+        m.noise.weight.data.fill_(0.25)
+        m.activate.bias.data = torch.randn(C) * 0.2
+    tr.bias.data = torch.randn(1, 3, 1, 1) * 0.1
+    sd = {}
+    for nm, m in (("c1", c1), ("c2", c2), ("tr", tr)):
+        sd.update({f"{nm}.{k}": v.clone() for k, v in m.state_dict().items()})
+    x = torch.randn(B, 2 * C, H, H)
+    st = [torch.randn(B, S) for _ in range(3)]
+    n1, n2 = torch.randn(1, 1, H, H), torch.randn(B, 1, H, H)
+    skip = torch.randn(B, 3, H, H)
+    r1 = O.styled_conv(sd, "c1", x, st[0], n1)
+    r2 = O.styled_conv(sd, "c2", r1, st[1], n2)
+    r3 = O.to_rgb(sd, "tr", r2, st[2], skip, upsample=False)
+    c1, c2, tr = c1.to(DEV), c2.to(DEV), tr.to(DEV)
+    assert _lib.load().cips3d_fused_flat_conv_supported(C, H, H)
+    y = hip.modconv1x1(cu(x), c1.conv.modulated_weight(cu(st[0]), packed=True), C, epilogue=0)
+    out2, rgb = hip.fused_up_conv(y, None, cu(n1), c1.noise.weight, c1.activate.bias,
+                                  c2.conv.modulated_weight(cu(st[1]), packed=True), cu(n2), c2.noise.weight,
+                                  c2.activate.bias, tr.conv.modulated_weight(cu(st[2]), packed=False), tr.bias, cu(skip),
+                                  want_out2=not last, flat=True)
+    assert rgb.shape == (B, 3, H, H)
+    if not last:
+        assert maxdiff(out2.cpu(), r2) < 3e-5 * max(1.0, float(r2.abs().max()))
+    assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
+    # ... and without a skip image
+    _, rgb0 = hip.fused_up_conv(y, None, cu(n1), c1.noise.weight, c1.activate.bias,
+                                c2.conv.modulated_weight(cu(st[1]), packed=True), cu(n2), c2.noise.weight,
+                                c2.activate.bias, tr.conv.modulated_weight(cu(st[2]), packed=False), tr.bias, None,
+                                want_out2=False, flat=True)
+    assert maxdiff(rgb0.cpu(), r3 - skip) < 3e-5 * max(1.0, float(r3.abs().max()))
+
+
+@pytest.mark.parametrize("C,mode", [(64, "fp32"), (64, "bf16"), (64, "split"), (128, "split"), (256, "fp32"), (256, "split")])
+def test_flat_stage_chains_the_next_block(C, mode):
+    """The flat form of cips3d_fused_up_conv_next: y_next = W_next out2 from the registers, at the block's own resolution, against
+    the separate GEMM of the stored out2; rgb / out2 unchanged by the chained work; a batch-strided first noise map."""
+    torch.manual_seed(11)
+    H, B = 64, 2
+    bf16, split = mode == "bf16", mode == "split"
+    y = torch.randn(B, C, H, H, device=DEV)
+    n1, n2 = torch.randn(B, 1, H, H, device=DEV), torch.randn(1, 1, H, H, device=DEV)
+    nw1, nw2 = torch.full((1,), 0.3, device=DEV), torch.full((1,), -0.2, device=DEV)
+    b1, b2 = torch.randn(C, device=DEV) * 0.2, torch.randn(C, device=DEV) * 0.2
+    W2, Wn, Wr = torch.randn(C, C, device=DEV), torch.randn(C // 2, C, device=DEV), torch.randn(3, C, device=DEV)
+    s2, sn, sr = (torch.randn(B, C, device=DEV) * 0.3 + 1 for _ in range(3))
+
+    def mod(W, s, flags):
+        out = torch.empty(B * W.shape[0] * C, device=DEV)
+        _lib.check(_lib.load().cips3d_modulate_weights(W.data_ptr(), s.data_ptr(), C, out.data_ptr(), B, W.shape[0], C, 1,
+                                                       1.0 / math.sqrt(C), flags, torch.cuda.current_stream().cuda_stream), "mod")
+        return out
+
+    sp16 = hip.MOD_SPLIT16 if split else 0
+    wm2 = mod(W2, s2, hip.MOD_DEMODULATE | hip.MOD_PACKED | sp16)
+    wmn_std = mod(Wn, sn, hip.MOD_DEMODULATE | hip.MOD_PACKED | (hip.MOD_SPLIT if split else 0))
+    wmn_chn = mod(Wn, sn, hip.MOD_DEMODULATE | hip.MOD_PACKED | hip.MOD_CHAINED | sp16)
+    wmr = mod(Wr, sr, 0)
+    brgb = torch.randn(3, device=DEV) * 0.1
+    skip = torch.randn(B, 3, H, H, device=DEV)
+    kw = dict(bf16=bf16, split=split, flat=True)
+    out2, rgb = hip.fused_up_conv(y, None, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, **kw)
+    ref = hip.modconv1x1(out2, wmn_std, C // 2, epilogue=0, bf16=bf16, split=split)
+    o2, rgb2, y_next = hip.fused_up_conv(y, None, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, wm_next=wmn_chn, **kw)
+    assert y_next.shape == (B, C // 2, H, H)
+    tol = 2e-6 if not split else 4e-6
+    assert maxdiff(o2, out2) <= (0 if not split else 2e-6 * float(out2.abs().max())) and maxdiff(rgb2, rgb) <= 4e-6 * float(rgb.abs().max())
+    assert maxdiff(y_next, ref) < tol * float(ref.abs().max())
+    _, rgb3, y3 = hip.fused_up_conv(y, None, n1, nw1, b1, wm2, n2, nw2, b2, wmr, brgb, skip, wm_next=wmn_chn, want_out2=False, **kw)
+    assert torch.equal(rgb3, rgb2) and torch.equal(y3, y_next)
+    # the exact-fp32 form of the same stage is the reference of the other two arithmetics
+    if mode != "fp32":
+        wm2_f = mod(W2, s2, hip.MOD_DEMODULATE | hip.MOD_PACKED)
+        o_f, rgb_f = hip.fused_up_conv(y, None, n1, nw1, b1, wm2_f, n2, nw2, b2, wmr, brgb, skip, flat=True)
+        lim = 3e-2 if bf16 else 3e-6
+        assert maxdiff(out2, o_f) < lim * float(o_f.abs().max()) and maxdiff(rgb, rgb_f) < lim * float(rgb_f.abs().max())
+
+
+def test_flat_stage_refuses_what_it_does_not_tile():
+    lib = _lib.load()
+    assert lib.cips3d_fused_flat_conv_supported(64, 256, 256) and lib.cips3d_fused_flat_conv_supported(32, 64, 64)
+    assert not lib.cips3d_fused_flat_conv_supported(64, 256, 96)      # 64-pixel wave rows
+    assert not lib.cips3d_fused_flat_conv_supported(64, 6, 64)        # 4-row tiles
+    assert not lib.cips3d_fused_flat_conv_supported(48, 64, 64)
+    y = torch.randn(1, 64, 6, 64, device=DEV)
+    z = torch.zeros(64, device=DEV)
+    wm = torch.zeros(64 * 64, device=DEV)
+    with pytest.raises(RuntimeError):
+        hip.fused_up_conv(y, None, None, None, z, wm, None, None, z, flat=True)
+
+
+@pytest.mark.parametrize("res,precision", [(256, "fp32"), (512, "fp32"), (256, "fp32_exact"), (256, "bf16"), (256, "bf16_storage")])
+def test_flat_blocks_of_a_low_resolution_generator(monkeypatch, res, precision):
+    """A 256^2 (512^2) FFHQ generator still walks the 512 and 1024 (1024) blocks, at its final resolution: the plan runs them as
+    flat stages chained behind the last up-sampling stage.  Same image as the per-layer launches (CIPS3D_FLAT_STAGES=0: two
+    GEMMs + ToRGB per block), and the uint8 image leaves the last of them."""
+    from cips_3dplusplus_amd import plan as planmod
+    cfg = configs.ffhq_G_cfg(res, 2)
+    G = pkg.build_generator(cfg, DEV, seed=2)
+    G.set_precision(precision)
+    B = 2
+    zs, nb, _ = weights.synth_inputs(cfg, batch=B, seed=5)
+    e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[0.2, 0.05], [-0.1, 0.1]], device=DEV))
+    kw = dict(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=64, near=n, far=fa,
+              noise_bufs=[cu(b) for b in nb], nerf_cfg=dict(N_samples=8, perturb=False, static_viewdirs=False))
+    monkeypatch.setattr(planmod, "FLAT_STAGES", True)
+    a = G(**kw)["rgb"].clone()
+    pl = G._forward_plan(B, 64, 8, False)
+    heads = [li for li in pl._layer_info if li.get("flat_head")]
+    assert len(heads) == {256: 2, 512: 1}[res] and all(h.get("chained") for h in heads) and pl.u8_capable
+    assert a.shape == (B, 3, res, res)
+    u8 = torch.empty(B, 3, res, res, dtype=torch.uint8, device=DEV)
+    with torch.no_grad():
+        G(**kw, rgb_out=u8)
+    assert torch.equal(u8, hip.rgb_to_uint8(a))
+    monkeypatch.setattr(planmod, "FLAT_STAGES", False)
+    G._plans.clear()
+    b = G(**kw)["rgb"].clone()
+    assert not any(li.get("flat_head") for li in G._forward_plan(B, 64, 8, False)._layer_info)
+    G._plans.clear()
+    # (bf16_storage: conv1's result of a flat block is one more tensor stored as bf16 -- the mode's rule for every fused stage)
+    lim = {"fp32": 2e-5, "fp32_exact": 2e-5, "bf16": 2e-3, "bf16_storage": 2e-2}[precision]
+    d, r = maxdiff(a, b), float(b.abs().max())
+    print(f"flat stages vs per-layer launches at {res}^2 [{precision}]: {d:.2e} (max |rgb| {r:.2f})")
+    assert d < lim * max(r, 1.0)
+
+
 @pytest.mark.parametrize("C,bf16", [(64, False), (64, True), (128, False), (128, True), (256, False), (256, True)])
 def test_fused_stage_also_computes_next_low_res_gemm(C, bf16):
     """cips3d_fused_up_conv_next: y_next = W_next out2 taken from the registers that hold out2 (split K over the wave rows)
