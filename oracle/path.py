@@ -294,7 +294,8 @@ def modulated_conv2d(sd, prefix, x, style, demodulate=True, upsample=False, bf16
         p = (4 - 2) - (k - 1)
         return upfirdn2d(y, sd[prefix + ".blur.kernel"], pad=((p + 1) // 2 + 1, p // 2 + 1))
     y = F.conv2d(x.reshape(1, B * Cin, H, W), w.view(B * Cout, Cin, k, k), padding=k // 2, groups=B)
-    return y.view(B, Cout, y.shape[2], y.shape[3])
+    y = y.view(B, Cout, y.shape[2], y.shape[3])
+    return _bf16_round(y) if bf16_store else y      # (not in the reference: see decoder_forward)
 
 
 def styled_conv(sd, prefix, x, style, noise, upsample=False, bf16_gemm=False, bf16_store=False):
@@ -347,8 +348,12 @@ def decoder_forward(sd, cfg, features, styles, noise, prefix="decoder", bf16_gem
     skip = to_rgb(sd, prefix + ".to_rgb1", out, styles[:, 1])
     i = 1
     for s, st in enumerate(lay["stages"]):
+        # bf16_store (not in the reference; the product's "bf16_storage" mode): the conv result that a block's first StyledConv hands
+        # to its FIR / activation is kept as bf16 -- in every up-sampling block, and in every block above the NeRF resolution that
+        # does not up-sample (the 512 / 1024 blocks of a 256^2 generator: the product runs them as flat stages of the same kernel)
+        store = bf16_store and (st["up"] or out.shape[-1] > features.shape[-1])
         out = styled_conv(sd, f"{prefix}.convs.{2 * s}", out, styles[:, i], noise[2 * s + 1],
-                          upsample=st["up"], bf16_gemm=bf16_gemm, bf16_store=bf16_store and st["up"])
+                          upsample=st["up"], bf16_gemm=bf16_gemm, bf16_store=store)
         out = styled_conv(sd, f"{prefix}.convs.{2 * s + 1}", out, styles[:, i + 1], noise[2 * s + 2], bf16_gemm=bf16_gemm)
         skip = to_rgb(sd, f"{prefix}.to_rgbs.{s}", out, styles[:, i + 2], skip, upsample=st["up"])
         i += 2

@@ -82,7 +82,7 @@ def _psnr(a, b):
 
 
 def test_generator_bf16_storage_vs_oracle_and_fp32():
-    """256^2 generator (both up-sampling stages fused and chained): the storage mode against the oracle with the same
+    """256^2 generator (both up-sampling stages and the two flat blocks behind them fused and chained): the storage mode against the oracle with the same
     operand / storage roundings (bounded like the compute mode: accumulation order + rare rounding flips), against exact
     fp32 (PSNR), and the plan really switches the flag."""
     cfg = configs.ffhq_G_cfg(256, 2)
@@ -109,7 +109,9 @@ def test_generator_bf16_storage_vs_oracle_and_fp32():
     p_s, p_c = _psnr(r16s, r32), _psnr(r16, r32)
     print(f"bf16 storage mode, 256^2: vs oracle(storage) max-abs {d:.3e} on range {scale:.2f}; PSNR vs fp32 {p_s:.1f} dB "
           f"(compute-only mode {p_c:.1f} dB)")
-    assert d < 2e-2 * scale and _psnr(r16s.cpu(), ref) > 55.0
+    # (four tensors are stored as bf16 here -- the conv results of the two up-sampling blocks and of the two flat blocks behind
+    # them: a value that the two accumulation orders round to different bf16 neighbours is a 2^-8 relative step)
+    assert d < 2e-2 * scale and _psnr(r16s.cpu(), ref) > 53.0
     assert p_s > 35.0
     G.set_decoder_precision("fp32")
     assert torch.equal(G(**kw)["rgb"], r32)

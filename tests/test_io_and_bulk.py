@@ -340,14 +340,15 @@ def test_styles_resident_refuses_a_stale_plan():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("res,B", [(1024, 1), (1024, 2), (256, 3)])
-def test_uint8_image_straight_from_the_last_stage(res, B):
-    """`Generator.forward(rgb_out=<uint8 tensor>)` (cips3d_forward_io.rgb_is_u8 / CIPS3D_RGB_U8): the last up-sampling stage stores
+@pytest.mark.parametrize("res,B,flat", [(1024, 1, True), (1024, 2, True), (256, 3, True), (256, 3, False)])
+def test_uint8_image_straight_from_the_last_stage(monkeypatch, res, B, flat):
+    """`Generator.forward(rgb_out=<uint8 tensor>)` (cips3d_forward_io.rgb_is_u8 / CIPS3D_RGB_U8): the last fused stage stores
     the image as uint8 -- exactly hip.rgb_to_uint8 of the fp32 image the same forward would have written, every other output
     unchanged; a float32 `rgb_out` receives the fp32 image in place."""
     import cips_3dplusplus_amd as pkg
-    from cips_3dplusplus_amd import configs, hip
+    from cips_3dplusplus_amd import configs, hip, plan as planmod
     from cips_3dplusplus_amd.camera import Camera
+    monkeypatch.setattr(planmod, "FLAT_STAGES", flat)
     G = pkg.build_generator(configs.ffhq_G_cfg(res, 2), "cuda", seed=5)
     g = torch.Generator(device="cuda").manual_seed(3)
     zs = [2.0 * torch.randn(B, 256, device="cuda", generator=g), 2.0 * torch.randn(B, 256, device="cuda", generator=g)]
@@ -355,15 +356,17 @@ def test_uint8_image_straight_from_the_last_stage(res, B):
     nb = [torch.randn(b.shape, device="cuda", generator=g) for b in G.create_noise_bufs(64, "cuda")]
     kw = dict(zs=zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, noise_bufs=nb, nerf_cfg=dict(N_samples=12, perturb=False),
               return_xyz=True)
-    # (the 1024^2 recipe ends in an up-sampling stage; the 256^2 one in two plain StyledConvs + ToRGB: fp32 output only)
-    assert G.can_emit_uint8(B, 64, 12) == (res == 1024)
+    # (the 1024^2 recipe ends in an up-sampling stage, the 256^2 one in the 512 / 1024 blocks at 256^2: flat stages of the same
+    # kernel -- or, with CIPS3D_FLAT_STAGES=0, two plain StyledConv launches + a ToRGB launch: fp32 output only)
+    capable = res == 1024 or flat
+    assert G.can_emit_uint8(B, 64, 12) == capable
     with torch.no_grad():
         ref = G(**kw)
         f32 = torch.full((B, 3, res, res), float("nan"), device="cuda")
         out32 = G(rgb_out=f32, **kw)
         assert out32["rgb"] is f32 and torch.equal(f32, ref["rgb"])
         u8 = torch.full((B, 3, res, res), 77, dtype=torch.uint8, device="cuda")
-        if res != 1024:
+        if not capable:
             with pytest.raises(RuntimeError, match="uint8"):
                 G(rgb_out=u8, **kw)
             return
