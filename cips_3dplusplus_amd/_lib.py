@@ -78,7 +78,8 @@ class NerfParams(C.Structure):
                 ("x_pts", C.c_void_p), ("x_rays_d", C.c_void_p), ("x_viewdirs", C.c_void_p), ("x_z_vals", C.c_void_p),
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
                 ("features_planes", C.c_int32), ("raw_density", C.c_int32),
-                ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p), ("packed32", C.c_void_p)]
+                ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p), ("packed32", C.c_void_p),
+                ("zero_words", C.c_void_p), ("n_zero_words", C.c_int64)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -225,7 +226,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 27           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 28           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

@@ -13,14 +13,6 @@
     if (rc_ != 0) return rc_; \
   } while (0)
 
-namespace {
-// a frame of a sequence (io.styles_resident): the measured range rows start from zero, as after the style phase's zeroing launch
-__global__ void __launch_bounds__(256) range_reset_kernel(float* __restrict__ p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0.f;
-}
-}  // namespace
-
 extern "C" int64_t cips3d_sizeof_plan(void) { return (int64_t)sizeof(cips3d_generator_plan); }
 extern "C" int64_t cips3d_sizeof_io(void) { return (int64_t)sizeof(cips3d_forward_io); }
 extern "C" int64_t cips3d_sizeof_struct(int which) {
@@ -183,12 +175,8 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
     // a frame of a sequence: styles, FiLM / modulation tables and the modulated weights (with their range constants) are the
     // plan's, as the last full forward left them.  What every forward measures anew is zeroed; the call's draws (if any) take
     // a launch of their own.
-    if (ranged) {
-      if (P.range_volatile_words <= 0 || P.range_volatile_words > P.range_ws_words) return CIPS3D_E_BADARG;
-      hipLaunchKernelGGL(range_reset_kernel, dim3((P.range_volatile_words + 255) / 256), dim3(256), 0, as_stream(stream), P.range_ws,
-                         P.range_volatile_words);
-      TRY(cips3d_launch_status());
-    }
+    // (the zeroing rides on the render launch: cips3d_nerf_params.zero_words, below)
+    if (ranged && (P.range_volatile_words <= 0 || P.range_volatile_words > P.range_ws_words)) return CIPS3D_E_BADARG;
     if (IO.rng_n_normal < 0 || IO.rng_n_uniform < 0 || (IO.rng_n_normal > 0 && !IO.rng_normal) || (IO.rng_n_uniform > 0 && !IO.rng_uniform))
       return CIPS3D_E_BADARG;
     if (IO.rng_n_normal > 0 || IO.rng_n_uniform > 0)
@@ -215,6 +203,10 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   if (feat_planes && !feat_p16 && !ranged) return CIPS3D_E_BADARG;      // split-fp16 planes carry exponents: the plan owes the rows
   float* feat32 = (feat_planes && !np.features_planes) ? P.act[1] : P.features;
   np.o_features = feat32;
+  // a frame of a sequence: what every forward measures anew (the volatile range rows; the style phase's zeroing launch in a full
+  // forward) is cleared by the render launch on its way out -- nothing of that launch lives there, everything behind it does
+  np.zero_words = nullptr; np.n_zero_words = 0;
+  if (IO.styles_resident && ranged) { np.zero_words = P.range_ws; np.n_zero_words = P.range_volatile_words; }
   TRY(cips3d_nerf_render(&np, stream));
   if (IO.ev_nerf_stop) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_stop), as_stream(stream));
   if (!fused_finish)

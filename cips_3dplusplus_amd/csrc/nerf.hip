@@ -1020,6 +1020,13 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     };
     if (P.n_chunks == WAVES) combine(std::integral_constant<int, WAVES>{});
     else combine(std::integral_constant<int, 0>{});
+    // cips3d_nerf_params.zero_words: scratch of the caller that its NEXT launches expect zeroed (the decoder's measured range rows
+    // in a frame of a sequence: a launch of its own otherwise).  Every workgroup clears a slice on its way out -- at the end,
+    // where the registers are free and no load of the kernel sits behind the stores.
+    if (P.zero_words) {
+      for (int64_t i = (int64_t)blockIdx.x * (WAVES * 64) + threadIdx.x; i < P.n_zero_words; i += (int64_t)gridDim.x * (WAVES * 64))
+        P.zero_words[i] = 0.f;
+    }
     STAMP(6);   // fused finish
     STAMP_FLUSH();
     return;
@@ -1264,6 +1271,13 @@ extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
   return nerf_shape_plan(p, &l0m);
 }
 
+namespace {
+__global__ void __launch_bounds__(256) nerf_zero_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+}  // namespace
+
 extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   if (!p) return CIPS3D_E_BADARG;
   const cips3d_nerf_params& P = *p;
@@ -1280,11 +1294,24 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
       P.n_chunks > P.n_samples)
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
+  if ((P.zero_words == nullptr) != (P.n_zero_words == 0) || P.n_zero_words < 0) return CIPS3D_E_BADARG;
+  if (P.B == 0 && P.zero_words) {
+    hipLaunchKernelGGL(nerf_zero_kernel, dim3((unsigned)ceil_div<int64_t>(P.n_zero_words, 256)), dim3(256), 0, as_stream(stream), P.zero_words, P.n_zero_words);
+    return cips3d_launch_status();
+  }
   if (P.B == 0) return 0;
+  const bool other_kernel = fuse && (cips3d_nerf_ws_applies(p) || cips3d_nerf_pair_applies(p));
+  static const int zero_ride = getenv("CIPS3D_ZERO_RIDE") ? atoi(getenv("CIPS3D_ZERO_RIDE")) : 1;     // A/B knob: 0 = always the launch in front
+  const bool zero_in_front = P.zero_words && (!fuse || other_kernel || !zero_ride);
+  if (zero_in_front) {        // only the default kernel's fused finish clears the words itself
+    hipLaunchKernelGGL(nerf_zero_kernel, dim3((unsigned)ceil_div<int64_t>(P.n_zero_words, 256)), dim3(256), 0, as_stream(stream), P.zero_words, P.n_zero_words);
+    if (const int rc = cips3d_launch_status()) return rc;
+  }
   if (fuse && cips3d_nerf_ws_applies(p)) return cips3d_nerf_render_ws(p, stream);
   if (fuse && cips3d_nerf_pair_applies(p)) return cips3d_nerf_render_pair(p, stream);
   NerfArgs a;
   a.p = P;
+  if (zero_in_front) { a.p.zero_words = nullptr; a.p.n_zero_words = 0; }
   a.groups = ceil_div(P.n_rays > 0 ? P.n_rays : P.img_size * P.img_size, RAYS);
   a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
   a.chunk = ceil_div(P.n_samples, P.n_chunks);

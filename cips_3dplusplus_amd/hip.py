@@ -255,6 +255,9 @@ def _nerf_params(kw):
     for f in ("x_pts", "x_rays_d", "x_viewdirs", "x_z_vals"):          # explicit-geometry mode
         setattr(p, f, dev_ptr(kw.get(f), f, True))
     p.n_rays = int(kw.get("n_rays", 0))
+    zw = kw.get("zero_words")                                          # float scratch the launch leaves zeroed (cips3d_nerf_params.zero_words)
+    if zw is not None:
+        p.zero_words, p.n_zero_words = dev_ptr(zw, "zero_words"), zw.numel()
     p.raw_density = int(bool(kw.get("raw_density", False)))            # with_sdf = False (backward: sigmoid_beta = None)
     for f in ("B", "img_size", "n_samples", "hidden", "depth", "static_viewdirs", "n_chunks"):
         setattr(p, f, int(kw[f]))

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 27  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 28  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -215,6 +215,12 @@ typedef struct cips3d_nerf_params {
    * stream cips3d_nerf_pack_weights32 wrote, instead of three fp16 products per fp32 product over `packed` (which is then not
    * read).  hidden == 256, no stash (CIPS3D_E_UNSUPP otherwise); camera-driven or explicit geometry, fused or separate finish. */
   const float* packed32;
+  /* optional (both or neither): n_zero_words floats the launch leaves ZEROED -- scratch that the caller's next launches expect
+   * cleared (cips3d_generator_forward: the decoder's measured range rows in a frame of a sequence).  The default kernel's fused
+   * finish clears them on its way out, any other form of the launch with one small kernel in front.  Nothing of the render
+   * launch itself may live there. */
+  float* zero_words;
+  int64_t n_zero_words;
 } cips3d_nerf_params;
 
 /* The exact-fp32 weight stream of cips3d_nerf_params.packed32 (cips3d_nerf_packed_floats(hidden, depth) floats, as `packed`):

@@ -512,6 +512,22 @@ def test_fused_upsampling_stage_vs_oracle(C, H, B, last):
     assert maxdiff(rgb.cpu(), r3) < 3e-5 * max(1.0, float(r3.abs().max()))
 
 
+@pytest.mark.parametrize("S,N,B,n_words", [(64, 24, 1, 30000), (64, 128, 1, 70001), (10, 7, 2, 1500), (64, 24, 2, 1)])
+def test_render_launch_leaves_the_callers_scratch_zeroed(S, N, B, n_words):
+    """cips3d_nerf_params.zero_words: the render launch clears a scratch range of its caller (the decoder's measured range rows in
+    a frame of a sequence) -- inside the default kernel's fused finish, or with a small launch in front where the shape takes
+    another route (ragged ray counts) -- exactly that range, and the maps do not change."""
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=4)
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.2, -0.1]] * B, device=DEV))
+    styles = cu(weights.det_normal("zw.styles", (B, 3, 256), 0.5, 2))
+    ref = G.renderer.render(e, f, n, fa, styles, S, N, return_sdf=True)
+    buf = torch.full((n_words + 64,), 7.0, device=DEV)
+    new = G.renderer.render(e, f, n, fa, styles, S, N, return_sdf=True, zero_words=buf[:n_words])
+    assert float(buf[:n_words].abs().max()) == 0.0 and bool((buf[n_words:] == 7.0).all())
+    for a, b in zip(ref, new):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("C,H,B,last", [(32, 64, 1, True), (64, 64, 2, False), (128, 64, 1, False), (256, 64, 1, False), (32, 128, 2, True)])
 def test_flat_stage_vs_oracle(C, H, B, last):
     """CIPS3D_STAGE_FLAT: a block that does not up-sample -- StyledConv + StyledConv + ToRGB at one resolution (the 512 / 1024
