@@ -810,6 +810,18 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       const u32x4_t zz = {0u, 0u, 0u, 0u};
       b0 = __builtin_bit_cast(h8, qd == 0 ? q0 : (qd == 1 ? q1 : zz));
     }
+#ifndef CIPS3D_PINGPONG
+#define CIPS3D_PINGPONG 1
+#endif
+    // The hidden layers alternate between the two activation register sets (X -> Y, Y -> X) instead of copying every layer's
+    // output back into its input's registers (128 registers' worth of v_mov per layer and sample: 5 % of the sample loop's VALU
+    // instructions at D = 2, 12 % at D = 8).  The view layer reads X: with an odd number of hidden layers layer 0 writes Y and one
+    // Y -> X layer runs in front of the pairs (a third copy of the layer's code; entering the pair loop at its second half would
+    // be an irreducible loop, and that form spilled 250 registers).
+    constexpr bool PP = CIPS3D_PINGPONG && !F32;      // (the exact-fp32 instantiation spills 170 registers in this form: it keeps the copies)
+    const bool odd_hidden = PP && ((D - 1) & 1);
+    float chead[3] = {0.f, 0.f, 0.f};
+    auto layer0 = [&](auto& Oh, auto& Ol) {
 #pragma unroll
     for (int m = 0; m < NT / 2; ++m) {
       float v8[8];
@@ -846,17 +858,41 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
           for (int i = 0; i < 4; ++i) sdf = fmaf(ws4[i], v8[hf * 4 + i], sdf);
         }
       }
-      put8<F32>(v8, Xh[m], Xl[m]);
+      put8<F32>(v8, Oh[m], Ol[m]);
     }
-    float chead[3] = {0.f, 0.f, 0.f};
-    STAMP(1);   // sample setup + layer 0
+    };
     // ---- hidden layers 1 .. D-1
+    if constexpr (PP) {
+      int l = 1;
+      if (odd_hidden) {          // layer 0 -> Y, the odd hidden layer Y -> X; then pairs
+        layer0(Yh, Yl);
+        STAMP(1);   // sample setup + layer 0
+        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, D == 2, ring, s_film + 2 * H, s_wd, s_wc,
+                                          s_ws, vx, vy, vz, STASH ? stash_s : nullptr, wave, lane,
+                                          q4o, afrag_lane + opq, Yh[0] STAMP_ARG);
+        l = 2;
+      } else {
+        layer0(Xh, Xl);
+        STAMP(1);   // sample setup + layer 0
+      }
+      for (; l < D; l += 2) {
+        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, false, ring, s_film + l * 2 * H, s_wd, s_wc,
+                                          s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
+                                          q4o, afrag_lane + opq, Xh[0] STAMP_ARG);
+        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, l + 1 == D - 1, ring, s_film + (l + 1) * 2 * H, s_wd, s_wc,
+                                          s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)l * 16 * H : nullptr, wave, lane,
+                                          q4o, afrag_lane + opq, Yh[0] STAMP_ARG);
+      }
+    } else {
+    layer0(Xh, Xl);
+    STAMP(1);   // sample setup + layer 0
     for (int l = 1; l < D; ++l) {
       mfma_layer<NT, TPS, false, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
                                         s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
                                         q4o, afrag_lane + opq, Xh[0] STAMP_ARG);
 #pragma unroll
       for (int i = 0; i < NT / 2; ++i) { Xh[i] = Yh[i]; Xl[i] = Yl[i]; }
+    }
     }
     STAMP(2);   // hidden layers
     // ---- sigma head on h_D (volume_renderer.py:148): the per-lane partial was accumulated where h_D was produced
