@@ -295,6 +295,14 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #ifndef CIPS3D_HALF_PERIOD
 #define CIPS3D_HALF_PERIOD 0
 #endif
+#ifndef CIPS3D_SPREAD_DMA
+#define CIPS3D_SPREAD_DMA 0
+#endif
+#ifndef CIPS3D_SPREAD_FROM
+#define CIPS3D_SPREAD_FROM 0
+#endif
+  constexpr bool SPREAD = CIPS3D_SPREAD_DMA && !CIPS3D_HALF_PERIOD && NT == 16;     // (hidden 256: 8 or 4 pieces per wave and step)
+  constexpr int SPREAD_FROM = CIPS3D_SPREAD_FROM;
   auto issue_slab = [&](int seq_next) {
     if (seq_next < ring.seq_end) {
       const int nxt = seq_next % ring.per_sample;
@@ -311,10 +319,18 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
       } else {
         __syncthreads();                     // gamma_g
       }
-    } else if (ring.seq + 1 < ring.seq_end) {
+    } else if (!SPREAD && ring.seq + 1 < ring.seq_end) {
       const int nxt = (ring.seq + 1) % ring.per_sample;
       stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
     }
+    // SPREAD (-DCIPS3D_SPREAD_DMA=1, A/B): the wave's pieces of the next slab are requested one per MFMA group inside the matrix
+    // block instead of in one burst behind the barrier (where all eight waves' 64 requests queue up at once: 0.46k cycles of a
+    // 4.4k-cycle step in the stamps).  Measured, same box, HIP events, processes interleaved x3: 81.0 -> 82.4 us at N = 24,
+    // 391.2 -> 399.4 at N = 128 (from the fifth group on: 83.5 / 401.0): a request between two MFMA groups holds the wave's
+    // in-order issue longer than the burst does.  Not the default.
+    const bool spread_next = SPREAD && ring.seq + 1 < ring.seq_end;
+    const float* spread_src = ring.packed + (int64_t)((ring.seq + 1) % ring.per_sample) * SLAB;
+    float* spread_dst = ring.lds + ((ring.seq + 1) & 1) * SLAB;
     STAMP(8);    // (in-layer stamps: the phase before the first one of a layer is charged to slot 12 / 11 of the previous step)
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
     const int o_base = sl * (TPS * 16) + q4o;          // this lane's first output unit of the step
@@ -376,6 +392,11 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
         for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));
         if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
+        if constexpr (SPREAD) {
+          constexpr int PER_WAVE = SLAB * 4 / 1024 / WAVES;
+          static_assert(!SPREAD || (PER_WAVE <= 2 * MB && (SLAB * 4 / 1024) % WAVES == 0), "one piece per MFMA group");
+          if (g >= SPREAD_FROM && g - SPREAD_FROM < PER_WAVE && spread_next) stage_piece(spread_src, spread_dst, (g - SPREAD_FROM) * WAVES + wave, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F32) {      // fh / fl: the fp32 fragments of the k-block's two 16-unit halves; k ascending, the bit-exact chain
           const f32x4 x0 = __builtin_bit_cast(f32x4, Xh[m]), x1 = __builtin_bit_cast(f32x4, Xl[m]);
