@@ -178,7 +178,9 @@ class ForwardPlan:
         # also computes the next stage's low-res GEMM from its registers: the next up-conv's weights are then packed in the
         # chained order and its own GEMM launch disappears.
         # A block of the same shape that does NOT up-sample, above the NeRF resolution (the blocks at the NeRF resolution belong
-        # to the planes run below), takes the same kernel in its flat form: stage_kind 2.
+        # to the planes run below), takes the same kernel in its flat form: stage_kind 2.  (At the NeRF resolution itself -- a 64^2
+        # generator's 128 .. 1024 blocks -- the four flat launches take what the eight planes launches they replace do:
+        # 0.456 against 0.457 ms per view, measured; left with the run.)
         def stage_kind(i):
             if i + 2 >= len(layer_info):
                 return 0
