@@ -14,6 +14,7 @@ stats final $B --steps 50 --repeats 2
 stats n64 $B --steps 30 --repeats 2 --n-samples 64
 stats config3_bf16 $B --batch 4 --decoder-precision bf16 --steps 30 --repeats 2
 stats fp32_exact $B --decoder-precision fp32_exact --steps 30 --repeats 2
+stats config2_r256 $B --res 256 --steps 50 --repeats 2
 stats multiview python3 tools/bench_multiview.py --chunks 1 --rounds 2
 stats conv3x3_tool python3 tools/bench_conv3x3.py
 stats upfirdn2d_tool python3 tools/bench_upfirdn2d.py
