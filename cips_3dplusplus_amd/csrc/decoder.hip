@@ -1372,6 +1372,22 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // rides in the FMA that adds it (patch_store).  The request sits BEHIND the uniform loads of the prologue (FIR taps, biases): an
   // LDS-DMA counts as a memory write for the compiler, and uniform loads behind one are no longer scalar loads -- issued at the very
   // top, the 16 taps alone came back in vector registers and the C = 32 / 64 stages spilled 43 / 34.
+  // The first patches go out in FRONT of the LDS-DMA requests: behind them, the compiler waited for vmcnt(0) -- the A fragments, the
+  // noise tile, the ToRGB rows, all from a cold L2 -- before it reused the DMAs' address registers for the patch addresses.  Same
+  // box (rocprofv3 / unprofiled bench, variants interleaved): C = 32 stage 38.5 -> 37.3 us, the view 0.3481 -> 0.3474 ms.
+  // (Measured with it and NOT kept: the patch rows as register quads from the load to the FIR, all of a stage's patches under ONE
+  // interior / edge branch -- the interior path then issues its six 16-byte loads back to back with no wait between them, where
+  // today every row's load is waited for before its middle pair is copied to an even register pair -- 39.1 / 32.9 / 25.1 / 23.1 us
+  // for C = 32 / 64 / 128 / 256 against 37.3 / 32.3 / 23.3 / 21.5: the co-resident workgroups cover those waits, the quads cost
+  // registers and copies in the K loop.)
+#ifndef CIPS3D_FUSED_PATCH_FIRST
+#define CIPS3D_FUSED_PATCH_FIRST 1
+#endif
+  constexpr bool PATCH_FIRST = CIPS3D_FUSED_PATCH_FIRST && TILE_DMA;
+  if constexpr (PATCH_FIRST) {
+    patch_load(0);
+    if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
+  }
   if constexpr (TILE_DMA) {
     const bool have_nz = a.noise1 && a.nw1 && !(CIPS3D_FUSED_AB & 128);
     if (have_nz) nw1_u = a.nw1[0];
@@ -1397,8 +1413,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
     }
   }
-  patch_load(0);
-  if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
+  if constexpr (!PATCH_FIRST) {
+    patch_load(0);
+    if (DEEP) patch_load_into(1, pw);          // stage s's patches live in set s & 1 (pv: even, pw: odd)
+  }
 
   // Range of the split operands (cips3d_range, common.h).  act1 is split as act1 2^-e1, e1 from the bound
   // U1 = c1 max|y_lo| + c0 (conv1's constants: FIR gain, noise, bias); conv2's accumulators come back with 2^-8 2^e1.  In the
