@@ -2179,6 +2179,11 @@ extern "C" int cips3d_fused_up_conv_next(const float* y_lo, const float* fir, co
     // tile shapes / register budgets picked by sweep on MI355X (profiles/r01_i_*): time per stage in the comment
     // C = 32 (one K stage): with the epilogue's operands (noise2, bias2, skip patch) requested after the MFMAs instead of up
     // front the kernel needs 71 instead of 93 registers: seven instead of five resident waves per SIMD, -6 us at 1024^2
+    // (round 5, what bounds it: 503.6 VALU instructions per wave x 32 768 waves = 64.5 k issue cycles per SIMD = 30.7 us of its
+    // 37.3 -- the stage is VALU-issue bound.  With no arithmetic (-DCIPS3D_FUSED_AB=60) 201.7 VALU / 26.2 us, with no loads either
+    // (252) 136.8 VALU / 16.7 us.  Not the wave launch rate: a wave that owns all 32 channels of its 64 pixels (<32, 2, 1, 4, 1, 32,
+    // 4>: half the waves, no cross-wave ToRGB exchange) takes 39.6 against 39.4 us on one box, eight waves per workgroup 41.0.  The
+    // conv2 epilogue written as channel-pair v_pk_*_f32 by hand: 37.4 against 37.5 -- hipcc's SLP pass had packed it already.)
     case 32: return launch_fused<32, 1, 2, 2, 1, 32, CIPS3D_C32_MINW, false, false, true>(a, st);   // 2 rows x 64, 4 waves     46 us @1024^2
     case 64: return launch_fused<64, 2, 2, 2, 1, 16, 4>(a, st);      // 2 rows x 64, 4 waves, BK 16     42 us @512^2
     case 128: return launch_fused<128, 4, 2, 4, 1, 32, 2>(a, st);    // 4 rows x 64                     33 us @256^2
