@@ -839,7 +839,10 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     // instructions at D = 2, 12 % at D = 8).  The view layer reads X: with an odd number of hidden layers layer 0 writes Y and one
     // Y -> X layer runs in front of the pairs (a third copy of the layer's code; entering the pair loop at its second half would
     // be an irreducible loop, and that form spilled 250 registers).
-    constexpr bool PP = CIPS3D_PINGPONG && !F32;      // (the exact-fp32 instantiation spills 170 registers in this form: it keeps the copies)
+    // (the exact-fp32 instantiation spills 170 registers in this form and keeps the copies; so does the optional L0M instantiation,
+    // whose feature map moved by 1.6e-4 against the VALU form with an odd number of hidden layers in this form -- rgb, sdf and the
+    // other maps agreed; not chased: that instantiation is off by default and the slower one, tools/test_optional_builds.sh)
+    constexpr bool PP = CIPS3D_PINGPONG && !F32 && !L0M;
     const bool odd_hidden = PP && ((D - 1) & 1);
     float chead[3] = {0.f, 0.f, 0.f};
     auto layer0 = [&](auto& Oh, auto& Ol) {
