@@ -616,6 +616,30 @@ def test_flat_stage_chains_the_next_block(C, mode):
         assert maxdiff(out2, o_f) < lim * float(o_f.abs().max()) and maxdiff(rgb, rgb_f) < lim * float(rgb_f.abs().max())
 
 
+@pytest.mark.parametrize("res,S,B", [(256, 32, 2), (256, 48, 1), (512, 32, 1), (1024, 16, 1), (256, 16, 3)])
+def test_planned_forward_at_other_nerf_resolutions(res, S, B):
+    """The one-call forward against the per-op launches at NeRF resolutions other than the recipes' 64: the planes run, the chained
+    up-sampling stages and the flat stages behind them pick their shapes from the plan (192^2 / 128^2 / 64^2 flat blocks, a
+    1024 recipe whose last stage is 256^2)."""
+    cfg = configs.ffhq_G_cfg(res, 2)
+    G = pkg.build_generator(cfg, DEV, seed=3)
+    zs, nb, _ = weights.synth_inputs(cfg, batch=B, seed=7, img_size=S)
+    g = torch.Generator(device=DEV).manual_seed(S)
+    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=0.2 * torch.randn(B, 2, device=DEV, generator=g))
+    kw = dict(zs=[cu(z) for z in zs], cam_poses=e, focals=f, img_size=S, near=n, far=fa, noise_bufs=[cu(b) for b in nb],
+              nerf_cfg=dict(N_samples=6, perturb=False, static_viewdirs=False))
+    a = G(**kw)["rgb"].clone()
+    key = (B, S, 6, False)
+    assert G._plans.get(key) is not None
+    n_flat = sum(1 for li in G._plans[key]._layer_info if li.get("flat_head"))
+    assert n_flat == {256: 2, 512: 1, 1024: 0}[res]
+    G._plans[key] = None                                   # force the per-op path
+    b = G(**kw)["rgb"].clone()
+    up = {256: 4, 512: 8, 1024: 16}[res]
+    assert a.shape == (B, 3, up * S, up * S)
+    assert maxdiff(a, b) < 3e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_flat_stage_refuses_what_it_does_not_tile():
     lib = _lib.load()
     assert lib.cips3d_fused_flat_conv_supported(64, 256, 256) and lib.cips3d_fused_flat_conv_supported(32, 64, 64)
