@@ -119,10 +119,17 @@ def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=16.0):
         timed = times[warm:]
         torch.set_num_threads(1)
         t1 = one_view()
+        # SURVEY 8d asks for "all physical cores" beside it: one view with every host thread torch was given (slower than `cores`
+        # threads on the GPU box's 128-thread host -- which is why `value` is not timed there)
+        t_allthr = None
+        if all_threads != cores:
+            torch.set_num_threads(all_threads)
+            one_view()
+            t_allthr = one_view()
     torch.set_num_threads(all_threads)
     per_view = statistics.median(timed) / batch
     return {"value": 1.0 / per_view, "unit": "views/s", "cores": cores, "host_threads": all_threads, "kind": "port",
-            "value_1_thread": batch / t1,
+            "value_1_thread": batch / t1, "value_all_threads": (batch / t_allthr) if t_allthr else 1.0 / per_view,
             "sample": f"median of {len(timed)} forward(s) of the same workload after {warm} warm-up(s) "
                       f"({per_view * 1e3:.0f} ms/view with {cores} of {all_threads} host threads: more are slower; "
                       f"{t1 / batch * 1e3:.0f} ms/view with 1 thread, one view)"}
@@ -513,14 +520,17 @@ def multiview_workload(dev, repeats, n_frames=8, n_samples=128, res=1024):
                 out = run(c, h)
             torch.cuda.synchronize()
             elapsed[k].append((time.perf_counter() - t0) / 3)
-    med = statistics.median(elapsed["chunk1_hoisted"])
+    # `value` is the quantity every round has reported: each frame recomputes its style tables, as the reference's frame loop does
+    # (render_video_web_v10.py:1806-1826).  The sequence plan (tables resident after the first frame) is a variant beside it.
+    med = statistics.median(elapsed["chunk1_per_frame_tables"])
     assert out["rgb"].dtype == torch.uint8 and out["rgb"].shape[0] == n_frames
     return {"tag": "config4_multiview_8f_n128", "what": "BASELINE config 4, the demo loop's semantics on one GPU: sample_multi_view(yaw, 8 frames, N = 128, truncation 0.5, "
-                    "fixed noise buffers, perturb off, xyz returned, uint8 frames), one frame per call; the sequence's style tables "
-                    "(mapping networks, FiLM table, 26 modulated decoder matrices) are computed by the first frame and resident for the "
-                    "other seven (styles_resident; bit-identical to per-frame recomputation)",
+                    "fixed noise buffers, perturb off, xyz returned, uint8 frames), one frame per call, every frame recomputing its style "
+                    "tables (value); variants: the sequence's tables (mapping networks, FiLM table, 26 modulated decoder matrices) computed "
+                    "by the first frame and resident for the other seven (chunk1_hoisted: sample_multi_view's default, bit-identical), "
+                    "and all eight frames in one batch (chunk8_hoisted)",
             "metric": "rendered views/s", "value": n_frames / med, "unit": "views/s", "ms_per_step": med / n_frames * 1e3,
-            "steps": 3 * n_frames, "repeats": repeats, "ms_per_step_repeats": [e / n_frames * 1e3 for e in elapsed["chunk1_hoisted"]], "dtype": DTYPE_NAMES["fp32"],
+            "steps": 3 * n_frames, "repeats": repeats, "ms_per_step_repeats": [e / n_frames * 1e3 for e in elapsed["chunk1_per_frame_tables"]], "dtype": DTYPE_NAMES["fp32"],
             "variants_views_per_s": {k: n_frames / statistics.median(v) for k, v in elapsed.items()},
             "config": {"workload": f"ffhq_r{res}_nerf64x64x{n_samples}_D2_B1 x {n_frames} frames (multiview.sample_multi_view)"}}
 
@@ -569,7 +579,7 @@ def compact(line, detail_name):
     cb = line.get("cpu_baseline")
     if cb:
         out["cpu_baseline"] = {k: (_r(v) if not isinstance(v, str) else v[:120]) for k, v in cb.items()
-                               if k in ("value", "unit", "cores", "kind", "sample", "error")}
+                               if k in ("value", "unit", "cores", "kind", "sample", "error", "value_1_thread", "value_all_threads", "host_threads")}
     if "also" in line:
         rows = []
         for e in line["also"][:14]:

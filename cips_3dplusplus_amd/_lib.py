@@ -98,7 +98,6 @@ class NerfBwdFusedParams(C.Structure):
 
 _SIGS = {
     "cips3d_abi_version": (c_int, []),
-    "cips3d_build_features": (c_int, []),
     "cips3d_strerror": (C.c_char_p, [c_int]),
     "cips3d_fused_bias_act": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_f32, c_f32,
                                       C.c_void_p]),
@@ -226,7 +225,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 28           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 29           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

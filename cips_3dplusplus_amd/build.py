@@ -17,16 +17,10 @@ CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(PKG, "libcips3d_hip.so")
 ARCH = "gfx950"
-# CIPS3D_EXPERIMENTAL=1: also compile the two measured-slower render-kernel dataflows of csrc/experimental/  and their
-# dispatch (-DCIPS3D_EXPERIMENTAL); the default library carries neither
-EXPERIMENTAL = os.environ.get("CIPS3D_EXPERIMENTAL") == "1"
 SOURCES = ["bias_act.hip", "upfirdn2d.hip", "linear.hip", "camera.hip", "nerf.hip", "decoder.hip", "chain.hip", "conv3x3.hip", "forward.hip", "backward.hip", "decoder_grad.hip", "nerf_bwd.hip", "nerf_bwd_fused.hip", "render_ops.hip", "rng.hip", "optim.hip"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
          "-Wno-unused-function", "-fno-gpu-rdc", "-fgpu-flush-denormals-to-zero" if False else ""]
 FLAGS = [f for f in FLAGS if f] + os.environ.get("CIPS3D_HIPCC_FLAGS", "").split()
-if EXPERIMENTAL:
-    SOURCES += ["experimental/nerf_pair.hip", "experimental/nerf_ws.hip"]
-    FLAGS += ["-DCIPS3D_EXPERIMENTAL", f"-I{CSRC}"]
 
 
 def hipcc():
@@ -44,8 +38,6 @@ def source_hash():
     snapshot copy to the GPU box, contents do."""
     import hashlib
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
-    if EXPERIMENTAL:
-        files += sorted(os.path.join(CSRC, "experimental", f) for f in os.listdir(os.path.join(CSRC, "experimental")) if f.endswith(".hip"))
     files += [os.path.join(os.path.dirname(PKG), "include", "cips3d_hip.h"), os.path.abspath(__file__)]
     # (per-file flags included: a knob that only changes those -- CIPS3D_CHAIN_SLP -- must invalidate the library too; a probe of
     # round 4 compared two "builds" that were the same file because it did not)
@@ -69,9 +61,7 @@ def up_to_date():
 # one of whose forms -- op_sel:[0,1,0], the low lane reading the HIGH register of the src1 pair -- returns run-to-run different sums in
 # the bf16 chain kernel (named and reproduced by hand in profiles/r05_slp_fold_cause.md); the shipped fold spells its FMAs in inline
 # asm as well, and tests/test_host.py checks the kernel's assembly for the form
-FILE_FLAGS = {"chain.hip": [] if os.environ.get("CIPS3D_CHAIN_SLP") == "1" else ["-fno-slp-vectorize"],
-              # nerf_pair.hip: one wave per SIMD -- a packed-fp32 instruction beside MFMAs costs more than the two it replaces
-              "experimental/nerf_pair.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"chain.hip": [] if os.environ.get("CIPS3D_CHAIN_SLP") == "1" else ["-fno-slp-vectorize"]}
 
 
 def _compile(src, keep_temps):
@@ -108,10 +98,25 @@ def build_library(force=False, keep_temps=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _sweep_objects():
+    """Objects (and -save-temps files) of an earlier build that did not finish: the lock is held, so nothing in OBJ is in use."""
+    for f in os.listdir(OBJ):
+        if f.endswith((".o", ".tmp")):
+            try:
+                os.remove(os.path.join(OBJ, f))
+            except OSError:
+                pass
+
+
 def _build_locked(keep_temps, verbose):
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, keep_temps), srcs))
+    _sweep_objects()
+    try:
+        with cf.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+            results = list(ex.map(lambda s: _compile(s, keep_temps), srcs))
+    except BaseException:
+        _sweep_objects()              # a failed or interrupted compile leaves nothing behind (the objects travel with gpurun snapshots)
+        raise
     objs = [o for o, _ in results]
     if verbose:
         for _, log in results:

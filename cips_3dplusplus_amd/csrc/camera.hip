@@ -4,16 +4,6 @@
 #include "common.h"
 
 extern "C" int cips3d_abi_version(void) { return CIPS3D_ABI_VERSION; }
-extern "C" int cips3d_build_features(void) {
-  int f = 0;
-#ifdef CIPS3D_EXPERIMENTAL
-  f |= 1;
-#endif
-#ifdef CIPS3D_NERF_L0M
-  f |= 2;
-#endif
-  return f;
-}
 
 extern "C" const char* cips3d_strerror(int code) {
   if (code == 0) return "success";

@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         v[r] = acc[i][c][r] * kpre;
-        if (a.epilogue == 1) v[r] = lrelu02((v[r] + nz[c] * nw) + bias4[i][r]) * kact;
+        if (a.epilogue == 1) v[r] = lrelu02(fmaf(nw, nz[c], v[r]) + bias4[i][r]) * kact;
       }
       // (columns past HW repeat the last pixel without its noise: a value the patch maximum may include -- it only has to bound)
       mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));

@@ -234,11 +234,10 @@ __global__ void __launch_bounds__(256) modconv3x3_kernel(Conv3Args a) {
   if (oy >= OH || ox >= OW) return;
   const int HWo = OH * OW;
   f32x4 nz = {0.f, 0.f, 0.f, 0.f};
+  float nw = 0.f;
   if (a.epilogue == 1 && a.noise && a.noise_w) {
     nz = *reinterpret_cast<const f32x4*>(a.noise + (int64_t)b * a.noise_bstride + (oy * OW + ox));
-    const float nw = a.noise_w[0];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) nz[c] *= nw;
+    nw = a.noise_w[0];
   }
   float* ob = a.out + (int64_t)b * a.Cout * HWo + (oy * OW + ox);
 #pragma unroll
@@ -250,7 +249,7 @@ __global__ void __launch_bounds__(256) modconv3x3_kernel(Conv3Args a) {
       if (a.epilogue == 1) {
         const float bs = a.bias[obase + r];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz[c]) + bs) * 1.41421356237309515f;
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02(fmaf(nw, nz[c], v[c]) + bs) * 1.41421356237309515f;
       }
       *reinterpret_cast<f32x4*>(ob + (obase + r) * HWo) = v;
     }

@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (ACTBWD && NS == 2 && BK == 32
       }
       if (a.epilogue == 1) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = lrelu02((v[c] + nz4[c] * nw) + bias4[i][r]) * 1.41421356237309515f;
+        for (int c = 0; c < 4; ++c) v[c] = lrelu02(fmaf(nw, nz4[c], v[c]) + bias4[i][r]) * 1.41421356237309515f;
       }
       if constexpr (ACTBWD) {
         const f32x4 yv = aby[i][r];
@@ -889,10 +889,10 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
       float4 nz = make_float4(0.f, 0.f, 0.f, 0.f);
       if (noise) nz = *reinterpret_cast<const float4*>(noise + (int64_t)b * noise_bstride + (int64_t)(2 * iy + py) * OW + 4 * qx);
       float4 r;
-      r.x = lrelu02((o[py][0] + noise_w * nz.x) + bs) * 1.41421356237309515f;
-      r.y = lrelu02((o[py][1] + noise_w * nz.y) + bs) * 1.41421356237309515f;
-      r.z = lrelu02((o[py][2] + noise_w * nz.z) + bs) * 1.41421356237309515f;
-      r.w = lrelu02((o[py][3] + noise_w * nz.w) + bs) * 1.41421356237309515f;
+      r.x = lrelu02(fmaf(noise_w, nz.x, o[py][0]) + bs) * 1.41421356237309515f;
+      r.y = lrelu02(fmaf(noise_w, nz.y, o[py][1]) + bs) * 1.41421356237309515f;
+      r.z = lrelu02(fmaf(noise_w, nz.z, o[py][2]) + bs) * 1.41421356237309515f;
+      r.w = lrelu02(fmaf(noise_w, nz.w, o[py][3]) + bs) * 1.41421356237309515f;
       cips3d_store_wt16(dst + (int64_t)py * OW, r);
       mx = fmaxf(fmaxf(fmaxf(fabsf(r.x), fabsf(r.y)), fmaxf(fabsf(r.z), fabsf(r.w))), mx);
     }
@@ -916,6 +916,8 @@ __global__ void __launch_bounds__(256) up2_fir_act_kernel(const float* __restric
 }
 
 // StyledConv epilogue on its own (generality path): out = lrelu(x + noise_w*noise + bias[c], 0.2)*sqrt(2)
+// (NoiseInjection as ONE fused multiply-add in every kernel of the library: `image + weight * noise` of model_v3.py:317-341 with
+// one rounding instead of two -- the same value in the fused stages, the chain, the per-layer GEMM and the differentiable forward)
 __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                                              int64_t noise_bstride, const float* __restrict__ nwp,
                                                              const float* __restrict__ bias, float* __restrict__ out,
@@ -926,8 +928,8 @@ __global__ void __launch_bounds__(256) noise_bias_act_kernel(const float* __rest
     const int64_t n = i % HW;
     const int c = (int)((i / HW) % C);
     const int b = (int)(i / (HW * C));
-    const float nz = noise ? noise_w * noise[(int64_t)b * noise_bstride + n] : 0.f;
-    out[i] = lrelu02((x[i] + nz) + bias[c]) * 1.41421356237309515f;
+    const float nz = noise ? noise[(int64_t)b * noise_bstride + n] : 0.f;
+    out[i] = lrelu02(fmaf(noise_w, nz, x[i]) + bias[c]) * 1.41421356237309515f;
   }
 }
 
@@ -1258,13 +1260,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   // registers that buy a sixth resident wave per SIMD
   constexpr bool LATE = LATE_OPS;
   f32x4 nz2 = {0.f, 0.f, 0.f, 0.f};
+  float nw2_u = 0.f;                        // NoiseInjection.weight of conv2 (applied by the FMA that adds the noise)
   f32x4 bias4[WM];
   auto load_epilogue_ops = [&]() {
     if (a.noise2 && a.nw2 && !(CIPS3D_FUSED_AB & 128)) {
       nz2 = *reinterpret_cast<const f32x4*>(a.noise2 + (int64_t)b * a.nbs2 + (oy * OW + ox));
-      const float nw = a.nw2[0];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) nz2[c] *= nw;
+      nw2_u = a.nw2[0];
     }
 #pragma unroll
     for (int i = 0; i < WM; ++i) bias4[i] = *reinterpret_cast<const f32x4*>(a.bias2 + (wm_i * WM + i) * 16 + 4 * q);
@@ -1348,8 +1349,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          // (TILE_DMA: the tile holds the raw noise, its weight rides in the FMA -- one rounding where `o + (nw * noise)` had two)
-          const float on = TILE_DMA ? fmaf(nw1_u, nz[c], o[py][c]) : o[py][c] + nz[c];
+          // (the tile holds the raw noise, its weight rides in the FMA: see noise_bias_act_kernel)
+          const float on = fmaf(nw1_u, nz[c], o[py][c]);
           v[c] = (CIPS3D_FUSED_AB & 32) ? on : lrelu02(on + bs);
         }
         if constexpr (SPLIT && !(CIPS3D_FUSED_AB & 32)) {          // split once here (with the activation's gain and range scale: cips3d_split_word);
@@ -1464,14 +1465,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
   if constexpr (TILE_DMA) {
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's LDS-DMA pieces (and, needed right behind the barrier anyway, its patches)
   } else {
+  if (a.noise1 && a.nw1 && !(CIPS3D_FUSED_AB & 128)) nw1_u = a.nw1[0];
   if (tid < BN / 4) {
     const int r = tid / (TW / 4), x4 = tid % (TW / 4);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (a.noise1 && a.nw1 && !(CIPS3D_FUSED_AB & 128)) {
       v = *reinterpret_cast<const f32x4*>(a.noise1 + (int64_t)b * a.nbs1 + ((oy0 + r) * OW + ox0 + x4 * 4));
-      const float nw = a.nw1[0];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] *= nw;
     }
     *reinterpret_cast<f32x4*>(s_nz1 + r * TW + x4 * 4) = v;
   }
@@ -1591,7 +1590,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, MINW) fused_up_conv_kernel(Fus
       }
       // (chained split form: v = out2 2^-e2 from here on -- the B operand of the next GEMM; the ToRGB sums are scaled back once)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = (CIPS3D_FUSED_AB & 16) ? v[c] : lrelu02((v[c] + nz2[c]) + bias4[i][r]) * kact2;
+      for (int c = 0; c < 4; ++c) v[c] = (CIPS3D_FUSED_AB & 16) ? v[c] : lrelu02(fmaf(nw2_u, nz2[c], v[c]) + bias4[i][r]) * kact2;
       if (NEXT) {   // keep the activated value where the accumulator was: it is the next GEMM's B operand
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[i][c][r] = v[c];

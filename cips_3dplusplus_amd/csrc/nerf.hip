@@ -233,14 +233,8 @@ __global__ void __launch_bounds__(256) nerf_pack32_kernel(const float* __restric
 // block, (Xh[m], Xl[m]) are the bits of the fp32 activations of o-tiles 2m, 2m + 1 (the MFMA D layout IS the B operand of
 // v_mfma_f32_16x16x4_f32: k-step r of k-quarter q <-> unit 16 T + 4 q + r), eight 32-cycle MFMAs per (tile, k-block) where the
 // split kernel issues three 16-cycle ones.  Two waves per SIMD as in the split kernel: one wave's sine epilogue runs under
-// the other's matrix block, which nerf_pair.hip's one-wave form of the same arithmetic cannot do (252 us; this one: see DESIGN).
-// L0M (layer 0 and the view-direction columns on the matrix cores): fragment table geometry and the power of two of the points
-constexpr int L0M_TILE_FLOATS = 48 * 4;      // one o-tile of the table: 48 lane slots x 16 bytes
-#ifndef CIPS3D_L0M_VIEW
-#define CIPS3D_L0M_VIEW 1                    // 0: L0M covers layer 0 only, the view-direction columns stay three FMAs per unit (A/B)
-#endif
-constexpr int L0M_POINT_EXP = 8;             // the point fragment holds n 2^8 (|n| <~ 1.5: normalised coordinates)
-__host__ __device__ constexpr int nerf_table_floats(int H, int L, bool l0m) { return L * 2 * H + (l0m ? (CIPS3D_L0M_VIEW ? 16 : 19) : 10) * H; }
+// the other's matrix block (a one-wave-per-SIMD form of the same arithmetic measured 252 us; this one: see DESIGN).
+__host__ __device__ constexpr int nerf_table_floats(int H, int L) { return L * 2 * H + 10 * H; }
 
 template <bool F32>
 __device__ __forceinline__ void put8(const float (&v)[8], h8& hi, h8& lo) {
@@ -252,12 +246,11 @@ __device__ __forceinline__ void put8(const float (&v)[8], h8& hi, h8& lo) {
   }
 }
 
-template <int NT, int TPS, bool VIEW, bool STASH, bool F32 = false, bool L0M = false>
+template <int NT, int TPS, bool VIEW, bool STASH, bool F32 = false>
 __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], h8 (&Yh)[NT / 2], h8 (&Yl)[NT / 2],
                                            float (&FA)[NT * 4], float wgt, float (&chead)[3], float& sdf_acc, bool last,
                                            Ring& ring, const float* film_l, const float* s_wd, const float* s_wc,
-                                           const float* s_ws, float vx, float vy, float vz, float* stash_l, int wave, int lane, int q4o,
-                                           const float* afrag_lane, const h8& bd STAMP_PARAM) {
+                                           const float* s_ws, float vx, float vy, float vz, float* stash_l, int wave, int lane, int q4o STAMP_PARAM) {
   constexpr int H = NT * 16;
   constexpr int TILE = 16 * H;          // floats (= 4-byte hi/lo pairs) of one o-tile's A fragments
   constexpr int SLAB = TILE * TPS;
@@ -279,75 +272,20 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
   // that one wave's matrix block always faces the other's epilogue): correct, but 127 us instead of 97 -- a matrix block
   // that has the SIMD to itself is bound by its own A-fragment reads (8 x [8 ds_read_b128 -> wait -> 12 MFMAs]; the second
   // wave is what hides that latency today), and double-buffering the fragments needs 32 registers the kernel does not have.
-#ifdef CIPS3D_NO_STAGGER
-  const bool late_epilogue = false;
-#else
   const bool late_epilogue = __builtin_amdgcn_readfirstlane(wave) >= WAVES / 2;
-#endif
-  // CIPS3D_HALF_PERIOD (A/B): the upper half of the waves runs HALF A STEP behind the lower half instead of taking the one step
-  // barrier early -- two workgroup barriers per step, one in front of every wave's matrix block and one behind it, and the upper
-  // waves execute one more at the start of the kernel (the lower ones one more at its end).  Barrier "beta_g" is then the lower
-  // waves' barrier in front of matrix block g and the upper waves' behind block g - 1: behind it nobody reads slab g - 1 any
-  // more, every wave requests its pieces of slab g + 1 there and waits for them in front of its own beta_{g+1}.  Between two
-  // barriers one wave of every SIMD is in its matrix block and the other in its epilogue.  Measured (round 4, same box,
-  // rocprofv3): 86.4 us against the stagger's 80.6 -- as with round 2's fp16-less attempt (127 against 97): a matrix block that has
-  // the SIMD to itself does not run twice as fast as two that share it.  Not the default.
-#ifndef CIPS3D_HALF_PERIOD
-#define CIPS3D_HALF_PERIOD 0
-#endif
-#ifndef CIPS3D_SPREAD_DMA
-#define CIPS3D_SPREAD_DMA 0
-#endif
-#ifndef CIPS3D_SPREAD_FROM
-#define CIPS3D_SPREAD_FROM 0
-#endif
-  constexpr bool SPREAD = CIPS3D_SPREAD_DMA && !CIPS3D_HALF_PERIOD && NT == 16;     // (hidden 256: 8 or 4 pieces per wave and step)
-  constexpr int SPREAD_FROM = CIPS3D_SPREAD_FROM;
-  auto issue_slab = [&](int seq_next) {
-    if (seq_next < ring.seq_end) {
-      const int nxt = seq_next % ring.per_sample;
-      stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + (seq_next & 1) * SLAB, wave, lane);
-    }
-  };
 #pragma unroll
   for (int sl = 0; sl < STEPS; ++sl) {
-    if (CIPS3D_HALF_PERIOD) {
-      if (!late_epilogue) {                  // beta_g in front of the lower waves' block
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of slab g
-        __syncthreads();
-        issue_slab(ring.seq + 1);
-      } else {
-        __syncthreads();                     // gamma_g
-      }
-    } else if (!SPREAD && ring.seq + 1 < ring.seq_end) {
+    if (ring.seq + 1 < ring.seq_end) {
       const int nxt = (ring.seq + 1) % ring.per_sample;
       stage_slab<SLAB>(ring.packed + (int64_t)nxt * SLAB, ring.lds + ((ring.seq + 1) & 1) * SLAB, wave, lane);
     }
-    // SPREAD (-DCIPS3D_SPREAD_DMA=1, A/B): the wave's pieces of the next slab are requested one per MFMA group inside the matrix
-    // block instead of in one burst behind the barrier (where all eight waves' 64 requests queue up at once: 0.46k cycles of a
-    // 4.4k-cycle step in the stamps).  Measured, same box, HIP events, processes interleaved x3: 81.0 -> 82.4 us at N = 24,
-    // 391.2 -> 399.4 at N = 128 (from the fifth group on: 83.5 / 401.0): a request between two MFMA groups holds the wave's
-    // in-order issue longer than the burst does.  Not the default.
-    const bool spread_next = SPREAD && ring.seq + 1 < ring.seq_end;
-    const float* spread_src = ring.packed + (int64_t)((ring.seq + 1) % ring.per_sample) * SLAB;
-    float* spread_dst = ring.lds + ((ring.seq + 1) & 1) * SLAB;
     STAMP(8);    // (in-layer stamps: the phase before the first one of a layer is charged to slot 12 / 11 of the previous step)
     const float* slab = ring.lds + (ring.seq & 1) * SLAB;
     const int o_base = sl * (TPS * 16) + q4o;          // this lane's first output unit of the step
     f32x4 acc[TPS];
     // (opaque per step: as loop invariants the operand copies of vx, vy, vz were hoisted out of the sample loop and spilled)
     float vxo = vx, vyo = vy, vzo = vz;
-    if (VIEW && !(L0M && CIPS3D_L0M_VIEW)) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
-    if constexpr (VIEW && L0M && CIPS3D_L0M_VIEW) {
-      // the three view-direction columns as ONE more k-block of the split MFMA (L0M: see the layer-0 block of the kernel): the
-      // lane's A fragment of o-tile (sl * TPS + tt) from the fragment table, the ray's direction fragment bd (built once per ray)
-#pragma unroll
-      for (int tt = 0; tt < TPS; ++tt) {
-        h8 fa = *reinterpret_cast<const h8*>(afrag_lane + (sl * TPS + tt) * L0M_TILE_FLOATS);
-        asm volatile("" : "+v"(fa));          // (one fragment at a time: four in flight were part of the nine spilled registers)
-        acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, bd, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-      }
-    } else
+    if (VIEW) asm volatile("" : "+v"(vxo), "+v"(vyo), "+v"(vzo));
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
       const int o4 = o_base + tt * 16;
@@ -365,16 +303,8 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
     // (the form of the fp32 kernel) left each wave bound by 8 LDS round trips per step -- ~3.2k cycles for 1.5k of its own
     // matrix work (in-kernel stamps) -- 92.0 us; the next half's 4 reads requested before the current half's 6 MFMAs, through
     // the compiler (which drains lgkmcnt to 0 at every wait, the fresh prefetch included) 89.2 us; the wait provoked in FRONT
-    // of the next reads (below) 87.3 us, matrix block ~2.0k cycles per step; inline-asm reads three groups ahead with
-    // hand-counted waits (CIPS3D_ASM_FRAGS) another 0.9 us.
-#ifndef CIPS3D_ASM_FRAGS
-#define CIPS3D_ASM_FRAGS 0      // 1: nerf_mlp.h:matrix_block (inline-asm reads three groups ahead, hand-counted waits): 87.6 against
-#endif                          // 88.5 us on one box -- not worth leaving the compiler's hazard handling (see matrix_block)
-#if CIPS3D_ASM_FRAGS
-    if constexpr (!F32) matrix_block<NT, TPS>(slab, Xh, Xl, acc, lane);      // (the inline-asm matrix block is the split kernel's)
-    else
-#endif
-    {     // A/B form: reads one half k-block ahead through the compiler, its wait provoked in front of the next reads
+    // of the next reads (below) 87.3 us, matrix block ~2.0k cycles per step.
+    {
       constexpr int HT = TPS / 2;
       h8 fh[2][HT], fl[2][HT];
       auto load_half = [&](int buf, int m, int half) {
@@ -392,11 +322,6 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 #pragma unroll
         for (int t = 0; t < HT; ++t) asm volatile("" : "+v"(fh[cur][t]), "+v"(fl[cur][t]));
         if (g + 1 < 2 * MB) load_half(cur ^ 1, (g + 1) >> 1, (g + 1) & 1);
-        if constexpr (SPREAD) {
-          constexpr int PER_WAVE = SLAB * 4 / 1024 / WAVES;
-          static_assert(!SPREAD || (PER_WAVE <= 2 * MB && (SLAB * 4 / 1024) % WAVES == 0), "one piece per MFMA group");
-          if (g >= SPREAD_FROM && g - SPREAD_FROM < PER_WAVE && spread_next) stage_piece(spread_src, spread_dst, (g - SPREAD_FROM) * WAVES + wave, lane);
-        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (F32) {      // fh / fl: the fp32 fragments of the k-block's two 16-unit halves; k ascending, the bit-exact chain
           const f32x4 x0 = __builtin_bit_cast(f32x4, Xh[m]), x1 = __builtin_bit_cast(f32x4, Xl[m]);
@@ -427,15 +352,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
       }
     }
     STAMP(9);    // matrix block
-    if (CIPS3D_HALF_PERIOD) {
-      if (late_epilogue) {                   // beta_{g+1} behind the upper waves' block g
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        issue_slab(ring.seq + 2);
-      } else {
-        __syncthreads();                     // gamma_g
-      }
-    } else if (late_epilogue) {
+    if (late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's piece of slab seq+1 has landed
       __syncthreads();
     }
@@ -488,7 +405,7 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
     }
     STAMP(11);   // epilogue
     // slab seq+1 has landed for every wave before anyone reads it / before slot (seq&1) is reused
-    if (!CIPS3D_HALF_PERIOD && !late_epilogue) {
+    if (!late_epilogue) {
       __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)  (expcnt/lgkmcnt untouched)
       __syncthreads();
     }
@@ -504,10 +421,9 @@ __device__ __forceinline__ void mfma_layer(const h8 (&Xh)[NT / 2], const h8 (&Xl
 }
 
 // XG: explicit-geometry instantiation (compile-time so that the camera-driven hot path keeps its register allocation)
-template <int NT, int TPS, bool XG, bool STASH, bool F32 = false, bool L0M = false>
+template <int NT, int TPS, bool XG, bool STASH, bool F32 = false>
 __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) {
   static_assert(!(F32 && STASH), "the differentiable forward stashes the split kernel's accumulators");
-  static_assert(!(L0M && (F32 || STASH)), "layer 0 on the matrix cores: split-fp16 inference instantiations only");
   constexpr int H = NT * 16;
   constexpr int SLAB = 16 * H * TPS;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -516,15 +432,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const int L = D + 1;
   float* ringmem = lds;                      // 2 * SLAB
   float* s_film = ringmem + (a.fuse_finish ? nerf_ring_floats(H, TPS, true) : 2 * SLAB);   // L * 2 * H
-  // L0M: s_w0 / s_wd are replaced by ONE table of A fragments, [o-tile][48 lane slots][8 fp16] (12 H floats): the three columns of
-  // layer 0 and the three view-direction columns of the view layer as split-fp16 k-slots of one v_mfma_f32_16x16x32_f16 block
-  //   k 0..8   layer 0 : w_hi(x,y,z), w_hi(x,y,z), w_lo(x,y,z)   against the point fragment  n_hi(x,y,z), n_lo(x,y,z), n_hi(x,y,z)
-  //   k 9..17  view    : the same nine for the direction columns, against the direction fragment (zero in k 0..8 and vice versa)
-  // lane (r, q) of an A fragment holds k = 8 q .. 8 q + 7 of row r: lane slots 0..47 (q = 0, 1, 2); q = 3 re-reads q = 2's slot,
-  // whose k 24..31 face zeros in both B fragments (every table entry is a finite fp16 value).
-  float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed      (L0M: the fragment table, 12 H floats)
-  float* s_wd = s_w0 + (L0M ? (CIPS3D_L0M_VIEW ? 6 : 12) : 3) * H;    // [3][H]  view-direction columns of the view layer   (L0M: second half of the table; layer-0-only L0M: behind it)
-  float* s_ws = s_wd + (L0M && CIPS3D_L0M_VIEW ? 6 : 3) * H;    // [H]     sigma head
+  float* s_w0 = s_film + L * 2 * H;          // [3][H]  first-layer weights, transposed
+  float* s_wd = s_w0 + 3 * H;                // [3][H]  view-direction columns of the view layer
+  float* s_ws = s_wd + 3 * H;                // [H]     sigma head
   float* s_wc = s_ws + H;                    // [3][H]  rgb head
 
   const int tid = threadIdx.x;
@@ -561,14 +471,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   const bool ray_ok = task_ok && ray < R;
   const int rayc = ray < R ? ray : R - 1;
 
-#ifndef CIPS3D_EARLY_SLAB
-#define CIPS3D_EARLY_SLAB 0      // A/B (round 5): 1 = the first weight slab's LDS-DMA is requested in FRONT of the table staging
-#endif
-#if CIPS3D_EARLY_SLAB
-  stage_slab<SLAB>(F32 ? P.packed32 : P.packed, ringmem, wave, lane);
-#endif
   // ---- stage the small per-view tables
-  int dir_exp = 0;                             // L0M: power of two the direction fragment carries
   {
     // FiLM table: s_film[l][0][o] = gamma, s_film[l][1][o] = gamma * bias_l[o] + beta, so that
     // sin(gamma * (W x + bias) + beta) = sin(gamma * (W x) + c) costs one FMA per unit.
@@ -577,59 +480,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     const float* film_b = P.film + (int64_t)b * L * 2 * H;
     const float* scales = (F32 ? P.packed32 : P.packed) + (int64_t)D * H * H;      // (packed32: all ones)
     const float view_scale = scales[2 * (D - 1)];
-    float l0_unscale = 1.f;                    // L0M: 2^-(s0 + L0M_POINT_EXP), folded into layer 0's FiLM multiplier
-    if constexpr (L0M) {
-      // Powers of two for the two fragment blocks (as nerf_scale_kernel picks them for the packed layers): 2^s0 max|W_0| in
-      // [512, 1024); the direction columns carry the view layer's 2^s, lowered by 2^e_d (which the direction fragment takes
-      // over) when they are so much larger than the hidden columns that 2^s W_d would leave fp16's range.  Maxima through two LDS
-      // words (bit patterns of non-negative floats order as unsigned integers) in the not yet written FiLM rows.
-      unsigned* s_mx = reinterpret_cast<unsigned*>(s_film);
-      if (tid < 2) s_mx[tid] = 0u;
-      __syncthreads();
-      {
-        float m0 = 0.f, md = 0.f;
-        for (int i = tid; i < 3 * H; i += WAVES * 64) {
-          m0 = fmaxf(m0, fabsf(P.w_first[i]));
-          md = fmaxf(md, fabsf(P.w_view[(i / 3) * (H + 3) + H + (i % 3)]));
-        }
-        atomicMax(&s_mx[0], __float_as_uint(m0));
-        atomicMax(&s_mx[1], __float_as_uint(md));
-      }
-      __syncthreads();
-      const unsigned b0 = s_mx[0], bdm = s_mx[1];
-      __syncthreads();                         // (the words are FiLM rows from here on)
-      auto clampi = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
-      const int E0 = (int)((b0 >> 23) & 0xffu), Ed = (int)((bdm >> 23) & 0xffu);
-      const int s0 = (E0 == 0 || E0 == 255) ? 0 : clampi(136 - E0, -100, 100);           // 2^s0 m0 in [512, 1024)
-      const int sv = (int)((__float_as_uint(view_scale) >> 23) & 0xffu) - 127;
-      const int ed = (Ed == 0 || Ed == 255) ? 0 : clampi((Ed - 126 + sv) - 10, 0, 15);   // 2^(sv - ed) md < 1024 (ed <= 15: |v| <= 1)
-      const float k0 = cips3d_pow2(s0), kd = cips3d_pow2(clampi(sv - ed, -126, 127));
-      l0_unscale = cips3d_pow2(clampi(-(s0 + L0M_POINT_EXP), -126, 127));
-      dir_exp = ed;                            // (workgroup-uniform: the direction fragment is built from v 2^ed)
-      _Float16* tab = reinterpret_cast<_Float16*>(s_w0);
-      for (int i = tid; i < NT * 48; i += WAVES * 64) {
-        const int t = i / 48, ls = i - t * 48, r = ls & 15, q = ls >> 4, o = t * 16 + r;
-        float w0[3], wd[3];
-        _Float16 h0[3], l0[3], hd[3], ld[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          w0[k] = P.w_first[o * 3 + k] * k0;
-          wd[k] = P.w_view[o * (H + 3) + H + k] * kd;
-          cips3d_split16(w0[k], h0[k], l0[k]);
-          cips3d_split16(wd[k], hd[k], ld[k]);
-        }
-        const _Float16 z = (_Float16)0.f;
-        h8 v;
-        if (q == 0) v = h8{h0[0], h0[1], h0[2], h0[0], h0[1], h0[2], l0[0], l0[1]};
-        else if (q == 1) v = h8{l0[2], hd[0], hd[1], hd[2], hd[0], hd[1], hd[2], ld[0]};
-        else v = h8{ld[1], ld[2], z, z, z, z, z, z};
-        *reinterpret_cast<h8*>(tab + (int64_t)i * 8) = v;
-      }
-    }
-#ifndef CIPS3D_BATCHED_STAGING
-#define CIPS3D_BATCHED_STAGING 1     // 0: the round-1 form -- one loop per table, every iteration its own dependent round trips (A/B)
-#endif
-#if CIPS3D_BATCHED_STAGING
     // Every global load of the staging is requested before the first one is waited for: the loops below used to be a chain of
     // ~12 dependent memory round trips (each table's loop: load -> wait -> LDS store, per iteration; L2 is cold at a kernel's
     // start) -- ~10 k cycles of a workgroup's 146 k at the published shape (in-kernel stamps).  Two elements per
@@ -652,8 +502,8 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         }
         if (i < 3 * H) {
           const int k = i / H, o = i - k * H;
-          if constexpr (!L0M) w0v[e] = P.w_first[o * 3 + k];
-          if constexpr (!(L0M && CIPS3D_L0M_VIEW)) wdv[e] = P.w_view[o * (H + 3) + H + k];
+          w0v[e] = P.w_first[o * 3 + k];
+          wdv[e] = P.w_view[o * (H + 3) + H + k];
           wcv[e] = P.w_rgb[i];
         }
       }
@@ -663,12 +513,12 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         const int i = fi[e];
         if (i < L * H) {
           const int l = i / H, o = i - l * H;
-          s_film[(l * 2) * H + o] = (l >= 1 ? gm[e] * sc[e] : gm[e] * l0_unscale) * FILM_UNIT;
+          s_film[(l * 2) * H + o] = (l >= 1 ? gm[e] * sc[e] : gm[e]) * FILM_UNIT;
           s_film[(l * 2 + 1) * H + o] = fmaf(gm[e], lb[e], bt[e]) * FILM_UNIT;
         }
         if (i < 3 * H) {
-          if constexpr (!L0M) s_w0[i] = w0v[e];
-          if constexpr (!(L0M && CIPS3D_L0M_VIEW)) s_wd[i] = wdv[e] * view_scale;
+          s_w0[i] = w0v[e];
+          s_wd[i] = wdv[e] * view_scale;
           s_wc[i] = wcv[e];
         }
       }
@@ -676,22 +526,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     }
     for (int i = tid + NTH; i < H; i += NTH) s_ws[i] = P.w_sigma[i];      // (hidden widths above the workgroup size: none today)
   }
-#else
-    for (int i = tid; i < L * H; i += WAVES * 64) {
-      const int l = i / H, o = i - l * H;
-      const float gm = film_b[(l * 2) * H + o];
-      s_film[(l * 2) * H + o] = (l >= 1 ? gm * scales[2 * (l - 1) + 1] : gm * l0_unscale) * FILM_UNIT;
-      s_film[(l * 2 + 1) * H + o] = fmaf(gm, P.layer_bias[i], film_b[(l * 2 + 1) * H + o]) * FILM_UNIT;
-    }
-    for (int i = tid; i < 3 * H; i += WAVES * 64) {
-      const int k = i / H, o = i - k * H;
-      if constexpr (!L0M) s_w0[i] = P.w_first[o * 3 + k];
-      if constexpr (!(L0M && CIPS3D_L0M_VIEW)) s_wd[i] = P.w_view[o * (H + 3) + H + k] * view_scale;
-      s_wc[i] = P.w_rgb[i];
-    }
-    for (int i = tid; i < H; i += WAVES * 64) s_ws[i] = P.w_sigma[i];
-  }
-#endif
 
   const float b_sigma = P.b_sigma[0], b_rgb0 = P.b_rgb[0], b_rgb1 = P.b_rgb[1], b_rgb2 = P.b_rgb[2];
   const bool raw_density = __builtin_amdgcn_readfirstlane(P.raw_density) != 0;
@@ -747,22 +581,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     return P.perturb_u ? z0 + (zbase(k + 1) - z0) * u : z0;
   };
 
-  // L0M: this lane's slot of the fragment table (q = 3 re-reads q = 2's: zeros face it) and the ray's direction fragment
-  //   k 9..17 = v_hi(x,y,z), v_lo(x,y,z), v_hi(x,y,z) of v 2^dir_exp:  q = 1 holds k 8..15, q = 2 holds k 16..23
-  const float* afrag_lane = s_w0 + (lane < 48 ? lane : lane - 16) * 4;
-  const float kv = L0M ? cips3d_uniform(cips3d_pow2(__builtin_amdgcn_readfirstlane(dir_exp))) : 1.f;
-  auto dir_fragment = [&]() -> h8 {          // (rebuilt per sample from vx, vy, vz: held across the sample loop it spilled)
-    float x_ = vx, y_ = vy, z_ = vz;
-    asm volatile("" : "+v"(x_), "+v"(y_), "+v"(z_));
-    const unsigned wx = cips3d_split_word(x_, kv), wy = cips3d_split_word(y_, kv), wz = cips3d_split_word(z_, kv);   // {hi | lo << 16}
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    // q = 1: {0, hx | hy, hz | lx, ly | lz, hx}  ->  dwords {hx << 16, hy | hz << 16, lx | ly << 16, lz | hx << 16}
-    const u32x4_t q1 = {wx << 16, (wy & 0xffffu) | (wz << 16), (wx >> 16) | (wy & 0xffff0000u), (wz >> 16) | (wx << 16)};
-    const u32x4_t q2 = {(wy & 0xffffu) | (wz << 16), 0u, 0u, 0u};            // q = 2: {hy, hz, 0, ...}
-    const u32x4_t zz = {0u, 0u, 0u, 0u};
-    return __builtin_bit_cast(h8, qd == 1 ? q1 : (qd == 2 ? q2 : zz));
-  };
-
   // ---- per-lane compositing state
   float FA[NT * 4];
 #pragma unroll
@@ -775,17 +593,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
   ring.seq = 0;
   ring.per_sample = D * (NT / TPS);
   ring.seq_end = a.chunk * ring.per_sample;
-#if !CIPS3D_EARLY_SLAB
   stage_slab<SLAB>(ring.packed, ringmem, wave, lane);
-#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
-#if CIPS3D_HALF_PERIOD
-  if (__builtin_amdgcn_readfirstlane(wave) >= WAVES / 2) {      // beta_0 of the upper waves: half a step behind from here on
-    __syncthreads();
-    if (1 < ring.seq_end) stage_slab<SLAB>(ring.packed + (int64_t)(1 % ring.per_sample) * SLAB, ringmem + SLAB, wave, lane);
-  }
-#endif
 
   const int s_begin = c * a.chunk;
   STAMP(0);   // prologue
@@ -816,65 +626,31 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     if constexpr (STASH) stash_s = P.stash + (((task0 + wave) * a.chunk + si) * D) * (int64_t)(16 * H);
     float sdf = 0.f;            // sigma head partial of this lane's units (taken where h_D is produced in fp32)
     // ---- layer 0: 3 -> H, in D layout, split into the hi / lo B fragments of the first MFMA layer.
-    // VALU form: three FMAs per unit.  L0M: one v_mfma_f32_16x16x32_f16 per o-tile -- the point fragment {n_hi, n_lo, n_hi} of
-    // n 2^8 against the table's {w_hi, w_hi, w_lo} of 2^s0 W_0 (three exact fp16 products per fp32 product, fp32 accumulate, as in
-    // every other layer; 2^-(s0 + 8) rides in the FiLM multiplier): 3 x 64 VALU instructions of a lane become 16 MFMAs of the wave.
-    h8 b0 = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (L0M) {
-      const float kp = (float)(1 << L0M_POINT_EXP);
-      const unsigned wx = cips3d_split_word(nx, kp), wy = cips3d_split_word(ny, kp), wz = cips3d_split_word(nz, kp);   // {hi | lo << 16}
-      typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-      const unsigned hxy = (wx & 0xffffu) | (wy << 16);
-      // q = 0: {hx, hy, hz, lx, ly, lz, hx, hy};  q = 1: {hz, 0, ...};  q >= 2: zeros
-      const u32x4_t q0 = {hxy, (wz & 0xffffu) | (wx & 0xffff0000u), (wy >> 16) | (wz & 0xffff0000u), hxy};
-      const u32x4_t q1 = {wz & 0xffffu, 0u, 0u, 0u};
-      const u32x4_t zz = {0u, 0u, 0u, 0u};
-      b0 = __builtin_bit_cast(h8, qd == 0 ? q0 : (qd == 1 ? q1 : zz));
-    }
-#ifndef CIPS3D_PINGPONG
-#define CIPS3D_PINGPONG 1
-#endif
     // The hidden layers alternate between the two activation register sets (X -> Y, Y -> X) instead of copying every layer's
     // output back into its input's registers (128 registers' worth of v_mov per layer and sample: 5 % of the sample loop's VALU
     // instructions at D = 2, 12 % at D = 8).  The view layer reads X: with an odd number of hidden layers layer 0 writes Y and one
     // Y -> X layer runs in front of the pairs (a third copy of the layer's code; entering the pair loop at its second half would
     // be an irreducible loop, and that form spilled 250 registers).
-    // (the exact-fp32 instantiation spills 170 registers in this form and keeps the copies; so does the optional L0M instantiation,
-    // whose feature map moved by 1.6e-4 against the VALU form with an odd number of hidden layers in this form -- rgb, sdf and the
-    // other maps agreed; not chased: that instantiation is off by default and the slower one, tools/test_optional_builds.sh)
-    constexpr bool PP = CIPS3D_PINGPONG && !F32 && !L0M;
+    // (the exact-fp32 instantiation spills 170 registers in this form and keeps the copies)
+    constexpr bool PP = !F32;
     const bool odd_hidden = PP && ((D - 1) & 1);
     float chead[3] = {0.f, 0.f, 0.f};
     auto layer0 = [&](auto& Oh, auto& Ol) {
 #pragma unroll
     for (int m = 0; m < NT / 2; ++m) {
       float v8[8];
-      f32x4 pre2[2];
-      if constexpr (L0M) {
-        // (one o-tile at a time where registers are short: both fragments in flight together spilled nine registers)
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-          const h8 fa = *reinterpret_cast<const h8*>(afrag_lane + opq + (2 * m + hf) * L0M_TILE_FLOATS);
-          pre2[hf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, b0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
-      }
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
         const int o4 = (2 * m + hf) * 16 + q4o;
         const f32x4 g4 = *reinterpret_cast<const f32x4*>(s_film + o4);
         const f32x4 c4 = *reinterpret_cast<const f32x4*>(s_film + H + o4);
-        if constexpr (L0M) {
+        const f32x4 wx = *reinterpret_cast<const f32x4*>(s_w0 + o4);
+        const f32x4 wy = *reinterpret_cast<const f32x4*>(s_w0 + H + o4);
+        const f32x4 wz = *reinterpret_cast<const f32x4*>(s_w0 + 2 * H + o4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v8[hf * 4 + i] = FILM_SIN(fmaf(g4[i], pre2[hf][i], c4[i]));
-        } else {
-          const f32x4 wx = *reinterpret_cast<const f32x4*>(s_w0 + o4);
-          const f32x4 wy = *reinterpret_cast<const f32x4*>(s_w0 + H + o4);
-          const f32x4 wz = *reinterpret_cast<const f32x4*>(s_w0 + 2 * H + o4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
-            v8[hf * 4 + i] = FILM_SIN(fmaf(g4[i], pre, c4[i]));
-          }
+        for (int i = 0; i < 4; ++i) {
+          const float pre = fmaf(wz[i], nz, fmaf(wy[i], ny, wx[i] * nx));
+          v8[hf * 4 + i] = FILM_SIN(fmaf(g4[i], pre, c4[i]));
         }
         if (D == 1) {           // no hidden MFMA layer: this is h_D
           const f32x4 ws4 = *reinterpret_cast<const f32x4*>(s_ws + o4);
@@ -891,29 +667,29 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
       if (odd_hidden) {          // layer 0 -> Y, the odd hidden layer Y -> X; then pairs
         layer0(Yh, Yl);
         STAMP(1);   // sample setup + layer 0
-        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, D == 2, ring, s_film + 2 * H, s_wd, s_wc,
+        mfma_layer<NT, TPS, false, STASH, F32>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, D == 2, ring, s_film + 2 * H, s_wd, s_wc,
                                           s_ws, vx, vy, vz, STASH ? stash_s : nullptr, wave, lane,
-                                          q4o, afrag_lane + opq, Yh[0] STAMP_ARG);
+                                          q4o STAMP_ARG);
         l = 2;
       } else {
         layer0(Xh, Xl);
         STAMP(1);   // sample setup + layer 0
       }
       for (; l < D; l += 2) {
-        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, false, ring, s_film + l * 2 * H, s_wd, s_wc,
+        mfma_layer<NT, TPS, false, STASH, F32>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, false, ring, s_film + l * 2 * H, s_wd, s_wc,
                                           s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
-                                          q4o, afrag_lane + opq, Xh[0] STAMP_ARG);
-        mfma_layer<NT, TPS, false, STASH, F32, L0M>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, l + 1 == D - 1, ring, s_film + (l + 1) * 2 * H, s_wd, s_wc,
+                                          q4o STAMP_ARG);
+        mfma_layer<NT, TPS, false, STASH, F32>(Yh, Yl, Xh, Xl, FA, 0.f, chead, sdf, l + 1 == D - 1, ring, s_film + (l + 1) * 2 * H, s_wd, s_wc,
                                           s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)l * 16 * H : nullptr, wave, lane,
-                                          q4o, afrag_lane + opq, Yh[0] STAMP_ARG);
+                                          q4o STAMP_ARG);
       }
     } else {
     layer0(Xh, Xl);
     STAMP(1);   // sample setup + layer 0
     for (int l = 1; l < D; ++l) {
-      mfma_layer<NT, TPS, false, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
+      mfma_layer<NT, TPS, false, STASH, F32>(Xh, Xl, Yh, Yl, FA, 0.f, chead, sdf, l == D - 1, ring, s_film + l * 2 * H, s_wd, s_wc,
                                         s_ws, vx, vy, vz, STASH ? stash_s + (int64_t)(l - 1) * 16 * H : nullptr, wave, lane,
-                                        q4o, afrag_lane + opq, Xh[0] STAMP_ARG);
+                                        q4o STAMP_ARG);
 #pragma unroll
       for (int i = 0; i < NT / 2; ++i) { Xh[i] = Yh[i]; Xl[i] = Yl[i]; }
     }
@@ -940,11 +716,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     STAMP(3);   // sigma head + weight
     // ---- view layer -> features, folded into FA; rgb head partial sums
     float sdf_unused = 0.f;
-    h8 bd = h8{0, 0, 0, 0, 0, 0, 0, 0};
-    if constexpr (L0M && CIPS3D_L0M_VIEW) bd = dir_fragment();
-    mfma_layer<NT, TPS, true, STASH, F32, L0M>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
+    mfma_layer<NT, TPS, true, STASH, F32>(Xh, Xl, Yh, Yl, FA, w, chead, sdf_unused, false, ring, s_film + D * 2 * H, s_wd, s_wc, s_ws,
                                      vx, vy, vz, STASH ? stash_s + (int64_t)(D - 1) * 16 * H : nullptr, wave, lane,
-                                     q4o, afrag_lane + opq, bd STAMP_ARG);
+                                     q4o STAMP_ARG);
     float c0 = chead[0], c1 = chead[1], c2 = chead[2];
     c0 += __shfl_xor(c0, 16, 64); c1 += __shfl_xor(c1, 16, 64); c2 += __shfl_xor(c2, 16, 64);
     c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
@@ -968,9 +742,6 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
     }
   }
 
-#if CIPS3D_HALF_PERIOD
-  if (__builtin_amdgcn_readfirstlane(wave) < WAVES / 2) __syncthreads();      // the barrier the upper waves took at the start
-#endif
   STAMP(5);   // last compositing tail
 #ifdef CIPS3D_CLOCK
   if (tid == 0) {
@@ -1202,11 +973,11 @@ __global__ void __launch_bounds__(256) nerf_finish4_kernel(const float* __restri
   }
 }
 
-template <int NT, int TPS, bool XG, bool STASH, bool F32 = false, bool L0M = false>
+template <int NT, int TPS, bool XG, bool STASH, bool F32 = false>
 int launch_render_x(const NerfArgs& a, hipStream_t st) {
   const cips3d_nerf_params& P = a.p;
   constexpr int H = NT * 16;
-  const size_t lds_bytes = sizeof(float) * (nerf_ring_floats(H, TPS, a.fuse_finish != 0) + (size_t)nerf_table_floats(H, P.depth + 1, L0M));
+  const size_t lds_bytes = sizeof(float) * (nerf_ring_floats(H, TPS, a.fuse_finish != 0) + (size_t)nerf_table_floats(H, P.depth + 1));
   if (lds_bytes > 160 * 1024) return CIPS3D_E_UNSUPP;
   // the attribute is per device (a process may render on several GPUs) and the flag is shared by host threads
   static std::atomic<unsigned long long> attr_set{0};
@@ -1214,13 +985,13 @@ int launch_render_x(const NerfArgs& a, hipStream_t st) {
   if (hipError_t e = hipGetDevice(&dev_id); e != hipSuccess) return (int)e;
   const unsigned long long bit = 1ull << (dev_id & 63);
   if (dev_id >= 64 || !(attr_set.load(std::memory_order_acquire) & bit)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG, STASH, F32, L0M>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_render_kernel<NT, TPS, XG, STASH, F32>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     attr_set.fetch_or(bit, std::memory_order_release);
   }
   const int64_t wgs = (int64_t)P.B * a.tasks_per_view / WAVES;
-  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG, STASH, F32, L0M>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
+  hipLaunchKernelGGL((nerf_render_kernel<NT, TPS, XG, STASH, F32>), dim3((unsigned)wgs), dim3(WAVES * 64), lds_bytes, st, a);
   return cips3d_launch_status();
 }
 
@@ -1230,9 +1001,6 @@ int launch_render(const NerfArgs& a, hipStream_t st) {
     if constexpr (NT == 16) return a.p.x_pts ? launch_render_x<NT, TPS, true, false, true>(a, st) : launch_render_x<NT, TPS, false, false, true>(a, st);
     else return CIPS3D_E_UNSUPP;
   }
-#ifdef CIPS3D_NERF_L0M
-  if (a.l0m) return a.p.x_pts ? launch_render_x<NT, TPS, true, false, false, true>(a, st) : launch_render_x<NT, TPS, false, false, false, true>(a, st);
-#endif
   if (a.p.x_pts) return launch_render_x<NT, TPS, true, false>(a, st);
   return a.p.stash ? launch_render_x<NT, TPS, false, true>(a, st) : launch_render_x<NT, TPS, false, false>(a, st);
 }
@@ -1286,50 +1054,18 @@ extern "C" int64_t cips3d_nerf_part_floats(int B, int img_size, int hidden, int 
 }
 
 // fused finish: needs the chunk waves of a ray group in one workgroup (n_chunks divides 8), the tables large enough for the scalar exchange
-// and the partial exchange + tables within the 160 KB of LDS
-// Layer 0 and the view-direction columns on the matrix cores (L0M instantiations): split-fp16 inference, when the fragment table
-// fits beside the ring.  CIPS3D_NERF_L0M=0: the VALU form (A/B knob).
-// Measured (round 5, same box, HIP events, tools/nerf_l0m_ab.sh): 85.6 us against 82.4 at the headline shape (N = 24: three samples
-// per wave, the longer prologue -- two more barriers, the maxima, the table -- and 9 spilled registers outweigh it), 388.3 against
-// 390.4 at N = 128: ~280 fewer VALU instructions and 64 fewer LDS reads per sample for 32 more MFMAs buy 0.5 %.  So the
-// instantiations exist only in a library built with -DCIPS3D_NERF_L0M (CIPS3D_HIPCC_FLAGS; cips3d_build_features() bit 1) and
-// run there unless CIPS3D_NERF_L0M=0 says otherwise.
-static bool nerf_l0m_wanted(const cips3d_nerf_params* p) {
-#ifdef CIPS3D_NERF_L0M
-  const char* knob = getenv("CIPS3D_NERF_L0M");       // read per call (the parity test switches it inside one process)
-  return (!knob || atoi(knob) != 0) && !p->packed32 && !p->stash;
-#else
-  (void)p;
-  return false;
-#endif
-}
-// (fuse the finish?, L0M?) of a call: the fused finish first (worth more), then L0M where its larger table still fits
-static int nerf_shape_plan(const cips3d_nerf_params* p, bool* l0m) {
-  *l0m = false;
+// and the partial exchange + tables within the 160 KB of LDS.  CIPS3D_NERF_FUSE_FINISH=0: the stand-alone nerf_finish launch (A/B knob).
+static int nerf_fuse_plan(const cips3d_nerf_params* p) {
   const int H = p->hidden, L = p->depth + 1;
   if (H != 32 && H != 64 && H != 128 && H != 256) return 0;
   const int TPS = H == 256 ? 4 : 2;
-  const bool want = nerf_l0m_wanted(p);
-  auto fits = [&](bool fuse, bool m) { return sizeof(float) * ((size_t)nerf_ring_floats(H, TPS, fuse) + nerf_table_floats(H, L, m)) <= 160 * 1024; };
-  bool fuse = false;
-  if (p->o_features && p->o_thumb && p->o_xyz && p->o_mask) {
-    static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
-    if (!off && p->n_chunks >= 1 && WAVES % p->n_chunks == 0 && nerf_table_floats(H, L, false) >= WAVES * 8 * RAYS) fuse = fits(true, false);
-  }
-  *l0m = want && fits(fuse, true);
-  return fuse ? 1 : 0;
+  if (!(p->o_features && p->o_thumb && p->o_xyz && p->o_mask)) return 0;
+  static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
+  if (off || p->n_chunks < 1 || WAVES % p->n_chunks != 0 || nerf_table_floats(H, L) < WAVES * 8 * RAYS) return 0;
+  return sizeof(float) * ((size_t)nerf_ring_floats(H, TPS, true) + nerf_table_floats(H, L)) <= 160 * 1024 ? 1 : 0;
 }
 
-// fused finish: needs the chunk waves of a ray group in one workgroup (n_chunks divides 8), the tables large enough for the scalar exchange
-// and the partial exchange + tables within the 160 KB of LDS
-extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) {
-  if (!p || !p->o_features || !p->o_thumb || !p->o_xyz || !p->o_mask) return 0;
-  static const int off = getenv("CIPS3D_NERF_FUSE_FINISH") ? atoi(getenv("CIPS3D_NERF_FUSE_FINISH")) == 0 : 0;   // A/B knob
-  if (off) return 0;
-  if (cips3d_nerf_ws_applies(p) || cips3d_nerf_pair_applies(p)) return 1;     // those forms only exist fused, with their own work split
-  bool l0m;
-  return nerf_shape_plan(p, &l0m);
-}
+extern "C" int cips3d_nerf_fuses_finish(const cips3d_nerf_params* p) { return p ? nerf_fuse_plan(p) : 0; }
 
 namespace {
 __global__ void __launch_bounds__(256) nerf_zero_kernel(float* __restrict__ p, int64_t n) {
@@ -1360,15 +1096,11 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
     return cips3d_launch_status();
   }
   if (P.B == 0) return 0;
-  const bool other_kernel = fuse && (cips3d_nerf_ws_applies(p) || cips3d_nerf_pair_applies(p));
-  static const int zero_ride = getenv("CIPS3D_ZERO_RIDE") ? atoi(getenv("CIPS3D_ZERO_RIDE")) : 1;     // A/B knob: 0 = always the launch in front
-  const bool zero_in_front = P.zero_words && (!fuse || other_kernel || !zero_ride);
-  if (zero_in_front) {        // only the default kernel's fused finish clears the words itself
+  const bool zero_in_front = P.zero_words && !fuse;
+  if (zero_in_front) {        // only the fused finish clears the words itself
     hipLaunchKernelGGL(nerf_zero_kernel, dim3((unsigned)ceil_div<int64_t>(P.n_zero_words, 256)), dim3(256), 0, as_stream(stream), P.zero_words, P.n_zero_words);
     if (const int rc = cips3d_launch_status()) return rc;
   }
-  if (fuse && cips3d_nerf_ws_applies(p)) return cips3d_nerf_render_ws(p, stream);
-  if (fuse && cips3d_nerf_pair_applies(p)) return cips3d_nerf_render_pair(p, stream);
   NerfArgs a;
   a.p = P;
   if (zero_in_front) { a.p.zero_words = nullptr; a.p.n_zero_words = 0; }
@@ -1376,7 +1108,6 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
   a.tasks_per_view = ceil_div(a.groups * P.n_chunks, WAVES) * WAVES;
   a.chunk = ceil_div(P.n_samples, P.n_chunks);
   a.fuse_finish = fuse;
-  { bool m; nerf_shape_plan(p, &m); a.l0m = m ? 1 : 0; }
   a.t_end = (float)(1.0 - 1.0 / (double)P.n_samples);
   a.t_step = P.n_samples > 1 ? a.t_end / (float)(P.n_samples - 1) : 0.f;
   hipStream_t st = as_stream(stream);

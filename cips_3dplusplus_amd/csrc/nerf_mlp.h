@@ -18,23 +18,6 @@
 #define FILM_SIN cips3d_sin
 #endif
 
-// Two measured-slower dataflows of the render kernel live under csrc/experimental/ and are compiled only into a
-// library built with CIPS3D_EXPERIMENTAL=1 (cips_3dplusplus_amd/build.py: -DCIPS3D_EXPERIMENTAL + the two sources); the default
-// library has neither their code nor their dispatch.  cips3d_build_features() bit 0 says which library is loaded.
-#ifdef CIPS3D_EXPERIMENTAL
-// experimental/nerf_pair.hip: the 32-points-per-wave render kernel (library-internal; run-time opt-in CIPS3D_NERF_PAIR=1)
-int cips3d_nerf_pair_applies(const cips3d_nerf_params* p);
-int cips3d_nerf_render_pair(const cips3d_nerf_params* p, void* stream);
-// experimental/nerf_ws.hip: the weight-stationary render kernel (library-internal; run-time opt-in CIPS3D_NERF_WS=1)
-int cips3d_nerf_ws_applies(const cips3d_nerf_params* p);
-int cips3d_nerf_render_ws(const cips3d_nerf_params* p, void* stream);
-#else
-static inline int cips3d_nerf_pair_applies(const cips3d_nerf_params*) { return 0; }
-static inline int cips3d_nerf_render_pair(const cips3d_nerf_params*, void*) { return CIPS3D_E_UNSUPP; }
-static inline int cips3d_nerf_ws_applies(const cips3d_nerf_params*) { return 0; }
-static inline int cips3d_nerf_render_ws(const cips3d_nerf_params*, void*) { return CIPS3D_E_UNSUPP; }
-#endif
-
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -50,7 +33,7 @@ struct NerfArgs {
   int tasks_per_view;  // groups * n_chunks rounded up to a multiple of WAVES
   int chunk;           // samples per chunk (uniform trip count)
   int fuse_finish;     // the workgroup's eight chunk waves combine their partials in LDS and write the final maps
-  int l0m;             // nerf.hip: the L0M instantiation runs (layer 0 + view-direction columns on the matrix cores)
+  int pad_;             // (keeps the 8-byte alignment of what follows explicit)
   float t_end, t_step; // torch.linspace(0, 1 - 1/N, N): last value and step, computed on the host (kernel arguments are
                        // re-readable scalars; computed in the kernel they ended up as spilled VGPR copies)
 };
@@ -91,66 +74,6 @@ __device__ __forceinline__ void stage_slab(const float* __restrict__ gsrc, float
     const int piece = j * NW + wave;
     if (PIECES % NW == 0 || piece < PIECES) stage_piece(gsrc, lds_dst, piece, lane);
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Matrix block of one slab step with hand-counted LDS waits.  The compiler's waitcnt pass does not count these ds_read_b128
-// (every wait it inserts drains lgkmcnt to 0, the just-issued prefetch included), so a prefetch can lead by one group at
-// most.  Here the fragment reads and their waits are inline asm: group G = (k-block m, o-tile tt) = one hi and one lo
-// fragment and three MFMAs; four fragment buffers (the same 32 registers as eight fragments of a k-block), reads issued
-// THREE groups ahead, and before group G's MFMAs `s_waitcnt lgkmcnt(2 x younger groups)` -- LDS reads return in order, so
-// "at most the N youngest still in flight" means group G's two have landed.  A buffer is rewritten right after its last
-// reader was issued: the reader takes it as SrcA only (read in the instruction's first pass, long before an LDS read can
-// return).  NOT the default: the register allocator is free to park a finished accumulator chain in a fragment register, and a
-// read issued right behind an MFMA that takes that register as SrcC is a wait-state hazard the compiler would pad with
-// s_nop but cannot see inside the asm (harmless in practice -- an LDS read returns long after the MFMA has read SrcC, and the
-// parity suite passes -- but outside the ISA's rules); measured gain 1 %.
-// ------------------------------------------------------------------------------------------------
-template <int OFF>
-__device__ __forceinline__ void lds_read16_at(h8& d, unsigned addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_for(h8& a, h8& b) {
-  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
-}
-template <int NT, int TPS, int G>
-__device__ __forceinline__ void frag_issue(h8 (&fh)[4], h8 (&fl)[4], unsigned base) {
-  constexpr int NG = (NT / 2) * TPS, TILE = 16 * NT * 16;
-  if constexpr (G < NG) {
-    constexpr int m = G / TPS, tt = G % TPS;
-    lds_read16_at<(tt * TILE + (2 * m) * 256) * 4>(fh[G & 3], base);
-    lds_read16_at<(tt * TILE + (2 * m + 1) * 256) * 4>(fl[G & 3], base);
-  }
-}
-template <int NT, int TPS, int G>
-__device__ __forceinline__ void frag_groups(h8 (&fh)[4], h8 (&fl)[4], unsigned base, const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2],
-                                            f32x4 (&acc)[TPS]) {
-  constexpr int NG = (NT / 2) * TPS;
-  if constexpr (G < NG) {
-    constexpr int m = G / TPS, tt = G % TPS;
-    frag_issue<NT, TPS, G + 3>(fh, fl, base);
-    constexpr int younger = (NG - 1 - G) < 3 ? (NG - 1 - G) : 3;
-    lds_wait_for<2 * younger>(fh[G & 3], fl[G & 3]);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[G & 3], Xh[m], acc[tt], 0, 0, 0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[G & 3], Xl[m], acc[tt], 0, 0, 0);
-    acc[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[G & 3], Xh[m], acc[tt], 0, 0, 0);
-    frag_groups<NT, TPS, G + 1>(fh, fl, base, Xh, Xl, acc);
-  }
-}
-// all of a step's matrix work: acc[tt] += A(slab, tile tt) (Xh + Xl)
-template <int NT, int TPS>
-__device__ __forceinline__ void matrix_block(const float* slab, const h8 (&Xh)[NT / 2], const h8 (&Xl)[NT / 2], f32x4 (&acc)[TPS],
-                                             int lane) {
-  h8 fh[4], fl[4];
-  // LDS byte address of this lane's 16 bytes in the slab image (the low 32 bits of a generic pointer into LDS are its offset)
-  const unsigned base = (unsigned)(size_t)slab + (unsigned)lane * 16u;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // nothing of the compiler's in flight that the counts below would miss
-  frag_issue<NT, TPS, 0>(fh, fl, base);
-  frag_issue<NT, TPS, 1>(fh, fl, base);
-  frag_issue<NT, TPS, 2>(fh, fl, base);
-  frag_groups<NT, TPS, 0>(fh, fl, base, Xh, Xl, acc);
 }
 
 __device__ __forceinline__ float sigmoidf_acc(float v) { return 1.f / (1.f + expf(-v)); }

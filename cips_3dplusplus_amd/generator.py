@@ -194,6 +194,10 @@ class Generator(nn.Module):
         B = plan.B
         z_r = z_d = mean_r = mean_d = None
         ident = lambda t: (t.data_ptr(), t._version, tuple(t.shape))     # noqa: E731 (what a style table was computed from)
+        # The plan keeps STRONG references to the stamped tensors (`refs`) until its next full run: a freed latent's storage could
+        # otherwise be handed to a new tensor with the same address, shape and version 0, which would pass the check with stale
+        # tables.  Not detected: a tensor whose storage is swapped through `.data = ...` onto memory at the same address (versions do
+        # not move) -- do not rebind `.data` of latents, styles or weights between the frames of a resident sequence.
         # (a resident frame also promises unchanged WEIGHTS behind the tables: an optimiser step on the decoder or the mapping
         # networks between two frames bumps these versions; the renderer's are part of the plan's key)
         plist = self.__dict__.get("_stamp_params")
@@ -204,13 +208,16 @@ class Generator(nn.Module):
         wver = sum(p._version for p in plist[1])          # (versions only grow: the sum changes whenever one of them does)
         if style_render is not None and style_decoder is not None:
             stamp = ("w+", ident(style_render), ident(style_decoder), wver)
+            refs = (style_render, style_decoder)
             if not styles_resident:
                 plan.styles_r.copy_(style_render)       # explicit W+ styles bypass the mapping networks
                 plan.styles_d.copy_(style_decoder)
         else:
             stamp = ("z", ident(zs[0]), ident(zs[1]), float(truncation), wver)
+            refs = (zs[0], zs[1])
             if truncation < 1:
                 stamp += (ident(self.style_render_mean), ident(self.style_decoder_mean))
+                refs += (self.style_render_mean, self.style_decoder_mean)
             if not styles_resident:
                 z_r, z_d = zs[0].float(), zs[1].float()
                 if z_r.shape[0] != B or z_d.shape[0] != B:
@@ -234,7 +241,8 @@ class Generator(nn.Module):
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
-            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp, rgb_out=rgb_out)
+            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp, rgb_out=rgb_out,
+            style_refs=refs)
         # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
         m2 = mask.transpose(0, 1).contiguous()
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,

@@ -426,13 +426,15 @@ class ForwardPlan:
         return bound
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
-            events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None, rgb_out=None):
+            events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None, rgb_out=None,
+            style_refs=None):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
         one cips3d_rng_fill launch when both are fresh.
         styles_resident: a frame of a sequence (cips3d_forward_io.styles_resident): the style phase and the modulate table are
         skipped and the plan's tables are used as the last FULL run left them.  `style_stamp` identifies what those tables were
         computed from (latents / styles, truncation, means): a full run records it (with the call's bound of |noise|, which the
-        range constants carry), a resident run must present the same one or it raises.
+        range constants carry), a resident run must present the same one or it raises.  `style_refs`: the tensors the stamp names;
+        a full run keeps them alive until the next one, so that the addresses in the stamp cannot be recycled by the allocator.
         rgb_out: a contiguous tensor [B, 3, R, R] the image is written into instead of a fresh one -- float32, or uint8 on a plan
         that is `u8_capable` (the last up-sampling stage then stores cips3d_rgb_to_uint8 of the image directly)."""
         lib = _lib.load()
@@ -457,6 +459,7 @@ class ForwardPlan:
         else:
             hip.STYLE_EPOCH += 1
             self._resident_stamp = (stamp, hip.STYLE_EPOCH)
+            self._resident_refs = style_refs
         if hip.FAST_RNG and (fresh_noise or fresh_perturb):
             # the draw is made by the forward call itself (cips3d_forward_io.rng_*: spread over the mapping launches)
             n_n, n_u = (B * self.noise_total if fresh_noise else 0), (B * S * S if fresh_perturb else 0)

@@ -30,17 +30,12 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 28  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 29  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
 
 int cips3d_abi_version(void);
-/* Optional parts compiled into this library: bit 0 = the experimental render-kernel dataflows of csrc/experimental/ (32 points per
- * wave, weight-stationary; run-time opt-in through CIPS3D_NERF_PAIR=1 / CIPS3D_NERF_WS=1; build with CIPS3D_EXPERIMENTAL=1).  The
- * bit 1 = the render kernel's L0M instantiations (layer 0 and the view-direction columns as one more k-block of the split MFMA; built
- * with -DCIPS3D_NERF_L0M, measured slower at the published shape: DESIGN.md).  The default library returns 0. */
-int cips3d_build_features(void);
 /* human-readable text for a return code of any entry point (static storage) */
 const char* cips3d_strerror(int code);
 

@@ -417,21 +417,15 @@ def test_full_size_generator_golden(golden, tag, res, D, N, static, trunc):
     assert maxdiff(r["sdf"].flatten()[::stride].cpu(), fx[f"{tag}.sdf_s"]) < 1e-4
 
 
-@pytest.mark.parametrize("mode", ["fp32_exact", "pair", "ws"])
+@pytest.mark.parametrize("mode", ["fp32_exact"])
 @pytest.mark.parametrize("tag,res,D,N,static,trunc", [FULL[2], FULL[0]])
-def test_full_size_generator_golden_in_the_other_render_arithmetics(golden, monkeypatch, mode, tag, res, D, N, static, trunc):
+def test_full_size_generator_golden_in_the_other_render_arithmetics(golden, mode, tag, res, D, N, static, trunc):
     """The release-size reference goldens through the whole forward in IEEE-fp32 arithmetic (Generator.set_precision("fp32_exact"):
-    render kernel AND decoder on the fp32 matrix instruction) and through the two opt-in render kernels (32 points per wave,
-    CIPS3D_NERF_PAIR=1; weight-stationary, CIPS3D_NERF_WS=1): the same bars as the default path."""
+    render kernel AND decoder on the fp32 matrix instruction): the same bars as the default path."""
     fx = golden("full_size")
     cfg = configs.ffhq_G_cfg(res, D)
     G = pkg.build_generator(cfg, DEV, seed=1)
-    if mode == "fp32_exact":
-        G.set_precision("fp32_exact")
-    else:
-        if not (_lib.load().cips3d_build_features() & 1):
-            pytest.skip("library built without CIPS3D_EXPERIMENTAL=1 (csrc/experimental/ is not in it)")
-        monkeypatch.setenv("CIPS3D_NERF_PAIR" if mode == "pair" else "CIPS3D_NERF_WS", "1")
+    G.set_precision("fp32_exact")
     zs, nb, means = weights.synth_inputs(cfg, batch=1, seed=12345)
     G.style_render_mean, G.style_decoder_mean = cu(means[0]), cu(means[1])
     e, f, n, fa, _ = Camera.generate_camera_params(64, DEV, locations=torch.tensor([[0.31, -0.08]], device=DEV))
@@ -685,8 +679,16 @@ def test_flat_blocks_of_a_low_resolution_generator(monkeypatch, res, precision):
     # (bf16_storage: conv1's result of a flat block is one more tensor stored as bf16 -- the mode's rule for every fused stage)
     lim = {"fp32": 2e-5, "fp32_exact": 2e-5, "bf16": 2e-3, "bf16_storage": 2e-2}[precision]
     d, r = maxdiff(a, b), float(b.abs().max())
-    print(f"flat stages vs per-layer launches at {res}^2 [{precision}]: {d:.2e} (max |rgb| {r:.2f})")
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    psnr = 10 * math.log10(r * r / max(mse, 1e-300))
+    print(f"flat stages vs per-layer launches at {res}^2 [{precision}]: {d:.2e} (max |rgb| {r:.2f}), PSNR {psnr:.1f} dB")
     assert d < lim * max(r, 1.0)
+    # the flat stages' own check in the storage mode, independent of the oracle (whose bf16_store rounds conv1's result of a flat block
+    # because the product does): against the per-layer launches, which keep that tensor in fp32, the image moves by ONE more
+    # bf16-stored tensor per flat block -- far above the 53 dB floor test_generator_bf16_storage_vs_oracle_and_fp32 holds the whole
+    # mode to against the oracle
+    if precision == "bf16_storage":
+        assert psnr > 50.0
 
 
 @pytest.mark.parametrize("C,bf16", [(64, False), (64, True), (128, False), (128, True), (256, False), (256, True)])

@@ -19,16 +19,6 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-
-def _needs_experimental():
-    """The 32-points-per-wave and weight-stationary render kernels (csrc/experimental/) are compiled only into a library built with
-    CIPS3D_EXPERIMENTAL=1 (cips_3dplusplus_amd/build.py); the default library answers cips3d_build_features() == 0."""
-    from cips_3dplusplus_amd import _lib
-    if not (_lib.load().cips3d_build_features() & 1):
-        pytest.skip("library built without CIPS3D_EXPERIMENTAL=1: the experimental render kernels are not in it")
-    os.environ["CIPS3D_NERF_L0M"] = "0"        # (a library that also carries the L0M instantiations: compare like with like)
-
-
 def cu(t):
     return t.to(DEV).contiguous()
 
@@ -91,10 +81,10 @@ def test_split_nerf_is_as_accurate_as_fp32():
 
 @pytest.mark.parametrize("D,N,B", [(2, 24, 1), (8, 13, 2)])
 def test_exact_fp32_render_kernel_and_split_kernel_bracket_fp64_equally(D, N, B):
-    """VolumeFeatureRenderer.set_precision("fp32_exact") (csrc/nerf_pair.hip on v_mfma_f32_16x16x4_f32: IEEE fp32 products, the
+    """VolumeFeatureRenderer.set_precision("fp32_exact") (csrc/nerf.hip's F32 instantiation on v_mfma_f32_16x16x4_f32: IEEE fp32 products, the
     reference's F.linear arithmetic, cips3d/volume_renderer.py:15-35, 74-85) and the default split-fp16 kernel against the fp64
     oracle: both err like the fp32 oracle does; they differ from each other at the fp32 noise level; odd sample counts and
-    batches take the pair kernel's padded / multi-group paths; switching back restores the default bit for bit."""
+    batches take the padded / multi-group paths; switching back restores the default bit for bit."""
     cfg = configs.ffhq_G_cfg(256, D)
     G = pkg.build_generator(cfg, DEV, seed=5)
     sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
@@ -135,74 +125,6 @@ def test_exact_fp32_render_kernel_and_split_kernel_bracket_fp64_equally(D, N, B)
         assert 0 < d <= 4.0 * e_32 + 1e-6, name
     with pytest.raises(NotImplementedError):
         pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=0).renderer.set_precision("fp32_exact")
-
-
-@pytest.mark.parametrize("N,B,precision", [(24, 1, "fp32"), (23, 2, "fp32"), (24, 4, "fp32"), (24, 1, "fp32_exact"), (23, 2, "fp32_exact")])
-def test_pair_kernel_instantiations_match_the_default_kernel(monkeypatch, N, B, precision):
-    """csrc/nerf_pair.hip (32 points per wave, k-outer; opt-in with CIPS3D_NERF_PAIR=1 because it is the slower form on MI355X in
-    both arithmetics: DESIGN.md) computes the default kernel's arithmetic -- split-fp16, or exact fp32 against csrc/nerf.hip's F32
-    instantiation -- in another work shape: same products in the same order per accumulator, a different chunking of the
-    samples -- maps equal to fp32 summation noise, sdf bit for bit."""
-    _needs_experimental()
-    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=3)
-    G.renderer.set_precision(precision)
-    S = 64
-    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.3, -0.1]] * B, device=DEV) *
-                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
-    styles = cu(weights.det_normal("pk.styles", (B, 3, 256), 0.5, 2))
-    u = cu(weights.det_unit_uniform("pk.u", (B, S * S), 3))
-    monkeypatch.setenv("CIPS3D_NERF_PAIR", "0")
-    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    monkeypatch.setenv("CIPS3D_NERF_PAIR", "1")
-    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    names = ("thumb", "features", "sdf", "mask", "xyz")
-    for k, a, b in zip(names, ref, new):
-        d, r = maxdiff(a, b), float(a.abs().max())
-        assert bool(torch.isfinite(b).all()) and d <= 2e-6 * max(r, 1.0), (k, d, r)
-    assert torch.equal(ref[2], new[2])
-
-
-@pytest.mark.parametrize("N,B,D", [(24, 1, 2), (23, 2, 2), (9, 1, 3), (24, 1, 1), (6, 2, 6)])
-def test_weight_stationary_kernel_matches_the_default_kernel(monkeypatch, N, B, D):
-    """csrc/nerf_ws.hip (a workgroup owns a ray group, a wave 32 output units of every layer with their weights in registers, the
-    activations in LDS; opt-in with CIPS3D_NERF_WS=1: the slower dataflow on MI355X) computes the default kernel's
-    arithmetic -- the same products in the same order per accumulator -- with sums over units and samples in another order: maps
-    equal to fp32 summation noise.  Depths whose tables do not fit beside the activation images fall back to the default kernel."""
-    _needs_experimental()
-    G = pkg.build_generator(configs.ffhq_G_cfg(256, D), DEV, seed=5)
-    S = 64
-    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.25, -0.15]] * B, device=DEV) *
-                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
-    styles = cu(weights.det_normal("ws.styles", (B, D + 1, 256), 0.5, 2))
-    u = cu(weights.det_unit_uniform("ws.u", (B, S * S), 3))
-    monkeypatch.setenv("CIPS3D_NERF_WS", "0")
-    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    monkeypatch.setenv("CIPS3D_NERF_WS", "1")
-    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
-        d, r = maxdiff(a, b), float(a.abs().max())
-        assert bool(torch.isfinite(b).all()) and d <= 4e-6 * max(r, 1.0), (k, d, r)
-    if D <= 5:
-        assert not torch.equal(ref[1], new[1])              # the other kernel really ran
-
-
-@pytest.mark.parametrize("S", [10, 12, 33])
-def test_weight_stationary_kernel_on_ragged_ray_counts(monkeypatch, S):
-    """Ray counts that are not a multiple of the 16-ray group (and not of the default kernel's task grid): the last workgroup's
-    missing rays carry zero weights and are never stored."""
-    _needs_experimental()
-    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), DEV, seed=6)
-    B, N = 2, 7
-    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.1, 0.2], [-0.3, 0.0]], device=DEV))
-    styles = cu(weights.det_normal("wsr.styles", (B, 3, 256), 0.5, 2))
-    u = cu(weights.det_unit_uniform("wsr.u", (B, S * S), 3))
-    monkeypatch.setenv("CIPS3D_NERF_WS", "0")
-    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    monkeypatch.setenv("CIPS3D_NERF_WS", "1")
-    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
-        assert a.shape == b.shape and bool(torch.isfinite(b).all()), k
-        assert maxdiff(a, b) <= 4e-6 * max(float(a.abs().max()), 1.0), k
 
 
 def test_fp32_exact_mode_agrees_with_the_default():
@@ -452,30 +374,3 @@ def test_the_two_instruction_split_is_the_split():
             hi = r16(xe.double())
             lo = r16(xe.double() - hi.double())
             assert torch.equal(pr[:, 0].float(), hi.float()) and torch.equal(pr[:, 1].float(), lo.float())
-
-
-@pytest.mark.parametrize("N,B,D", [(24, 1, 2), (23, 2, 2), (9, 1, 3), (12, 1, 1), (8, 1, 6)])
-def test_layer0_on_the_matrix_cores_matches_the_valu_form(monkeypatch, N, B, D):
-    """The L0M instantiations of the render kernel (csrc/nerf.hip: layer 0's three columns and the view layer's three direction
-    columns as one more k-block of the split MFMA; only in a library built with -DCIPS3D_NERF_L0M, because they measured slower --
-    DESIGN.md) compute the default kernel's values with split-fp16 products where it uses fp32 FMAs: every map within fp32
-    summation noise of the VALU form, nothing non-finite; depths whose fragment table does not fit fall back to the VALU form."""
-    from cips_3dplusplus_amd import _lib
-    if not (_lib.load().cips3d_build_features() & 2):
-        pytest.skip("library built without -DCIPS3D_NERF_L0M")
-    G = pkg.build_generator(configs.ffhq_G_cfg(256, D), DEV, seed=7)
-    S = 64
-    e, f, n, fa, _ = Camera.generate_camera_params(S, DEV, locations=torch.tensor([[0.25, -0.15]] * B, device=DEV) *
-                                                    torch.linspace(1, 2, B, device=DEV)[:, None])
-    styles = cu(weights.det_normal("l0m.styles", (B, D + 1, 256), 0.5, 2))
-    u = cu(weights.det_unit_uniform("l0m.u", (B, S * S), 3))
-    monkeypatch.setenv("CIPS3D_NERF_L0M", "0")
-    ref = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    monkeypatch.setenv("CIPS3D_NERF_L0M", "1")
-    new = G.renderer.render(e, f, n, fa, styles, S, N, perturb_u=u, return_sdf=True)
-    for k, a, b in zip(("thumb", "features", "sdf", "mask", "xyz"), ref, new):
-        d, r = maxdiff(a, b), float(a.abs().max())
-        # (the two forms round layer 0's pre-activation differently by ~2^-22; every further FiLM-SIREN layer amplifies that a little)
-        assert bool(torch.isfinite(b).all()) and d <= (4e-6 if D <= 3 else 1.5e-5) * max(r, 1.0), (k, d, r)
-    if D <= 4:
-        assert not torch.equal(ref[1], new[1])              # the other instantiation really ran
