@@ -53,6 +53,11 @@ class AdamEntry(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
+class AdamHyper(C.Structure):
+    """cips3d_adam_hyper (include/cips3d_hip.h)."""
+    _fields_ = [("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int32)]
+
+
 class ActBwd(C.Structure):
     """cips3d_actbwd: operands of the activation-backward epilogue (include/cips3d_hip.h)."""
     _fields_ = [("y", C.c_void_p), ("rgb_w", C.c_void_p), ("drgb", C.c_void_p), ("d_bias", C.c_void_p),
@@ -79,7 +84,7 @@ class NerfParams(C.Structure):
                 ("o_features", C.c_void_p), ("o_thumb", C.c_void_p), ("o_xyz", C.c_void_p), ("o_mask", C.c_void_p),
                 ("features_planes", C.c_int32), ("raw_density", C.c_int32),
                 ("stash", C.c_void_p), ("bwd_sdf", C.c_void_p), ("bwd_crgb", C.c_void_p), ("packed32", C.c_void_p),
-                ("zero_words", C.c_void_p), ("n_zero_words", C.c_int64)]
+                ("zero_words", C.c_void_p), ("n_zero_words", C.c_int64), ("mask_planar", C.c_int32), ("pad3_", C.c_int32)]
 
 
 class NerfBwdGeom(C.Structure):
@@ -124,6 +129,7 @@ _SIGS = {
                                         C.c_void_p]),
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, c_f32, C.c_void_p]),
     "cips3d_absmax": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
+    "cips3d_absmax_raise": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
     "cips3d_amax_layout": (c_int, [C.POINTER(c_int), C.POINTER(c_int)]),
     "cips3d_split_words": (c_int, [c_f32p, c_f32, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),
     "cips3d_range_consts": (c_int, [c_f32p, c_int, c_f32p, c_f32, c_f32p, c_f32, c_f32p, c_f32p, c_int, C.c_void_p]),
@@ -190,6 +196,7 @@ _SIGS = {
     "cips3d_sizeof_grad_plan": (c_int, []),
     "cips3d_sizeof_grad_io": (c_int, []),
     "cips3d_adam_step": (c_int, [C.c_void_p, c_int, C.c_float, C.c_float, C.c_float, C.c_float, c_int, C.c_void_p]),
+    "cips3d_adam_step_groups": (c_int, [C.c_void_p, C.c_void_p, c_int, C.c_void_p, c_int, C.c_void_p]),
     "cips3d_gemm_wgrad_split": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_i64, c_f32p, c_f32p, c_int, C.c_void_p]),
     "cips3d_noise_bias_act_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_int, c_int, c_i64, C.c_void_p]),
@@ -206,6 +213,7 @@ _SIGS = {
     "cips3d_nerf_bwd_film_grad": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                           c_f32p, c_f32p, c_int, c_int, c_int, c_i64, C.c_void_p]),
     "cips3d_nerf_bwd_camera": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "cips3d_nerf_bwd_camera_acc": (c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_camera_params_bwd": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_f32p, C.c_void_p]),
     "cips3d_nerf_bwd_fused_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "cips3d_nerf_bwd_fused_stash_floats": (c_i64, [c_int, c_int, c_int, c_int, c_int, c_int]),

@@ -468,13 +468,25 @@ class FilmTableFn(Function):
     """gamma / beta of every FiLM layer in one launch (the renderer's own table, cips3d_linear_table) with the table backward."""
 
     @staticmethod
-    def forward(ctx, renderer, styles, *params):
-        B = styles.shape[0]
+    def _direct(styles, B):
+        """Can the heads read `styles` where it is?  (contiguous fp32 on the device; [B, ...], or [1, ...] broadcast to B views)"""
+        return (styles.is_cuda and styles.dtype == torch.float32 and styles.is_contiguous() and styles.shape[0] in (1, B))
+
+    @staticmethod
+    def forward(ctx, renderer, styles, B, *params):
         styles_buf, film, tab = renderer._film_table(B, styles.device)
-        styles_buf.copy_(styles)
+        direct = None
+        if FilmTableFn._direct(styles, B):
+            # the heads read the caller's tensor: no staging copy, and a [1, ...] latent serves all B views with row stride 0
+            direct = tab.repointed(styles_buf.data_ptr(), styles.detach(), 0 if styles.shape[0] == 1 and B > 1 else None)
+        ctx.direct = direct is not None
+        if direct is not None:
+            tab = direct
+        else:
+            styles_buf.copy_(styles)                # (broadcasts a [1, ...] latent)
         tab.run(B)
         ctx.renderer, ctx.B = renderer, B
-        ctx.save_for_backward(styles.detach().float().contiguous())
+        ctx.save_for_backward(styles.detach())
         return film.clone()
 
     @staticmethod
@@ -482,30 +494,45 @@ class FilmTableFn(Function):
         renderer, B = ctx.renderer, ctx.B
         (styles,) = ctx.saved_tensors
         styles_buf, film, tab = renderer._film_table(B, styles.device)
-        styles_buf.copy_(styles)
-        need_p = any(ctx.needs_input_grad[2:])
-        dstyles = torch.zeros_like(styles_buf) if ctx.needs_input_grad[1] else None
-        dW, woffs, db = tab.backward(B, film, _c(dfilm.float()), styles_buf, dstyles, need_dW=need_p, need_db=need_p)
-        outs = [None, dstyles]
+        x_base = styles_buf
+        direct = tab.repointed(styles_buf.data_ptr(), styles, 0 if styles.shape[0] == 1 and B > 1 else None) if ctx.direct else None
+        if direct is not None:
+            tab, x_base = direct, styles
+        else:
+            styles_buf.copy_(styles)                # the staging buffer may have been reused since the forward
+        need_p = any(ctx.needs_input_grad[3:])
+        # (direct + broadcast: the table backward's atomics add every view's gradient into the one row -- the sum `expand` would take)
+        dstyles = torch.zeros_like(x_base) if ctx.needs_input_grad[1] else None
+        dW, woffs, db = tab.backward(B, film, _c(dfilm.float()), x_base, dstyles, need_dW=need_p, need_db=need_p)
+        if dstyles is not None and dstyles.shape[0] != styles.shape[0]:
+            dstyles = dstyles.sum(0, keepdim=True)  # (staged broadcast: the direct form's atomics take this sum in the launch)
+        outs = [None, dstyles, None]
         row = 0
         for i, (d, wo) in enumerate(zip(tab._descs, woffs)):
-            nW, nb = ctx.needs_input_grad[2 + 2 * i], ctx.needs_input_grad[3 + 2 * i]
+            nW, nb = ctx.needs_input_grad[3 + 2 * i], ctx.needs_input_grad[4 + 2 * i]
             outs.append(dW[wo:wo + d.out_dim * d.in_dim].view(d.out_dim, d.in_dim) if (nW and dW is not None) else None)
             outs.append(db[row:row + d.out_dim] if (nb and db is not None) else None)
             row += d.out_dim
         return tuple(outs)
 
 
-def film_table(renderer, styles):
+def film_table(renderer, styles, batch=None):
     """gamma / beta of every FiLM layer from the W+ styles (B, D+1, style_dim) -> [B, D+1, 2, H]
-    (cips3d/volume_renderer.py:66-67 through LinearLayer :15-35)."""
+    (cips3d/volume_renderer.py:66-67 through LinearLayer :15-35).  batch: B views from ONE latent -- styles (1, D+1, style_dim)
+    is then broadcast inside the table launch (the inversion loop's `w_render.repeat(2, 1, 1)`, projector_v10.py:1131, without the
+    repeat and without the sum its backward is)."""
     net = renderer.network
+    B = styles.shape[0] if batch is None else int(batch)
+    if styles.shape[0] not in (1, B):
+        raise ValueError(f"{styles.shape[0]} latents for a batch of {B} views")
     if STYLE_TABLE and renderer.style_dim % 4 == 0:
         params = []
         for layer in list(net.pts_linears) + [net.views_linears]:
             for head in (layer.gamma, layer.beta):
                 params += [head.weight, head.bias]
-        return FilmTableFn.apply(renderer, styles, *params)
+        return FilmTableFn.apply(renderer, styles, B, *params)
+    if styles.shape[0] != B:
+        styles = styles.expand(B, -1, -1)
     rows = []
     for l, layer in enumerate(list(net.pts_linears) + [net.views_linears]):
         st = styles[:, l]
@@ -551,7 +578,7 @@ class NerfRenderFn(Function):
                                          renderer.N_layers_renderer, cam_poses.device)
         thumb, features, _, mask, xyz = renderer.render(cam_poses.detach(), focals, near, far, None, img_size, n_samples,
                                                         perturb_u=perturb_u, static_viewdirs=static_viewdirs, film=film,
-                                                        stash=fwd)
+                                                        stash=fwd, planar_mask=True)      # mask: [2,B,S,S]
         ctx.renderer = renderer
         ctx.fwd = fwd
         ctx.cfg = (img_size, n_samples, static_viewdirs)

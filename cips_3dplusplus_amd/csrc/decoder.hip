@@ -1963,6 +1963,15 @@ extern "C" int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void
   return cips3d_launch_status();
 }
 
+extern "C" int cips3d_absmax_raise(const float* x, int B, int64_t n, float* amax, void* stream) {
+  if (!x || !amax || B < 0 || n <= 0) return CIPS3D_E_BADARG;
+  if (B == 0) return 0;
+  int64_t blocks = ceil_div<int64_t>(n, 256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, (unsigned)B), dim3(256), 0, as_stream(stream), x, n, amax);
+  return cips3d_launch_status();
+}
+
 extern "C" int cips3d_range_consts(const float* bias, int n_bias, const float* noise_w, float noise_bound, const float* noise_amax,
                                    float w_gain, const float* fir, float* lconst, int B, void* stream) {
   if (!lconst || B < 0 || n_bias < 0 || (n_bias > 0 && !bias) || !(noise_bound >= 0.f) || !(w_gain >= 0.f)) return CIPS3D_E_BADARG;

@@ -167,6 +167,58 @@ __global__ void __launch_bounds__(256) rgb_bias_kernel(RgbBiasArgs a) {
     for (int i = 0; i < a.n_dst; ++i) unsafeAtomicAdd(a.dst[i] + ch, acc);
 }
 
+// One level of the skip chain's backward in ONE launch: the FIR transpose of the three-channel gradient image (up2_fir_bwd_kernel's
+// arithmetic) together with the ToRGB bias gradients on both sides of it -- d ToRGB.bias = sum_{b,p} drgb at a layer's resolution:
+// the sums of the image this kernel WRITES go to the layers of the lower resolution (dst_lo), the sums of the image it READS
+// (every element owned by exactly one thread: rows 2 iy, 2 iy + 1, columns 8 xq .. 8 xq + 7) to those of the upper one (dst_hi,
+// only the chain's first level has no producer that could have summed it).  grid (ceil(H W / 1024), 3, B).
+struct DrgbLevelArgs { const float* g_hi; const float* fir; float* g_lo; int H, W; float* dst_hi[8]; int n_hi; float* dst_lo[8]; int n_lo; };
+__global__ void __launch_bounds__(256) drgb_level_kernel(DrgbLevelArgs a) {
+  __shared__ float sh[4];
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int H = a.H, W = a.W, wq = W >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  float k[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) k[i] = a.fir[i];
+  float s_hi = 0.f, s_lo = 0.f;
+  if (idx < H * wq) {
+    const int xq = idx % wq, iy = idx / wq;
+    const int W2 = 2 * W, H2 = 2 * H;
+    const float* src = a.g_hi + ((int64_t)b * 3 + c) * H2 * W2;
+    const int x0 = 8 * xq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int oy = 2 * iy - 1 + t;
+      if (oy < 0 || oy >= H2) continue;
+      const float* row = src + (int64_t)oy * W2 + x0;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(row);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(row + 4);
+      const float lft = x0 > 0 ? row[-1] : 0.f;
+      const float rgt = x0 + 8 < W2 ? row[8] : 0.f;
+      const float v[10] = {lft, a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3], rgt};
+      if (t == 1 || t == 2) s_hi += ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a1[0] + a1[1]) + (a1[2] + a1[3]));
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[j] = fmaf(v[2 * j + u], k[t * 4 + u], acc[j]);
+    }
+    cips3d_store_wt16(a.g_lo + (((int64_t)b * 3 + c) * H + iy) * W + 4 * xq, acc);
+    s_lo = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  }
+  if (a.n_hi > 0) {
+    s_hi = block_sum_256(s_hi, sh);
+    if (threadIdx.x == 0)
+      for (int i = 0; i < a.n_hi; ++i) unsafeAtomicAdd(a.dst_hi[i] + c, s_hi);
+  }
+  if (a.n_lo > 0) {
+    s_lo = block_sum_256(s_lo, sh);
+    if (threadIdx.x == 0)
+      for (int i = 0; i < a.n_lo; ++i) unsafeAtomicAdd(a.dst_lo[i] + c, s_lo);
+  }
+}
+
 // dst[i] = sum of the slot copies (cips3d_slot_reduce)
 __global__ void __launch_bounds__(256) slot_reduce_kernel(const cips3d_slot_job* __restrict__ table, int n_jobs) {
   const int lane = threadIdx.x & 63;
@@ -332,17 +384,22 @@ extern "C" int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan,
   const cips3d_decoder_grad_io& IO = *io;
   const int B = P.B;
   if (B <= 0 || P.n_layers <= 0 || P.n_layers > CIPS3D_GRAD_MAX_LAYERS || !IO.features || !IO.rgb || !P.style_table ||
-      !P.mod_table || !P.amax_base || !P.feat_amax || !P.rgb[0] || !P.rgb[1])
+      !P.mod_table || !P.amax_base || !P.feat_amax || !P.rgb[0] || !P.rgb[1] || ((IO.style_table == nullptr) != (IO.styles == nullptr)))
     return CIPS3D_E_BADARG;
   for (int li = 0; li < P.n_layers; ++li)
     if (!grad_layer_ok(P.layers[li])) return CIPS3D_E_BADARG;
-  hipStream_t st = as_stream(stream);
-  // every amax row of the step (forward outputs and backward gradients) starts at zero: the kernels only raise them
-  if (hipMemsetAsync(P.amax_base, 0, (size_t)P.amax_bytes, st) != hipSuccess) return CIPS3D_E_BADARG;
-  TRY(cips3d_linear_table(P.style_table, P.style_n, P.style_rows, B, stream));
+  // the style heads read the W+ styles from the plan's copy (style_table) or straight from the caller's tensor (io.style_table:
+  // the same table with its x pointers on that tensor -- one copy launch less per step)
+  const cips3d_linear_desc* style_table = IO.style_table ? IO.style_table : P.style_table;
+  // every amax row of the forward starts at zero (the kernels only raise them): cleared by the style heads' launch
+  if (P.amax_bytes > 0 && P.amax_bytes / 4 < (1 << 30))
+    TRY(cips3d_linear_table_zero(style_table, P.style_n, P.style_rows, B, reinterpret_cast<float*>(P.amax_base), (int)(P.amax_bytes / 4), stream));
+  else
+    TRY(cips3d_linear_table(style_table, P.style_n, P.style_rows, B, stream));
   TRY(cips3d_modulate_table(P.mod_table, P.mod_n, P.mod_rows, B, 0.f, stream));
   // the features' maximum: a feature is a convex combination of sines (nerf.hip), but a caller may hand in anything
-  TRY(cips3d_absmax(IO.features, B, (int64_t)P.layers[0].Cin * P.layers[0].H * P.layers[0].W, P.feat_amax, stream));
+  // (feat_amax lies in the block that was just cleared)
+  TRY(cips3d_absmax_raise(IO.features, B, (int64_t)P.layers[0].Cin * P.layers[0].H * P.layers[0].W, P.feat_amax, stream));
   const float* x = IO.features;
   const float* x_amax = P.feat_amax;
   const float* skip = nullptr;
@@ -439,33 +496,52 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
   if (hipMemsetAsync(P.zero_base, 0, (size_t)P.zero_bytes, st) != hipSuccess) return CIPS3D_E_BADARG;
 
   // ---- gradient images of the skip chain: one per resolution, from the output down (ToRGB.forward: rgb = conv + up(skip))
+  // One launch per resolution change (drgb_level_kernel: FIR transpose + the bias sums of the levels on both sides of it); a
+  // decoder without an up-sampling ToRGB, or more than eight ToRGBs at one resolution, takes rgb_bias_kernel for the rest.
   const float* drgb_of[CIPS3D_GRAD_MAX_LAYERS] = {};
   {
-    const float* cur = IO.d_rgb;
-    int slot = 0;
+    struct Level { const float* g; int H, W; const float* fir; float* dst[8]; int n; };
+    Level lv[6] = {};
+    int nl = 0, slot = 0;
+    lv[0].g = IO.d_rgb;
     RgbBiasArgs ba{};
     ba.B = B;
-    auto flush = [&]() -> int {
-      if (ba.n_dst == 0) return 0;
-      hipLaunchKernelGGL(rgb_bias_kernel, dim3(64, 3), dim3(256), 0, st, ba);
-      ba.n_dst = 0;
-      return cips3d_launch_status();
-    };
     for (int li = P.n_layers - 1; li >= 0; --li) {
       const cips3d_grad_layer& L = P.layers[li];
       if (L.kind < 2) continue;
-      drgb_of[li] = cur;
-      if (ba.n_dst == 8) TRY(flush());
-      ba.drgb = cur; ba.HW = (int64_t)L.H * L.W;
-      ba.dst[ba.n_dst++] = L.d_bias;
+      drgb_of[li] = lv[nl].g;
+      lv[nl].H = L.H; lv[nl].W = L.W;
+      if (lv[nl].n == 8) {        // (overflow of one level's list: settle these eight now)
+        ba.drgb = lv[nl].g; ba.HW = (int64_t)L.H * L.W; ba.n_dst = 8;
+        for (int i = 0; i < 8; ++i) ba.dst[i] = lv[nl].dst[i];
+        hipLaunchKernelGGL(rgb_bias_kernel, dim3(64, 3), dim3(256), 0, st, ba);
+        TRY(cips3d_launch_status());
+        lv[nl].n = 0;
+      }
+      lv[nl].dst[lv[nl].n++] = L.d_bias;
       if (L.kind == 3) {          // the skip came through the FIR up-sampler: its gradient lives at half the resolution
-        TRY(flush());
-        if (slot >= 4 || !P.drgb_lo[slot]) return CIPS3D_E_BADARG;
-        TRY(cips3d_up2_fir_bwd(cur, L.fir, P.drgb_lo[slot], nullptr, B, 3, L.H / 2, L.W / 2, stream));
-        cur = P.drgb_lo[slot++];
+        if (slot >= 4 || !P.drgb_lo[slot] || nl >= 5) return CIPS3D_E_BADARG;
+        if ((L.W / 2) % 4) return CIPS3D_E_UNSUPP;
+        lv[nl].fir = L.fir;
+        lv[++nl].g = P.drgb_lo[slot++];
       }
     }
-    TRY(flush());
+    for (int t = 0; t < nl; ++t) {
+      DrgbLevelArgs a{};
+      a.g_hi = lv[t].g; a.fir = lv[t].fir; a.g_lo = const_cast<float*>(lv[t + 1].g);
+      a.H = lv[t].H / 2; a.W = lv[t].W / 2;
+      if (t == 0) { a.n_hi = lv[0].n; for (int i = 0; i < lv[0].n; ++i) a.dst_hi[i] = lv[0].dst[i]; }
+      a.n_lo = lv[t + 1].n;
+      for (int i = 0; i < lv[t + 1].n; ++i) a.dst_lo[i] = lv[t + 1].dst[i];
+      hipLaunchKernelGGL(drgb_level_kernel, dim3((unsigned)ceil_div(a.H * (a.W / 4), 256), 3, (unsigned)B), dim3(256), 0, st, a);
+      TRY(cips3d_launch_status());
+    }
+    if (nl == 0 && lv[0].n > 0) {
+      ba.drgb = lv[0].g; ba.HW = (int64_t)lv[0].H * lv[0].W; ba.n_dst = lv[0].n;
+      for (int i = 0; i < lv[0].n; ++i) ba.dst[i] = lv[0].dst[i];
+      hipLaunchKernelGGL(rgb_bias_kernel, dim3(64, 3), dim3(256), 0, st, ba);
+      TRY(cips3d_launch_status());
+    }
   }
 
   // ---- StyledConvs, last to first
@@ -542,8 +618,8 @@ extern "C" int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan
   if (P.slot_table) TRY(cips3d_slot_reduce(P.slot_table, P.slot_n, P.slot_blocks, stream));
   TRY(cips3d_modulate_table_bwd(P.modbwd_table, P.modbwd_n, P.modbwd_blocks, B, stream));
   if (P.d_styles || P.d_style_W)
-    TRY(cips3d_linear_table_bwd(P.style_table, P.style_n, P.style_rows, P.style_dim, B, P.s_all, P.ds_all, P.styles, P.d_styles,
-                                P.style_w_offsets, P.d_style_W, P.d_style_b, stream));
+    TRY(cips3d_linear_table_bwd(IO.style_table ? IO.style_table : P.style_table, P.style_n, P.style_rows, P.style_dim, B, P.s_all, P.ds_all,
+                                IO.style_table ? IO.styles : P.styles, P.d_styles, P.style_w_offsets, P.d_style_W, P.d_style_b, stream));
   if (P.d_noise_w && P.nw_parts && P.nw_stride > 0) {
     hipLaunchKernelGGL(row_sums_kernel, dim3((unsigned)n_conv), dim3(256), 0, st, P.nw_parts, P.nw_stride, P.d_noise_w);
     TRY(cips3d_launch_status());

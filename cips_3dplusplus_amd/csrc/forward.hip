@@ -193,6 +193,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
   if (IO.ev_nerf_start) hipEventRecord(reinterpret_cast<hipEvent_t>(IO.ev_nerf_start), as_stream(stream));
   // the chunk partials are combined inside the render kernel when the shape allows it, else by cips3d_nerf_finish
   np.o_features = P.features; np.o_thumb = IO.thumb; np.o_xyz = IO.xyz; np.o_mask = IO.mask;
+  np.mask_planar = IO.mask_planar;
   const bool fused_finish = cips3d_nerf_fuses_finish(&np) != 0;
   // the first decoder layer reads split-fp16 planes (flags bit 2): the render kernel's fused finish writes them directly,
   // the stand-alone finish writes fp32 into the spare activation buffer and a conversion pass follows.  bf16 planes16

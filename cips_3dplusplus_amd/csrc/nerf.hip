@@ -833,7 +833,9 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
         } else if (k < 6) {
           P.o_xyz[((int64_t)b * 3 + (k - 3)) * R + gray] = acc;
         } else {
-          P.o_mask[((int64_t)b * 2 + 0) * R + gray] = acc;
+          const int64_t m0 = P.mask_planar ? (int64_t)b * R + gray : (int64_t)b * 2 * R + gray;     // [2,B,R] or [B,2,R]
+          const int64_t m1 = m0 + (P.mask_planar ? (int64_t)P.B * R : (int64_t)R);
+          P.o_mask[m0] = acc;
           float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
           for (int cc = 0; cc < WAVES; ++cc) {
@@ -843,7 +845,7 @@ __global__ void __launch_bounds__(WAVES * 64, 2) nerf_render_kernel(NerfArgs a) 
               sz = fmaf(Tp[cc], xs[(wb + cc) * 8 * RAYS + 5 * RAYS + rr], sz);
             }
           }
-          P.o_mask[((int64_t)b * 2 + 1) * R + gray] = -sqrtf((sx * sx + sy * sy) + sz * sz);
+          P.o_mask[m1] = -sqrtf((sx * sx + sy * sy) + sz * sz);
         }
       }
     }
@@ -1091,6 +1093,7 @@ extern "C" int cips3d_nerf_render(const cips3d_nerf_params* p, void* stream) {
     return CIPS3D_E_BADARG;
   if ((P.stash || P.bwd_sdf || P.bwd_crgb) && !(P.stash && P.bwd_sdf && P.bwd_crgb && !P.x_pts)) return CIPS3D_E_BADARG;
   if ((P.zero_words == nullptr) != (P.n_zero_words == 0) || P.n_zero_words < 0) return CIPS3D_E_BADARG;
+  if (P.mask_planar && !fuse) return CIPS3D_E_UNSUPP;       // (the stand-alone finish writes [B,2,R])
   if (P.B == 0 && P.zero_words) {
     hipLaunchKernelGGL(nerf_zero_kernel, dim3((unsigned)ceil_div<int64_t>(P.n_zero_words, 256)), dim3(256), 0, as_stream(stream), P.zero_words, P.n_zero_words);
     return cips3d_launch_status();

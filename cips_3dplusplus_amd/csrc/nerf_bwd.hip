@@ -559,6 +559,16 @@ extern "C" int cips3d_nerf_bwd_camera(const cips3d_nerf_bwd_geom* G, const float
   return cips3d_launch_status();
 }
 
+extern "C" int cips3d_nerf_bwd_camera_acc(const cips3d_nerf_bwd_geom* G, const float* dptsn, const float* dvd_pt,
+                                          const float* ddnorm, float* dcam, void* stream) {
+  if (!geom_ok(G) || !dptsn || !dvd_pt || !ddnorm || !dcam) return CIPS3D_E_BADARG;
+  if (G->B == 0) return 0;
+  const int R = G->img_size * G->img_size;
+  hipLaunchKernelGGL(camera_chain_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, as_stream(stream), *G, dptsn,
+                     dvd_pt, ddnorm, dcam);
+  return cips3d_launch_status();
+}
+
 extern "C" int cips3d_camera_params_bwd(const float* locations, const float* up, const float* dextrinsics, int B,
                                         float* dlocations, void* stream) {
   if (!locations || !dextrinsics || !dlocations || B < 0) return CIPS3D_E_BADARG;

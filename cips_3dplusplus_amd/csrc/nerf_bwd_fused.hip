@@ -79,31 +79,42 @@ struct FusedArgs {
 __host__ __device__ constexpr int64_t align4(int64_t v) { return (v + 3) & ~(int64_t)3; }
 
 // ------------------------------------------------------------------------------------------------ small preparation kernels
-__global__ void __launch_bounds__(256) prep_tables_kernel(const float* __restrict__ w_first, const float* __restrict__ w_view,
-                                                          const float* __restrict__ w_sigma, const float* __restrict__ w_rgb,
-                                                          const float* __restrict__ packed, int H, int D,
-                                                          float* __restrict__ tables) {
-  const float view_scale = packed[(int64_t)D * H * H + 2 * (D - 1)];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < 3 * H; i += gridDim.x * 256) {
-    const int k = i / H, o = i - k * H;
-    tables[i] = w_first[o * 3 + k];
-    tables[3 * H + i] = w_view[(int64_t)o * (H + 3) + H + k] * view_scale;
-    tables[7 * H + i] = w_rgb[i];
-    if (i < H) tables[6 * H + i] = w_sigma[i];
-  }
-}
-
-// in [B][H][R] -> out [B][R][H]
-__global__ void __launch_bounds__(256) transpose_hr_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int R) {
+// The three preparation steps of cips3d_nerf_bwd_fused as ONE launch (they were three dependent ~5 us launches in front of the
+// backward's first kernel): blocks [0, n_t) transpose d_features, [n_t, n_t + n_p) stage the small tables, the rest zero the
+// FiLM sums and the camera gradient (which the kernels behind accumulate into with atomics).
+__global__ void __launch_bounds__(256) nerf_bwd_prep_kernel(const float* __restrict__ d_features, float* __restrict__ dFt, int H, int R,
+                                                            int tiles_r, int tiles_h, int n_t, const float* __restrict__ w_first,
+                                                            const float* __restrict__ w_view, const float* __restrict__ w_sigma,
+                                                            const float* __restrict__ w_rgb, const float* __restrict__ packed, int D,
+                                                            float* __restrict__ tables, int n_p, float* __restrict__ z0, int nz0,
+                                                            float* __restrict__ z1, int nz1) {
   __shared__ float tile[32][33];
-  const int b = blockIdx.z;
-  const int r0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int j = ty; j < 32; j += 8)
-    if (h0 + j < H && r0 + tx < R) tile[j][tx] = in[((int64_t)b * H + h0 + j) * R + r0 + tx];
-  __syncthreads();
-  for (int j = ty; j < 32; j += 8)
-    if (r0 + j < R && h0 + tx < H) out[((int64_t)b * R + r0 + j) * H + h0 + tx] = tile[tx][j];
+  const int bid = blockIdx.x;
+  if (bid < n_t) {
+    const int b = bid / (tiles_r * tiles_h), rem = bid % (tiles_r * tiles_h);
+    const int r0 = (rem % tiles_r) * 32, h0 = (rem / tiles_r) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+      if (h0 + j < H && r0 + tx < R) tile[j][tx] = d_features[((int64_t)b * H + h0 + j) * R + r0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+      if (r0 + j < R && h0 + tx < H) dFt[((int64_t)b * R + r0 + j) * H + h0 + tx] = tile[tx][j];
+  } else if (bid < n_t + n_p) {
+    const float view_scale = packed[(int64_t)D * H * H + 2 * (D - 1)];
+    for (int i = (bid - n_t) * 256 + threadIdx.x; i < 3 * H; i += n_p * 256) {
+      const int k = i / H, o = i - k * H;
+      tables[i] = w_first[o * 3 + k];
+      tables[3 * H + i] = w_view[(int64_t)o * (H + 3) + H + k] * view_scale;
+      tables[7 * H + i] = w_rgb[i];
+      if (i < H) tables[6 * H + i] = w_sigma[i];
+    }
+  } else {
+    const int nb = (int)gridDim.x - n_t - n_p;
+    for (int i = (bid - n_t - n_p) * 256 + threadIdx.x; i < nz0 + nz1; i += nb * 256) {
+      if (i < nz0) z0[i] = 0.f;
+      else z1[i - nz0] = 0.f;
+    }
+  }
 }
 
 // transposed packed stream, consumption order of the backward: j = 0 view layer, j >= 1 hidden layer l = D - j.
@@ -988,12 +999,13 @@ extern "C" int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* pp, voi
   a.ddnorm = take(B * R);
   a.sums = take((int64_t)B * L * 2 * H);
 
-  hipLaunchKernelGGL(prep_tables_kernel, dim3(ceil_div(3 * H, 256)), dim3(256), 0, st, P.w_first, P.w_view, P.w_sigma, P.w_rgb,
-                     P.packed, H, D, a.tables);
-  hipLaunchKernelGGL(transpose_hr_kernel, dim3((unsigned)ceil_div<int64_t>(R, 32), (unsigned)ceil_div(H, 32), (unsigned)B),
-                     dim3(256), 0, st, P.d_features, a.dFt, H, (int)R);
-  if (hipError_t e = hipMemsetAsync(a.sums, 0, sizeof(float) * (size_t)B * L * 2 * H, st); e != hipSuccess) return (int)e;
-  if (int rc = cips3d_launch_status()) return rc;
+  {
+    const int tiles_r = (int)ceil_div<int64_t>(R, 32), tiles_h = ceil_div(H, 32), n_t = tiles_r * tiles_h * B, n_p = ceil_div(3 * H, 256);
+    const int nz0 = B * L * 2 * H, nz1 = 12 * B, n_z = ceil_div(nz0 + nz1, 1024);
+    hipLaunchKernelGGL(nerf_bwd_prep_kernel, dim3((unsigned)(n_t + n_p + n_z)), dim3(256), 0, st, P.d_features, a.dFt, H, (int)R, tiles_r,
+                       tiles_h, n_t, P.w_first, P.w_view, P.w_sigma, P.w_rgb, P.packed, D, a.tables, n_p, a.sums, nz0, P.dcam, nz1);
+    if (int rc = cips3d_launch_status()) return rc;
+  }
   int rc;
   switch (H) {
     case 32: rc = launch_fused<2, 2>(a, st); break;
@@ -1008,5 +1020,5 @@ extern "C" int cips3d_nerf_bwd_fused(const cips3d_nerf_bwd_fused_params* pp, voi
   hipLaunchKernelGGL(finalize_film_kernel, dim3(ceil_div(B * L * H, 256)), dim3(256), 0, st, a.sums, P.layer_bias, P.packed, B,
                      L, H, P.dfilm);
   if ((rc = cips3d_launch_status())) return rc;
-  return cips3d_nerf_bwd_camera(&G, a.dptsn, a.dvd, a.ddnorm, P.dcam, st);
+  return cips3d_nerf_bwd_camera_acc(&G, a.dptsn, a.dvd, a.ddnorm, P.dcam, st);      // (dcam: zeroed by the preparation launch)
 }

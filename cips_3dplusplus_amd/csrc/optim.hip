@@ -14,23 +14,27 @@ namespace {
 constexpr int ADAM_MAX = 48;            // entries per launch (kernel-argument budget: 48 x 40 B + prefix sums)
 constexpr int ADAM_BLOCK_ELEMS = 4096;  // 256 threads x 4 float4
 
+constexpr int ADAM_HYPERS = 8;          // distinct (lr, betas, eps, step) sets per launch: parameter groups of several optimisers
+struct AdamHyper { float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps; };
 struct AdamArgs {
   cips3d_adam_entry e[ADAM_MAX];
   int blk_begin[ADAM_MAX + 1];          // exclusive prefix sums of the workgroups per entry
   int n;
-  float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps;
+  AdamHyper h[ADAM_HYPERS];
+  unsigned char hidx[ADAM_MAX];         // entry -> its set
 };
 
 __global__ void __launch_bounds__(256) adam_kernel(AdamArgs a) {
   int ei = 0;
   while (ei + 1 < a.n && (int)blockIdx.x >= a.blk_begin[ei + 1]) ++ei;          // (uniform: <= 48 scalar compares)
   const cips3d_adam_entry E = a.e[ei];
+  const AdamHyper hy = a.h[a.hidx[ei]];
   const int64_t base = (int64_t)((int)blockIdx.x - a.blk_begin[ei]) * ADAM_BLOCK_ELEMS;
-  const float omb1 = 1.f - a.b1, omb2 = 1.f - a.b2;
+  const float omb1 = 1.f - hy.b1, omb2 = 1.f - hy.b2;
   auto upd = [&](float& p, float g, float& m, float& v) {
-    m = fmaf(a.b1, m, omb1 * g);
-    v = fmaf(a.b2, v, (omb2 * g) * g);
-    p -= a.lr_over_bc1 * (m / (sqrtf(v) * a.inv_sqrt_bc2 + a.eps));
+    m = fmaf(hy.b1, m, omb1 * g);
+    v = fmaf(hy.b2, v, (omb2 * g) * g);
+    p -= hy.lr_over_bc1 * (m / (sqrtf(v) * hy.inv_sqrt_bc2 + hy.eps));
   };
   const bool vec = ((reinterpret_cast<uintptr_t>(E.p) | reinterpret_cast<uintptr_t>(E.g) | reinterpret_cast<uintptr_t>(E.m) |
                      reinterpret_cast<uintptr_t>(E.v)) & 15) == 0;
@@ -155,29 +159,60 @@ extern "C" int cips3d_sqdiff_pair_bwd(const float* a0, const float* b0, int64_t 
   return cips3d_launch_status();
 }
 
-extern "C" int cips3d_adam_step(const cips3d_adam_entry* entries, int n_entries, float lr, float beta1, float beta2, float eps,
-                                int step, void* stream) {
-  if (!entries || n_entries < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return CIPS3D_E_BADARG;
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  for (int first = 0; first < n_entries; first += ADAM_MAX) {
+static bool adam_hyper_of(const cips3d_adam_hyper& g, AdamHyper* out) {
+  if (g.step < 1 || !(g.beta1 >= 0.f && g.beta1 < 1.f) || !(g.beta2 >= 0.f && g.beta2 < 1.f)) return false;
+  const double bc1 = 1.0 - pow((double)g.beta1, g.step), bc2 = 1.0 - pow((double)g.beta2, g.step);
+  *out = AdamHyper{(float)((double)g.lr / bc1), (float)(1.0 / sqrt(bc2)), g.beta1, g.beta2, g.eps};
+  return true;
+}
+
+// entries of several parameter groups (and optimisers) share launches: entry i takes the hyper-parameters hypers[group_of[i]]
+extern "C" int cips3d_adam_step_groups(const cips3d_adam_entry* entries, const int* group_of, int n_entries,
+                                       const cips3d_adam_hyper* hypers, int n_hypers, void* stream) {
+  if (!entries || !group_of || !hypers || n_entries < 0 || n_hypers <= 0) return CIPS3D_E_BADARG;
+  for (int i = 0; i < n_entries; ++i) {
+    if (group_of[i] < 0 || group_of[i] >= n_hypers) return CIPS3D_E_BADARG;
+    const cips3d_adam_entry& E = entries[i];
+    if (!E.p || !E.g || !E.m || !E.v || E.n < 0) return CIPS3D_E_BADARG;
+  }
+  int first = 0;
+  while (first < n_entries) {
     AdamArgs a;
-    a.n = n_entries - first < ADAM_MAX ? n_entries - first : ADAM_MAX;
-    int blocks = 0;
-    for (int i = 0; i < a.n; ++i) {
-      const cips3d_adam_entry& E = entries[first + i];
-      if (!E.p || !E.g || !E.m || !E.v || E.n < 0) return CIPS3D_E_BADARG;
-      a.e[i] = E;
-      a.blk_begin[i] = blocks;
-      blocks += (int)ceil_div<int64_t>(E.n, ADAM_BLOCK_ELEMS);
+    int local_of[ADAM_HYPERS], n_local = 0, blocks = 0;
+    a.n = 0;
+    while (first + a.n < n_entries && a.n < ADAM_MAX) {
+      const int gi = group_of[first + a.n];
+      int li = 0;
+      while (li < n_local && local_of[li] != gi) ++li;
+      if (li == n_local) {
+        if (n_local == ADAM_HYPERS) break;                 // a ninth set: the next launch
+        if (!adam_hyper_of(hypers[gi], &a.h[n_local])) return CIPS3D_E_BADARG;
+        local_of[n_local++] = gi;
+      }
+      a.e[a.n] = entries[first + a.n];
+      a.hidx[a.n] = (unsigned char)li;
+      a.blk_begin[a.n] = blocks;
+      blocks += (int)ceil_div<int64_t>(entries[first + a.n].n, ADAM_BLOCK_ELEMS);
+      ++a.n;
     }
     a.blk_begin[a.n] = blocks;
-    a.lr_over_bc1 = (float)((double)lr / bc1);
-    a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    a.b1 = beta1; a.b2 = beta2; a.eps = eps;
+    first += a.n;
     if (blocks == 0) continue;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), a);
     const int rc = cips3d_launch_status();
     if (rc != 0) return rc;
+  }
+  return 0;
+}
+
+extern "C" int cips3d_adam_step(const cips3d_adam_entry* entries, int n_entries, float lr, float beta1, float beta2, float eps,
+                                int step, void* stream) {
+  if (!entries || n_entries < 0 || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return CIPS3D_E_BADARG;
+  const cips3d_adam_hyper h{lr, beta1, beta2, eps, step};
+  for (int first = 0; first < n_entries; first += ADAM_MAX) {
+    int zeros[ADAM_MAX] = {};
+    const int n = n_entries - first < ADAM_MAX ? n_entries - first : ADAM_MAX;
+    if (const int rc = cips3d_adam_step_groups(entries + first, zeros, n, &h, 1, stream)) return rc;
   }
   return 0;
 }

@@ -56,7 +56,8 @@ class DecoderGradPlan(C.Structure):
 
 class DecoderGradIO(C.Structure):
     _fields_ = [("features", C.c_void_p), ("noise", C.c_void_p * MAX_LAYERS), ("noise_bstride", C.c_int64 * MAX_LAYERS),
-                ("rgb", C.c_void_p), ("d_rgb", C.c_void_p), ("d_features", C.c_void_p)]
+                ("rgb", C.c_void_p), ("d_rgb", C.c_void_p), ("d_features", C.c_void_p),
+                ("style_table", C.c_void_p), ("styles", C.c_void_p)]
 
 
 class Unsupported(RuntimeError):
@@ -316,11 +317,21 @@ class GradPlan:
                 raise RuntimeError(f"noise {k}: shape {tuple(nz.shape)} for a {i['Ho']}x{i['Wo']} layer")
             io.noise[k] = dev_ptr(nz, "noise")
             io.noise_bstride[k] = i["Ho"] * i["Wo"] if (nz.shape[0] == self.B and self.B > 1) else 0
+        if getattr(self, "_direct", None) is not None:
+            io.style_table, io.styles = self._direct[0]._dev.data_ptr(), self._direct[1].data_ptr()
         return io
 
     def forward(self, features, styles, noise):
         lib = _lib.load()
-        self.styles_buf.copy_(styles)
+        # the style heads read the caller's W+ tensor where it is when its address is a steady one (a parameter the optimiser
+        # updates in place: hip.LinearTable.repointed), else from the plan's staging copy
+        self._direct = None
+        if styles.is_cuda and styles.dtype == torch.float32 and styles.is_contiguous() and tuple(styles.shape) == tuple(self.styles_buf.shape):
+            tab = self._style_tab.repointed(self.styles_buf.data_ptr(), styles)
+            if tab is not None:
+                self._direct = (tab, styles)
+        if self._direct is None:
+            self.styles_buf.copy_(styles)
         H, W = self.out_hw
         rgb = torch.empty(self.B, 3, H, W, device=self.dev)
         io = self._io(features, noise)

@@ -243,8 +243,8 @@ class Generator(nn.Module):
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
             marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp, rgb_out=rgb_out,
             style_refs=refs)
-        # mask [B,2,S,S] -> two contiguous [B,1,S,S] maps: free at batch 1, ONE transposing copy beyond (two slice copies before)
-        m2 = mask.transpose(0, 1).contiguous()
+        # mask arrives as [2,B,S,S] (plan.run): two contiguous [B,1,S,S] maps without a copy
+        m2 = mask
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,
                 "sdf": sdf if return_sdf else None, "xyz": xyz if return_xyz else None,
                 "mask": m2[0].unsqueeze(1), "depth": m2[1].unsqueeze(1)}
@@ -327,7 +327,9 @@ class Generator(nn.Module):
             return (v if torch.is_tensor(v) else torch.full((B, 1, 1), float(v), device=dev)).detach()
 
         static = bool(nerf_cfg.get("static_viewdirs", False))
-        film = AG.film_table(self.renderer, style_render)
+        # (style_render may hold ONE latent for the B views of the call: the FiLM table broadcasts it -- the inversion loop's
+        # `w_render.repeat(2, 1, 1)`, projector_v10.py:1131, without the repeat launch and the sum its backward is)
+        film = AG.film_table(self.renderer, style_render, batch=B)
         rparams = [p for _, p in AG.nerf_named_parameters(self.renderer)]
         if not any(p.requires_grad for p in rparams):
             rparams = []
@@ -343,7 +345,7 @@ class Generator(nn.Module):
                 sdf = self.renderer.render(cam_poses.detach(), per_view(focals), per_view(near), per_view(far), None, img_size,
                                            N, perturb_u=perturb_u, static_viewdirs=static, return_sdf=True,
                                            film=film.detach())[2]
-        m2 = mask.transpose(0, 1).contiguous()          # one copy for both maps (see _planned_forward)
+        m2 = mask                                       # [2,B,S,S] (NerfRenderFn renders with planar_mask)
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None, "sdf": sdf,
                 "xyz": xyz if return_xyz else None, "mask": m2[0].unsqueeze(1), "depth": m2[1].unsqueeze(1)}
 

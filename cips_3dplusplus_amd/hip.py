@@ -161,6 +161,37 @@ class LinearTable:
         host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
         self._dev = host.to(self.device)
 
+    def repointed(self, x_base, x_tensor, x_stride=None):
+        """This table with every head reading its input from `x_tensor` (a contiguous fp32 tensor laid out like the staging
+        buffer whose base address is `x_base`) instead of from that buffer -- the caller's own W+ styles, without the copy launch
+        into the staging buffer.  x_stride = 0: ONE row broadcast to every sample of the batch (a [1, ...] latent for B views; the
+        backward's atomics then sum the batch's gradients into that row).  The uploaded descriptors are cached per (address,
+        stride): a parameter that an optimiser updates in place keeps its address from step to step, so the steady state uploads
+        nothing.  Returns None the first time an address is seen (a tensor that is new on every call would cost an upload per
+        call -- more than the copy it saves): the caller then stages as before."""
+        key = (x_tensor.data_ptr(), x_stride)
+        cache = self.__dict__.setdefault("_repointed", {})
+        ent = cache.get(key)
+        if ent is None:
+            seen, self.__dict__["_repoint_seen"] = self.__dict__.get("_repoint_seen"), key
+            if seen != key:
+                return None
+            if len(cache) >= 4:
+                cache.clear()
+            ent = LinearTable(self.device)
+            for d in self._descs:
+                c = _lib.LinearDesc.from_buffer_copy(d)
+                c.x = x_tensor.data_ptr() + (d.x - x_base)
+                if x_stride is not None:
+                    c.x_stride = x_stride
+                ent._descs.append(c)
+            ent._rows = self._rows
+            ent._keep = list(self._keep)
+            ent._upload()
+            cache[key] = ent
+        ent._keep_x = x_tensor
+        return ent
+
     def run(self, B):
         if not self._descs:
             return
@@ -290,6 +321,10 @@ def nerf_render_maps(**kw):
     mask = torch.empty(B, 2, *shp, device=dev)
     p.o_features, p.o_thumb, p.o_xyz, p.o_mask = dev_ptr(features), dev_ptr(thumb), dev_ptr(xyz), dev_ptr(mask)
     fused = bool(lib.cips3d_nerf_fuses_finish(C.byref(p)))
+    planar = bool(kw.get("planar_mask"))          # mask as [2,B,...]: written that way by the fused finish, one transposing copy otherwise
+    if planar and fused:
+        mask = torch.empty(2, B, *shp, device=dev)
+        p.o_mask, p.mask_planar = dev_ptr(mask), 1
     part = None
     if not fused:
         R = n_rays if n_rays > 0 else S * S
@@ -302,6 +337,8 @@ def nerf_render_maps(**kw):
     if not fused:
         check(lib.cips3d_nerf_finish_rays(p.part, p.n_chunks, B, n_rays if n_rays > 0 else S * S, H, dev_ptr(features),
                                           dev_ptr(thumb), dev_ptr(xyz), dev_ptr(mask), stream_ptr()), "cips3d_nerf_finish_rays")
+        if planar:
+            mask = mask.transpose(0, 1).contiguous()
     return features, thumb, xyz, mask
 
 

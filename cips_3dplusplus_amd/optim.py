@@ -43,19 +43,12 @@ class HipAdam(torch.optim.Optimizer):
             if v not in (_UNSUPPORTED[k], None, False, 0):
                 raise NotImplementedError(f"HipAdam implements plain Adam only: {k}={v!r} is not supported")
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
-        lib = _lib.load()
+    def _collect(self, entries, group_of, hypers, keep, updated):
+        """Append this optimiser's work to the shared lists of one cips3d_adam_step_groups call."""
         for group in self.param_groups:
             # (param_groups of a loaded torch.optim.Adam state_dict carry its other options)
             self._check_options({k: v for k, v in group.items() if k in _UNSUPPORTED})
-            by_step = {}
-            updated = []
-            keep = []
+            slot_of_step = {}
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -72,13 +65,38 @@ class HipAdam(torch.optim.Optimizer):
                 if g.dtype != torch.float32:
                     g = g.float()
                 keep.append(g)
-                e = _lib.AdamEntry(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                by_step.setdefault(st["step"], []).append(e)
-            for step, entries in by_step.items():
-                arr = (_lib.AdamEntry * len(entries))(*entries)
-                _lib.check(lib.cips3d_adam_step(arr, len(entries), float(group["lr"]), float(group["betas"][0]),
-                                                float(group["betas"][1]), float(group["eps"]), int(step), _lib.stream_ptr()),
-                           "cips3d_adam_step")
-            for p in updated:
-                _bump_version(p)
+                hi = slot_of_step.get(st["step"])
+                if hi is None:                            # one hyper-parameter set per (group, step count)
+                    hi = slot_of_step[st["step"]] = len(hypers)
+                    hypers.append(_lib.AdamHyper(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]),
+                                                 float(group["eps"]), int(st["step"])))
+                entries.append(_lib.AdamEntry(p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()))
+                group_of.append(hi)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        step_many([self])
         return loss
+
+
+@torch.no_grad()
+def step_many(optimizers):
+    """One step of several HipAdam optimisers in SHARED launches (cips3d_adam_step_groups: 48 tensors per launch whatever group or
+    optimiser they belong to) -- the three optimisers of an inversion step are 3 launches instead of 6."""
+    entries, group_of, hypers, keep, updated = [], [], [], [], []
+    for o in optimizers:
+        if not isinstance(o, HipAdam):
+            raise TypeError("step_many takes HipAdam optimisers")
+        o._collect(entries, group_of, hypers, keep, updated)
+    if entries:
+        arr = (_lib.AdamEntry * len(entries))(*entries)
+        gof = (C.c_int * len(group_of))(*group_of)
+        hyp = (_lib.AdamHyper * len(hypers))(*hypers)
+        _lib.check(_lib.load().cips3d_adam_step_groups(arr, gof, len(entries), hyp, len(hypers), _lib.stream_ptr()),
+                   "cips3d_adam_step_groups")
+    for p in updated:
+        _bump_version(p)

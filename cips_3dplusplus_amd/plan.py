@@ -54,7 +54,7 @@ class ForwardIO(C.Structure):
                 ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
                 ("noise_bound", C.c_float), ("pad2_", C.c_int32),
                 ("ev_marks", C.c_void_p), ("ev_info", C.c_void_p), ("ev_count", C.c_void_p), ("n_ev_marks", C.c_int32),
-                ("styles_resident", C.c_int32), ("rgb_is_u8", C.c_int32), ("pad4_", C.c_int32)]
+                ("styles_resident", C.c_int32), ("rgb_is_u8", C.c_int32), ("mask_planar", C.c_int32)]
 
 
 # A fused up-sampling stage also computes the next stage's low-resolution GEMM (cips3d_fused_up_conv_next); 0 = every
@@ -336,6 +336,10 @@ class ForwardPlan:
         n.static_viewdirs, n.n_chunks = int(self.static), n_chunks
         n.part = part.data_ptr()
         p.features = features.data_ptr()
+        # does this shape's render launch combine its chunk partials itself?  (then the mask can leave it as two planar maps)
+        probe = _lib.NerfParams.from_buffer_copy(n)
+        probe.o_features = probe.o_thumb = probe.o_xyz = probe.o_mask = features.data_ptr()
+        self.mask_planar = bool(_lib.load().cips3d_nerf_fuses_finish(C.byref(probe)))
 
         # ---- decoder workspace
         act = torch.empty(2, max_act, device=dev)
@@ -515,7 +519,10 @@ class ForwardPlan:
                 io.rgb_is_u8 = 1
         thumb = torch.empty(B, 3, S, S, device=dev)
         xyz = torch.empty(B, 3, S, S, device=dev)
-        mask = torch.empty(B, 2, S, S, device=dev)
+        # `mask` is returned as [2, B, S, S]: the background-weight map of every view, then the depth map of every view (the two
+        # tensors Generator.forward hands out).  A render launch that fuses its finish writes that layout itself.
+        mask = torch.empty((2, B, S, S) if self.mask_planar else (B, 2, S, S), device=dev)
+        io.mask_planar = int(self.mask_planar)
         io.rgb, io.thumb, io.xyz, io.mask = rgb.data_ptr(), thumb.data_ptr(), xyz.data_ptr(), mask.data_ptr()
         if events is not None:
             io.ev_nerf_start, io.ev_nerf_stop = events
@@ -525,4 +532,6 @@ class ForwardPlan:
                    "cips3d_generator_forward")
         if sdf is not None:
             sdf = sdf.view(B, S, S, self.N, 1)
+        if not self.mask_planar:
+            mask = mask.transpose(0, 1).contiguous()
         return rgb, thumb, xyz, mask, sdf

@@ -40,6 +40,11 @@ def _adam(groups):
     return torch.optim.Adam(groups)
 
 
+def _all_hip_adam(opts):
+    from .optim import HipAdam
+    return len(opts) > 0 and all(isinstance(o, HipAdam) for o in opts)
+
+
 def cur_lr(step, num_steps, initial_learning_rate=1.0, lr_rampdown_length=0.25, lr_rampup_length=0.05):
     """projector_v10.py:174-186."""
     t = step / num_steps
@@ -96,14 +101,17 @@ class FlipProjector:
 
     # ---- optimisers (projector_v10.py:279-390)
     def _cam_optimizer(self, optim_cam, lr_cam, azim_init, bs):
-        azim = torch.zeros(bs, 1, device=self.device)
-        elev = torch.zeros(bs, 1, device=self.device)
-        azim[:, 0] = torch.tensor(azim_init[:bs], dtype=torch.float32)
+        """-> (locations [bs, 2] = (azim, elev) per view, optimiser).  The reference keeps azim and elev as two [bs, 1] parameters of
+        one Adam group and concatenates them every step (projector_v10.py:279-300, 240-241); Adam is element-wise, so ONE [bs, 2]
+        parameter takes exactly the same steps -- without the cat launch of every forward and the two slice copies its backward is.
+        `azim` / `elev` of the returned dict and of `on_step` are its two columns."""
+        loc = torch.zeros(bs, 2, device=self.device)
+        loc[:, 0] = torch.tensor(azim_init[:bs], dtype=torch.float32)
         groups = []
         if optim_cam:
-            azim, elev = nn.Parameter(azim), nn.Parameter(elev)
-            groups.append({"params": [azim, elev], "lr": lr_cam, "initial_lr": lr_cam, "betas": (0.9, 0.999)})
-        return azim, elev, _adam(groups) if groups else None
+            loc = nn.Parameter(loc)
+            groups.append({"params": [loc], "lr": lr_cam, "initial_lr": lr_cam, "betas": (0.9, 0.999)})
+        return loc, _adam(groups) if groups else None
 
     def _render_optimizer(self, G, mean_r, optim_render_w, lr_render_w, bs, optim_render_params=False):
         w = mean_r.detach().reshape(1, 1, -1).repeat(bs, G.N_layers_renderer + 1, 1).contiguous()
@@ -134,11 +142,13 @@ class FlipProjector:
         return w, noise_bufs, _adam(groups) if groups else None
 
     # ---- one generator call of the loop (projector_v10.py:211-277)
-    def g_forward(self, G, style_render, style_decoder, noise_bufs, cam_cfg, nerf_cfg, rot, trans, flip_w_decoder=False):
+    def g_forward(self, G, style_render, style_decoder, noise_bufs, cam_cfg, nerf_cfg, rot, trans=None, flip_w_decoder=False):
+        """rot, trans: azimuth and elevation [B, 1] each -- or rot = the [B, 2] locations and trans = None."""
         cam_cfg = dict(cam_cfg)
         img_size = cam_cfg.pop("img_size")
         cam_cfg = {k: v for k, v in cam_cfg.items() if k in ("fov_ang", "dist_radius")}
-        extr, focal, near, far, _ = Camera.generate_camera_params(img_size, self.device, locations=torch.cat([rot, trans], 1),
+        extr, focal, near, far, _ = Camera.generate_camera_params(img_size, self.device,
+                                                                  locations=rot if trans is None else torch.cat([rot, trans], 1),
                                                                   **cam_cfg)
         if flip_w_decoder:
             style_decoder = style_decoder.detach().flip(dims=(0,))      # only the decoder parameters are updated
@@ -158,7 +168,9 @@ class FlipProjector:
         G.decoder.requires_grad_(True)
         with torch.no_grad():
             mean_r, mean_d = G.get_mean_latent(w_avg_samples, self.device)
-        azim, elev, opt_cam = self._cam_optimizer(optim_cam, lr_cam, list(azim_init), bs_cam)
+        loc, opt_cam = self._cam_optimizer(optim_cam, lr_cam, list(azim_init), bs_cam)
+        azim, elev = loc.detach()[:, 0:1], loc.detach()[:, 1:2]          # (views: they follow the optimiser's in-place updates)
+        one = torch.ones((), device=self.device)                         # d loss / d loss, allocated once (backward() would fill one per step)
         w_render, opt_render = self._render_optimizer(G, mean_r, optim_render_w, lr_render_w, bs_render, optim_render_params)
         w_decoder, noise_bufs, opt_dec = self._decoder_optimizer(
             G, mean_d, optim_decoder_w, optim_decoder_params, optim_noise_bufs, zero_noise_bufs, lr_decoder_w,
@@ -183,23 +195,27 @@ class FlipProjector:
                         w_render.copy_(torch.lerp(mean_r.reshape(1, 1, -1).expand_as(w_render), w_render, truncation_psi))
                 if (step + flip_w_decoder_every - 1) % flip_w_decoder_every == 0 and step != N_steps - 1:
                     flip_w_decoder = True
+            # (one NeRF latent for both views, bs_render = 1: the generator broadcasts it inside the FiLM table's launch)
             rgb, thumb, _ = self.g_forward(
-                G, w_render if w_render.shape[0] == 2 else w_render.repeat(2, 1, 1),
-                w_decoder if w_decoder.shape[0] == 2 else w_decoder.repeat(2, 1, 1), noise_bufs, cam_cfg, nerf_cfg,
-                rot=azim, trans=elev, flip_w_decoder=flip_w_decoder)
+                G, w_render, w_decoder if w_decoder.shape[0] == 2 else w_decoder.repeat(2, 1, 1), noise_bufs, cam_cfg, nerf_cfg,
+                rot=loc, flip_w_decoder=flip_w_decoder)
             loss = loss_fn(rgb, thumb)
             if optim_noise_bufs and regularize_noise_weight > 0:
                 loss = loss + regularize_noise_weight * noise_regulariser(noise_bufs)
             for o in opts:
                 o.zero_grad(set_to_none=True)
-            loss.backward()
-            for o in opts:
-                o.step()
+            loss.backward(one if loss.dim() == 0 and loss.dtype == one.dtype else None)
+            if _all_hip_adam(opts):
+                from .optim import step_many
+                step_many(opts)                          # the three optimisers' tensors share launches
+            else:
+                for o in opts:
+                    o.step()
             if on_step is not None:
                 on_step(step, loss, azim, elev)
             else:
                 history.append(loss.detach())
-        return {"azim": azim.detach(), "elev": elev.detach(), "w_render_opt": w_render.detach(),
+        return {"azim": azim.clone(), "elev": elev.clone(), "w_render_opt": w_render.detach(),
                 "w_decoder_opt": w_decoder.detach(), "render_state_dict": G.renderer.state_dict(),
                 "decoder_state_dict": G.decoder.state_dict(), "noise_bufs": [b.detach() for b in noise_bufs], "padding": 0,
                 "loss_history": torch.stack(history).cpu() if history else None, "G": G}

@@ -192,10 +192,11 @@ class VolumeFeatureRenderer(nn.Module):
 
     @torch.no_grad()
     def render(self, cam_poses, focals, near, far, styles, img_size, N_samples, perturb_u=None,
-               static_viewdirs=False, return_sdf=False, n_chunks=None, film=None, stash=None, zero_words=None):
+               static_viewdirs=False, return_sdf=False, n_chunks=None, film=None, stash=None, zero_words=None, planar_mask=False):
         """cam_poses (B,3,4), focals/near/far (B,1,1), styles (B,D+1,style_dim)
         -> thumb_rgb (B,3,S,S), features (B,H,S,S), sdf (B,S,S,N,1)|None, mask (B,2,S,S), xyz (B,3,S,S)
-        zero_words: a float32 scratch tensor the launch leaves zeroed (cips3d_nerf_params.zero_words)."""
+        zero_words: a float32 scratch tensor the launch leaves zeroed (cips3d_nerf_params.zero_words).
+        planar_mask: mask comes back as (2,B,S,S) -- the layout Generator.forward splits into its `mask` and `depth` maps."""
         B = cam_poses.shape[0]
         dev = cam_poses.device
         D, H = self.N_layers_renderer, self.hidden_dim
@@ -228,7 +229,7 @@ class VolumeFeatureRenderer(nn.Module):
                         static_viewdirs=int(bool(static_viewdirs)), n_chunks=n_chunks, sdf=sdf,
                         raw_density=not self.with_sdf, packed32=None if stash is not None else self.packed32(),
                         stash=None if stash is None else stash["stash"], bwd_sdf=None if stash is None else stash["sdf"],
-                        bwd_crgb=None if stash is None else stash["crgb"], zero_words=zero_words)
+                        bwd_crgb=None if stash is None else stash["crgb"], zero_words=zero_words, planar_mask=planar_mask)
         if sdf is not None:
             sdf = sdf.view(B, img_size, img_size, N_samples, 1)
         return thumb, features, sdf, mask, xyz

@@ -216,6 +216,11 @@ typedef struct cips3d_nerf_params {
    * launch itself may live there. */
   float* zero_words;
   int64_t n_zero_words;
+  /* != 0 (fused finish only; CIPS3D_E_UNSUPP when the shape does not fuse): o_mask is laid out [2, B, R] -- the background
+   * weight of every view, then -|xyz| of every view: the two maps `Generator.forward` returns, each contiguous, without the
+   * transposing copy a batch of [B, 2, R] needs */
+  int32_t mask_planar;
+  int32_t pad3_;
 } cips3d_nerf_params;
 
 /* The exact-fp32 weight stream of cips3d_nerf_params.packed32 (cips3d_nerf_packed_floats(hidden, depth) floats, as `packed`):
@@ -301,6 +306,8 @@ typedef struct cips3d_reduce_job {
 } cips3d_reduce_job;
 /* amax[b][*] = max_i |x[b][i]|, x [B][n] (zeroes the slots, then one pass; HBM-bound) */
 int cips3d_absmax(const float* x, int B, int64_t n, float* amax, void* stream);
+/* the same pass over slots the caller has zeroed already (or that hold maxima this tensor's are to be merged with): one launch */
+int cips3d_absmax_raise(const float* x, int B, int64_t n, float* amax, void* stream);
 /* Test hook for the split itself (n even): words[i] = {hi | lo << 16} of x[i] * k -- even i through the fused form (the exact
  * product t k is split), odd i through the plain form on the fp32 product -- and, per pair (x[2j], x[2j+1]),
  * pairs[2j] = [hi_0 | hi_1 << 16], pairs[2j+1] = [lo_0 | lo_1 << 16] of the values themselves. */
@@ -657,7 +664,8 @@ typedef struct cips3d_forward_io {
    * up-sampling stage).  Only plans whose last layers form a fused up-sampling stage can do it: CIPS3D_E_UNSUPP otherwise (the
    * caller then renders fp32 and converts). */
   int32_t rgb_is_u8;
-  int32_t pad4_;
+  /* != 0: `mask` is [2, B, S, S] (cips3d_nerf_params.mask_planar); only for plans whose render launch fuses its finish */
+  int32_t mask_planar;
 } cips3d_forward_io;
 
 #define CIPS3D_MARK_START 0
@@ -831,6 +839,12 @@ typedef struct cips3d_adam_entry {
 } cips3d_adam_entry;
 int cips3d_adam_step(const cips3d_adam_entry* entries, int n_entries, float lr, float beta1, float beta2, float eps, int step,
                      void* stream);
+/* The same update for the tensors of SEVERAL parameter groups / optimisers in shared launches (48 tensors and up to 8 distinct
+ * hyper-parameter sets per launch): entry i takes hypers[group_of[i]].  The three optimisers of an inversion step (camera,
+ * NeRF W+, decoder W+ + decoder parameters: 125 tensors in 4 groups) are then 3 launches instead of 6. */
+typedef struct cips3d_adam_hyper { float lr, beta1, beta2, eps; int32_t step; } cips3d_adam_hyper;
+int cips3d_adam_step_groups(const cips3d_adam_entry* entries, const int* group_of, int n_entries, const cips3d_adam_hyper* hypers,
+                            int n_hypers, void* stream);
 
 /* The two squared-difference terms of the inversion loss (models/projector_v10.py:1173-1174:
  * `(target - synth).square().sum() * rgb_weight + (target_thumb - synth_thumb).square().sum() * thumb_weight`; with
@@ -908,6 +922,10 @@ typedef struct cips3d_decoder_grad_io {
   float* rgb;                /* forward: [B,3,Hf,Wf] */
   const float* d_rgb;        /* backward: gradient of rgb */
   float* d_features;         /* backward: [B, Cin0, H0, W0] or NULL */
+  /* optional (both or neither): the plan's style table re-pointed at the caller's own contiguous W+ tensor `styles`
+   * [B, n_latent, style_dim] -- forward and backward then read the styles where they are instead of from the plan's copy */
+  const cips3d_linear_desc* style_table;
+  const float* styles;
 } cips3d_decoder_grad_io;
 int cips3d_decoder_grad_forward(const cips3d_decoder_grad_plan* plan, const cips3d_decoder_grad_io* io, void* stream);
 int cips3d_decoder_grad_backward(const cips3d_decoder_grad_plan* plan, const cips3d_decoder_grad_io* io, void* stream);
@@ -983,6 +1001,9 @@ int cips3d_nerf_bwd_film_grad(float* buf, const float* pre, const float* film, i
 /* dptsn [B,3,P], dvd_pt [B,3,P] (d loss / d viewdir per point), ddnorm [B,R] -> dcam [B,3,4] */
 int cips3d_nerf_bwd_camera(const cips3d_nerf_bwd_geom* geom, const float* dptsn, const float* dvd_pt, const float* ddnorm,
                            float* dcam, void* stream);
+/* the same, ADDED to a dcam the caller has zeroed (cips3d_nerf_bwd_fused clears it in its preparation launch) */
+int cips3d_nerf_bwd_camera_acc(const cips3d_nerf_bwd_geom* geom, const float* dptsn, const float* dvd_pt, const float* ddnorm,
+                               float* dcam, void* stream);
 /* ---- NeRF half, fused backward (csrc/nerf_bwd_fused.hip): the same gradients as the sequence above -- d loss / d film
  * [B,L,2,H] and d loss / d cam_poses [B,3,4] from d_features [B,H,R] and d_thumb [B,3,R] -- with the point MLP kept in the
  * register file in both directions (the reference gets them from autograd through cips3d/volume_renderer.py:39-160 and

@@ -15,15 +15,18 @@ for r in rows[:40]:
 PY
 }
 python3 tools/bench_inversion.py --steps 104 > $O/bench_one_call.json 2> $O/bench.err; cat $O/bench_one_call.json
-CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0 python3 tools/bench_inversion.py --steps 104 > $O/bench_per_op.json 2>> $O/bench.err; cat $O/bench_per_op.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/bench_inversion.py --steps 44 > $O/kt.log 2>&1
+[ -n "$QUICK" ] || { CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0 python3 tools/bench_inversion.py --steps 104 > $O/bench_per_op.json 2>> $O/bench.err; cat $O/bench_per_op.json; }
+# (104 steps: the one-time launches of the run -- mean latents, weight packing, ~260 fills of the Adam state -- are ~3 per step of the average)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 tools/bench_inversion.py --steps 104 > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/inversion_kernel_stats.csv
-summ $O/inversion_kernel_stats.csv 44 > $O/inversion_summary.txt; head -30 $O/inversion_summary.txt
+summ $O/inversion_kernel_stats.csv 104 > $O/inversion_summary.txt; head -30 $O/inversion_summary.txt
+if [ -z "$QUICK" ]; then
 export CIPS3D_ONE_CALL_DECODER=0 CIPS3D_HIP_ADAM=0 CIPS3D_FUSED_ADAM=0
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt0 -- python3 tools/bench_inversion.py --steps 44 > $O/kt0.log 2>&1
 unset CIPS3D_ONE_CALL_DECODER CIPS3D_FUSED_ADAM CIPS3D_HIP_ADAM
 cp $(find $O/kt0 -name "*kernel_stats.csv" | head -1) $O/inversion_per_op_kernel_stats.csv
 summ $O/inversion_per_op_kernel_stats.csv 44 > $O/inversion_per_op_summary.txt; head -3 $O/inversion_per_op_summary.txt
+fi
 rocprofv3 --kernel-trace --output-format csv -d $O/tr -- python3 tools/bench_inversion.py --steps 24 > $O/tr.log 2>&1
 python3 - $(find $O/tr -name "*kernel_trace.csv" | head -1) > $O/inversion_step_trace.txt <<'PY'
 import csv, sys, re
