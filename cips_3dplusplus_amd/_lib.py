@@ -48,14 +48,6 @@ class ReduceJob(C.Structure):
                 ("n4", C.c_int64), ("HW4", C.c_int64), ("slot_stride", C.c_int64), ("n_slots", C.c_int32), ("n_bias", C.c_int32)]
 
 
-class PlanesLayer(C.Structure):
-    """cips3d_planes_layer: one layer of cips3d_modconv1x1_planes_seq (include/cips3d_hip.h)."""
-    _fields_ = [("x_planes", C.c_void_p), ("wm", C.c_void_p), ("out", C.c_void_p),
-                ("out_format", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("epilogue", C.c_int32),
-                ("noise", C.c_void_p), ("noise_bstride", C.c_int64), ("noise_w", C.c_void_p), ("bias", C.c_void_p),
-                ("rgb_w", C.c_void_p), ("rgb_part", C.c_void_p), ("rg", Range)]
-
-
 class AdamEntry(C.Structure):
     """cips3d_adam_entry (include/cips3d_hip.h)."""
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
@@ -137,7 +129,6 @@ _SIGS = {
                                         C.c_void_p]),
     "cips3d_modulate_table": (c_int, [C.c_void_p, c_int, c_int, c_int, c_f32, C.c_void_p]),
     "cips3d_absmax": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
-    "cips3d_modconv1x1_planes_seq": (c_int, [C.c_void_p, c_int, c_int, c_i64, C.c_void_p, C.c_void_p, c_int, C.c_void_p]),
     "cips3d_absmax_raise": (c_int, [c_f32p, c_int, c_i64, c_f32p, C.c_void_p]),
     "cips3d_amax_layout": (c_int, [C.POINTER(c_int), C.POINTER(c_int)]),
     "cips3d_split_words": (c_int, [c_f32p, c_f32, C.c_void_p, C.c_void_p, c_i64, C.c_void_p]),

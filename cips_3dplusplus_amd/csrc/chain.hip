@@ -112,135 +112,522 @@ struct ChainArgs {
 // NP = planes per operand: 2 = split-fp16 (hi, lo; three fp16 MFMAs per tile and k-block), 1 = bf16 (one bf16 MFMA)
 template <int WM, int WGM, int WGN, int BK, int NS, int NP = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[NS * (16 * WM * WGM * BK + BK * 64 * WGN) * NP / 2];
-#define CH_BX blockIdx.x
-#define CH_BY blockIdx.y
-#define CH_BZ blockIdx.z
-#define CH_GX gridDim.x
-#define CH_SEQ false
-#define CH_A0 false
-#include "chain_tile_body.h"
-#undef CH_BX
-#undef CH_BY
-#undef CH_BZ
-#undef CH_GX
-#undef CH_SEQ
-#undef CH_A0
-}
+#ifdef CIPS3D_CHAIN_STAMPS
+  unsigned long long ts_[6];
+  CSTAMP(0);
+#endif
+  constexpr int NW = WGM * WGN;
+  constexpr int BM = 16 * WM * WGM, BN = 64 * WGN;
+  constexpr int A_STAGE = BM * BK * NP / 2, B_STAGE = BK * BN * NP / 2, STAGE = A_STAGE + B_STAGE;   // floats (NP 2-byte planes)
+  constexpr int A_PIECES = A_STAGE / 256, B_PIECES = B_STAGE / 256, PIECES = A_PIECES + B_PIECES;
+  constexpr int PW = PIECES / NW;
+  constexpr int KB = BK / 32, KQ = KB * NP;      // KQ = 1 KB A pieces per o-tile and stage
+  static_assert(PIECES % NW == 0 && BK % 32 == 0, "tile shape");
+  static_assert(NP != 2 || BN == CIPS3D_PLANES_EXP_BLOCK, "one planes exponent per workgroup pixel block");
+  __shared__ __attribute__((aligned(16))) float lds[NS * STAGE];
 
-// One output tile (BM output channels x BN pixels of sample blk_z) of one layer as a step of chain_seq_kernel's walk through several
-// layers: the same body at an explicit grid position; its side outputs for the next layer (exponent, patch maxima) leave as
-// write-through stores like the planes themselves (a consumer on another CU reads them behind the hop's counter).
-template <int WM, int WGM, int WGN, int BK, int NS, int NP = 2>
-__device__ __forceinline__ void chain_tile(const ChainArgs& a, float* lds, const int blk_x, const int blk_y, const int blk_z,
-                                           const int grid_x, const bool a0_resident) {
-#define CH_BX blk_x
-#define CH_BY blk_y
-#define CH_BZ blk_z
-#define CH_GX grid_x
-#define CH_SEQ true
-#define CH_A0 a0_resident
-#include "chain_tile_body.h"
-#undef CH_BX
-#undef CH_BY
-#undef CH_BZ
-#undef CH_GX
-#undef CH_SEQ
-#undef CH_A0
-}
-
-// the weight pieces of K stage 0 of a layer into ring slot 0 (what chain_tile's stage_load(0) would request for them)
-template <int WM, int WGM, int WGN, int BK, int NP = 2>
-__device__ __forceinline__ void chain_prefetch_a0(const ChainArgs& a, float* lds, const int blk_y, const int blk_z) {
-  constexpr int NW = WGM * WGN, BM = 16 * WM * WGM, BN = 64 * WGN;
-  constexpr int A_STAGE = BM * BK * NP / 2, B_STAGE = BK * BN * NP / 2;
-  constexpr int A_PIECES = A_STAGE / 256, PIECES = A_PIECES + B_STAGE / 256, PW = PIECES / NW, KQ = (BK / 32) * NP;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int m0 = blk_y * BM, K = a.Cin;
-  const float* ab = a.wmp + (int64_t)blk_z * a.Cout * K * NP / 2;
-#pragma unroll
-  for (int j = 0; j < PW; ++j) {
-    const int piece = j * NW + wave;
-    if (piece < A_PIECES) {
-      const int ot_l = piece / KQ, kq_l = piece % KQ;
-      const char* ub = reinterpret_cast<const char*>(ab + ((((m0 >> 4) + ot_l) * ((K >> 5) * NP) + kq_l) * 256));
-      unsigned vo = lane * 16;
-      asm volatile("" : "+s"(ub), "+v"(vo));
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + vo),
-                                       (__attribute__((address_space(3))) void*)(lds + piece * 256), 16, 0, 0);
-    }
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Several consecutive layers of the run in ONE launch ("measure one hop").  A workgroup keeps its tile
-// position (pixel block x, 64-channel row block y, sample) through every layer.  Layer l + 1's tile reads ALL channels of its
-// own pixel block -- the tiles (x, 0 .. Cout/64 - 1) of layer l -- and nothing else of the activations, so the dependency is per
-// pixel-block COLUMN: one counter per (sample, x), no grid barrier.  Hop (MI355X_MICROARCH.md, inter-workgroup visibility, the form
-// with an acquire): every wave drains its write-through stores (s_waitcnt vmcnt(0)), workgroup barrier, one lane adds 1 to the
-// column's counter (agent scope); one lane polls it (relaxed, L1-bypassing) until all row blocks of the column have arrived,
-// agent-scope acquire fence (this CU's L1 invalidated), wait, barrier, next layer.  The next layer's first weight stage does not
-// depend on the hop and is requested in front of the poll.
-// Placement: the columns' workgroups are taken from the linear block id so that the Cout/64 workgroups of a column are 8 apart --
-// dealt to ONE XCD by the round-robin dispatch (their hand-off stays in that L2) -- and within 64 consecutive ids (progress needs
-// 64 co-resident workgroups, not the whole grid).
-// `sync`: [B][columns][2] int32, zero before the first launch; the last workgroup out of a column clears its two words again.
-// ------------------------------------------------------------------------------------------------
-constexpr int CHAIN_SEQ_MAX = 10;
-struct ChainSeqArgs {
-  ChainArgs layer[CHAIN_SEQ_MAX];
-  int n_layers;
-  int cols, rows;            // the common grid of the layers: pixel blocks, 64-channel row blocks
-  int* sync;
-  int* fault;                // set to 1 when a poll gave up (a co-residency assumption failed): the outputs are then garbage
-  int prefetch_a;            // != 0: the next layer's first weight stage is requested in front of the poll (A/B)
-};
-
-template <int WM, int WGM, int WGN, int BK, int NS>
-__global__ void __launch_bounds__(64 * WGM * WGN) chain_seq_kernel(ChainSeqArgs s) {
-  constexpr int STAGE_FLOATS = (16 * WM * WGM * BK + BK * 64 * WGN) * 2 / 2;
-  __shared__ __attribute__((aligned(16))) float lds[NS * STAGE_FLOATS];
   const int tid = threadIdx.x;
-  const int bz = blockIdx.z;
-  // linear id -> (column, row): id = 64 g + 8 y + c8  ->  column 8 g + c8, row y   (rows == 8, cols % 8 == 0: checked by the host)
-  const int id = blockIdx.x;
-  const int bx = 8 * (id >> 6) + (id & 7), by = (id >> 3) & 7;
-  int* cnt = s.sync + ((int64_t)bz * s.cols + bx) * 2;
-  bool a0 = false;
-  for (int l = 0; l < s.n_layers; ++l) {
-    chain_tile<WM, WGM, WGN, BK, NS, 2>(s.layer[l], lds, bx, by, bz, s.cols, a0);
-    if (l + 1 == s.n_layers) break;
-    // ---- hop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's write-through stores have been acknowledged
-    __syncthreads();                                     // ... and every wave's; nobody reads the ring any more
-    a0 = s.prefetch_a != 0 && !s.layer[l].rgb_part;      // (a ToRGB fold exchanges its partial sums through ring slot 0)
-    if (a0) chain_prefetch_a0<WM, WGM, WGN, BK, 2>(s.layer[l + 1], lds, by, bz);
-    if (tid == 0) {
-      typedef __attribute__((address_space(1))) int gi32_t;
-      gi32_t* c = reinterpret_cast<gi32_t*>(reinterpret_cast<uintptr_t>(cnt));
-      __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int want = s.rows * (l + 1);
-      int spins = 0;
-      while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        __builtin_amdgcn_s_sleep(2);
-        if (++spins > (1 << 22)) { *s.fault = 1; break; }      // (~1 s: a row block of this column never became resident)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int wm_i = wave / WGN, wn_i = wave % WGN;
+  const int q = lane >> 4, col = lane & 15;
+  const int b = blockIdx.z;
+
+  // The riding ToRGB fold (cips3d_reduce_job): one extra row of workgroups (blockIdx.y == Cout / BM) that the host adds to the
+  // grid of a launch that leaves CUs free (the 512 -> 256 exit of the 64^2 run: 128 tiles).  As in torgb_reduce_kernel a float4
+  // position is shared by four slot groups (group g adds slots g, g + 4, ... in that order, absent ones of a batch of four as
+  // zeros; then the groups 0 .. 3, the biases, the skip): here the groups are the lane quarters of a wave, 16 positions per wave.
+  if constexpr (NP == 2) {
+    if (a.ride.part && (int)blockIdx.y == a.Cout / BM) {
+      constexpr int RIDE_K = 12;                 // loads per lane: n_slots <= 4 * RIDE_K
+      const int64_t wv = ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * NW + wave;
+      const int64_t ride_i = wv * 16 + col;
+      const bool ride_on = ride_i < a.ride.n4;
+      f32x4 rsl[RIDE_K], rsk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < RIDE_K; ++k)
+        rsl[k] = (ride_on && q + 4 * k < a.ride.n_slots)
+                     ? *reinterpret_cast<const f32x4*>(a.ride.part + (q + 4 * k) * a.ride.slot_stride + ride_i * 4)
+                     : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ride_on && a.ride.skip && q == 0) rsk = *reinterpret_cast<const f32x4*>(a.ride.skip + ride_i * 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int it = 0; it < RIDE_K / 4; ++it)
+        if (q + 16 * it < a.ride.n_slots) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += rsl[4 * it + u][c];
+        }
+#pragma unroll
+      for (int g = 1; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float o = __shfl(v[c], col + 16 * g, 64);
+          if (q == 0) v[c] += o;
+        }
+      if (ride_on && q == 0) {
+        const int ch = (int)((ride_i / a.ride.HW4) % 3);
+        float bs = 0.f;
+        for (int k = 0; k < a.ride.n_bias; ++k) bs += a.ride.bias[k][ch];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] += bs;
+        if (a.ride.skip) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += rsk[c];
+        }
+        *reinterpret_cast<f32x4*>(a.ride.out + ride_i * 4) = v;
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      return;
     }
-    __syncthreads();
   }
-  // ---- leave the column's words zeroed for the next launch: the last of its workgroups out clears them
-  if (s.n_layers > 1) {
-    __syncthreads();
-    if (tid == 0) {
-      typedef __attribute__((address_space(1))) int gi32_t;
-      gi32_t* c = reinterpret_cast<gi32_t*>(reinterpret_cast<uintptr_t>(cnt));
-      if (__hip_atomic_fetch_add(c + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s.rows - 1) {
-        __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(c + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int HW = a.HW, K = a.Cin;
+  const int nstage = K / BK;
+  // 4 * NW LDS words for the workgroup reductions after the main loop (max|in| of the pixel block; max|out| of an fp32 exit).
+  // They live in the ring slot the LAST K stage does not use -- dead for every wave once it is past that stage's barrier.  (A
+  // separate __shared__ array moved the ring off LDS offset 0 and rounded the allocation up past 96 KB: every layer of the
+  // run was 2.3 us, 20 %, slower for it.)
+  float* s_part = lds + (nstage % NS) * STAGE;
+  const _Float16* xb = a.x + (int64_t)b * K * HW * NP;           // (Cin/8) * NP planes * HW * 8 two-byte elements
+  const float* ab = a.wmp + (int64_t)b * a.Cout * K * NP / 2;   // 2-byte elements, NP planes
+
+  auto stage_load = [&](int st) {
+    float* dstA = lds + (st % NS) * STAGE;
+    float* dstB = dstA + A_STAGE;
+    const int k0 = st * BK;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const int piece = j * NW + wave;
+      // (saddr form of the LDS-DMA: a uniform base advanced on the scalar unit + a 32-bit lane offset, both made opaque so that
+      // instruction selection sees base + zext(offset) -- with per-lane 64-bit pointers every piece first needed a
+      // v_lshl_add_u64 into the register pair the previous piece was still issuing from)
+      if (piece < A_PIECES) {
+        const int ot_l = piece / KQ, kq_l = piece % KQ;
+        const char* ub = reinterpret_cast<const char*>(ab + ((((m0 >> 4) + ot_l) * ((K >> 5) * NP) + (k0 >> 5) * NP + kq_l) * 256));
+        unsigned vo = lane * 16;
+        asm volatile("" : "+s"(ub), "+v"(vo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + vo),
+                                         (__attribute__((address_space(3))) void*)(dstA + piece * 256), 16, 0, 0);
+      } else {
+        const int pb = piece - A_PIECES;
+        const int row = pb / (BN / 64), chunk = pb % (BN / 64);     // row = (channel block of the stage) * NP + plane
+        int n = n0 + chunk * 64 + lane;
+        if (n > HW - 1) n = HW - 1;                                  // clamp: those columns are never stored
+        const char* ub = reinterpret_cast<const char*>(xb + ((int64_t)((k0 >> 3) * NP + row) * HW) * 8);
+        unsigned vo = (unsigned)n * 16u;
+        asm volatile("" : "+s"(ub), "+v"(vo));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + vo),
+                                         (__attribute__((address_space(3))) void*)(dstB + pb * 256), 16, 0, 0);
       }
+    }
+  };
+
+  // this lane's four pixels: 16 c + col of the wave's 64-pixel strip (c = MFMA column tile)
+  const int nl = wn_i * 64 + col;
+  int npx[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) npx[c] = n0 + nl + 16 * c;
+
+  float nz[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bias4[WM];
+  f32x4 wrgb[WM][3];
+  float nw = 0.f;
+  float kin = NP == 2 ? kSplitInv : 1.f;     // accumulator -> true value: the weights' 2^-8 and the input planes' 2^e
+  float kout = 1.f, kback = 1.f;             // true value -> what this launch stores (2^-e' for a planes output) and back
+  float lc0 = 0.f, lc1 = 0.f;                // the layer's bound constants (planes output)
+  float pin = 0.f;                           // this lane's entries of the input's patch maxima (planes output)
+  // a planes output under range tracking: the exponent follows from max|in| of this pixel block and the layer's constants
+#ifndef CIPS3D_CHAIN_AB
+#define CIPS3D_CHAIN_AB 0        // timing-only ablations: 1 no range work at all, 2 no patch-maxima store, 3 no patch-maxima load
+#endif
+  const bool track = CIPS3D_CHAIN_AB != 1 && NP == 2 && a.out_fmt == 1 && a.lconst;
+  // The epilogue's operands are REQUESTED here (pure loads into registers, right behind the first stage's LDS-DMA) and only
+  // turned into what the epilogue needs after the main loop (finish_ops).  Round 5: in the old form -- loads and their arithmetic
+  // interleaved -- `a.x_exp ? a.x_exp[..] : a.x_exp_const` became ONE flat load of a selected address (array or kernarg word), a
+  // flat load's result needs vmcnt(0), and that wait sat in front of every other operand load: the whole first stage had to land
+  // before the remaining ~5 dependent round trips (bound constants, patch maxima, noise, bias, ToRGB rows) even started --
+  // 1-2 us per launch in front of the main loop.
+#ifndef CIPS3D_CHAIN_LATE_OPS
+#define CIPS3D_CHAIN_LATE_OPS 1     // 0: finish_ops right behind issue_ops, as before round 5 (A/B)
+#endif
+  int e_raw = 0;
+  f32x4 lc_raw = {0.f, 0.f, 0.f, 0.f};
+  auto issue_ops = [&]() {
+    if constexpr (NP == 2) {
+      const int nblk = (HW + BN - 1) / BN;
+      if (a.x_exp) {        // (an agent-scope relaxed load: a plain global load the compiler cannot fold into a select of addresses)
+        typedef const __attribute__((address_space(1))) int gi32_t;
+        e_raw = __hip_atomic_load(reinterpret_cast<gi32_t*>(reinterpret_cast<uintptr_t>(a.x_exp + b * nblk + blockIdx.x)),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (track) {
+        const float* lc = a.lconst + b * 4;
+        lc_raw = f32x4{lc[0], lc[1], lc[2], 0.f};
+        if (a.x_pmax && CIPS3D_CHAIN_AB != 3) {      // the 2 x Cin/16 patch maxima of this pixel block are contiguous: one load per wave (Cin <= 512)
+          const int n_half = (HW + 63) / 64, per = K >> 4;
+          const int n_ent = (2 * (int)blockIdx.x + 1 < n_half ? 2 : 1) * per;
+          const float* pp = a.x_pmax + ((int64_t)b * n_half + 2 * blockIdx.x) * per;
+          if (lane < n_ent) pin = pp[lane];        // (entries past the first 64 -- Cin > 512 only -- follow in finish_ops)
+        }
+      }
+    }
+    if (a.epilogue == 1) {
+      if (a.noise && a.noise_w) {
+        nw = a.noise_w[0];
+        const float* nzp = a.noise + (int64_t)b * a.noise_bstride;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (npx[c] < HW) nz[c] = nzp[npx[c]];
+      }
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+        bias4[i] = *reinterpret_cast<const f32x4*>(a.bias + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    }
+    if (a.rgb_part) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+          wrgb[i][ch] = *reinterpret_cast<const f32x4*>(a.rgb_w + (int64_t)b * 3 * a.Cout + ch * a.Cout + m0 + (wm_i * WM + i) * 16 + 4 * q);
+    }
+  };
+  auto finish_ops = [&]() {
+    if constexpr (NP == 2) {
+      const int e_in = a.x_exp ? __builtin_amdgcn_readfirstlane(e_raw) : a.x_exp_const;
+      kin = cips3d_uniform(kin * cips3d_pow2(e_in));
+      if (track) {
+        lc0 = lc_raw[0];
+        lc1 = fmaxf(lc_raw[1], 1.41421356237309515f * lc_raw[2]);
+        if (a.x_pmax && CIPS3D_CHAIN_AB != 3) {
+          const int n_half = (HW + 63) / 64, per = K >> 4;
+          const int n_ent = (2 * (int)blockIdx.x + 1 < n_half ? 2 : 1) * per;
+          const float* pp = a.x_pmax + ((int64_t)b * n_half + 2 * blockIdx.x) * per;
+          for (int i = lane + 64; i < n_ent; i += 64) pin = fmaxf(pin, pp[i]);
+        } else {
+          // no patch maxima: the caller's constant, or what the input's own exponent says -- its producer put a bound of ITS
+          // output below 2^15 2^e_in.  That is a bound of a bound (another ~2^5 of slack: the stored values then top out near
+          // 2^5 instead of 2^10, still > 27 bits above the pair's floor), so a run alternates: every other layer leaves patch
+          // maxima for its consumer (forward.hip), which halves what the tracking costs (0.45 us per writing layer)
+          pin = a.x_max_const > 0.f ? a.x_max_const : cips3d_pow2(e_in + 15);
+        }
+      }
+    }
+  };
+  auto load_ops = [&]() {
+    issue_ops();
+    if (!CIPS3D_CHAIN_LATE_OPS) finish_ops();
+  };
+  f32x4 acc[WM][4];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[i][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Ring of NS stages, loads NS - 1 stages ahead; the epilogue's operand loads go out first (older than every stage, so the
+  // first counted wait retires them).  What bounds this kernel (in-kernel stamps, tools/chain_stamps.py, 512 -> 512 at 64^2):
+  // 3.1k cycles to the first landed stage, 12.6k for the 8 K stages, 2.5k epilogue -- and inside a stage ~1000 cycles of
+  // waiting for the stage's data against ~450 of DMA issue and ~350 of fragment reads + MFMA issue.  A third ring slot,
+  // 32-deep stages with 4 or 6 slots, and issuing the DMA behind the MFMAs (all waves, or only the SIMD partners) change
+  // nothing or lose: the loop moves 48 KB per stage and CU in ~1600 cycles = 30 B/clk per CU = 18 TB/s chip-wide, which is
+  // the L2 -> LDS gather rate of this part (MI355X_MICROARCH.md, "Indexed rows: gather into LDS": 66-73 GB/s per CU).  The
+  // launch is bound by L2 -> CU bandwidth for its 384 KB of operand tiles per CU, not by latency and not by the matrix pipe.
+  // (Round 6: the run as ONE persistent launch -- this body as the per-layer step of a multi-layer kernel, one counter per pixel-block
+  // column between layers, bit-identical results -- was built and measured: a hop cost 2.2-2.4 us where a launch boundary between two
+  // of these kernels costs 0.7 us (nine layers 118.2 us in one launch, 104.6 us as nine).  Commit 47e2af1 has the kernel,
+  // profiles/r06_chain_seq_hop.jsonl the numbers; it is not in the tree.)
+  // (It is the CU's whole L2 port, not the LDS-DMA path: with the A fragments loaded global -> registers directly, one stage
+  // ahead, and only the B tile through the ring -- half the DMA bytes, parity-green -- a layer took 11.48 us against 11.34.)
+  static_assert(NS >= 2 && (NS - 2) * PW <= 63, "counted vmcnt");
+  // (NS = 2: the operand loads ride BEHIND the first stage's DMA -- the loop's first wait is vmcnt(0) anyway, and in front
+  // of it they delayed the first stage: 0.367 -> 0.384 ms per forward; deeper rings: in front, older than every counted stage)
+  if (NS > 2) load_ops();
+#pragma unroll
+  for (int s0 = 0; s0 < NS - 1; ++s0)
+    if (s0 < nstage) stage_load(s0);
+  if (NS == 2) load_ops();
+
+#ifdef CIPS3D_CHAIN_STAMPS
+  unsigned long long ph_[4] = {0, 0, 0, 0}, tp_ = __builtin_amdgcn_s_memtime();
+#define PSTAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ph_[i] += t_ - tp_; tp_ = t_; } while (0)
+#else
+#define PSTAMP(i)
+#endif
+  for (int st = 0; st < nstage; ++st) {
+    int younger = nstage - 1 - st;
+    if (younger > NS - 2) younger = NS - 2;
+    // stage st has landed when at most the `younger` stages issued after it are still in flight
+    switch (younger) {
+      case 0: __builtin_amdgcn_s_waitcnt(vmcnt_imm(0)); break;
+      case 1: __builtin_amdgcn_s_waitcnt(vmcnt_imm(PW)); break;
+      case 2: __builtin_amdgcn_s_waitcnt(vmcnt_imm(2 * PW)); break;
+      case 3: __builtin_amdgcn_s_waitcnt(vmcnt_imm(3 * PW)); break;
+      case 4: __builtin_amdgcn_s_waitcnt(vmcnt_imm(4 * PW)); break;
+      default: __builtin_amdgcn_s_waitcnt(vmcnt_imm(5 * PW)); break;
+    }
+    __builtin_amdgcn_s_barrier();
+#ifdef CIPS3D_CHAIN_STAMPS
+    if (st == 0) CSTAMP(1);          // first stage landed
+#endif
+    if (st + NS - 1 < nstage) stage_load(st + NS - 1);
+    PSTAMP(1);                         // DMA issue
+    const float* sA = lds + (st % NS) * STAGE;
+    const float* sB = sA + A_STAGE;
+    if constexpr (NP == 2) {
+      h8 ah[KB][WM], al[KB][WM], bh[KB][4], bl[KB][4];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          ah[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb) * 256 + lane * 4);
+          al[kb][i] = *reinterpret_cast<const h8*>(sA + ((wm_i * WM + i) * KQ + 2 * kb + 1) * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {      // row (4 kb + q) * 2 + plane, pixel nl + 16 c: [row][BN px][4 floats]
+          bh[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 0) * BN + nl + 16 * c) * 4);
+          bl[kb][c] = *reinterpret_cast<const h8*>(sB + (((kb * 4 + q) * 2 + 1) * BN + nl + 16 * c) * 4);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bl[kb][c], acc[i][c], 0, 0, 0);
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kb][i], bh[kb][c], acc[i][c], 0, 0, 0);
+          }
+    } else {
+      bf8 af[KB][WM], bf[KB][4];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          af[kb][i] = *reinterpret_cast<const bf8*>(sA + ((wm_i * WM + i) * KQ + kb) * 256 + lane * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)        // row 4 kb + q (channel block), pixel nl + 16 c
+          bf[kb][c] = *reinterpret_cast<const bf8*>(sB + ((kb * 4 + q) * BN + nl + 16 * c) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            acc[i][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb][i], bf[kb][c], acc[i][c], 0, 0, 0);
+    }
+    PSTAMP(2);                         // fragment reads + MFMA issue
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  CSTAMP(2);                         // main loop
+  if (CIPS3D_CHAIN_LATE_OPS) finish_ops();
+  if (track) {
+    // max|in| of the pixel block from the lanes' entries (wave-uniform, no LDS), the bound, the exponent, its powers of two
+    const float m_in = cips3d_wave_max_uniform(pin);
+    const int e = cips3d_split_exp(fmaf(lc1, m_in * 1.000001f, lc0));
+    kout = cips3d_uniform(cips3d_pow2(-e));
+    kback = cips3d_uniform(cips3d_pow2(e));
+    if (blockIdx.y == 0 && tid == 0) a.out_exp[b * ((HW + BN - 1) / BN) + blockIdx.x] = e;
+  }
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 4)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // probe: every load of this wave -- the epilogue's operands -- has returned
+#endif
+  // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
+  float prgb[3][4];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
+  // v below is the STORED value, out * kout (kout = 1 unless the output is planes): the power of two rides on the constants
+  // the epilogue multiplies by anyway, the ToRGB partial sums and the recorded maximum are taken from v and scaled back once
+  const float kact = 1.41421356237309515f * kout;
+  const float kpre = a.epilogue == 1 ? kin : kin * kout;      // (one uniform multiplier: no branch per value)
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+    const int obase = m0 + (wm_i * WM + i) * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[i][c][r] * kpre;
+        if (a.epilogue == 1) v[r] = lrelu02(fmaf(nw, nz[c], v[r]) + bias4[i][r]) * kact;
+      }
+      // (columns past HW repeat the last pixel without its noise: a value the patch maximum may include -- it only has to bound)
+      mx = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fmaxf(fabsf(v[2]), fabsf(v[3])), mx));
+#if CIPS3D_FOLD_PK == 3
+      // probe (tools/pk_fold_probe.sh, round 5): EXACTLY the four instruction forms hipcc's SLP build emits for one column (read
+      // off its assembly: profiles/r05_slp_fold_isa.md) -- r = 0: v_pk_fma_f32 D, W, V01, 0 op_sel_hi:[1,0,0] (fresh accumulator,
+      // inline constant 0, broadcast of the pair's low register); r = 1: ... V01 ... op_sel:[0,1,0] (broadcast of the pair's HIGH
+      // register); r = 2, 3: op_sel_hi:[1,0,1] -- round 4's hand-written probe covered only the last form.  CIPS3D_FOLD_FORMS
+      // masks which of the first two are used (bit 0: r = 0, bit 1: r = 1); a cleared bit falls back to the last form.
+#ifndef CIPS3D_FOLD_FORMS
+#define CIPS3D_FOLD_FORMS 3
+#endif
+      if (a.rgb_part) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+        const f32x2_t v01 = {v[0], v[1]}, v23 = {v[2], v[3]}, v1x = {v[1], 0.f}, v3x = {v[3], 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+        const f32x2_t w0 = {wrgb[i][1][0], wrgb[i][2][0]}, w1 = {wrgb[i][1][1], wrgb[i][2][1]}, w2 = {wrgb[i][1][2], wrgb[i][2][2]},
+                      w3 = {wrgb[i][1][3], wrgb[i][2][3]};
+        if ((CIPS3D_FOLD_FORMS & 1) && i == 0) {
+          // (the compiler's first instruction starts the accumulator: prgb is zero before the first row tile)
+          asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(p12) : "v"(w0), "v"(v01));
+        } else {
+          asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w0), "v"(v01));
+        }
+        if (CIPS3D_FOLD_FORMS & 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(p12) : "v"(w1), "v"(v01));
+        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w1), "v"(v1x));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w2), "v"(v23));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w3), "v"(v3x));
+        prgb[1][c] = p12[0];
+        prgb[2][c] = p12[1];
+      }
+#elif CIPS3D_FOLD_PK == 2
+      // probe (tools/pk_fold_probe.sh): the SLP build's instruction pattern written by hand -- channel 0 as v_fmac_f32, channels
+      // 1 / 2 as ONE register pair per product assembled by two v_mov_b32 into fixed registers and consumed by v_pk_fma_f32 with
+      // an op_sel_hi broadcast of v[r] -- with CIPS3D_FOLD_NOP wait states between the v_movs and the packed instruction
+      if (a.rgb_part) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+          const f32x2_t vb = {v[r], 0.f};
+          asm volatile("v_mov_b32 v126, %1\n\tv_mov_b32 v127, %2\n\t"
+                       ".if %4 > 0\n\ts_nop %4 - 1\n\t.endif\n\t"
+                       "v_pk_fma_f32 %0, v[126:127], %3, %0 op_sel_hi:[1,0,1]"
+                       : "+v"(p12) : "v"(wrgb[i][1][r]), "v"(wrgb[i][2][r]), "v"(vb), "n"(CIPS3D_FOLD_NOP) : "v126", "v127");
+        }
+        prgb[1][c] = p12[0];
+        prgb[2][c] = p12[1];
+      }
+#else
+      if (a.rgb_part) {
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 2)
+        asm volatile("s_nop 7\n\ts_nop 7");          // probe: distance between the producers of v[] and the packed chain
+#endif
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            // one v_fmac_f32 per product, written out: nothing can pair the channel-1 / channel-2 accumulations into
+            // v_pk_fma_f32 (see the build note in the header of this file; VALU results feed VALU here: no hazard state to keep)
+#if CIPS3D_FOLD_PK        /* reproducer builds only (tools/pk_fold_probe.sh): the C form SLP packs */
+            prgb[ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[ch][c]);
+#else
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[ch][c]) : "v"(wrgb[i][ch][r]), "v"(v[r]));
+#endif
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 1)
+        asm volatile("s_nop 7\n\ts_nop 7");          // probe: distance between the packed chain and whatever follows it
+#endif
+      }
+#endif
+      if (npx[c] < HW) {
+        if (a.out_fmt == 1) {
+          // planes: channels obase + 4 q + r live in channel block (obase >> 3) + (q >> 1), elements 4 (q & 1) + r
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          unsigned h0, l0, h1, l1;
+          cips3d_split_pair(v[0], v[1], h0, l0);
+          cips3d_split_pair(v[2], v[3], h1, l1);
+          const h4 hi = __builtin_bit_cast(h4, u32x2_t{h0, h1}), lo = __builtin_bit_cast(h4, u32x2_t{l0, l1});
+          _Float16* dst = reinterpret_cast<_Float16*>(a.out) +
+                          ((((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * 2) * HW + npx[c]) * 8 + 4 * (q & 1);
+          cips3d_store_wt8(dst, hi);                      // (write-through: common.h)
+          cips3d_store_wt8(dst + (int64_t)HW * 8, lo);
+        } else if (a.out_fmt == 3) {
+          // planes16: the same channel block / element positions, one bf16 plane (round to nearest even: the operand rounding
+          // of the bf16 mode)
+          unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) +
+                                (((int64_t)b * (a.Cout >> 3) + (obase >> 3) + (q >> 1)) * HW + npx[c]) * 8 + 4 * (q & 1);
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const bf16x2_t p0 = __builtin_convertvector(f32x2_t{v[0], v[1]}, bf16x2_t);
+          const bf16x2_t p1 = __builtin_convertvector(f32x2_t{v[2], v[3]}, bf16x2_t);
+          cips3d_store_wt8(dst, u32x2_t{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1)});
+        } else if (a.out_fmt == 2) {
+          unsigned short* dst = reinterpret_cast<unsigned short*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const bf16x2_t p = __builtin_convertvector(f32x2_t{v[r], v[r + 1]}, bf16x2_t);
+            const unsigned bits = __builtin_bit_cast(unsigned, p);
+            dst[(int64_t)r * HW] = (unsigned short)(bits & 0xffffu);
+            dst[(int64_t)(r + 1) * HW] = (unsigned short)(bits >> 16);
+          }
+        } else {
+          float* dst = reinterpret_cast<float*>(a.out) + ((int64_t)b * a.Cout + obase + 4 * q) * HW + npx[c];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cips3d_store_wt(dst + (int64_t)r * HW, v[r]);
+        }
+      }
+    }
+  }
+#ifdef CIPS3D_CHAIN_STAMPS
+  CSTAMP(3);                         // epilogue arithmetic + stores issued
+  __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
+  CSTAMP(4);                         // stores acknowledged
+  if (tid == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_chain_stamps[i], ts_[i + 1] - ts_[i]);
+    atomicAdd(&g_chain_stamps[7], 1ull);
+    atomicAdd(&g_chain_stamps[4], ph_[0]);
+    atomicAdd(&g_chain_stamps[5], ph_[1]);
+    atomicAdd(&g_chain_stamps[6], ph_[2]);
+  }
+#endif
+  if (CIPS3D_CHAIN_AB != 1 && CIPS3D_CHAIN_AB != 2 && a.out_pmax && n0 + wn_i * 64 < HW) {
+    // this wave's patch (16 WM channels x 64 pixels): its largest |out|, one plain store per 16 channels
+    static_assert(BN == 64 * WGN, "a wave column = one 64-pixel half block");
+    const float m = cips3d_wave_max_uniform(mx * kback);
+    if (lane < WM)
+      a.out_pmax[((int64_t)b * ((HW + 63) / 64) + (n0 >> 6) + wn_i) * (a.Cout >> 4) + (m0 >> 4) + wm_i * WM + lane] = m;
+  }
+  if (a.out_amax) {        // fp32 / bf16 exit: the workgroup's largest |out| raises one slot of the sample's amax array
+    const float m = cips3d_workgroup_max(mx * kback, s_part, wave, lane, NW);
+    if (tid == 0) cips3d_amax_raise_if(a.out_amax + b * CIPS3D_AMAX_FLOATS, m, blockIdx.y * gridDim.x + blockIdx.x);
+  }
+  if (!a.rgb_part) return;
+#if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 8)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // probe: nothing of this wave in flight, then everybody here
+  __syncthreads();
+#endif
+  // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
+  // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v = prgb[ch][c] * kback;
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      prgb[ch][c] = v;
+    }
+  __syncthreads();
+  float* s_red = lds;                                   // [WGM][3][BN]
+  if (q == 0) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_red[(wm_i * 3 + ch) * BN + nl + 16 * c] = prgb[ch][c];
+  }
+  __syncthreads();
+  if (wm_i == 0 && q < 3) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (npx[c] >= HW) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int m = 0; m < WGM; ++m) v += s_red[(m * 3 + q) * BN + nl + 16 * c];
+      cips3d_store_wt(a.rgb_part + ((int64_t)blockIdx.y * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c]), v);
     }
   }
 }
@@ -455,37 +842,5 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
   if (cfg == 1) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 3>), grid, dim3(512), 0, as_stream(stream), a);
   else if (cfg == 2) hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 32, 4>), grid, dim3(512), 0, as_stream(stream), a);
   else hipLaunchKernelGGL((chain_gemm_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), a);
-  return cips3d_launch_status();
-}
-
-// Several consecutive planes layers in one launch (chain_seq_kernel): layers[l + 1].x_planes == layers[l].out etc. is the caller's
-// business; every layer is a planes -> planes GEMM of the same grid (Cout == 512 -> 8 row blocks, ceil(HW / 128) % 8 == 0 pixel
-// blocks) with range tracking as cips3d_modconv1x1_planes takes it (rg.ride unsupported).
-extern "C" int cips3d_modconv1x1_planes_seq(const cips3d_planes_layer* layers, int n_layers, int B, int64_t HW, int32_t* sync,
-                                            int32_t* fault, int flags, void* stream) {
-  if (!layers || n_layers < 1 || n_layers > CHAIN_SEQ_MAX || B < 0 || HW <= 0 || !sync || !fault) return CIPS3D_E_BADARG;
-  if (B == 0) return 0;
-  ChainSeqArgs s{};
-  s.n_layers = n_layers;
-  s.cols = (int)ceil_div<int64_t>(HW, 128);
-  s.rows = 8;
-  s.sync = sync;
-  s.fault = fault;
-  s.prefetch_a = (flags & 1) ? 1 : 0;
-  if (s.cols % 8 != 0) return CIPS3D_E_UNSUPP;
-  for (int l = 0; l < n_layers; ++l) {
-    const cips3d_planes_layer& L = layers[l];
-    if (!L.x_planes || !L.wm || !L.out || L.Cin <= 0 || L.Cout <= 0 || (L.rgb_w == nullptr) != (L.rgb_part == nullptr) ||
-        (L.epilogue != 0 && L.epilogue != 1) || (L.epilogue == 1 && !L.bias))
-      return CIPS3D_E_BADARG;
-    if (L.out_format != 1 || L.Cout != 64 * s.rows || !cips3d_planes_supported(L.Cin, L.Cout, HW) || L.rg.ride) return CIPS3D_E_UNSUPP;
-    if (!L.rg.lconst || !L.rg.out_exp) return CIPS3D_E_BADARG;
-    if (L.rg.x_pmax && L.Cin > 512) return CIPS3D_E_UNSUPP;
-    s.layer[l] = ChainArgs{reinterpret_cast<const _Float16*>(L.x_planes), L.wm, L.out, 1, B, L.Cin, L.Cout, (int)HW, L.epilogue, L.noise,
-                           L.noise_bstride, L.noise_w, L.bias, L.rgb_w, L.rgb_part, L.rg.x_exp, L.rg.x_exp_const, L.rg.x_pmax,
-                           L.rg.x_max_const, L.rg.lconst, nullptr, L.rg.out_exp, L.rg.out_pmax, cips3d_reduce_job{}};
-  }
-  dim3 grid((unsigned)(s.cols * s.rows), 1u, (unsigned)B);
-  hipLaunchKernelGGL((chain_seq_kernel<1, 4, 2, 64, 2>), grid, dim3(512), 0, as_stream(stream), s);
   return cips3d_launch_status();
 }

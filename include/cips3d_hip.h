@@ -484,23 +484,6 @@ int cips3d_fused_up_conv(const float* y_lo, const float* fir, const float* noise
 /* (rg, CIPS3D_GEMM_SPLIT mode: x_amax = amax of y_lo, lconst = conv1's constants, lconst2 = conv2's; next_amax <- max |y_next|.
  * out2 is not tracked -- the register budget of the C = 32 stage; use cips3d_absmax before a split GEMM reads a stored out2) */
 
-/* Several consecutive layers of a split-planes run in ONE launch (csrc/chain.hip: chain_seq_kernel): layer l + 1 reads layer l's
- * planes, exponents and patch maxima behind a per-pixel-block counter instead of behind a launch boundary.  Every layer is what
- * cips3d_modconv1x1_planes computes for (x_planes, wm, out, out_format = 1, ..., rg) -- bit for bit -- with Cout == 512 and
- * ceil(HW / 128) % 8 == 0 (CIPS3D_E_UNSUPP otherwise); rg.ride is not supported.  n_layers <= 10.
- * sync: [B][ceil(HW / 128)][2] int32, zero before the first call; every call leaves it zeroed.  fault: one int32 the kernel sets
- * to 1 if a hop's poll gave up (the launch's workgroups were not co-resident: outputs invalid); the caller zeroes and checks it.
- * flags bit 0: request the next layer's first weight stage in front of the hop's poll. */
-typedef struct cips3d_planes_layer {
-  const void* x_planes; const float* wm; void* out;
-  int32_t out_format, Cin, Cout, epilogue;
-  const float* noise; int64_t noise_bstride; const float* noise_w; const float* bias;
-  const float* rgb_w; float* rgb_part;
-  cips3d_range rg;
-} cips3d_planes_layer;
-int cips3d_modconv1x1_planes_seq(const cips3d_planes_layer* layers, int n_layers, int B, int64_t HW, int32_t* sync, int32_t* fault,
-                                 int flags, void* stream);
-
 /* General k x k modulated convolution (k odd, padding k/2), direct form; used for k = 3 configs.
  * transpose2 = 1 computes conv_transpose2d(stride 2, padding 0): out is (2H-1+k-1)^2. */
 int cips3d_modconv_kxk(const float* x, const float* wm, float* out, int B, int Cin, int Cout,
