@@ -169,7 +169,7 @@ _SIGS = {
     "cips3d_rng_words": (c_int, [C.c_uint64, C.c_uint64, C.c_void_p, c_i64, C.c_void_p]),
     "cips3d_modconv3x3_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "cips3d_modconv3x3": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_int, c_int, c_int, c_f32p, c_int, c_f32p,
-                                  c_i64, c_f32p, c_f32p, C.c_void_p]),
+                                  c_i64, c_f32p, c_f32p, C.c_void_p, C.c_void_p]),
     "cips3d_rays_in_world": (c_int, [c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "cips3d_z_vals": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),
     "cips3d_z_vals_stratified": (c_int, [c_f32p, c_f32p, c_f32p, c_int, c_int, c_int, c_f32p, C.c_void_p]),

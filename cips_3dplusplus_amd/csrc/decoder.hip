@@ -212,6 +212,24 @@ __device__ __forceinline__ void modulate_row(const float* __restrict__ W, const 
       auto* blk = cips3d_g(reinterpret_cast<_Float16*>(wm_)) + ((((int64_t)b * (Cin >> 4) + (i >> 4)) * (Cout >> 5) + (o >> 5)) * 1024);
       blk[((q << 4) | (i & 15)) * 8 + j] = hi;
       blk[512 + ((q << 4) | (i & 15)) * 8 + j] = lo;
+    } else if ((packed & 16) && ksq > 1) {     // split-fp16 tap-PAIR fragments of the 3x3 kernel (conv3x3.hip: modconv3x3_split_kernel)
+      // [b][pair 5][o-tile][16-channel stage][hi | lo][lane][8]: lane quarter q holds channels 8 (q & 1) .. + 7 of tap 2 pair + (q >> 1)
+      const int i = e / ksq;
+      const int tap = (packed & 8) ? ksq - 1 - e % ksq : e % ksq;
+      const int pr = tap >> 1, hh = tap & 1;
+      const int ot = o >> 4, kq = i >> 4, cg = (i >> 3) & 1, j = i & 7;
+      const float sv = v * kSplitScale;
+      _Float16 hi, lo;
+      cips3d_split16(sv, hi, lo);
+      auto* blk = cips3d_g(reinterpret_cast<_Float16*>(wm_)) + ((((int64_t)b * 5 + pr) * (Cout >> 4) + ot) * (Cin >> 4) + kq) * 1024;
+      const int ln = ((((hh << 1) | cg) << 4) | (o & 15)) * 8 + j;
+      blk[ln] = hi;
+      blk[512 + ln] = lo;
+      if (tap == ksq - 1) {         // the tenth tap of the last pair: zero weights
+        const int lz = ((((2 | cg)) << 4) | (o & 15)) * 8 + j;
+        blk[lz] = (_Float16)0.f;
+        blk[512 + lz] = (_Float16)0.f;
+      }
     } else if (packed & 16) {     // split-fp16 fragments (ksq == 1)
       const int i = e;
       const int ot = o >> 4, kb = i >> 5, j = i & 7, q = (i >> 3) & 3;      // natural k order: k = 8 q + j
@@ -1910,7 +1928,8 @@ extern "C" int cips3d_modulate_weights(const float* W, const float* s, int64_t s
   if ((packed & 32) && (ksq != 1 || (packed & 24))) return CIPS3D_E_UNSUPP;
   if ((packed & 64) && (ksq != 1 || (packed & 63) != 1)) return CIPS3D_E_UNSUPP;
   if (packed && ksq == 1 && (Cout % 32 != 0 || Cin % 8 != 0)) return CIPS3D_E_UNSUPP;
-  if ((packed & 16) && (ksq != 1 || (packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
+  if ((packed & 16) && ksq == 1 && ((packed & 7) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
+  if ((packed & 16) && ksq != 1 && (ksq != 9 || (packed & ~8) != 17)) return CIPS3D_E_UNSUPP;      // 3x3: PACKED | SPLIT [| FLIP] only
   if ((packed & 128) && (ksq != 1 || (packed & 127) != 1 || Cin % 32 != 0)) return CIPS3D_E_UNSUPP;
   if (packed && ksq != 1 && (ksq != 9 || (packed & 7) != 1 || Cout % 16 != 0 || Cin % 16 != 0)) return CIPS3D_E_UNSUPP;
   const int64_t rows = (int64_t)B * Cout;

@@ -213,10 +213,13 @@ class StyledConv(nn.Module):
             return hip.modconv1x1(x, wm, conv.out_channel, epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias,
                                   bf16=self.bf16, split=split)
         if conv.tiled3x3(H, W):
+            # (the default precision runs every decoder GEMM on split-fp16 products, this one included; "fp32_exact" and the
+            # bf16 modes keep the fp32 matrix instruction here)
+            split = self.split and not self.bf16
             if wm is None:
-                wm = conv.modulated_weight(style, packed=True, flip=conv.upsample)
+                wm = conv.modulated_weight(style, packed=True, flip=conv.upsample, split=split)
             return hip.modconv3x3(x, wm, conv.out_channel, up=conv.upsample, fir=conv.blur.kernel if conv.upsample else None,
-                                  epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias)
+                                  epilogue=1, noise=noise, noise_w=nw, bias=self.activate.bias, split=split)
         y = conv(x, style)
         return hip.noise_bias_act(y, noise, nw, self.activate.bias)
 
@@ -362,7 +365,7 @@ class Decoder(nn.Module):
             return hip.modulate_weights(conv.weight, s_buf, total, B, conv.out_channel, conv.in_channel,
                                         conv.kernel_size ** 2, conv.scale, conv.demodulate, packed, s_offset=offs[idx],
                                         flip=packed and conv.kernel_size == 3 and conv.upsample,
-                                        split=packed and conv.kernel_size == 1 and m.split and not m.bf16)
+                                        split=packed and isinstance(m, StyledConv) and m.split and not m.bf16)
 
         H, W = features.shape[2], features.shape[3]
         out = self.conv1(features, styles[:, 0], noise=noise[0], wm=wm_of(0, H, W))

@@ -446,7 +446,8 @@ def modulate_weights(W, s, s_stride, B, Cout, Cin, ksq, scale, demodulate, packe
                      split=False, bf16=False):
     lib = _lib.load()
     if out is None:
-        out = torch.empty(B * Cout * Cin * ksq, device=W.device, dtype=torch.float32)
+        # (the 3x3 kernel's split-fp16 tap-pair fragments hold ten taps per weight row: five pairs, the tenth tap zero)
+        out = torch.empty(B * Cout * Cin * (10 if (split and packed and ksq == 9) else ksq), device=W.device, dtype=torch.float32)
     flags = ((MOD_DEMODULATE if demodulate else 0) | (MOD_PACKED if packed else 0) | (MOD_FLIP if flip else 0) |
              (MOD_SPLIT if split else 0) | (MOD_BF16 if bf16 else 0))
     check(lib.cips3d_modulate_weights(dev_ptr(W, "W"), dev_ptr(s, "s") + 4 * s_offset, s_stride, dev_ptr(out), B, Cout, Cin,
@@ -809,9 +810,11 @@ def modconv3x3_supported(Cin, Cout, H, W, up):
     return bool(_lib.load().cips3d_modconv3x3_supported(Cin, Cout, H, W, int(bool(up))))
 
 
-def modconv3x3(x, wm_packed, Cout, up=False, fir=None, epilogue=0, noise=None, noise_w=None, bias=None):
+def modconv3x3(x, wm_packed, Cout, up=False, fir=None, epilogue=0, noise=None, noise_w=None, bias=None, split=False, x_amax=None):
     """3x3 modulated conv on the LDS-tiled MFMA kernel (csrc/conv3x3.hip).  x [B,Cin,H,W]; wm_packed from
-    modulate_weights(..., ksq=9, packed=True, flip=up); up: conv_transpose2d(stride 2) + Blur(fir) fused -> [B,Cout,2H,2W]."""
+    modulate_weights(..., ksq=9, packed=True, flip=up); up: conv_transpose2d(stride 2) + Blur(fir) fused -> [B,Cout,2H,2W].
+    split: fp32-equivalent split-fp16 products (wm_packed from modulate_weights(..., split=True) as well); x is split as x * 2^-e
+    from its measured maximum (x_amax: its amax array, else the one attached to x, else measured here)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     OH, OW = (2 * H, 2 * W) if up else (H, W)
@@ -821,9 +824,13 @@ def modconv3x3(x, wm_packed, Cout, up=False, fir=None, epilogue=0, noise=None, n
         if noise.shape[0] not in (1, B) or tuple(noise.shape[-2:]) != (OH, OW):
             raise RuntimeError(f"noise must be (1|{B},1,{OH},{OW}), got {tuple(noise.shape)}")
         nb = OH * OW if (noise.shape[0] == B and B > 1) else 0
+    rg, _keep = None, None
+    if split:
+        rg, _keep = _range(x_amax=x_amax if x_amax is not None else amax_of(x))
     check(lib.cips3d_modconv3x3(dev_ptr(x, "x"), dev_ptr(wm_packed, "wm"), dev_ptr(out), B, Cin, Cout, H, W, int(bool(up)),
-                                dev_ptr(fir, "fir", True), int(epilogue), dev_ptr(noise, "noise", True), nb,
-                                dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True), stream_ptr()),
+                                dev_ptr(fir, "fir", True), int(epilogue) | (GEMM_SPLIT if split else 0), dev_ptr(noise, "noise", True), nb,
+                                dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),
+                                C.byref(rg) if rg is not None else None, stream_ptr()),
           "cips3d_modconv3x3")
     return out
 

@@ -530,12 +530,15 @@ int cips3d_modconv1x1_planes16(const void* x_planes16, const float* wm, void* ou
  *           applied to the input tile in LDS (the two convolutions commute), nothing full-size is materialised
  * wm: cips3d_modulate_weights(..., ksq = 9, CIPS3D_MOD_PACKED [| CIPS3D_MOD_FLIP for up = 1]).
  * epilogue = 1 fuses NoiseInjection + bias + leaky ReLU * sqrt(2) as in cips3d_modconv1x1 (noise at the OUTPUT size).
+ * epilogue | CIPS3D_GEMM_SPLIT: fp32-equivalent split-fp16 products (v_mfma_f32_16x16x32_f16, two taps per 32-deep step); wm then
+ * additionally CIPS3D_MOD_SPLIT-packed (tap-pair fragments: B * Cout * Cin * 10 floats are written); rg->x_amax = the measured
+ * per-sample maximum of x (cips3d_absmax; NULL: x is split unscaled -- for data of O(1)).  rg is not read otherwise.
  * cips3d_modconv3x3_supported: Cin % 16 == 0, Cout % 16 == 0, output width % 4 == 0 (plain: W % 4 == 0); other shapes use
  * cips3d_modconv_kxk. */
 int cips3d_modconv3x3_supported(int Cin, int Cout, int H, int W, int up);
 int cips3d_modconv3x3(const float* x, const float* wm, float* out, int B, int Cin, int Cout, int H, int W, int up,
                       const float* fir, int epilogue, const float* noise, int64_t noise_bstride, const float* noise_w,
-                      const float* bias, void* stream);
+                      const float* bias, const cips3d_range* rg, void* stream);
 
 /* ------------------------------------------------------------------ whole forward, one call */
 

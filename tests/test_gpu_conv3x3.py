@@ -66,6 +66,48 @@ def test_modconv3x3_vs_oracle(cin, cout, H, W, up, B, demod):
     assert maxdiff(y.cpu(), ref) < 3e-5 * max(1.0, float(ref.abs().max())), (cin, cout, H, W, up)
 
 
+def test_split_tap_pair_packing_matches_plain_layout():
+    """cips3d_modulate_weights(ksq = 9, PACKED | SPLIT [| FLIP]): the tap-pair fragments of modconv3x3_split_kernel hold hi + lo of
+    2^8 w of the plain layout -- lane quarter q = channels 8 (q & 1) .. + 7 of tap 2 pair + (q >> 1), zeros in the tenth tap."""
+    B, Cin, Cout = 2, 32, 48
+    m, _ = _conv(Cin, Cout, False, True, 1)
+    m = m.to(DEV)
+    style = cu(weights.det_normal("c3.style", (B, 32), 1.0, 1))
+    plain = m.modulated_weight(style, packed=False).view(B, Cout, Cin, 9).cpu()
+    for flip in (False, True):
+        buf = m.modulated_weight(style, packed=True, flip=flip, split=True)
+        n = B * 10 * Cout * Cin * 2                                    # fp16 elements written (five tap pairs)
+        h = buf.view(torch.float16)[:n].view(B, 5, Cout // 16, Cin // 16, 2, 4, 16, 8).float().cpu()   # b, pair, ot, kq, plane, q, o_lo, j
+        val = (h[:, :, :, :, 0] + h[:, :, :, :, 1]) / 256.0            # hi + lo of 2^8 w
+        # q = 2 h + cg: tap = 2 pair + h, channel = 16 kq + 8 cg + j
+        v = val.view(B, 5, Cout // 16, Cin // 16, 2, 2, 16, 8)         # b, pair, ot, kq, h, cg, o_lo, j
+        w = v.permute(0, 2, 6, 3, 5, 7, 1, 4).reshape(B, Cout, Cin, 10)    # b, (ot, o_lo), (kq, cg, j), (pair, h) = tap
+        assert float(w[..., 9].abs().max()) == 0.0
+        got = w[..., :9].flip(-1) if flip else w[..., :9]
+        assert maxdiff(got, plain) <= 2.0 ** -21 * float(plain.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout,H,W,up,B,demod,scale", [
+    (16, 16, 8, 8, False, 1, True, 1.0), (32, 48, 12, 20, False, 2, True, 1e-6), (64, 32, 7, 68, False, 1, False, 3e4),
+    (128, 128, 32, 64, False, 1, True, 1.0), (16, 32, 5, 6, True, 2, True, 1.0), (64, 64, 16, 16, True, 1, True, 1e5),
+    (128, 64, 9, 40, True, 1, False, 1e-5), (32, 16, 64, 64, True, 1, True, 1.0), (512, 512, 16, 16, False, 1, True, 1.0)])
+def test_modconv3x3_split_vs_oracle(cin, cout, H, W, up, B, demod, scale):
+    """modconv3x3_split_kernel (three fp16 products per fp32 product on v_mfma_f32_16x16x32_f16, two taps per MFMA step) against
+    the oracle at the fp32 kernel's bar, on data of any magnitude (the input is split under its measured maximum)."""
+    m, sd = _conv(cin, cout, up, demod, cin + cout + H)
+    x = weights.det_normal("c3.x", (B, cin, H, W), 1.0, H) * scale
+    style = weights.det_normal("c3.s", (B, 32), 1.0, W)
+    ref = O.modulated_conv2d({"m." + k: v for k, v in sd.items()}, "m", x, style, demodulate=demod, upsample=up)
+    m = m.to(DEV)
+    wm = m.modulated_weight(cu(style), packed=True, flip=up, split=True)
+    y = hip.modconv3x3(cu(x), wm, cout, up=up, fir=m.blur.kernel if up else None, split=True)
+    y32 = m(cu(x), cu(style))
+    assert y.shape == ref.shape
+    r = max(float(ref.abs().max()), 1e-30)
+    assert maxdiff(y.cpu(), ref) < 3e-5 * r, (cin, cout, H, W, up, maxdiff(y.cpu(), ref) / r)
+    assert maxdiff(y, y32) < 3e-5 * r
+
+
 @pytest.mark.parametrize("up,per_sample_noise", [(False, False), (False, True), (True, False), (True, True)])
 def test_styled_conv_k3_fused_epilogue_vs_oracle(up, per_sample_noise):
     dec = _dec()
@@ -83,8 +125,10 @@ def test_styled_conv_k3_fused_epilogue_vs_oracle(up, per_sample_noise):
     ref = O.styled_conv({"s." + k: v for k, v in sd.items()}, "s", x, style, nz, upsample=up)
     sc = sc.to(DEV)
     assert sc.conv.tiled3x3(H, W)
-    y = sc(cu(x), cu(style), noise=cu(nz))
-    assert y.shape == ref.shape and maxdiff(y.cpu(), ref) < 3e-5 * max(1.0, float(ref.abs().max()))
+    for split in (True, False):                 # the default arithmetic (split-fp16 products) and the fp32 matrix instruction
+        sc.split = split
+        y = sc(cu(x), cu(style), noise=cu(nz))
+        assert y.shape == ref.shape and maxdiff(y.cpu(), ref) < 3e-5 * max(1.0, float(ref.abs().max())), split
 
 
 def test_k3_generator_uses_the_tiled_kernel_and_matches_the_reference(golden):
