@@ -138,7 +138,7 @@ def cpu_baseline(cfg, nerf_cfg, batch, seconds_budget=16.0):
 class ForwardWorkload:
     """One BASELINE configuration of the generator forward: builds the generator + inputs, runs steps."""
 
-    def __init__(self, dev, rank, world, res, depth, n_samples, batch, precision, deterministic):
+    def __init__(self, dev, rank, world, res, depth, n_samples, batch, precision, deterministic, lanes=1):
         import cips_3dplusplus_amd as pkg
         from cips_3dplusplus_amd import configs
         from cips_3dplusplus_amd.camera import Camera
@@ -158,6 +158,11 @@ class ForwardWorkload:
             self.noise_bufs = [torch.randn(b.shape, device=dev, generator=g) for b in self.noise_bufs]
         self.pending = None
         self.last_gathered = None
+        # views in flight: consecutive (independent) steps alternate between `lanes` streams (pipeline.ViewPipeline); the timed
+        # regions end with every lane drained and the device synchronised.  1 = every step on the one current stream.
+        from cips_3dplusplus_amd.pipeline import ViewPipeline
+        self.lanes = lanes
+        self.pipe = ViewPipeline(self.G, lanes, device=dev) if lanes > 1 else None
 
     def name(self):
         return f"ffhq_r{self.res}_nerf64x64x{self.n_samples}_D{self.depth}_B{self.B}_{self.precision}"
@@ -166,11 +171,20 @@ class ForwardWorkload:
         return (f"test__rendering_time loop body: perturb={not self.deterministic}, "
                 f"{'fixed' if self.deterministic else 'fresh'} decoder noise, random-init weights")
 
-    def render(self):
+    def render(self, post=None):
+        """One view (batch) on the next lane.  post: applied to the image on the same lane (the uint8 conversion of the gather)."""
         e, f, n, fa, _ = self.cam
-        with torch.no_grad():                       # `with torch.set_grad_enabled(False)`, test_cips3dpp.py:724
-            return self.G(zs=self.zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1,
-                          noise_bufs=self.noise_bufs, nerf_cfg=self.nerf_cfg)["rgb"]
+
+        def one():
+            with torch.no_grad():                   # `with torch.set_grad_enabled(False)`, test_cips3dpp.py:724
+                rgb = self.G(zs=self.zs, cam_poses=e, focals=f, img_size=64, near=n, far=fa, truncation=1,
+                             noise_bufs=self.noise_bufs, nerf_cfg=self.nerf_cfg)["rgb"]
+            return post(rgb) if post is not None else rgb
+        if self.pipe is None:
+            return one()
+        # (the inputs were made and synchronised before the first timed region: no ordering behind the caller's stream, whose
+        # per-step gather waits would otherwise chain the views)
+        return self.pipe.run(one, wait_inputs=False)
 
     def fp32_equivalence(self):
         """One view rendered in the default arithmetic (split-fp16 products in the point MLP and the decoder GEMMs) and with
@@ -194,17 +208,22 @@ class ForwardWorkload:
     def step(self):
         from cips_3dplusplus_amd import hip
         from cips_3dplusplus_amd.multiview import gather_views_async
-        rgb = self.render()
-        if self.world > 1:
-            # the one exchange step of the path: finished images -> rank 0.  uint8 on the device first (what the
-            # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
-            # step i overlaps the rendering of step i+1.
-            if self.pending is not None:
-                self.pending.wait(assemble=False)       # the gathered blocks stay on rank 0; no per-step concatenation copy
-            self.pending = gather_views_async(hip.rgb_to_uint8(rgb), self.B * self.world)
-        return rgb
+        if self.world == 1:
+            return self.render()
+        # the one exchange step of the path: finished images -> rank 0.  uint8 on the device first (what the
+        # demo loop turns every frame into anyway) = 4x fewer bytes over xGMI; asynchronous, so the gather of
+        # step i overlaps the rendering of step i+1.
+        u8 = self.render(post=hip.rgb_to_uint8)
+        if self.pipe is not None:
+            self.pipe.wait_lane(self.pipe.last_lane)    # the caller's stream (where the collective is enqueued) behind this view's lane
+        if self.pending is not None:
+            self.pending.wait(assemble=False)           # the gathered blocks stay on rank 0; no per-step concatenation copy
+        self.pending = gather_views_async(u8, self.B * self.world)
+        return u8
 
     def barrier(self):
+        if self.pipe is not None:
+            self.pipe.drain()
         if self.world > 1:
             if self.pending is not None:
                 self.last_gathered = self.pending.wait(assemble=True) if self.keep_last else self.pending.wait(assemble=False)
@@ -505,19 +524,21 @@ def multiview_workload(dev, repeats, n_frames=8, n_samples=128, res=1024):
     cam_cfg = {"img_size": 64, "fov_ang": configs.FFHQ_CAM_CFG["fov_ang"], "dist_radius": configs.FFHQ_CAM_CFG["dist_radius"]}
     ncfg = {"N_samples": n_samples, "perturb": False, "static_viewdirs": False}
     nb = G.create_noise_bufs(64, dev)
-    run = lambda chunk=1, hoist=True: sample_multi_view(G, cam_cfg, ncfg, zs, view_mode="yaw", N_frames=n_frames,   # noqa: E731
-                                                        truncation_ratio=0.5, N_samples=n_samples, noise_bufs=nb, chunk=chunk, hoist=hoist)
-    variants = {"chunk1_hoisted": (1, True), "chunk1_per_frame_tables": (1, False), "chunk8_hoisted": (n_frames, True)}
-    for c, h in variants.values():                   # mean latents (10 000 samples, cached on G), plans, allocator
-        run(c, h)
-        run(c, h)
+    run = lambda chunk=1, hoist=True, lanes=2: sample_multi_view(G, cam_cfg, ncfg, zs, view_mode="yaw", N_frames=n_frames,   # noqa: E731
+                                                                 truncation_ratio=0.5, N_samples=n_samples, noise_bufs=nb, chunk=chunk,
+                                                                 hoist=hoist, lanes=lanes)
+    variants = {"chunk1_per_frame_tables": (1, False, 2), "chunk1_per_frame_tables_one_stream": (1, False, 1),
+                "chunk1_hoisted": (1, True, 2), "chunk1_hoisted_one_stream": (1, True, 1), "chunk8_hoisted": (n_frames, True, 1)}
+    for c, h, l in variants.values():                # mean latents (10 000 samples, cached on G), plans, allocator
+        run(c, h, l)
+        run(c, h, l)
     torch.cuda.synchronize()
     elapsed = {k: [] for k in variants}
     for _ in range(repeats):                         # interleaved in one process: same-box, same-clock comparison
-        for k, (c, h) in variants.items():
+        for k, (c, h, l) in variants.items():
             t0 = time.perf_counter()
             for _ in range(3):
-                out = run(c, h)
+                out = run(c, h, l)
             torch.cuda.synchronize()
             elapsed[k].append((time.perf_counter() - t0) / 3)
     # `value` is the quantity every round has reported: each frame recomputes its style tables, as the reference's frame loop does
@@ -526,13 +547,32 @@ def multiview_workload(dev, repeats, n_frames=8, n_samples=128, res=1024):
     assert out["rgb"].dtype == torch.uint8 and out["rgb"].shape[0] == n_frames
     return {"tag": "config4_multiview_8f_n128", "what": "BASELINE config 4, the demo loop's semantics on one GPU: sample_multi_view(yaw, 8 frames, N = 128, truncation 0.5, "
                     "fixed noise buffers, perturb off, xyz returned, uint8 frames), one frame per call, every frame recomputing its style "
-                    "tables (value); variants: the sequence's tables (mapping networks, FiLM table, 26 modulated decoder matrices) computed "
+                    "tables, frames alternating between two streams (value: sample_multi_view's lanes = 2; *_one_stream: lanes = 1); variants: the sequence's tables (mapping networks, FiLM table, 26 modulated decoder matrices) computed "
                     "by the first frame and resident for the other seven (chunk1_hoisted: sample_multi_view's default, bit-identical), "
                     "and all eight frames in one batch (chunk8_hoisted)",
             "metric": "rendered views/s", "value": n_frames / med, "unit": "views/s", "ms_per_step": med / n_frames * 1e3,
             "steps": 3 * n_frames, "repeats": repeats, "ms_per_step_repeats": [e / n_frames * 1e3 for e in elapsed["chunk1_per_frame_tables"]], "dtype": DTYPE_NAMES["fp32"],
             "variants_views_per_s": {k: n_frames / statistics.median(v) for k, v in elapsed.items()},
             "config": {"workload": f"ffhq_r{res}_nerf64x64x{n_samples}_D2_B1 x {n_frames} frames (multiview.sample_multi_view)"}}
+
+
+def measure_with_single_stream(wl, steps, warmup, repeats, batch, kernel_events=True, single_too=True):
+    """The workload's timed regions (views in flight as configured), then -- when it runs more than one lane -- a few regions
+    of the same steps on ONE stream: the quantity every earlier round reported, and where the dominant kernel's duration is taken
+    (alone on the chip).  -> (median region s, region times, kernel ms for the roofline, events, kernel ms in flight | None,
+    single-stream dict | None)."""
+    med, elapsed, kern_ms, n_ev = wl.measure(steps, warmup, repeats, kernel_events=kernel_events)
+    if wl.pipe is None or not single_too:
+        return med, elapsed, kern_ms, n_ev, None, None
+    pipe, wl.pipe = wl.pipe, None
+    try:
+        m1, e1, k1, n1 = wl.measure(steps, max(3, warmup // 4), min(3, repeats), kernel_events=kernel_events)
+    finally:
+        wl.pipe = pipe
+    single = {"value": steps * batch / m1, "unit": "views/s", "ms_per_step": m1 / steps * 1e3,
+              "ms_per_step_repeats": [e / steps * 1e3 for e in e1],
+              "what": "the same steps issued on one stream (views strictly one after the other): the `value` of rounds 1-5"}
+    return med, elapsed, (k1 if k1 else kern_ms), (n1 if k1 else n_ev), kern_ms, single
 
 
 LINE_LIMIT = 6144                          # the driver's record keeps a bounded tail of stdout: round 4's 36 KB line was not parsed
@@ -552,9 +592,11 @@ def _r(x, sig=4):
 def _roof_head(rf):
     if not rf:
         return None
-    keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms")
-    out = {k: _r(rf.get(k)) for k in keys}
+    keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "in_flight_avg_launch_ms")
+    out = {k: _r(rf.get(k)) for k in keys if k in rf}
     out["kernel"] = str(out["kernel"] or "")[:60]
+    if "measured_in" in rf:
+        out["measured_in"] = "single-stream regions of this run"
     return out
 
 
@@ -589,8 +631,12 @@ def compact(line, detail_name):
             else:
                 row.update(value=_r(e.get("value")), unit=e.get("unit"), ms_per_step=_r(e.get("ms_per_step")),
                            frac=_r((e.get("roofline") or {}).get("frac")))
+                if e.get("single_stream_views_per_s"):
+                    row["one_stream"] = _r(e["single_stream_views_per_s"])
             rows.append(row)
         out["also"] = rows
+    if "single_stream" in line:
+        out["single_stream"] = {k: _r(v, 6) for k, v in line["single_stream"].items() if k in ("value", "ms_per_step")}
     if "fp32_equivalence" in line and "max_abs_rgb_difference_split_vs_fp32_mfma" in line["fp32_equivalence"]:
         out["split_vs_fp32_exact_max_abs"] = _r(line["fp32_equivalence"]["max_abs_rgb_difference_split_vs_fp32_mfma"])
     out["detail"] = detail_name
@@ -660,6 +706,8 @@ def main():
     ap.add_argument("--depth", type=int, default=2)
     ap.add_argument("--n-samples", type=int, default=24)
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="views in flight: consecutive steps alternate between this many streams (pipeline.ViewPipeline); 1 = one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the other BASELINE configurations (N=64, config 3, config 5)")
     ap.add_argument("--no-kernel-events", action="store_true", help="A/B: no HIP events around the dominant kernel (roofline = null)")
@@ -703,9 +751,10 @@ def main():
         else:
             dist.init_process_group(backend=backend)
 
-    wl = ForwardWorkload(dev, rank, world, a.res, a.depth, a.n_samples, a.batch, a.decoder_precision, a.deterministic)
+    wl = ForwardWorkload(dev, rank, world, a.res, a.depth, a.n_samples, a.batch, a.decoder_precision, a.deterministic, lanes=a.lanes)
     wl.keep_last = a.dump_gathered is not None
-    med, elapsed, kern_ms, n_ev = wl.measure(a.steps, a.warmup, a.repeats, kernel_events=not a.no_kernel_events)
+    med, elapsed, kern_ms, n_ev, kern_in_flight, single = measure_with_single_stream(
+        wl, a.steps, a.warmup, a.repeats, a.batch, kernel_events=not a.no_kernel_events, single_too=(world == 1))
     if a.dump_gathered and rank == 0:
         frames = wl.last_gathered if world > 1 else None
         if frames is None:
@@ -728,9 +777,21 @@ def main():
             "repeats": a.repeats, "ms_per_step_repeats": [e / a.steps * 1e3 for e in elapsed],
             "preroll_ms_per_step": [e / a.steps * 1e3 for e in wl.preroll],
             "config": {"workload": wl.name(), "loop": wl.note(), "views_per_step_per_gpu": B, "img_size": 64, "n_samples": a.n_samples,
-                       "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}"},
+                       "N_layers_renderer": a.depth, "resolution": a.res, "parallelism": f"views x{world}",
+                       "views_in_flight": wl.lanes,
+                       "streams": (f"consecutive steps alternate between {wl.lanes} HIP streams (independent views overlap: one view's launch-bound "
+                                   "style phase runs under another's large kernels); regions end drained + device-synchronised") if wl.lanes > 1
+                                  else "one stream"},
             "roofline": wl.roofline(kern_ms, n_ev, kernels=(world == 1)),
         }
+        if line["roofline"] and kern_in_flight is not None:
+            # The kernel's duration is taken where it has the chip to itself: the single-stream regions of this run.  In the
+            # headline's regions two views are in flight and the launch shares the chip with the other view's small kernels
+            # (its wall time there: in_flight_avg_launch_ms) -- that is time of the step, not of this kernel's work.
+            line["roofline"]["in_flight_avg_launch_ms"] = kern_in_flight
+            line["roofline"]["measured_in"] = "the single-stream timed regions of this run (single_stream); in_flight_avg_launch_ms: the headline's regions"
+        if single is not None:
+            line["single_stream"] = single
         if world == 1 and a.decoder_precision == "fp32":
             # the default arithmetic (split-fp16 products) against the fp32 matrix instruction on this run's own inputs
             try:
@@ -766,15 +827,17 @@ def main():
                              dict(n_samples=24, batch=4, precision="bf16_storage"))):
                 # (a secondary entry must never cost the headline line: a failure is reported in its place)
                 try:
-                    w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False)
+                    w2 = ForwardWorkload(dev, 0, 1, kw.get("res", 1024), kw.get("depth", 2), kw["n_samples"], kw["batch"], kw["precision"], False,
+                                         lanes=a.lanes)
                     steps2 = max(10, a.steps // 2)
-                    m2, e2, k2, n2 = w2.measure(steps2, max(3, a.warmup // 2), a.repeats)
+                    m2, e2, k2, n2, k2f, s2 = measure_with_single_stream(w2, steps2, max(3, a.warmup // 2), a.repeats, kw["batch"])
                     also.append({"tag": short, "what": tag, "metric": "rendered views/s", "value": steps2 * kw["batch"] / m2, "unit": "views/s",
                                  "ms_per_step": m2 / steps2 * 1e3, "steps": steps2, "repeats": a.repeats,
+                                 "single_stream_views_per_s": s2["value"] if s2 else None,
                                  "ms_per_step_repeats": [e / steps2 * 1e3 for e in e2],
                                  "preroll_ms_per_step": [e / steps2 * 1e3 for e in w2.preroll],
                                  "dtype": DTYPE_NAMES[kw["precision"]],
-                                 "config": {"workload": w2.name()}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
+                                 "config": {"workload": w2.name(), "views_in_flight": w2.lanes}, "roofline": w2.roofline(k2, n2, kernels=kw["batch"] == 4)})
                     del w2
                 except Exception as exc:       # noqa: BLE001
                     also.append({"tag": short, "what": tag, "error": f"{type(exc).__name__}: {exc}"[:400]})

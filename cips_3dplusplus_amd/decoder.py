@@ -326,15 +326,16 @@ class Decoder(nn.Module):
             i += 2
         return seq
 
-    def _style_table(self, B, device):
+    def _style_table(self, B, device, lane=0):
         key = (B, self.conv1.conv.modulation.weight.data_ptr())
-        ent = self._tables.get(B)
+        slot = B if lane == 0 else (B, lane)
+        ent = self._tables.get(slot)
         if ent is None or ent[0] != key:
             seq = self._mod_layers()
             total = sum(m.conv.in_channel for m, _ in seq)
             styles_buf = torch.empty(B, self.n_latent, self.style_dim, device=device)
             s_buf = torch.empty(B, total, device=device)
-            tab = hip.LinearTable(device)
+            tab = hip.LinearTable(device, lane)
             offs, off = [], 0
             for m, li in seq:
                 mod = m.conv.modulation
@@ -343,7 +344,7 @@ class Decoder(nn.Module):
                 offs.append(off)
                 off += m.conv.in_channel
             ent = (key, styles_buf, s_buf, tab, offs, total)
-            self._tables[B] = ent
+            self._tables[slot] = ent
         return ent[1:]
 
     def forward(self, features, styles, rgbd_in=None, transform=None, noise=None, mesh_path=None):

@@ -176,20 +176,45 @@ class Generator(nn.Module):
         from . import plan as _plan
         if not hasattr(self, "_plans"):
             self._plans = {}
+        # Plans (workspaces, style tables) belong to a LANE = the stream the call is issued on: forwards on different streams share
+        # nothing they write and may be in flight together (pipeline.ViewPipeline alternates independent views between two streams:
+        # one view's latency-bound style phase runs under another's large kernels).  Lane 0 = the first stream seen (self._plans).
+        lane = self._lane_of_current_stream()
+        plans = self._plans if lane == 0 else self.__dict__.setdefault("_lane_plans", {}).setdefault(lane, {})
         key = (B, img_size, N, static)
-        ent = self._plans.get(key, 0)
+        ent = plans.get(key, 0)
         if ent is None:
             return None
         if ent == 0 or ent.key != _plan.ForwardPlan.weights_key(self):
             try:
-                ent = _plan.ForwardPlan(self, B, img_size, N, static)
+                ent = _plan.ForwardPlan(self, B, img_size, N, static, lane=lane)
             except _plan.PlanUnsupported:
                 ent = None
-            self._plans[key] = ent
+            plans[key] = ent
         return ent
 
+    MAX_LANES = 8
+
+    def _lane_of_current_stream(self):
+        if not torch.cuda.is_available():
+            return 0
+        if torch.cuda.is_current_stream_capturing():
+            # a forward captured into a graph runs on lane 0's plan (capture streams come and go; building a plan inside a capture
+            # is not possible): do not replay it while an eager forward of lane 0 is in flight
+            return 0
+        from ._lib import stream_ptr
+        sid = stream_ptr()
+        lanes = self.__dict__.setdefault("_stream_lanes", {})
+        lane = lanes.get(sid)
+        if lane is None:
+            if len(lanes) >= self.MAX_LANES:
+                raise RuntimeError(f"Generator.forward was called on more than {self.MAX_LANES} different streams: every stream keeps "
+                                   "its own forward plans (workspaces, style tables); reuse streams")
+            lane = lanes[sid] = len(lanes)
+        return lane
+
     def _planned_forward(self, plan, zs, cam_poses, focals, near, far, perturb_u, noise_bufs, truncation, style_render,
-                         style_decoder, return_sdf, return_xyz, fresh_perturb=False, styles_resident=False, rgb_out=None):
+                         style_decoder, return_sdf, return_xyz, fresh_perturb=False, styles_resident=None, rgb_out=None):
         from . import hip
         B = plan.B
         z_r = z_d = mean_r = mean_d = None
@@ -205,7 +230,9 @@ class Generator(nn.Module):
             plist = (id(self.decoder.conv1.conv.weight),
                      [p for m in (self.decoder, self.style, self.style_decoder) for p in m.parameters()])
             self.__dict__["_stamp_params"] = plist
-        wver = sum(p._version for p in plist[1])          # (versions only grow: the sum changes whenever one of them does)
+        # (versions only grow: the sum changes whenever one of them does.  Walking ~150 parameters is ~30 us of host time: only calls
+        # that belong to a sequence -- styles_resident given as True or False -- pay it; the default None records no stamp)
+        wver = sum(p._version for p in plist[1]) if styles_resident is not None else None
         if style_render is not None and style_decoder is not None:
             stamp = ("w+", ident(style_render), ident(style_decoder), wver)
             refs = (style_render, style_decoder)
@@ -241,7 +268,8 @@ class Generator(nn.Module):
             near.float().reshape(B).contiguous(), far.float().reshape(B).contiguous(),
             None if perturb_u is None else perturb_u.float().reshape(B, -1).contiguous(), noise_bufs,
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
-            marks=None if marks is None else marks.io_fields(), styles_resident=styles_resident, style_stamp=stamp, rgb_out=rgb_out,
+            marks=None if marks is None else marks.io_fields(), styles_resident=bool(styles_resident),
+            style_stamp=stamp if styles_resident is not None else None, rgb_out=rgb_out,
             style_refs=refs)
         # mask arrives as [2,B,S,S] (plan.run): two contiguous [B,1,S,S] maps without a copy
         m2 = mask
@@ -353,13 +381,15 @@ class Generator(nn.Module):
                        path_reg=False, style_render=None, style_decoder=None, noise_bufs=None, randomize_noise=True,
                        eikonal_reg=False, return_sdf=False, return_xyz=False, N_rays_forward=None, N_rays_grad=None,
                        N_samples_forward=None, nerf_cfg={}, recompute_mean=False, project_noise=False, mesh_path=None,
-                       renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, styles_resident=False,
+                       renderer_detach=None, sample_idx_h=None, sample_idx_w=None, perturb_u=None, styles_resident=None,
                        rgb_out=None, **kwargs):
-        """styles_resident (extension of the reference's call surface; multiview.sample_multi_view uses it): this call is a frame
-        of a sequence that renders ONE latent from many cameras (render_video_web_v10.py:1792-1824) -- the previous call of the
-        same shape already ran the mapping networks, the style heads and the modulate table for exactly these zs / styles /
-        truncation / noise buffers, and this call reuses its tables (bit-identical to recomputing them; plan.run checks the
-        promise).  Ignored on the per-op path.
+        """styles_resident (extension of the reference's call surface; multiview.sample_multi_view uses it): True = this call is a
+        frame of a sequence that renders ONE latent from many cameras (render_video_web_v10.py:1792-1824) -- the previous call of
+        the same shape (and stream) already ran the mapping networks, the style heads and the modulate table for exactly these zs /
+        styles / truncation / noise buffers, and this call reuses its tables (bit-identical to recomputing them; plan.run checks
+        the promise).  False = the full first frame of such a sequence: it records what its tables were computed from.  None
+        (default) = a call outside any sequence: nothing is recorded (the record walks every parameter's version: ~30 us of host
+        time per call), and a resident call cannot follow it.  Ignored on the per-op path.
         rgb_out (extension): a preallocated contiguous [B, 3, R, R] tensor that receives `rgb` -- float32, or uint8 (the image
         leaves the last up-sampling stage as uint8: hip.rgb_to_uint8's bits without the fp32 image's round trip; planned
         forwards whose decoder ends in a fused stage, `can_emit_uint8`).  `ret["rgb"]` is that tensor."""
@@ -396,7 +426,7 @@ class Generator(nn.Module):
                 self.style_render_mean, self.style_decoder_mean = self.get_mean_latent(10000, dev)
             return self._planned_forward(plan, zs, cam_poses, per_view(focals), per_view(near), per_view(far), perturb_u,
                                          noise_bufs, truncation, style_render, style_decoder, return_sdf, return_xyz,
-                                         fresh_perturb=fresh_perturb, styles_resident=bool(styles_resident), rgb_out=rgb_out)
+                                         fresh_perturb=fresh_perturb, styles_resident=styles_resident, rgb_out=rgb_out)
         if rgb_out is not None:
             raise NotImplementedError("rgb_out needs the planned forward (k = 1 decoder with tiled widths, no style mixing)")
         if fresh_perturb:

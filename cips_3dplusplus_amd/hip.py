@@ -120,14 +120,19 @@ def linear(x, W, bias=None, out=None, w_scale=1.0, b_scale=1.0, pixelnorm=False,
 
 # Bumped by everything that rewrites a module's style tables (FiLM table, modulation table: LinearTable.run, a full
 # ForwardPlan.run).  A forward with styles_resident=True (plan.py) is only valid while nothing did since its plan's last full run.
-STYLE_EPOCH = 0
+# Bumped by everything that rewrites a module's style tables (FiLM table, decoder modulations): a forward plan's resident frame
+# (plan.run, styles_resident) checks that nothing has since its last full run.  One counter per LANE: the tables of lane k > 0 are
+# private to the forward plans of that lane (Generator.forward on another stream, pipeline.ViewPipeline).
+import collections
+STYLE_EPOCHS = collections.defaultdict(int)
 
 
 class LinearTable:
     """A device-resident table of independent dense heads evaluated by one launch."""
 
-    def __init__(self, device):
+    def __init__(self, device, lane=0):
         self.device = device
+        self.lane = lane
         self._descs = []
         self._rows = 0
         self._dev = None
@@ -136,7 +141,7 @@ class LinearTable:
     def __deepcopy__(self, memo):
         # descriptors hold raw device pointers of the ORIGINAL module; the owners key their caches on parameter
         # addresses and rebuild the table for a copied module
-        return LinearTable(self.device)
+        return LinearTable(self.device, self.lane)
 
     def add(self, W, bias, x, x_stride, out, out_stride, w_scale=1.0, b_scale=1.0, out_scale=1.0, out_shift=0.0,
             x_offset=0, out_offset=0):
@@ -178,7 +183,7 @@ class LinearTable:
                 return None
             if len(cache) >= 4:
                 cache.clear()
-            ent = LinearTable(self.device)
+            ent = LinearTable(self.device, self.lane)
             for d in self._descs:
                 c = _lib.LinearDesc.from_buffer_copy(d)
                 c.x = x_tensor.data_ptr() + (d.x - x_base)
@@ -197,8 +202,7 @@ class LinearTable:
             return
         if self._dev is None:
             self._upload()
-        global STYLE_EPOCH
-        STYLE_EPOCH += 1
+        STYLE_EPOCHS[self.lane] += 1
         check(_lib.load().cips3d_linear_table(self._dev.data_ptr(), len(self._descs), self._rows, B, stream_ptr()),
               "cips3d_linear_table")
 

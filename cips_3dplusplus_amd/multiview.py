@@ -92,9 +92,10 @@ def _join(parts):
     return torch.cat(parts, 0)
 
 
-def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, chunk=1):
+def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, chunk=1, finish=None):
     """render_fn(lo, hi) -> dict of tensors whose dim 0 is the view index for views [lo, hi).
-    Every rank renders its block in `chunk`-view calls; the entries named in `keys` are gathered to dst."""
+    Every rank renders its block in `chunk`-view calls; the entries named in `keys` are gathered to dst.
+    finish: called once behind the rank's last render call, before anything reads the results (a ViewPipeline's drain)."""
     ws = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank(group) if ws > 1 else 0
     if n_views < ws:
@@ -106,6 +107,8 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
         out = render_fn(a, min(a + chunk, hi))
         for k in keys:
             parts[k].append(out[k])
+    if finish is not None:
+        finish()
     result = {}
     for k in keys:
         if parts[k]:
@@ -122,7 +125,7 @@ def render_views_sharded(render_fn, n_views, keys=("rgb",), dst=0, group=None, c
 def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, truncation_ratio=0.5, N_samples=128,
                       zero_noise_bufs=False, noise_bufs=None, azim_range=(-0.77, 0.77), elev=0.0, circle=None,
                       trans_max=0.04, only_rotate=False, chunk=1, gather=("rgb", "thumb_rgb", "xyz"), to_uint8=True,
-                      group=None, hoist=True, uint8_in_kernel=True):
+                      group=None, hoist=True, uint8_in_kernel=True, lanes=2):
     """The frame loop of `_sample_multi_view_web` (render_video_web_v10.py:1651-1899) without the web page: one z pair,
     one set of noise buffers, `perturb=False`, a camera trajectory (`yaw` / `circle` / `translate_rotate`), one
     `G(...)` call per `chunk` frames with `truncation=truncation_ratio, return_xyz=True`.  With torch.distributed
@@ -136,7 +139,10 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
     frames; the reference offers the same hoist through `style_render=` / `style_decoder=`, models/model_v3.py:875-914).
     Bit-identical to `hoist=False`, which recomputes them per frame.
     `uint8_in_kernel` (default): where the decoder ends in a fused up-sampling stage (the 1024^2 recipes) the uint8 frame is written
-    by that kernel, straight into the rank's frame block (`rgb_out`); False: fp32 image + `hip.rgb_to_uint8` (same bits)."""
+    by that kernel, straight into the rank's frame block (`rgb_out`); False: fp32 image + `hip.rgb_to_uint8` (same bits).
+    `lanes` (default 2): the rank's calls alternate between that many streams (pipeline.ViewPipeline: frames are independent of each
+    other, one frame's launch-bound phases run under another's large kernels); the results are ordered behind all of them before
+    anything reads them.  With `hoist`, every lane computes the sequence's tables once (its first call).  1: one stream."""
     from . import hip
     from .camera import yaw_trajectory, circle_trajectory, cameras_from_trajectory, translate_rotate_cameras
     dev = next(G.parameters()).device
@@ -167,7 +173,9 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
     if zero_noise_bufs:
         noise_bufs = [torch.zeros_like(b) for b in noise_bufs]
 
-    full_done = set()                  # call shapes (views per call) whose tables this sequence has computed
+    from .pipeline import pipeline_for
+    pipe = pipeline_for(G, lanes=lanes if dev.type == "cuda" else 1, device=dev)
+    full_done = [set() for _ in range(pipe.lanes)]     # per lane: call shapes (views per call) whose tables this sequence has computed
     ws = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     lo, hi = view_slice(n_views, dist.get_rank(group) if ws > 1 else 0, ws)
     frames_u8 = None                   # this rank's uint8 frames land in ONE block (no concatenation copy at the end)
@@ -183,20 +191,28 @@ def sample_multi_view(G, cam_cfg, nerf_cfg, zs, view_mode="yaw", N_frames=8, tru
                 R = G._forward_plan(b - a, img_size, int(N_samples), static).out_res
                 frames_u8 = torch.empty(hi - lo, 3, R, R, dtype=torch.uint8, device=dev)
             direct = frames_u8[a - lo:b - lo]
-        with torch.no_grad():
-            r = G(zs=zs, cam_poses=ext[a:b].contiguous(), focals=foc[a:b].contiguous(), img_size=img_size,
-                  near=near[a:b].contiguous(), far=far[a:b].contiguous(), noise_bufs=noise_bufs,
-                  truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True,
-                  styles_resident=hoist and full_done == {b - a}, rgb_out=direct)
-        full_done.clear()              # (a call of another shape rewrites the shared style tables: only the last shape is resident)
-        full_done.add(b - a)
-        if to_uint8 and direct is None:
-            r = dict(r)
-            if frames_u8 is None:
-                frames_u8 = torch.empty((hi - lo,) + tuple(r["rgb"].shape[1:]), dtype=torch.uint8, device=dev)
-            r["rgb"] = hip.rgb_to_uint8(r["rgb"], out=frames_u8[a - lo:b - lo])
+        lane = pipe.next_lane()
+        done = full_done[lane]
+        cams = (ext[a:b].contiguous(), foc[a:b].contiguous(), near[a:b].contiguous(), far[a:b].contiguous())
+
+        def one_call():
+            nonlocal frames_u8
+            with torch.no_grad():
+                r = G(zs=zs, cam_poses=cams[0], focals=cams[1], img_size=img_size, near=cams[2], far=cams[3], noise_bufs=noise_bufs,
+                      truncation=truncation_ratio, nerf_cfg=ncfg, return_xyz=True,
+                      styles_resident=hoist and done == {b - a}, rgb_out=direct)
+            if to_uint8 and direct is None:
+                r = dict(r)
+                if frames_u8 is None:
+                    frames_u8 = torch.empty((hi - lo,) + tuple(r["rgb"].shape[1:]), dtype=torch.uint8, device=dev)
+                r["rgb"] = hip.rgb_to_uint8(r["rgb"], out=frames_u8[a - lo:b - lo])
+            return r
+
+        r = pipe.run(one_call)
+        done.clear()                   # (a call of another shape rewrites the lane's style tables: only the last shape is resident)
+        done.add(b - a)
         return r
 
-    out = render_views_sharded(render, n_views, keys=gather, group=group, chunk=chunk)
+    out = render_views_sharded(render, n_views, keys=gather, group=group, chunk=chunk, finish=pipe.drain)
     out["trajectory"] = traj
     return out

@@ -81,8 +81,12 @@ def _upload(array):
 
 
 class ForwardPlan:
-    def __init__(self, G, B, img_size, N_samples, static_viewdirs, n_chunks=None):
+    def __init__(self, G, B, img_size, N_samples, static_viewdirs, n_chunks=None, lane=0):
+        """lane: which set of the modules' style tables (FiLM table, decoder modulations, their staging buffers) the plan runs
+        on.  Lane 0 is the one every other path of the package shares; a lane k > 0 is private to the plans of that lane, so that
+        forwards issued on different streams (Generator.forward keys its plans by the current stream) can be in flight together."""
         lib = _lib.load()
+        self.lane = lane
         if lib.cips3d_sizeof_plan() != C.sizeof(GeneratorPlan) or lib.cips3d_sizeof_io() != C.sizeof(ForwardIO):
             raise RuntimeError("cips3d_generator_plan / cips3d_forward_io layout mismatch between python and the library")
         dev = G.renderer.sigmoid_beta.device
@@ -120,7 +124,7 @@ class ForwardPlan:
         p.style_xch, p.style_sync, p.style_xch_dim = self.style_xch.data_ptr(), self.style_sync.data_ptr(), xdim
 
         # ---- FiLM heads (renderer owns styles staging + film + table)
-        styles_r, film, film_tab = ren._film_table(B, dev)
+        styles_r, film, film_tab = ren._film_table(B, dev, lane)
         if film_tab._dev is None:
             film_tab._upload()
         p.styles_r = styles_r.data_ptr()
@@ -128,7 +132,7 @@ class ForwardPlan:
         self.styles_r = styles_r
 
         # ---- decoder modulations
-        styles_d, s_buf, mod_tab, offs, total = dec._style_table(B, dev)
+        styles_d, s_buf, mod_tab, offs, total = dec._style_table(B, dev, lane)
         if mod_tab._dev is None:
             mod_tab._upload()
         p.styles_d = styles_d.data_ptr()
@@ -456,13 +460,13 @@ class ForwardPlan:
         if styles_resident:
             # (the FiLM / modulation tables belong to the modules and are shared by every plan of this batch size: nothing may
             # have rewritten them since -- hip.STYLE_EPOCH)
-            if stamp is None or (stamp, hip.STYLE_EPOCH) != getattr(self, "_resident_stamp", None):
+            if stamp is None or (stamp, hip.STYLE_EPOCHS[self.lane]) != getattr(self, "_resident_stamp", None):
                 raise RuntimeError("styles_resident=True, but this plan's style tables were not computed from these latents / "
                                    "truncation / noise bound by the last full forward (run one frame without styles_resident first)")
             io.styles_resident = 1
         else:
-            hip.STYLE_EPOCH += 1
-            self._resident_stamp = (stamp, hip.STYLE_EPOCH)
+            hip.STYLE_EPOCHS[self.lane] += 1
+            self._resident_stamp = (stamp, hip.STYLE_EPOCHS[self.lane])
             self._resident_refs = style_refs
         if hip.FAST_RNG and (fresh_noise or fresh_perturb):
             # the draw is made by the forward call itself (cips3d_forward_io.rng_*: spread over the mapping launches)

@@ -171,15 +171,16 @@ class VolumeFeatureRenderer(nn.Module):
                 self._packed_t = hip.nerf_pack_weights_t(w_hidden, net.views_linears.weight.detach().contiguous(), packed, H, D)
         return self._packed_t
 
-    def _film_table(self, B, device):
+    def _film_table(self, B, device, lane=0):
         net = self.network
         key = (B, net.views_linears.gamma.weight.data_ptr())
-        ent = self._tables.get(B)
+        slot = B if lane == 0 else (B, lane)
+        ent = self._tables.get(slot)
         if ent is None or ent[0] != key:
             D, H, S = self.N_layers_renderer, self.hidden_dim, self.style_dim
             styles_buf = torch.empty(B, D + 1, S, device=device)
             film = torch.empty(B, D + 1, 2, H, device=device)
-            tab = hip.LinearTable(device)
+            tab = hip.LinearTable(device, lane)
             layers = list(net.pts_linears) + [net.views_linears]
             for l, layer in enumerate(layers):
                 for j, head in enumerate((layer.gamma, layer.beta)):
@@ -187,7 +188,7 @@ class VolumeFeatureRenderer(nn.Module):
                             out_scale=float(head.std_init), out_shift=float(head.bias_init),
                             x_offset=l * S, out_offset=(l * 2 + j) * H)
             ent = (key, styles_buf, film, tab)
-            self._tables[B] = ent
+            self._tables[slot] = ent
         return ent[1], ent[2], ent[3]
 
     @torch.no_grad()

@@ -318,7 +318,10 @@ def test_styles_resident_refuses_a_stale_plan():
     with torch.no_grad():
         with pytest.raises(RuntimeError, match="styles_resident"):
             G(zs=zs, styles_resident=True, **kw)                  # no full forward yet
-        full = G(zs=zs, **kw)["rgb"]
+        G(zs=zs, **kw)                                           # a call outside any sequence (styles_resident=None) records nothing
+        with pytest.raises(RuntimeError, match="styles_resident"):
+            G(zs=zs, styles_resident=True, **kw)
+        full = G(zs=zs, styles_resident=False, **kw)["rgb"]      # the first (full) frame of a sequence
         assert torch.equal(G(zs=zs, styles_resident=True, **kw)["rgb"], full)
         with pytest.raises(RuntimeError, match="styles_resident"):
             G(zs=[zs[0].clone(), zs[1]], styles_resident=True, **kw)     # other latents
@@ -327,12 +330,12 @@ def test_styles_resident_refuses_a_stale_plan():
         zs[0].mul_(1.0)                                           # an in-place write bumps the version
         with pytest.raises(RuntimeError, match="styles_resident"):
             G(zs=zs, styles_resident=True, **kw)
-        full = G(zs=zs, **kw)["rgb"]
+        full = G(zs=zs, styles_resident=False, **kw)["rgb"]
         kw2 = dict(kw, nerf_cfg=dict(N_samples=12, perturb=False))
         G(zs=[z.clone() for z in zs], **kw2)                      # another plan of the same batch size rewrote the shared tables
         with pytest.raises(RuntimeError, match="styles_resident"):
             G(zs=zs, styles_resident=True, **kw)
-        assert torch.equal(G(zs=zs, **kw)["rgb"], full)
+        assert torch.equal(G(zs=zs, styles_resident=False, **kw)["rgb"], full)
         assert torch.equal(G(zs=zs, styles_resident=True, **kw)["rgb"], full)
         G.decoder.conv1.conv.weight.mul_(1.0)                     # an optimiser step on the decoder: the modulated weights are stale
         with pytest.raises(RuntimeError, match="styles_resident"):
@@ -379,3 +382,66 @@ def test_uint8_image_straight_from_the_last_stage(monkeypatch, res, B, flat):
         assert torch.equal(out[k], ref[k]), k
     with pytest.raises(RuntimeError, match="rgb_out"):
         G(rgb_out=torch.empty(B, 3, res, res + 1, dtype=torch.uint8, device="cuda"), **kw)
+
+
+@pytest.mark.gpu
+def test_views_in_flight_on_two_streams_equal_one_stream():
+    """pipeline.ViewPipeline: independent views issued alternately on two streams (each stream = a lane with its own forward plans
+    and style tables) come out bit-identical to the same calls on one stream -- with different latents and cameras per view, fixed
+    noise, more views than lanes (every lane's workspaces are reused), and a resident-styles sequence per lane."""
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs
+    from cips_3dplusplus_amd.camera import Camera
+    from cips_3dplusplus_amd.pipeline import ViewPipeline
+    dev = "cuda"
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), dev, seed=3)
+    g = torch.Generator(device=dev).manual_seed(5)
+    n = 7
+    zs = [[torch.randn(1, 256, device=dev, generator=g), torch.randn(1, 256, device=dev, generator=g)] for _ in range(n)]
+    locs = torch.randn(n, 2, device=dev, generator=g) * 0.3
+    nb = [torch.randn(b.shape, device=dev, generator=g) for b in G.create_noise_bufs(64, dev)]
+    cams = [Camera.generate_camera_params(64, dev, locations=locs[i:i + 1]) for i in range(n)]
+    kws = [dict(zs=zs[i], cam_poses=cams[i][0], focals=cams[i][1], img_size=64, near=cams[i][2], far=cams[i][3], noise_bufs=nb,
+                nerf_cfg=dict(N_samples=12, perturb=False, static_viewdirs=False), return_xyz=True) for i in range(n)]
+    with torch.no_grad():
+        ref = [{k: v.clone() for k, v in G(**kw).items() if torch.is_tensor(v)} for kw in kws]
+        pipe = ViewPipeline(G, lanes=2)
+        assert pipe.lanes == 2
+        outs = [pipe.submit(**kw) for kw in kws]
+        pipe.drain()
+        torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref, outs)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k)
+    assert len(G.__dict__["_stream_lanes"]) == 3 and set(G.__dict__["_lane_plans"]) == {1, 2}      # the test's stream + two lanes
+    # a sequence of one latent on each lane: the lane's own first call computes its tables, later ones reuse them
+    with torch.no_grad():
+        seq = []
+        for i in range(6):
+            lane = pipe.next_lane()
+            seq.append(pipe.submit(**{**kws[0], "cam_poses": cams[i][0], "styles_resident": i >= 2}))
+        pipe.drain()
+        want = [G(**{**kws[0], "cam_poses": cams[i][0]})["rgb"].clone() for i in range(6)]
+    for i in range(6):
+        assert torch.equal(seq[i]["rgb"], want[i]), i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hoist", [False, True])
+def test_sample_multi_view_lanes_are_bit_identical(hoist):
+    import cips_3dplusplus_amd as pkg
+    from cips_3dplusplus_amd import configs
+    from cips_3dplusplus_amd.multiview import sample_multi_view
+    dev = "cuda"
+    G = pkg.build_generator(configs.ffhq_G_cfg(256, 2), dev, seed=4)
+    g = torch.Generator(device=dev).manual_seed(9)
+    zs = [torch.randn(1, 256, device=dev, generator=g), torch.randn(1, 256, device=dev, generator=g)]
+    cam_cfg = {"img_size": 64, "fov_ang": 6, "dist_radius": 0.12}
+    nb = G.create_noise_bufs(64, dev)
+    kw = dict(view_mode="yaw", N_frames=7, truncation_ratio=0.5, N_samples=16, noise_bufs=nb, hoist=hoist)
+    a = sample_multi_view(G, cam_cfg, {"static_viewdirs": False}, zs, lanes=1, **kw)
+    b = sample_multi_view(G, cam_cfg, {"static_viewdirs": False}, zs, lanes=2, **kw)
+    c = sample_multi_view(G, cam_cfg, {"static_viewdirs": False}, zs, lanes=2, **kw)      # (the lanes' plans and tables are reused)
+    torch.cuda.synchronize()
+    for k in ("rgb", "thumb_rgb", "xyz"):
+        assert torch.equal(a[k], b[k]) and torch.equal(a[k], c[k]), k
