@@ -117,10 +117,15 @@ class VolumeFeatureRenderer(nn.Module):
 
     # ---- derived, weight-dependent device buffers (re-made when a parameter changes) ------------
     def _weights_key(self):
-        net = self.network
-        ps = [l.weight for l in net.pts_linears] + [l.bias for l in net.pts_linears] + \
-             [net.views_linears.weight, net.views_linears.bias]
-        return tuple((p.data_ptr(), p._version) for p in ps)
+        # (the parameter list is cached: walking the module tree is most of what this key costs per forward)
+        ent = self.__dict__.get("_wk_params")
+        w0 = self.network.views_linears._parameters["weight"]
+        if ent is None or ent[0] is not w0:
+            net = self.network
+            ps = [l.weight for l in net.pts_linears] + [l.bias for l in net.pts_linears] + \
+                 [net.views_linears.weight, net.views_linears.bias]
+            ent = self.__dict__["_wk_params"] = (w0, ps)
+        return tuple((p.data_ptr(), p._version) for p in ent[1])
 
     def set_precision(self, precision):
         """"fp32" (default): the point MLP's GEMMs as fp32-equivalent split-fp16 products (three exact fp16 products per fp32
