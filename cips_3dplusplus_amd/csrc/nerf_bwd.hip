@@ -266,6 +266,95 @@ __global__ void __launch_bounds__(256) composite_kernel(cips3d_nerf_bwd_geom G, 
   if (dbeta_ray) dbeta_ray[(int64_t)b * R + ray] = dbt;
 }
 
+// The same integration with one SAMPLE per thread: 32 rays x N samples per workgroup (N <= 32).  A thread per ray leaves the chip
+// to R*B / 64 waves (128 at 64^2, B = 2: 87 us for 0.4 M points); here the transcendental work and the loads of all samples run
+// side by side and only the products along the ray -- T_k, the suffix sum S_k, the per-ray sums -- are chained, each thread walking
+// the shared per-sample factors in the per-ray loop's own order (the results are the ones composite_kernel produces).
+// dynamic LDS: 7 * N * 32 floats.
+__global__ void __launch_bounds__(1024) composite_par_kernel(cips3d_nerf_bwd_geom G, const float* __restrict__ sdf,
+                                                             const float* __restrict__ crgb, const float* __restrict__ g,
+                                                             const float* __restrict__ dthumb,
+                                                             const float* __restrict__ sigmoid_beta, float* __restrict__ w,
+                                                             float* __restrict__ Tbuf, float* __restrict__ dsdf,
+                                                             float* __restrict__ dcrgb, float* __restrict__ ddnorm,
+                                                             float* __restrict__ dbeta_ray) {
+  extern __shared__ float comp_lds[];
+  const int b = blockIdx.y;
+  const int R = G.img_size * G.img_size;
+  const int N = G.n_samples;
+  const int lr = threadIdx.x & 31, k = threadIdx.x >> 5;
+  const int ray_u = blockIdx.x * 32 + lr;
+  const bool live = ray_u < R;
+  const int ray = live ? ray_u : R - 1;
+  const int64_t P = (int64_t)R * N;
+  float* F = comp_lds;                 // (1 - alpha_k) + 1e-10
+  float* Wl = F + N * 32;              // w_k
+  float* Gl = Wl + N * 32;             // G_k
+  float* Al = Gl + N * 32;             // d alpha_k * sigma_k * e_k
+  float* Zl = Al + N * 32;             // dz_k
+  float* Dl = Zl + N * 32;             // d sigma_k
+  float* Cl = Dl + N * 32;             // d sigma_k / d beta factor
+  const int li = k * 32 + lr;
+  const RayGeom r = ray_geom(G, b, ray);
+  const bool raw = sigmoid_beta == nullptr;
+  const float beta = raw ? 1.f : sigmoid_beta[0];
+  const int64_t o = (int64_t)k * R + ray;
+  const float dz = (k < N - 1 ? r.z(k + 1) - r.z(k) : 1e10f);
+  const float delta = dz * r.dnorm;
+  const float v = sdf[(int64_t)b * P + o];
+  const float sg = raw ? sigmoid_acc(v) : sigmoid_acc(-v / beta);
+  const float sigma = raw ? (v > 20.f ? v : log1pf(expf(v))) : sg / beta;
+  const float e = expf(-sigma * delta);
+  const float alpha = 1.f - e;
+  const float f = (1.f - alpha) + 1e-10f;
+  F[li] = f;
+  const float d0 = dthumb[((int64_t)b * 3 + 0) * R + ray], d1 = dthumb[((int64_t)b * 3 + 1) * R + ray],
+              d2 = dthumb[((int64_t)b * 3 + 2) * R + ray];
+  const float* cp = crgb + (int64_t)b * 3 * P + o;
+  const float s0 = sigmoid_acc(cp[0]), s1 = sigmoid_acc(cp[P]), s2 = sigmoid_acc(cp[2 * P]);
+  const float Gk = g[(int64_t)b * P + o] + 2.f * (d0 * s0 + d1 * s1 + d2 * s2);
+  Gl[li] = Gk;
+  __syncthreads();
+  float T = 1.f;
+  for (int j = 0; j < k; ++j) T *= F[j * 32 + lr];
+  const float wk = alpha * T;
+  Wl[li] = wk;
+  if (live) {
+    Tbuf[(int64_t)b * P + o] = T;
+    w[(int64_t)b * P + o] = wk;
+  }
+  __syncthreads();
+  float S = 0.f;      // sum_{j>k} w_j G_j
+  for (int j = N - 1; j > k; --j) S = fmaf(Wl[j * 32 + lr], Gl[j * 32 + lr], S);
+  const float dalpha = T * Gk - S / f;
+  const float dsigma = dalpha * delta * e;
+  Al[li] = dalpha * sigma * e;
+  Zl[li] = dz;
+  if (!raw) {
+    Dl[li] = dsigma;
+    Cl[li] = (sg * (1.f - sg) * v / beta - sg) / (beta * beta);
+  }
+  if (live) {
+    dsdf[(int64_t)b * P + o] = raw ? dsigma * sg : dsigma * (-sg * (1.f - sg) / (beta * beta));
+    float* dcp = dcrgb + (int64_t)b * 3 * P + o;
+    dcp[0] = 2.f * wk * d0 * s0 * (1.f - s0);
+    dcp[P] = 2.f * wk * d1 * s1 * (1.f - s1);
+    dcp[2 * P] = 2.f * wk * d2 * s2 * (1.f - s2);
+  }
+  __syncthreads();
+  if (!live) return;
+  if (k == 0) {
+    float dn = 0.f;     // d loss / d |rays_d|
+    for (int j = N - 1; j >= 0; --j) dn = fmaf(Al[j * 32 + lr], Zl[j * 32 + lr], dn);
+    ddnorm[(int64_t)b * R + ray] = dn;
+  } else if (k == 1 && dbeta_ray) {
+    float dbt = 0.f;
+    if (!raw)
+      for (int j = N - 1; j >= 0; --j) dbt = fmaf(Dl[j * 32 + lr], Cl[j * 32 + lr], dbt);
+    dbeta_ray[(int64_t)b * R + ray] = dbt;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------- row dots (renderer-weight gradients)
 // out[row][c] += sum_{b,p} a[b][row][p] * x[b][c][p mod Px]  (c < nx <= 3),   out[row][3] += sum_{b,p} a[b][row][p]
 // The narrow weight gradients of the point MLP: the first layer (x = normalised points), the view-direction columns of the
@@ -358,23 +447,28 @@ __global__ void __launch_bounds__(256) film_grad_kernel(float* __restrict__ buf,
 // ---------------------------------------------------------------------------------------------- camera chain
 // dptsn [B,3,P], dvd_pt [B,3,P] (d loss / d viewdir, per point) -> dcam [B,3,4] (atomics; zeroed by the host call).
 // pts_n = (o + d z) 2/span;  rays_d = Rm d_cam;  o = T;  viewdir = normalize(static ? d_cam : rays_d).
-__global__ void __launch_bounds__(256) camera_chain_kernel(cips3d_nerf_bwd_geom G, const float* __restrict__ dptsn,
-                                                           const float* __restrict__ dvd_pt,
-                                                           const float* __restrict__ ddnorm, float* __restrict__ dcam) {
-  __shared__ float sh[4];
+// grid (ceil(R / 64), B), 1024 threads: wave w of a workgroup owns a slice of the samples of the group's 64 rays (every term is
+// linear in the per-sample sums) -- a thread per ray alone is R*B/64 waves on the whole chip; 12 atomics per workgroup.
+__global__ void __launch_bounds__(1024) camera_chain_kernel(cips3d_nerf_bwd_geom G, const float* __restrict__ dptsn,
+                                                            const float* __restrict__ dvd_pt,
+                                                            const float* __restrict__ ddnorm, float* __restrict__ dcam) {
+  __shared__ float sh[12][16];
   const int b = blockIdx.y;
   const int R = G.img_size * G.img_size;
-  const int ray = blockIdx.x * 256 + threadIdx.x;
+  const int ray = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int slice = threadIdx.x >> 6;
   const int N = G.n_samples;
   const int64_t P = (int64_t)R * N;
   float v[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) v[i] = 0.f;
-  if (ray < R) {
+  const int per = (N + 15) / 16;
+  const int k_lo = slice * per, k_hi = min(N, k_lo + per);
+  if (ray < R && (k_lo < k_hi || slice == 0)) {
     const RayGeom r = ray_geom(G, b, ray);
     const float sc = 2.f / (r.farv - r.nearv);
     float dO[3] = {0.f, 0.f, 0.f}, dD[3] = {0.f, 0.f, 0.f}, dV[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < N; ++k) {
+    for (int k = k_lo; k < k_hi; ++k) {
       const float z = r.z(k);
       const int64_t o = (int64_t)b * 3 * P + (int64_t)k * R + ray;
 #pragma unroll
@@ -392,7 +486,7 @@ __global__ void __launch_bounds__(256) camera_chain_kernel(cips3d_nerf_bwd_geom 
       dD[1] += (dV[1] - r.vy * dotv) / r.vnorm;
       dD[2] += (dV[2] - r.vz * dotv) / r.vnorm;
     }
-    {   // |rays_d| enters the sample spacing of the compositing (nerf_utils.py:264-268)
+    if (slice == 0) {   // |rays_d| enters the sample spacing of the compositing (nerf_utils.py:264-268)
       const float gn = ddnorm[(int64_t)b * R + ray] / r.dnorm;
       dD[0] = fmaf(gn, r.dx, dD[0]); dD[1] = fmaf(gn, r.dy, dD[1]); dD[2] = fmaf(gn, r.dz, dD[2]);
     }
@@ -406,8 +500,15 @@ __global__ void __launch_bounds__(256) camera_chain_kernel(cips3d_nerf_bwd_geom 
   }
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    const float s = block_sum_256(v[i], sh);
-    if (threadIdx.x == 0) unsafeAtomicAdd(dcam + 12 * b + i, s);
+    const float s = wave_sum(v[i]);
+    if ((threadIdx.x & 63) == 0) sh[i][slice] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += sh[threadIdx.x][j];
+    unsafeAtomicAdd(dcam + 12 * b + threadIdx.x, s);
   }
 }
 
@@ -515,8 +616,13 @@ extern "C" int cips3d_nerf_bwd_composite(const cips3d_nerf_bwd_geom* G, const fl
     return CIPS3D_E_BADARG;
   if (G->B == 0) return 0;
   const int R = G->img_size * G->img_size;
-  hipLaunchKernelGGL(composite_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, as_stream(stream), *G, sdf,
-                     crgb, g, dthumb, sigmoid_beta, w, T_scratch, dsdf, dcrgb, ddnorm, dbeta_ray);
+  if (G->n_samples >= 2 && G->n_samples <= 32)
+    hipLaunchKernelGGL(composite_par_kernel, dim3((unsigned)ceil_div(R, 32), (unsigned)G->B), dim3(32 * G->n_samples),
+                       sizeof(float) * 7 * 32 * G->n_samples, as_stream(stream), *G, sdf, crgb, g, dthumb, sigmoid_beta, w,
+                       T_scratch, dsdf, dcrgb, ddnorm, dbeta_ray);
+  else
+    hipLaunchKernelGGL(composite_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, as_stream(stream), *G, sdf,
+                       crgb, g, dthumb, sigmoid_beta, w, T_scratch, dsdf, dcrgb, ddnorm, dbeta_ray);
   return cips3d_launch_status();
 }
 
@@ -554,7 +660,7 @@ extern "C" int cips3d_nerf_bwd_camera(const cips3d_nerf_bwd_geom* G, const float
   hipError_t e = hipMemsetAsync(dcam, 0, sizeof(float) * 12 * G->B, st);
   if (e != hipSuccess) return (int)e;
   const int R = G->img_size * G->img_size;
-  hipLaunchKernelGGL(camera_chain_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, st, *G, dptsn, dvd_pt,
+  hipLaunchKernelGGL(camera_chain_kernel, dim3((unsigned)ceil_div(R, 64), (unsigned)G->B), dim3(1024), 0, st, *G, dptsn, dvd_pt,
                      ddnorm, dcam);
   return cips3d_launch_status();
 }
@@ -564,7 +670,7 @@ extern "C" int cips3d_nerf_bwd_camera_acc(const cips3d_nerf_bwd_geom* G, const f
   if (!geom_ok(G) || !dptsn || !dvd_pt || !ddnorm || !dcam) return CIPS3D_E_BADARG;
   if (G->B == 0) return 0;
   const int R = G->img_size * G->img_size;
-  hipLaunchKernelGGL(camera_chain_kernel, dim3((unsigned)ceil_div(R, 256), (unsigned)G->B), dim3(256), 0, as_stream(stream), *G, dptsn,
+  hipLaunchKernelGGL(camera_chain_kernel, dim3((unsigned)ceil_div(R, 64), (unsigned)G->B), dim3(1024), 0, as_stream(stream), *G, dptsn,
                      dvd_pt, ddnorm, dcam);
   return cips3d_launch_status();
 }

@@ -269,7 +269,9 @@ def _renderer_sd(G):
     return {k: v.detach().cpu() for k, v in G.state_dict().items()}
 
 
-@pytest.mark.parametrize("D,static,perturb,N,S", [(2, False, False, 6, 8), (3, True, True, 5, 8), (2, False, True, 8, 16)])
+# (N = 36: more samples than the one-sample-per-thread compositing kernel takes -- the per-ray loop of composite_kernel)
+@pytest.mark.parametrize("D,static,perturb,N,S", [(2, False, False, 6, 8), (3, True, True, 5, 8), (2, False, True, 8, 16),
+                                                 (2, False, True, 36, 8)])
 def test_nerf_render_bwd_vs_oracle(D, static, perturb, N, S):
     cfg = configs.tiny_G_cfg(32, D, 1)
     G = pkg.build_generator(cfg, DEV, seed=3)
