@@ -1,9 +1,12 @@
-# final-build profiles of round 5 (r05), all from ONE box: smoke, bench lines, kernel-trace summaries (headline, N = 64, config 3,
+# final-build profiles of round 6 (r06), all from ONE box: smoke, bench lines, kernel-trace summaries (headline, N = 64, config 3,
 # fp32_exact, stand-alone 3x3 and upfirdn2d tools), the PMC passes of the headline + FETCH / WRITE passes of the N = 64 and batch-4
 # workloads, each summary stamped with the library's source hash (bench.py replays traffic only from a matching one)
 export TMPDIR=/tmp
-O=gpurun_out/r05; rm -rf $O; mkdir -p $O
-B="python3 bench.py --no-cpu-baseline --no-also"
+O=gpurun_out/r06; rm -rf $O; mkdir -p $O
+# kernel summaries and counters are taken with ONE view in flight (--lanes 1: every launch alone on the device, the durations
+# roofline.avg_launch_ms is measured against); `final_lanes2` is the same command with the default two lanes
+B="python3 bench.py --no-cpu-baseline --no-also --lanes 1"
+B2="python3 bench.py --no-cpu-baseline --no-also"
 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 stats() {   # stats <name> <program...>: rocprofv3 --kernel-trace --stats of a command, the kernel_stats.csv kept as <name>_kernel_stats.csv
   N=$1; shift
@@ -11,6 +14,7 @@ stats() {   # stats <name> <program...>: rocprofv3 --kernel-trace --stats of a c
   cp $(find $O/$N -name "*kernel_stats.csv" | head -1) $O/${N}_kernel_stats.csv; rm -rf $O/$N
 }
 stats final $B --steps 50 --repeats 2
+stats final_lanes2 $B2 --steps 50 --repeats 2
 stats n64 $B --steps 30 --repeats 2 --n-samples 64
 stats config3_bf16 $B --batch 4 --decoder-precision bf16 --steps 30 --repeats 2
 stats fp32_exact $B --decoder-precision fp32_exact --steps 30 --repeats 2
@@ -48,9 +52,9 @@ for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["_dur"])):
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
 # the bench lines last: with the summaries of THIS library copied where bench.py looks for them, the line carries measured traffic
-mkdir -p profiles; for f in pmc_all_kernels pmc_n64_traffic pmc_b4_traffic; do cp $O/$f.json profiles/r05_$f.json; done
+mkdir -p profiles; for f in pmc_all_kernels pmc_n64_traffic pmc_b4_traffic; do cp $O/$f.json profiles/r06_$f.json; done
 python3 bench.py --detail $O/bench_default_detail.json > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 5 --detail $O/bench_driver_form_detail.json > $O/bench_driver_form.json 2> $O/bench_driver_form.err
 python3 tools/bench_multiview.py > $O/multiview_ab.txt 2> /dev/null
-bash tools/render_clock.sh > $O/render_clock.log 2>&1 || true; cp gpurun_out/render_clock.jsonl $O/render_clock.jsonl 2> /dev/null
+python3 tools/graph_lanes_probe.py 3 > $O/graph_lanes_probe.json 2> /dev/null
 du -sh $O
