@@ -688,7 +688,7 @@ int cips3d_generator_forward(const cips3d_generator_plan* plan, const cips3d_for
  * mode 1: ONE launch of resident workgroups that hand each layer's outputs to each other through plan.style_xch
  * (CIPS3D_E_UNSUPP when the plan has no such workspace, a chain is absent, B > 8 or a width exceeds style_xch_dim);
  * mode -1: what cips3d_generator_forward does -- mode 0, or mode 1 (where supported) when the environment says
- * CIPS3D_STYLE_PHASE=1: the one launch measured slower on MI355X (DESIGN.md section 8).  Both modes give bit-identical
+ * CIPS3D_STYLE_PHASE=1: the one launch measured slower on MI355X (DESIGN.md section 11).  Both modes give bit-identical
  * results. */
 int cips3d_style_phase(const cips3d_generator_plan* plan, const cips3d_forward_io* io, int mode, void* stream);
 /* sizeof() of the two structs as the library sees them (layout check for foreign-language bindings) */

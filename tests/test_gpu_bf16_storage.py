@@ -247,7 +247,7 @@ def test_bf16_modes_run_the_64sq_layers_on_planes16():
 def test_config3_forward_is_deterministic():
     """Batch 4 at 1024^2 in both bf16 precisions: repeated forwards on fixed inputs are bit-identical.  (Two workgroups of the
     bf16 chain kernel share a CU at this batch size -- the occupancy under which the packed-FMA form of its ToRGB fold returned
-    run-to-run different sums, DESIGN section 12; chain.hip is built without SLP vectorisation since.)"""
+    run-to-run different sums, DESIGN section 5.3; chain.hip is built without SLP vectorisation since.)"""
     G = pkg.build_generator(configs.ffhq_G_cfg(1024, 2), DEV, seed=0)
     B = 4
     g = torch.Generator(device=DEV).manual_seed(3)

@@ -954,7 +954,7 @@ def test_mapping_modules_callable_like_the_reference():
 
 def test_forward_is_graph_capturable():
     """cips3d_generator_forward neither allocates nor synchronises: the whole forward can be captured into a HIP graph and
-    replayed bit-identically (the path is GPU-bound, so this is a property, not a speed-up: DESIGN.md section 6)."""
+    replayed bit-identically (a property, not a speed-up: replays do not overlap across streams the way eager lanes do)."""
     G = pkg.build_generator(configs.tiny_G_cfg(32, 2, 1), DEV, seed=9)
     e, f, n, fa, _ = Camera.generate_camera_params(8, DEV, locations=torch.tensor([[0.2, -0.1]], device=DEV))
     zs = [torch.randn(1, 32, device=DEV), torch.randn(1, 32, device=DEV)]

@@ -140,7 +140,7 @@ def test_forward_takes_the_one_launch_on_request_and_matches_the_launches(monkey
     monkeypatch.delenv("CIPS3D_STYLE_PHASE", raising=False)
     gen0 = int(plan.style_sync[0])
     a = G(**kw)["rgb"].clone()
-    assert int(plan.style_sync[0]) == gen0              # the default is the chain of launches (the faster one, DESIGN 8)
+    assert int(plan.style_sync[0]) == gen0              # the default is the chain of launches (the faster one, DESIGN section 11)
     monkeypatch.setenv("CIPS3D_STYLE_PHASE", "1")
     b = G(**kw)["rgb"].clone()
     assert int(plan.style_sync[0]) == gen0 + 1          # ... the one launch on request
