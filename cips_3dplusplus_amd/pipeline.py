@@ -15,11 +15,63 @@ makes calls on different streams independent of each other; this class supplies 
 forward there, and marks the returned tensors as in use by the caller's stream (allocator safety).  Nothing makes the caller's
 stream wait until `drain()` -- a wait per view would put every view behind the previous one again.
 Measured (MI355X, FFHQ 1024^2, D = 2, N = 24, batch 1): 0.318 ms per view with two lanes against 0.363 with one (+14 % views/s);
-a third lane adds nothing.
+a third lane adds nothing.  The lanes' streams are tested to run concurrently (`lane_streams`): two HIP streams may share a
+hardware queue, and a pipeline on such a pair is slower than no pipeline.
 """
 import weakref
 
 import torch
+
+
+# Lane streams are made once per device and shared by every pipeline of the process.  HIP serves its streams from a few hardware
+# queues and two streams of one queue run strictly one after the other -- measured on MI355X: of seven streams created in a row the
+# pairs (0,5), (1,4), (2,3) share a queue, and a two-lane pipeline on such a pair is SLOWER than one stream (0.369 against 0.355 ms
+# per view; 0.300 on any other pair).  The runtime does not say which queue a stream got, so candidates are tested: a stream joins
+# the pool only if a small launch on it overtakes a long one on every stream already in the pool.
+_LANE_STREAMS = {}
+_REJECTED = []          # (kept alive: a released stream would be handed out again)
+
+
+def _overtakes(a, b, dev):
+    """True when work enqueued on stream b (after a long launch on stream a) finishes first: different hardware queues."""
+    ea, eb = torch.cuda.Event(), torch.cuda.Event()
+    x = torch.zeros(1 << 22, device=dev)
+    y = torch.zeros(8, device=dev)
+    with torch.cuda.stream(b):                        # (a stream's first launch creates its queue: not part of the race)
+        y.add_(1.0)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(a):
+        try:
+            torch.cuda._sleep(6_000_000)              # ~3 ms of device spin
+        except Exception:                             # noqa: BLE001  (no spin kernel in this build: a long chain of passes instead)
+            for _ in range(400):
+                x.add_(1.0)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        y.add_(1.0)
+        eb.record(b)
+    eb.synchronize()
+    first = not ea.query()
+    ea.synchronize()
+    return first
+
+
+def lane_streams(device, n):
+    """`n` streams of `device` that run concurrently with each other (see above); fewer distinct queues than lanes: the rest are
+    taken as they come."""
+    dev = torch.device(device)
+    pool = _LANE_STREAMS.setdefault(str(dev), [])
+    tries = 0
+    while len(pool) < n and tries < 24:
+        tries += 1
+        s = torch.cuda.Stream(device=dev)
+        if all(_overtakes(p, s, dev) for p in pool):
+            pool.append(s)
+        else:
+            _REJECTED.append(s)
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
 
 
 class ViewPipeline:
@@ -29,7 +81,7 @@ class ViewPipeline:
         self._G = weakref.ref(G)               # (pipelines are cached per generator, weakly keyed: a strong reference here would pin it)
         dev = device if device is not None else next(G.parameters()).device
         self.device = torch.device(dev)
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(lanes)] if self.device.type == "cuda" and lanes > 1 else []
+        self.streams = lane_streams(self.device, lanes) if self.device.type == "cuda" and lanes > 1 else []
         self._next = 0
         self._dirty = set()
         self._callers = {}                     # raw stream id -> torch.cuda.Stream of a calling stream (the object costs ~10 us to build)

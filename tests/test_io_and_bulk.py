@@ -385,6 +385,23 @@ def test_uint8_image_straight_from_the_last_stage(monkeypatch, res, B, flat):
 
 
 @pytest.mark.gpu
+def test_lane_streams_are_served_by_different_hardware_queues():
+    """HIP maps streams onto a few hardware queues; two lanes on one queue run one after the other (measured: slower than one
+    stream).  pipeline.lane_streams hands out streams that demonstrably overtake each other, once per device, to every pipeline."""
+    import itertools
+    from cips_3dplusplus_amd import pipeline
+    dev = torch.device("cuda:0")
+    S = pipeline.lane_streams(dev, 3)
+    assert len({s.cuda_stream for s in S}) == 3
+    assert not pipeline._overtakes(S[0], S[0], dev)                     # the race itself: a stream does not overtake itself
+    for a, b in itertools.permutations(S, 2):
+        assert pipeline._overtakes(a, b, dev)
+    lin = torch.nn.Linear(2, 2).to(dev)
+    p1, p2 = pipeline.ViewPipeline(lin, 2), pipeline.ViewPipeline(lin, 2)
+    assert [s.cuda_stream for s in p1.streams] == [s.cuda_stream for s in p2.streams] == [s.cuda_stream for s in S[:2]]
+
+
+@pytest.mark.gpu
 def test_views_in_flight_on_two_streams_equal_one_stream():
     """pipeline.ViewPipeline: independent views issued alternately on two streams (each stream = a lane with its own forward plans
     and style tables) come out bit-identical to the same calls on one stream -- with different latents and cameras per view, fixed
