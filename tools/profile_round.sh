@@ -55,6 +55,6 @@ find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.cs
 mkdir -p profiles; for f in pmc_all_kernels pmc_n64_traffic pmc_b4_traffic; do cp $O/$f.json profiles/r06_$f.json; done
 python3 bench.py --detail $O/bench_default_detail.json > $O/bench_default.json 2> $O/bench_default.err
 python3 bench.py --steps 20 --warmup 5 --detail $O/bench_driver_form_detail.json > $O/bench_driver_form.json 2> $O/bench_driver_form.err
-python3 tools/bench_multiview.py > $O/multiview_ab.txt 2> /dev/null
+python3 tools/bench_multiview.py --lanes 1,2 > $O/multiview_ab.txt 2> /dev/null
 python3 tools/graph_lanes_probe.py 3 > $O/graph_lanes_probe.json 2> /dev/null
 du -sh $O
