@@ -292,18 +292,24 @@ __global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float
   // the second wave of each SIMD with the conversion instead changed nothing, more chunks cost more in atomics than they hide)
   constexpr int D = 4;
   f32x4 raw[D][NV];
+  // The loop below has NO branch around its loads and LDS stores: with `if (p < p_end)` around them the compiler could not count
+  // the loads in flight across the joins and put s_waitcnt vmcnt(0) in front of every use AND every issue -- each step then
+  // waited for the fetch it had just requested (a full memory round trip per 32 pixels, ~1 us: the ring was no ring).  A fetch
+  // past the chunk re-reads the chunk's last step instead (valid memory, never used), a step past the chunk is stashed as zeros.
+  const int64_t p_last = p_end - 32;
   auto fetch = [&](int slot, int64_t p) {
-    if (p < p_end) {
+    const int64_t pc = p < p_end ? p : p_last;
 #pragma unroll
-      for (int v = 0; v < NV; ++v) raw[slot][v] = *reinterpret_cast<const f32x4*>(src[v] + p);
-    }
+    for (int v = 0; v < NV; ++v) raw[slot][v] = *reinterpret_cast<const f32x4*>(src[v] + pc);
   };
-  auto stash = [&](int slot, int buf) {
+  auto stash = [&](int slot, int buf, int64_t p) {
+    const float live = p < p_end ? 1.f : 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
+      const float kv = ksc[v] * live;
       unsigned h0, l0, h1, l1;
-      cips3d_split_pair(raw[slot][v][0] * ksc[v], raw[slot][v][1] * ksc[v], h0, l0);
-      cips3d_split_pair(raw[slot][v][2] * ksc[v], raw[slot][v][3] * ksc[v], h1, l1);
+      cips3d_split_pair(raw[slot][v][0] * kv, raw[slot][v][1] * kv, h0, l0);
+      cips3d_split_pair(raw[slot][v][2] * kv, raw[slot][v][3] * kv, h1, l1);
       typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
       *reinterpret_cast<u32x2_t*>(&lds[buf][0][dst[v]]) = u32x2_t{h0, h1};
       *reinterpret_cast<u32x2_t*>(&lds[buf][1][dst[v]]) = u32x2_t{l0, l1};
@@ -316,16 +322,14 @@ __global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int d = 0; d < D; ++d) fetch(d, p_begin + 32 * d);
-  stash(0, 0);
+  stash(0, 0, p_begin);
   __syncthreads();
   const int arow = (wm * 16 * TM + r) * RS + 8 * q, brow = (BM + wn * 16 * TN + r) * RS + 8 * q;
   for (int64_t p0 = p_begin; p0 < p_end; p0 += 32 * D) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      const int64_t p = p0 + 32 * d;
-      if (p >= p_end) break;
+      const int64_t p = p0 + 32 * d;                // (steps past the chunk multiply zeros)
       const int buf = d & 1;                        // D is even: the buffer parity of a step is the parity of its slot
-      fetch(d, p + 32 * D);                         // slot d was stashed during the previous step
       cips3d_h8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -337,6 +341,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float
         bh[j] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][0][brow + 16 * j * RS]);
         bl[j] = *reinterpret_cast<const cips3d_h8*>(&lds[buf][1][brow + 16 * j * RS]);
       }
+      fetch(d, p + 32 * D);                         // slot d was stashed during the previous step
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-      if (p + 32 < p_end) stash((d + 1) % D, buf ^ 1);
+      stash((d + 1) % D, buf ^ 1, p + 32);
       __syncthreads();
     }
   }
@@ -615,6 +620,8 @@ extern "C" int cips3d_gemm_wgrad_split(const float* dy, const float* x, float* d
   // workgroup tile: 128 x 64 (eight waves, two per SIMD: one converts while the other multiplies) where the matrix is that
   // large -- the L2-port bytes go with 1 / BM + 1 / BN -- else 64 x 64 / 32 x 32 (four waves)
   const int big = (M >= 128 && K >= 64) ? 2 : ((M >= 64 && K >= 64) ? 1 : 0);
+  // (round 6, same box, 512 x 512 x 4096 x 2: 128 x 128 tiles in three wave layouts 33.1-38.0 us, 128 x 256 45.4 against 31.8 for
+  // 128 x 64; twice / four times the pixel chunks 34.1 / 41.8: the tile and the chunk count below stay)
   const int BM = big == 2 ? 128 : (big == 1 ? 64 : 32), BN = big ? 64 : 32;
   const int blocks = ceil_div(M, BM) * ceil_div(K, BN);
   // pixel chunks: one to two workgroups per CU -- every chunk costs M K atomic adds per sample (1.3 TB/s chip-wide,
