@@ -16,7 +16,9 @@ def _rel(a, ref):
     return float((a.double().cpu() - ref).abs().max() / ref.abs().max())
 
 
-@pytest.mark.parametrize("B,M,K,P", [(2, 512, 512, 4096), (1, 64, 32, 65536), (2, 32, 32, 1024), (3, 96, 160, 2048)])
+# (2144 pixels: chunks of 9 steps of 32 and a last one of 4 -- step counts that are no multiple of the register ring; 32: one step)
+@pytest.mark.parametrize("B,M,K,P", [(2, 512, 512, 4096), (1, 64, 32, 65536), (2, 32, 32, 1024), (3, 96, 160, 2048), (1, 64, 64, 2144),
+                                     (2, 128, 64, 2144), (1, 32, 32, 32)])
 @pytest.mark.parametrize("sa,sb", [(1.0, 1.0), (2.0 ** -30, 2.0 ** 17), (2.0 ** 20, 2.0 ** -24)])
 def test_split_wgrad_is_as_accurate_as_fp32_at_any_magnitude(B, M, K, P, sa, sb):
     """dwm[b] = dy[b] x[b]^T over the pixels on split-fp16 products: gradients of any magnitude (the scale comes from the
