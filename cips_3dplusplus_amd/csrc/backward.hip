@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN) wgrad_split_kernel(const float
   // (timing ablations): fetch + fragment reads + barriers alone 15.9 us (201 MB at 12.6 TB/s), + conversion 5.7, + MFMA 3.5,
   // + atomics 5: the phases of a step do not overlap (every wave of the CU is in the same phase between two barriers; starting
   // the second wave of each SIMD with the conversion instead changed nothing, more chunks cost more in atomics than they hide)
-  constexpr int D = 4;
+  constexpr int D = 4;       // (2, 6, 8 measured on config 5, same box x3: inside its 10 % run-to-run spread)
   f32x4 raw[D][NV];
   // The loop below has NO branch around its loads and LDS stores: with `if (p < p_end)` around them the compiler could not count
   // the loads in flight across the joins and put s_waitcnt vmcnt(0) in front of every use AND every issue -- each step then
