@@ -2026,7 +2026,11 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
                                        const float* bias, const float* rgb_w, float* rgb_part, int* n_row_blocks,
                                        const cips3d_range* rg, void* stream) {
   if ((rgb_w == nullptr) != (rgb_part == nullptr)) return CIPS3D_E_BADARG;
-  if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / gemm_block_rows(Cout) : 0;
+  // 128-row tiles for a grid of more than one 64 x 128 tile per CU (see below); the ToRGB partials then come in 128-row blocks
+  static const int big_tiles = getenv("CIPS3D_GEMM_BIG") ? atoi(getenv("CIPS3D_GEMM_BIG")) : 1;
+  const bool big = big_tiles && Cout >= 256 && Cout % 128 == 0 && Cin % 64 == 0 && HW > 0 && B > 0 &&
+                   (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) > 256;
+  if (n_row_blocks) *n_row_blocks = Cout > 0 ? Cout / (big ? 128 : gemm_block_rows(Cout)) : 0;
   if (!x || !wm || !out || B < 0 || Cin <= 0 || Cout <= 0 || HW <= 0) return CIPS3D_E_BADARG;
   if ((epilogue & CIPS3D_GEMM_BF16) && (epilogue & CIPS3D_GEMM_SPLIT)) return CIPS3D_E_BADARG;
   const int bf16 = (epilogue & CIPS3D_GEMM_BF16) ? 1 : (epilogue & CIPS3D_GEMM_SPLIT) ? 2 : 0;
@@ -2069,7 +2073,11 @@ extern "C" int cips3d_modconv1x1_torgb(const float* x, const float* wm, float* o
     // epilogue -- a third of a launch, with the L2 port idle -- runs under the other's K loop (inversion step +3.4 %, same box)
     static const int bk = getenv("CIPS3D_GEMM_BK") ? atoi(getenv("CIPS3D_GEMM_BK")) : 0;       // tuning knob (tools/): 32 | 64
     const bool one_round = (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) <= 256;
-    if ((bk ? bk == 64 : one_round) && Cin % 64 == 0) return launch_gemm<1, 4, 2, 64, 2>(a, st);
+    if (!big && (bk ? bk == 64 : one_round) && Cin % 64 == 0) return launch_gemm<1, 4, 2, 64, 2>(a, st);
+    // a grid of more than one 64 x 128 tile per CU (batch 2 and up: the inversion step): 128 x 128 tiles, 64-deep stages -- half
+    // the operand bytes per flop through the L2 port and one workgroup per CU again.  Inversion step, same box x3: 341.6-343.2 ->
+    // 348.8-349.4 steps/s with this form in the forward and the data-gradient GEMM (32-deep in 3 / 4 slots: 347.1-348.7 / 346.9-347.7)
+    if (big) return launch_gemm<2, 4, 2, 64, 2>(a, st);
     return launch_gemm<1, 4, 2, 32, 2>(a, st);
   }
   static const int ns2 = getenv("CIPS3D_GEMM_NS2") ? atoi(getenv("CIPS3D_GEMM_NS2")) : 1;     // (see cips3d_modconv1x1_actbwd)
@@ -2102,6 +2110,8 @@ extern "C" int cips3d_modconv1x1_actbwd(const float* g, const float* wm_t, float
     static const int bk = getenv("CIPS3D_GEMM_BK") ? atoi(getenv("CIPS3D_GEMM_BK")) : 0;       // tuning knob (tools/): 32 | 64
     const bool one_round = (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128) <= 256;
     if ((bk ? bk == 64 : one_round) && Cin % 64 == 0) return launch_gemm_actbwd<1, 4, 2, 64, 2>(a, st);
+    static const int big_tiles = getenv("CIPS3D_GEMM_BIG") ? atoi(getenv("CIPS3D_GEMM_BIG")) : 1;      // (see cips3d_modconv1x1_torgb)
+    if (big_tiles && Cout % 128 == 0 && Cin % 64 == 0) return launch_gemm_actbwd<2, 4, 2, 64, 2>(a, st);
     return launch_gemm_actbwd<1, 4, 2, 32, 2>(a, st);
   }
   // Short contractions (K <= 128: the decoder's 128 / 64 / 32-channel layers at 256^2 and above) are HBM-bound streams with

@@ -420,7 +420,8 @@ int cips3d_modconv1x1(const float* x, const float* wm, float* out, int B, int Ci
 /* The same GEMM with the ToRGB that FOLLOWS this conv folded into its epilogue (models/model_v3.py:602-632: ToRGB reads
  * the conv's output): every workgroup also writes the partial sums of its block of output rows,
  *   rgb_part[row_block][b][r][n] = sum_{o in block} rgb_w[b][r][o] * out[b][o][n]      (rgb_w plain [B,3,Cout])
- * and *n_row_blocks receives the number of row blocks (slots) written.  cips3d_torgb_reduce folds the slots of one or
+ * and *n_row_blocks receives the number of row blocks (slots) written (the tiling -- 32 to 128 rows per block -- follows the shape
+ * and the batch: size rgb_part for Cout / 32 blocks and fold what *n_row_blocks reports).  cips3d_torgb_reduce folds the slots of one or
  * several such layers, their biases and the skip image in a FIXED order (deterministic), replacing cips3d_torgb launches
  * that re-read the activations.  rgb_w == rgb_part == NULL: plain cips3d_modconv1x1. */
 #define CIPS3D_TORGB_FOLD_MAX 8

@@ -197,7 +197,8 @@ def test_planes_roundtrip_and_chain_gemm():
             got = hip.from_planes(out_p, H, H)
             rng = float(ref.abs().max())
             assert maxdiff(got, ref) < 4e-6 * rng, layer
-            assert maxdiff(part, part_ref) < 4e-6 * float(part_ref.abs().max()), layer
+            # (the two kernels may cut the rows into different blocks -- 64 or 128 rows per slot: what is defined is the slots' sum)
+            assert maxdiff(part.sum(0), part_ref.sum(0)) < 4e-6 * float(part_ref.sum(0).abs().max()), layer
             cur_p, cur_x = out_p, ref
         else:       # the low-resolution GEMM that leaves the run: fp32 and bf16 exits, no epilogue
             ref = hip.modconv1x1(cur_x, wm_x, Cout, epilogue=0)
