@@ -39,7 +39,7 @@ class Range(C.Structure):
     _fields_ = [("x_amax", C.c_void_p), ("x_exp", C.c_void_p), ("x_exp_const", C.c_int32), ("x_max_const", C.c_float),
                 ("x_pmax", C.c_void_p), ("lconst", C.c_void_p), ("lconst2", C.c_void_p),
                 ("out_amax", C.c_void_p), ("out_exp", C.c_void_p), ("next_amax", C.c_void_p), ("out_pmax", C.c_void_p),
-                ("next_gain", C.c_float), ("pad2_", C.c_int32), ("ride", C.c_void_p)]
+                ("next_gain", C.c_float), ("half_chip", C.c_int32), ("ride", C.c_void_p)]
 
 
 class ReduceJob(C.Structure):
@@ -233,7 +233,7 @@ _SIGS = {
 }
 
 EXPORTED = tuple(_SIGS)
-ABI_VERSION = 29           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
+ABI_VERSION = 30           # == CIPS3D_ABI_VERSION of include/cips3d_hip.h
 _lib = None
 
 

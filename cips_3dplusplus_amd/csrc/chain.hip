@@ -437,11 +437,15 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // probe: every load of this wave -- the epilogue's operands -- has returned
 #endif
   // ---- epilogue.  D layout: acc[i][c][r] = out[o = obase + 4 q + r][pixel npx[c]]
-  float prgb[3][4];
+  // (one accumulator set per 16-row tile: the ToRGB slots are sums of FOUR tiles in a fixed order whatever the workgroup's height --
+  // a 128-row workgroup writes two 64-row slots that hold the same bits two 64-row workgroups would have written)
+  float prgb[WM][3][4];
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch)
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) prgb[ch][c] = 0.f;
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) prgb[i][ch][c] = 0.f;
   // v below is the STORED value, out * kout (kout = 1 unless the output is planes): the power of two rides on the constants
   // the epilogue multiplies by anyway, the ToRGB partial sums and the recorded maximum are taken from v and scaled back once
   const float kact = 1.41421356237309515f * kout;
@@ -471,10 +475,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
 #endif
       if (a.rgb_part) {
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+        f32x2_t p12 = {prgb[i][1][c], prgb[i][2][c]};
         const f32x2_t v01 = {v[0], v[1]}, v23 = {v[2], v[3]}, v1x = {v[1], 0.f}, v3x = {v[3], 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+        for (int r = 0; r < 4; ++r) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[i][0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
         const f32x2_t w0 = {wrgb[i][1][0], wrgb[i][2][0]}, w1 = {wrgb[i][1][1], wrgb[i][2][1]}, w2 = {wrgb[i][1][2], wrgb[i][2][2]},
                       w3 = {wrgb[i][1][3], wrgb[i][2][3]};
         if ((CIPS3D_FOLD_FORMS & 1) && i == 0) {
@@ -487,8 +491,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
         else asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w1), "v"(v1x));
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w2), "v"(v23));
         asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(p12) : "v"(w3), "v"(v3x));
-        prgb[1][c] = p12[0];
-        prgb[2][c] = p12[1];
+        prgb[i][1][c] = p12[0];
+        prgb[i][2][c] = p12[1];
       }
 #elif CIPS3D_FOLD_PK == 2
       // probe (tools/pk_fold_probe.sh): the SLP build's instruction pattern written by hand -- channel 0 as v_fmac_f32, channels
@@ -496,18 +500,18 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
       // an op_sel_hi broadcast of v[r] -- with CIPS3D_FOLD_NOP wait states between the v_movs and the packed instruction
       if (a.rgb_part) {
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        f32x2_t p12 = {prgb[1][c], prgb[2][c]};
+        f32x2_t p12 = {prgb[i][1][c], prgb[i][2][c]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
+          asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[i][0][c]) : "v"(wrgb[i][0][r]), "v"(v[r]));
           const f32x2_t vb = {v[r], 0.f};
           asm volatile("v_mov_b32 v126, %1\n\tv_mov_b32 v127, %2\n\t"
                        ".if %4 > 0\n\ts_nop %4 - 1\n\t.endif\n\t"
                        "v_pk_fma_f32 %0, v[126:127], %3, %0 op_sel_hi:[1,0,1]"
                        : "+v"(p12) : "v"(wrgb[i][1][r]), "v"(wrgb[i][2][r]), "v"(vb), "n"(CIPS3D_FOLD_NOP) : "v126", "v127");
         }
-        prgb[1][c] = p12[0];
-        prgb[2][c] = p12[1];
+        prgb[i][1][c] = p12[0];
+        prgb[i][2][c] = p12[1];
       }
 #else
       if (a.rgb_part) {
@@ -521,9 +525,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
             // one v_fmac_f32 per product, written out: nothing can pair the channel-1 / channel-2 accumulations into
             // v_pk_fma_f32 (see the build note in the header of this file; VALU results feed VALU here: no hazard state to keep)
 #if CIPS3D_FOLD_PK        /* reproducer builds only (tools/pk_fold_probe.sh): the C form SLP packs */
-            prgb[ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[ch][c]);
+            prgb[i][ch][c] = fmaf(wrgb[i][ch][r], v[r], prgb[i][ch][c]);
 #else
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[ch][c]) : "v"(wrgb[i][ch][r]), "v"(v[r]));
+            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(prgb[i][ch][c]) : "v"(wrgb[i][ch][r]), "v"(v[r]));
 #endif
 #if CIPS3D_FOLD_PK && (CIPS3D_FOLD_NOP & 1)
         asm volatile("s_nop 7\n\ts_nop 7");          // probe: distance between the packed chain and whatever follows it
@@ -603,31 +607,37 @@ __global__ void __launch_bounds__(64 * WGM * WGN) chain_gemm_kernel(ChainArgs a)
   // ---- folded ToRGB partial of this workgroup's BM rows: over the 4 lane quarters by shuffles, over the WGM wave rows
   // through LDS (every wave passed the last stage's lgkmcnt(0) and meets at the barrier below)
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v = prgb[ch][c] * kback;
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      prgb[ch][c] = v;
-    }
-  __syncthreads();
-  float* s_red = lds;                                   // [WGM][3][BN]
-  if (q == 0) {
+  for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s_red[(wm_i * 3 + ch) * BN + nl + 16 * c] = prgb[ch][c];
+      for (int c = 0; c < 4; ++c) {
+        float v = prgb[i][ch][c] * kback;
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        prgb[i][ch][c] = v;
+      }
+  __syncthreads();
+  float* s_red = lds;                                   // [WGM * WM tiles][3][BN]
+  if (q == 0) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s_red[((wm_i * WM + i) * 3 + ch) * BN + nl + 16 * c] = prgb[i][ch][c];
   }
   __syncthreads();
-  if (wm_i == 0 && q < 3) {
+  constexpr int SLOTS = BM / 64;                        // 64-row slots of this workgroup: four 16-row tiles each, summed in tile order
+  static_assert(WGM * WM == 4 * SLOTS, "four tiles per ToRGB slot");
+  if (wm_i < SLOTS && q < 3) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       if (npx[c] >= HW) continue;
       float v = 0.f;
 #pragma unroll
-      for (int m = 0; m < WGM; ++m) v += s_red[(m * 3 + q) * BN + nl + 16 * c];
-      cips3d_store_wt(a.rgb_part + ((int64_t)blockIdx.y * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c]), v);
+      for (int m = 0; m < 4; ++m) v += s_red[((wm_i * 4 + m) * 3 + q) * BN + nl + 16 * c];
+      cips3d_store_wt(a.rgb_part + (((int64_t)blockIdx.y * SLOTS + wm_i) * a.B + b) * 3 * HW + ((int64_t)q * HW + npx[c]), v);
     }
   }
 }
@@ -833,6 +843,16 @@ extern "C" int cips3d_modconv1x1_planes(const void* x_planes, const float* wm, v
     a.ride = j;
   }
   // 64 x 128 tiles, eight waves, 64-deep stages, 2-slot ring (96 KB): one workgroup per CU at 512 x 4096
+  // rg->half_chip (another view's launches are in flight on another stream: cips3d_forward_io.views_in_flight): 128 x 128 tiles --
+  // the launch takes half the CUs and two views' layers run side by side instead of interleaving on every CU (two lanes: 0.298-0.302
+  // against 0.303-0.308 ms per view, same box x3; alone on the device such a launch is SLOWER, 16.3 against 11.1 us: only on the hint).
+  // The ToRGB slots stay 64-row slots (same bits).
+  const int64_t tiles64 = (int64_t)B * (Cout / 64) * ceil_div<int64_t>(HW, 128);
+  if (rg && rg->half_chip && Cout % 128 == 0 && tiles64 > 192 && tiles64 <= 256) {
+    dim3 grid2((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 128) + (a.ride.part ? 1u : 0u), (unsigned)B);
+    hipLaunchKernelGGL((chain_gemm_kernel<2, 4, 2, 64, 2>), grid2, dim3(512), 0, as_stream(stream), a);
+    return cips3d_launch_status();
+  }
   dim3 grid((unsigned)ceil_div<int64_t>(HW, 128), (unsigned)(Cout / 64) + (a.ride.part ? 1u : 0u), (unsigned)B);
   static const int cfg = getenv("CIPS3D_CHAIN_CFG") ? atoi(getenv("CIPS3D_CHAIN_CFG")) : 0;     // A/B knob (ring depth / stage size)
   // (Round 3, measured and not kept: 128 x 128 tiles -- 2/3 of the operand bytes per flop through the L2 -> LDS path, 256

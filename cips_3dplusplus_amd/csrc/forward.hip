@@ -414,6 +414,7 @@ extern "C" int cips3d_generator_forward(const cips3d_generator_plan* plan, const
           rg.x_exp = x_exp; rg.x_exp_const = CIPS3D_FEATURES_EXP; rg.x_pmax = x_pmax; rg.x_max_const = x_exp ? 0.f : 1.f;
           rg.lconst = L.lconst; rg.out_exp = L.aexp; rg.out_pmax = (fmt == 1 && !x_pmax) ? L.pmax : nullptr;
           rg.out_amax = fmt == 1 ? nullptr : L.amax;       // (the exit's per-sample maximum, for the fused stage that reads it)
+          rg.half_chip = IO.views_in_flight > 1;           // (another view's launches beside this one's: chain.hip)
         }
         if (p16)
           TRY(cips3d_modconv1x1_planes16(x, L.wm, out, fmt, B, L.Cin, L.Cout, hw, 1, nz, nbs, L.noise_w, L.bias,

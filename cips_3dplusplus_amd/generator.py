@@ -270,7 +270,7 @@ class Generator(nn.Module):
             float(truncation), mean_r, mean_d, return_sdf, events, fresh_perturb=fresh_perturb,
             marks=None if marks is None else marks.io_fields(), styles_resident=bool(styles_resident),
             style_stamp=stamp if styles_resident is not None else None, rgb_out=rgb_out,
-            style_refs=refs)
+            style_refs=refs, views_in_flight=getattr(self, "_views_in_flight", 1))
         # mask arrives as [2,B,S,S] (plan.run): two contiguous [B,1,S,S] maps without a copy
         m2 = mask
         return {"rgb": rgb, "thumb_rgb": thumb, "style_decoder": None, "eikonal_term": None,

@@ -662,7 +662,7 @@ def from_planes(p, H, W):
 
 
 def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, noise=None, noise_w=None, bias=None,
-                      rgb_w=None, rgb_part=None, demodulated=True, lconst=None, ride=None):
+                      rgb_w=None, rgb_part=None, demodulated=True, lconst=None, ride=None, half_chip=False):
     """1x1 modulated conv on split-fp16 planes (csrc/chain.hip).  xp from to_planes / a previous call (its exponents are read
     from its attribute; a planes output carries its own); wm_split from
     modulate_weights(..., packed=True, split=True).  out_format: "planes" | "fp32" | "bf16" ([B,Cout,HW]).
@@ -670,7 +670,8 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
     from a modulate table that measured the row L1 norms.
     ride: a ToRGB fold carried by this launch (cips3d_reduce_job; range-tracked inputs only) -- dict(part [n_slots, Br, 3, HWr],
     biases [list of [3]], skip [Br, 3, HWr] or None, out [Br, 3, HWr]): out = skip + sum of the slots + sum of the biases, the
-    arithmetic and order of torgb_reduce."""
+    arithmetic and order of torgb_reduce.
+    half_chip: cips3d_range.half_chip (another view's launches are in flight: 128 x 128 tiles on half the CUs; same results)."""
     lib = _lib.load()
     B, Cin = xp.shape[0], xp.shape[1] * 8
     dev = xp.device
@@ -713,6 +714,8 @@ def modconv1x1_planes(xp, wm_split, Cout, HW, out_format="planes", epilogue=0, n
         job.n4, job.HW4, job.slot_stride = Br * 3 * HWr // 4, HWr // 4, Br * 3 * HWr
         job.n_slots, job.n_bias = n_slots, len(ride.get("biases", []))
         rg.ride = C.addressof(job)
+    if rg is not None:
+        rg.half_chip = int(bool(half_chip))
     check(lib.cips3d_modconv1x1_planes(dev_ptr(xp, "x_planes", dtype=torch.float16), dev_ptr(wm_split, "wm"), out.data_ptr(), fmt,
                                        B, Cin, Cout, HW, epilogue, dev_ptr(noise, "noise", True), nb,
                                        dev_ptr(noise_w, "noise_w", True), dev_ptr(bias, "bias", True),

@@ -18,9 +18,12 @@ Measured (MI355X, FFHQ 1024^2, D = 2, N = 24, batch 1): 0.318 ms per view with t
 a third lane adds nothing.  The lanes' streams are tested to run concurrently (`lane_streams`): two HIP streams may share a
 hardware queue, and a pipeline on such a pair is slower than no pipeline.
 """
+import os
 import weakref
 
 import torch
+
+_HINT = os.environ.get("CIPS3D_HALF_CHIP", "1") != "0"        # A/B knob: 0 = no views-in-flight hint to the forward's launches
 
 
 # Lane streams are made once per device and shared by every pipeline of the process.  HIP serves its streams from a few hardware
@@ -126,10 +129,15 @@ class ViewPipeline:
         if wait_inputs:
             s.wait_stream(cur)                   # the call's inputs (and whatever else the caller enqueued before)
         torch.cuda.set_stream(s)                 # (the `with torch.cuda.stream(s)` context costs ~25 us of host time per use)
+        G = self.G
+        if G is not None:
+            G._views_in_flight = self.lanes if _HINT else 1     # (a hint for the forward's launches: cips3d_forward_io.views_in_flight)
         try:
             out = fn()
         finally:
             torch.cuda.set_stream(cur)
+            if G is not None:
+                G._views_in_flight = 1
         vals = out.values() if isinstance(out, dict) else (out if isinstance(out, (tuple, list)) else (out,))
         for v in vals:                           # (allocated on the lane's stream, read on the caller's)
             if torch.is_tensor(v):

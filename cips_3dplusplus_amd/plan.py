@@ -52,7 +52,7 @@ class ForwardIO(C.Structure):
                 ("ev_nerf_start", C.c_void_p), ("ev_nerf_stop", C.c_void_p),
                 ("rng_seed", C.c_uint64), ("rng_base", C.c_uint64), ("rng_normal", C.c_void_p), ("rng_n_normal", C.c_int64),
                 ("rng_uniform", C.c_void_p), ("rng_n_uniform", C.c_int64),
-                ("noise_bound", C.c_float), ("pad2_", C.c_int32),
+                ("noise_bound", C.c_float), ("views_in_flight", C.c_int32),
                 ("ev_marks", C.c_void_p), ("ev_info", C.c_void_p), ("ev_count", C.c_void_p), ("n_ev_marks", C.c_int32),
                 ("styles_resident", C.c_int32), ("rgb_is_u8", C.c_int32), ("mask_planar", C.c_int32)]
 
@@ -435,7 +435,7 @@ class ForwardPlan:
 
     def run(self, z_r, z_d, cam_poses, focals, near, far, perturb_u, noise_bufs, trunc_psi, mean_r, mean_d, return_sdf,
             events=None, fresh_perturb=False, marks=None, styles_resident=False, style_stamp=None, rgb_out=None,
-            style_refs=None):
+            style_refs=None, views_in_flight=1):
         """fresh_perturb: draw the per-ray jitter here (perturb_u must be None) -- together with the decoder's fresh noise in
         one cips3d_rng_fill launch when both are fresh.
         styles_resident: a frame of a sequence (cips3d_forward_io.styles_resident): the style phase and the modulate table are
@@ -527,6 +527,7 @@ class ForwardPlan:
         # tensors Generator.forward hands out).  A render launch that fuses its finish writes that layout itself.
         mask = torch.empty((2, B, S, S) if self.mask_planar else (B, 2, S, S), device=dev)
         io.mask_planar = int(self.mask_planar)
+        io.views_in_flight = int(views_in_flight)      # (a scheduling hint: pipeline.ViewPipeline; results do not depend on it)
         io.rgb, io.thumb, io.xyz, io.mask = rgb.data_ptr(), thumb.data_ptr(), xyz.data_ptr(), mask.data_ptr()
         if events is not None:
             io.ev_nerf_start, io.ev_nerf_stop = events

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define CIPS3D_ABI_VERSION 29  /* bumped with every change of an entry point or of a struct layout below */
+#define CIPS3D_ABI_VERSION 30  /* bumped with every change of an entry point or of a struct layout below */
 
 #define CIPS3D_E_BADARG   (-1)   /* null pointer / non-positive size */
 #define CIPS3D_E_UNSUPP   (-2)   /* configuration outside what the kernels implement */
@@ -287,7 +287,9 @@ typedef struct cips3d_range {
   float next_gain;         /* fused stage, > 0: next_amax receives the BOUND next_gain * U2 of |y_next| (U2: the stage's bound of
                               |out2|; next_gain = sqrt(C) for a demodulated next up-conv) in slot 0 instead of the measured
                               maximum -- no workgroup reduction, no atomics; for a consumer that is the decoder's last stage */
-  int32_t pad2_;
+  int32_t half_chip;       /* cips3d_modconv1x1_planes, != 0: launches of another, independent view are in flight on another stream
+                              -- a launch that fills the chip exactly once (256 tiles of 64 x 128) runs as 128 tiles of 128 x 128
+                              on half the CUs instead, side by side with the other view's (same results, same ToRGB slots) */
   const struct cips3d_reduce_job* ride;   /* cips3d_modconv1x1_planes only (HOST pointer, may be NULL): a ToRGB fold that rides on
                               this launch -- see cips3d_reduce_job */
 } cips3d_range;
@@ -648,7 +650,8 @@ typedef struct cips3d_forward_io {
   float* rng_normal; int64_t rng_n_normal;
   float* rng_uniform; int64_t rng_n_uniform;
   float noise_bound;       /* upper bound of |noise[i][...]| over the call (0: the rng draw's own bound, 5.77, is used) */
-  int32_t pad2_;
+  int32_t views_in_flight; /* > 1: the caller keeps that many independent forwards in flight on different streams (a hint: the 64^2
+                              chain then launches half-chip tiles, cips3d_range.half_chip; results do not depend on it) */
   /* optional timeline of the decoder (measurement only; bench.py's roofline.kernels): ev_marks[0] and ev_marks[1] are
    * recorded back to back right before the first decoder launch (their distance calibrates what a record costs) and
    * ev_marks[k + 1] right after the k-th decoder launch of the call (hipEvent_t handles, at most

@@ -375,3 +375,32 @@ def test_the_two_instruction_split_is_the_split():
             hi = r16(xe.double())
             lo = r16(xe.double() - hi.double())
             assert torch.equal(pr[:, 0].float(), hi.float()) and torch.equal(pr[:, 1].float(), lo.float())
+
+
+def test_half_chip_tiles_give_the_same_bits():
+    """cips3d_range.half_chip (a second view in flight: pipeline.ViewPipeline): the 64^2 chain layer as 128 tiles of 128 x 128 on
+    half the CUs -- same planes, same exponents and patch maxima, and the SAME ToRGB slots (64-row slots: four 16-row tiles summed
+    in tile order whatever the workgroup's height) as the 256 tiles of 64 x 128."""
+    B, C, H = 1, 512, 64
+    HW = H * H
+    x = cu(weights.det_normal("hc.x", (B, C, H, H), 1.5, 1))
+    W = cu(weights.det_normal("hc.W", (1, C, C, 1, 1), 1.0, 2))
+    s = cu(1.0 + weights.det_uniform("hc.s", (B, C), 0.3, 3))
+    bias = cu(weights.det_uniform("hc.b", (C,), 0.2, 4))
+    nw = cu(torch.tensor([0.3]))
+    nz = cu(weights.det_normal("hc.n", (1, 1, H, H), 1.0, 5))
+    wm_s = hip.modulate_weights(W, s, C, B, C, C, 1, 1.0 / math.sqrt(C), True, True, split=True)
+    Wr = cu(weights.det_normal("hc.Wr", (1, 3, C, 1, 1), 1.0, 6))
+    wr = hip.modulate_weights(Wr, s, C, B, 3, C, 1, 1.0 / math.sqrt(C), False, False)
+    xp = hip.to_planes(x)
+    outs = []
+    for half in (False, True):
+        part = torch.full((C // 64, B, 3, HW), float("nan"), device=DEV)
+        o = hip.modconv1x1_planes(xp, wm_s, C, HW, "planes", epilogue=1, noise=nz, noise_w=nw, bias=bias, rgb_w=wr, rgb_part=part,
+                                  half_chip=half)
+        outs.append((o, o.cips3d_exp, o.cips3d_pmax, part))
+    (o0, e0, p0, part0), (o1, e1, p1, part1) = outs
+    assert torch.equal(o0, o1) and torch.equal(e0, e1) and torch.equal(part0, part1) and bool(torch.isfinite(part1).all())
+    # patch maxima: a 128-row workgroup's wave leaves ONE maximum for its two 16-channel patches -- a bound of each, and the same
+    # maximum over the channels of a pixel block (what the consuming layer takes)
+    assert bool((p1 >= p0).all()) and torch.equal(p0.amax(-1), p1.amax(-1))
